@@ -1,0 +1,1066 @@
+// oracle/svgir_oracle.cpp
+//
+// TEST INFRASTRUCTURE ONLY.  CPU restatement (parity oracle) of the SVG-IR surfel-rasterizer hot path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The product
+// (svg-ir_amd/) never links, imports or calls it.
+//
+// PARITY STATUS: "parity unpinned" for the rasterizer part -- the reference ships no tests, golden vectors or
+// fixtures for this path and its implementation is CUDA-only (cannot be built or run in this image).  This file
+// restates, function by function, the arithmetic of
+//   /root/reference/svgss_rasterization/cuda_rasterizer/{auxiliary.h,forward.cu,backward.cu,rasterizer_impl.cu}
+//   /root/reference/rgss-rasterization/cuda_rasterizer/{auxiliary.h,forward.cu,backward.cu,rasterizer_impl.cu}
+// and is pinned indirectly by (tests/test_oracle_*.py): reference Python helpers imported in the authoring
+// container (SH evaluation, quaternion->matrix, camera matrices; fixtures under tests/golden/), an independent
+// PyTorch-autograd fp64 restatement of the forward pass, and fp64 finite differences.
+//
+// Two arithmetic modes: fp32 (literal: same operation order and the same float/double promotions as the CUDA
+// source) and fp64 (every quantity in double; used only for derivative checks).
+//
+// Build: see oracle/Makefile (g++ -O2 -fopenmp -ffp-contract=off -shared -fPIC).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+extern "C" {
+
+// Plain-C parameter block.  Pointers are HOST pointers to float (fp64 == 0) or double (fp64 != 0) arrays,
+// laid out exactly as the reference's tensors (row-major AoS [P,k]; images CHW).
+struct orc_params {
+    int variant;  // 0 = rgss (stage 1), 1 = svgss (stage 2)
+    int fp64;
+    int P, S, VS, D, M, W, H;
+    const void* bg;              // [3]
+    const void* means3D;         // [P,3]
+    const void* shs;             // [P,M,3] or null
+    const void* colors_precomp;  // [P,3] or null
+    const void* features;        // [P,S] or null when S == 0
+    const void* vfeatures;       // [P,VS] or null when VS == 0 (svgss only)
+    const void* opacities;       // [P]
+    const void* scales;          // [P,3] or null
+    const void* rotations;       // [P,4] or null
+    const void* cov3D_precomp;   // [P,6] or null
+    const void* viewmatrix;      // [16]  (W2C transposed, i.e. column-major W2C)
+    const void* projmatrix;      // [16]
+    const void* prcppoint;       // [2]   (svgss; unused by the arithmetic, Q11)
+    const void* patchbbox;       // [4]   (svgss) h0,w0,h1,w1
+    const void* campos;          // [3]
+    const void* config;          // [config_len] (svgss); rgss uses the constant {1,1,1}
+    int config_len;
+    double scale_modifier, tan_fovx, tan_fovy, cx, cy;
+    int prefiltered, computer_pseudo_normal, backward_geometry;
+    int num_threads;  // <=0: OpenMP default
+};
+
+}  // extern "C"
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = TILE * TILE;
+
+template <typename T>
+struct M3 {  // column-major 3x3, c[col][row]: the storage and product semantics the reference's matrix type has
+    T c[3][3];
+    M3() {}
+    M3(T a0, T a1, T a2, T b0, T b1, T b2, T d0, T d1, T d2) {
+        c[0][0] = a0; c[0][1] = a1; c[0][2] = a2;
+        c[1][0] = b0; c[1][1] = b1; c[1][2] = b2;
+        c[2][0] = d0; c[2][1] = d1; c[2][2] = d2;
+    }
+};
+template <typename T>
+M3<T> mul(const M3<T>& A, const M3<T>& B) {
+    M3<T> r;
+    for (int col = 0; col < 3; col++)
+        for (int row = 0; row < 3; row++)
+            r.c[col][row] = A.c[0][row] * B.c[col][0] + A.c[1][row] * B.c[col][1] + A.c[2][row] * B.c[col][2];
+    return r;
+}
+template <typename T>
+M3<T> tr(const M3<T>& A) {
+    M3<T> r;
+    for (int col = 0; col < 3; col++)
+        for (int row = 0; row < 3; row++) r.c[col][row] = A.c[row][col];
+    return r;
+}
+
+// SH basis constants (svgss auxiliary.h:23-40)
+const float kC0 = 0.28209479177387814f;
+const float kC1 = 0.4886025119029199f;
+const float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                      0.5462742152960396f};
+const float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                      -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+template <typename real>
+struct Oracle {
+    orc_params p;
+    int P, S, VS, D, M, W, H, T, gx, gy;
+    bool svgss;
+    real cfg[8];
+    bool surface, normalize_depth, pix_depth, lrn_cam;
+    real focal_x, focal_y, tanx, tany, smod;
+
+    // inputs
+    const real *bg, *means3D, *shs, *colors_precomp, *features, *vfeatures, *opac, *scales, *rots, *cov3D_pre;
+    const real *view, *proj, *patchbbox, *campos;
+
+    // geometry state (svgss rasterizer_impl.h:21-45 / rgss :21-44)
+    std::vector<real> depths, means2D, cov3D, conic_opacity, rgb, normal, Jinv, viewCos, lambda;
+    std::vector<uint8_t> clamped;
+    std::vector<int32_t> radii;
+    std::vector<uint32_t> tiles_touched, point_offsets;
+    // binning state
+    int R = 0;
+    std::vector<uint64_t> keys_unsorted, keys;
+    std::vector<uint32_t> vals_unsorted, point_list;
+    // image state
+    std::vector<uint32_t> ranges;  // [T,2]
+    std::vector<real> final_T, final_D;
+    std::vector<uint32_t> n_contrib;
+    // outputs
+    std::vector<real> out_color, out_normal, out_depth, out_opac, out_feature, out_vfeature, out_weights;
+    std::vector<real> out_pseudo_normal, out_surface_xyz;
+    // backward inputs
+    const real *g_color = nullptr, *g_normal = nullptr, *g_depth = nullptr, *g_opac = nullptr, *g_feature = nullptr,
+               *g_vfeature = nullptr;
+    // backward outputs
+    std::vector<real> dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, dL_dvfeature, dL_dnormal,
+        dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dviewmat, dL_dprojmat, dL_dcampos;
+    std::vector<real> present;  // mark_visible result as 0/1
+    double t_pre = 0, t_bin = 0, t_render = 0, t_brender = 0, t_bpre = 0;
+
+    static real lit(float f) { return (real)f; }
+
+    explicit Oracle(const orc_params& pp) : p(pp) {
+        P = p.P; S = p.S; VS = p.VS; D = p.D; M = p.M; W = p.W; H = p.H;
+        gx = (W + TILE - 1) / TILE; gy = (H + TILE - 1) / TILE; T = gx * gy;
+        svgss = p.variant == 1;
+        bg = (const real*)p.bg; means3D = (const real*)p.means3D; shs = (const real*)p.shs;
+        colors_precomp = (const real*)p.colors_precomp; features = (const real*)p.features;
+        vfeatures = (const real*)p.vfeatures; opac = (const real*)p.opacities; scales = (const real*)p.scales;
+        rots = (const real*)p.rotations; cov3D_pre = (const real*)p.cov3D_precomp; view = (const real*)p.viewmatrix;
+        proj = (const real*)p.projmatrix; patchbbox = (const real*)p.patchbbox; campos = (const real*)p.campos;
+        for (int i = 0; i < 8; i++) cfg[i] = 0;
+        if (svgss) {
+            // Q7: the reference reads config[3] from a 3-float tensor; out-of-range entries are taken as 0 here.
+            const real* c = (const real*)p.config;
+            for (int i = 0; i < 8 && i < p.config_len; i++) cfg[i] = c[i];
+        } else {
+            cfg[0] = cfg[1] = cfg[2] = 1;  // rgss auxiliary.h:41-46 compile-time constant
+        }
+        surface = cfg[0] > 0; normalize_depth = cfg[1] > 0; pix_depth = cfg[2] > 0; lrn_cam = cfg[3] > 0;
+        tanx = (real)p.tan_fovx; tany = (real)p.tan_fovy; smod = (real)p.scale_modifier;
+        // rasterizer_impl.cu:244-245
+        focal_y = (real)H / (lit(2.0f) * tany);
+        focal_x = (real)W / (lit(2.0f) * tanx);
+#if defined(_OPENMP)
+        if (p.num_threads > 0) omp_set_num_threads(p.num_threads);
+#endif
+    }
+
+    // ---- auxiliary.h helpers -------------------------------------------------------------------------------
+    static real ndc2pix(real v, int S_) {  // auxiliary.h:42-46 (double arithmetic, narrowed on return)
+        return (real)((((double)v + 1.0) * S_ - 1.0) * 0.5);
+    }
+    void xform4x3(const real* q, const real* m, real* o) const {  // auxiliary.h:65-73
+        o[0] = m[0] * q[0] + m[4] * q[1] + m[8] * q[2] + m[12];
+        o[1] = m[1] * q[0] + m[5] * q[1] + m[9] * q[2] + m[13];
+        o[2] = m[2] * q[0] + m[6] * q[1] + m[10] * q[2] + m[14];
+    }
+    void xform4x4(const real* q, const real* m, real* o) const {  // auxiliary.h:75-84
+        o[0] = m[0] * q[0] + m[4] * q[1] + m[8] * q[2] + m[12];
+        o[1] = m[1] * q[0] + m[5] * q[1] + m[9] * q[2] + m[13];
+        o[2] = m[2] * q[0] + m[6] * q[1] + m[10] * q[2] + m[14];
+        o[3] = m[3] * q[0] + m[7] * q[1] + m[11] * q[2] + m[15];
+    }
+    void xvec4x3(const real* q, const real* m, real* o) const {  // auxiliary.h:86-94
+        o[0] = m[0] * q[0] + m[4] * q[1] + m[8] * q[2];
+        o[1] = m[1] * q[0] + m[5] * q[1] + m[9] * q[2];
+        o[2] = m[2] * q[0] + m[6] * q[1] + m[10] * q[2];
+    }
+    void get_rect(real px, real py, int rad, uint32_t* rmin, uint32_t* rmax) const {  // auxiliary.h:53-63
+        const real r = (real)rad;
+        rmin[0] = (uint32_t)std::min(gx, std::max(0, (int)((px - r) / TILE)));
+        rmin[1] = (uint32_t)std::min(gy, std::max(0, (int)((py - r) / TILE)));
+        rmax[0] = (uint32_t)std::min(gx, std::max(0, (int)((px + r + TILE - 1) / TILE)));
+        rmax[1] = (uint32_t)std::min(gy, std::max(0, (int)((py + r + TILE - 1) / TILE)));
+    }
+    static real norm3_inplace(real* v) {  // auxiliary.h:236-242
+        real mod = std::max((real)std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), lit((float)0.00000001));
+        v[0] /= mod; v[1] /= mod; v[2] /= mod;
+        return mod;
+    }
+    // auxiliary.h:291-388.  Returns true when the surfel is seen at a grazing angle (=> culled).
+    bool local_homo(const real* pv, const real* nv, const real* ax0, const real* ax1, real* res) const {
+        const real qx = pv[0] / pv[2], qy = pv[1] / pv[2];
+        const real S_fix = 1000, Svp = (focal_x + focal_y) / 2;
+        real d0[3] = {qx + 1 / S_fix, qy, 1};
+        const real m0 = norm3_inplace(d0);
+        real d1[3] = {qx, qy + 1 / S_fix, 1};
+        const real m1 = norm3_inplace(d1);
+        const real thr = lit(0.01f);
+        const real c0 = d0[0] * nv[0] + d0[1] * nv[1] + d0[2] * nv[2];
+        const real c1 = d1[0] * nv[0] + d1[1] * nv[1] + d1[2] * nv[2];
+        if (std::fabs(c0 / m0) < thr || std::fabs(c1 / m1) < thr) return true;
+        const real t = pv[0] * nv[0] + pv[1] * nv[1] + pv[2] * nv[2];
+        const real t0 = t / c0, t1 = t / c1;
+        real xu0[3], xu1[3];
+        for (int i = 0; i < 3; i++) { xu0[i] = d0[i] * t0 - pv[i]; xu1[i] = d1[i] * t1 - pv[i]; }
+        real J[4];
+        J[0] = xu0[0] * ax0[0] + xu0[1] * ax0[1] + xu0[2] * ax0[2];
+        J[1] = xu1[0] * ax0[0] + xu1[1] * ax0[1] + xu1[2] * ax0[2];
+        J[2] = xu0[0] * ax1[0] + xu0[1] * ax1[1] + xu0[2] * ax1[2];
+        J[3] = xu1[0] * ax1[0] + xu1[1] * ax1[1] + xu1[2] * ax1[2];
+        const real k = Svp / S_fix;
+        for (int i = 0; i < 4; i++) res[i] = J[i] / k;
+        for (int i = 0; i < 3; i++) { res[4 + i] = ax0[i]; res[7 + i] = ax1[i]; }
+        return false;
+    }
+    static M3<real> quat2rot(const real* q) {  // forward.cu:165-180 (no normalisation, Q3)
+        const real r = q[0], x = q[1], y = q[2], z = q[3];
+        const real one = 1, two = 2;
+        return M3<real>(one - two * (y * y + z * z), two * (x * y - r * z), two * (x * z + r * y),
+                        two * (x * y + r * z), one - two * (x * x + z * z), two * (y * z - r * x),
+                        two * (x * z - r * y), two * (y * z + r * x), one - two * (x * x + y * y));
+    }
+    // forward.cu:186-226 incl. quirk Q1: `mod * surface ? 0 : scale.z`
+    void cov3d_fwd(const real* sc, const M3<real>& Rm, real* out) const {
+        M3<real> Sm(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        Sm.c[0][0] = smod * sc[0];
+        Sm.c[1][1] = smod * sc[1];
+        Sm.c[2][2] = (smod * (real)(surface ? 1 : 0)) != 0 ? (real)0 : sc[2];
+        const M3<real> Mm = mul(Sm, Rm);
+        const M3<real> Sg = mul(tr(Mm), Mm);
+        out[0] = Sg.c[0][0]; out[1] = Sg.c[0][1]; out[2] = Sg.c[0][2];
+        out[3] = Sg.c[1][1]; out[4] = Sg.c[1][2]; out[5] = Sg.c[2][2];
+    }
+    // forward.cu:74-139.  `t` is the view-space mean (Q2).
+    void cov2d_fwd(const real* tv, const real* c3, real* out, M3<real>* Tout = nullptr, real* tcl = nullptr) const {
+        real t[3] = {tv[0], tv[1], tv[2]};
+        const real limx = lit(1.3f) * tanx, limy = lit(1.3f) * tany;
+        const real txtz = t[0] / t[2], tytz = t[1] / t[2];
+        t[0] = std::min(limx, std::max(-limx, txtz)) * t[2];
+        t[1] = std::min(limy, std::max(-limy, tytz)) * t[2];
+        M3<real> J(focal_x / t[2], 0, -(focal_x * t[0]) / (t[2] * t[2]), 0, focal_y / t[2],
+                   -(focal_y * t[1]) / (t[2] * t[2]), 0, 0, 0);
+        M3<real> Wm(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+        M3<real> Tm = mul(Wm, J);
+        M3<real> V(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+        M3<real> cov = mul(mul(tr(Tm), tr(V)), Tm);
+        out[0] = cov.c[0][0] + lit(0.3f);
+        out[1] = cov.c[0][1];
+        out[2] = cov.c[1][1] + lit(0.3f);
+        if (Tout) *Tout = Tm;
+        if (tcl) { tcl[0] = t[0]; tcl[1] = t[1]; tcl[2] = t[2]; }
+    }
+    // forward.cu:20-71
+    void sh_fwd(int idx, real* out) {
+        const real* pos = means3D + 3 * idx;
+        real dir[3] = {pos[0] - campos[0], pos[1] - campos[1], pos[2] - campos[2]};
+        const real len = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        for (int i = 0; i < 3; i++) dir[i] = dir[i] / len;
+        const real* sh = shs + (size_t)idx * M * 3;
+        const real x = dir[0], y = dir[1], z = dir[2];
+        for (int c = 0; c < 3; c++) {
+            auto h = [&](int k) { return sh[3 * k + c]; };
+            real res = lit(kC0) * h(0);
+            if (D > 0) {
+                res = res - lit(kC1) * y * h(1) + lit(kC1) * z * h(2) - lit(kC1) * x * h(3);
+                if (D > 1) {
+                    const real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    res = res + lit(kC2[0]) * xy * h(4) + lit(kC2[1]) * yz * h(5) +
+                          lit(kC2[2]) * (lit(2.0f) * zz - xx - yy) * h(6) + lit(kC2[3]) * xz * h(7) +
+                          lit(kC2[4]) * (xx - yy) * h(8);
+                    if (D > 2) {
+                        res = res + lit(kC3[0]) * y * (lit(3.0f) * xx - yy) * h(9) + lit(kC3[1]) * xy * z * h(10) +
+                              lit(kC3[2]) * y * (lit(4.0f) * zz - xx - yy) * h(11) +
+                              lit(kC3[3]) * z * (lit(2.0f) * zz - lit(3.0f) * xx - lit(3.0f) * yy) * h(12) +
+                              lit(kC3[4]) * x * (lit(4.0f) * zz - xx - yy) * h(13) +
+                              lit(kC3[5]) * z * (xx - yy) * h(14) + lit(kC3[6]) * x * (xx - lit(3.0f) * yy) * h(15);
+                    }
+                }
+            }
+            res += lit(0.5f);
+            clamped[3 * idx + c] = res < 0;
+            out[c] = std::max(res, (real)0);
+        }
+    }
+
+    // ---- forward: per-Gaussian (svgss forward.cu:229-396, rgss forward.cu:176-318) --------------------------
+    void preprocess() {
+        depths.assign(P, 0); means2D.assign((size_t)P * 2, 0); cov3D.assign((size_t)P * 6, 0);
+        conic_opacity.assign((size_t)P * 4, 0); rgb.assign((size_t)P * 3, 0); normal.assign((size_t)P * 3, 0);
+        Jinv.assign((size_t)P * 10, 0); viewCos.assign(P, 0); lambda.assign((size_t)P * 2, 0);
+        clamped.assign((size_t)P * 3, 0); radii.assign(P, 0); tiles_touched.assign(P, 0);
+#pragma omp parallel for schedule(static)
+        for (int idx = 0; idx < P; idx++) {
+            const real* po = means3D + 3 * idx;
+            real ph[4], pv[3];
+            xform4x4(po, proj, ph);
+            const real pw = lit(1.0f) / (ph[3] + lit(0.0000001f));
+            const real pp[3] = {ph[0] * pw, ph[1] * pw, ph[2] * pw};
+            xform4x3(po, view, pv);
+            const real pix[2] = {ndc2pix(pp[0], W), ndc2pix(pp[1], H)};
+            if (svgss) {  // svgss auxiliary.h:146-171
+                const real x0 = patchbbox[1], y0 = patchbbox[0], x1 = patchbbox[3], y1 = patchbbox[2];
+                const real w = x1 - x0, h = y1 - y0, e = lit((float)0.2);
+                if (pv[2] < 0 || pix[0] < x0 - w * e || pix[0] >= x1 + w * e || pix[1] < y0 - h * e ||
+                    pix[1] >= y1 + h * e)
+                    continue;
+            } else {  // rgss auxiliary.h:146-170
+                if (pv[2] <= lit(0.2f)) continue;
+            }
+            real qn[4] = {1, 0, 0, 0};
+            if (rots) for (int i = 0; i < 4; i++) qn[i] = rots[4 * idx + i];
+            const M3<real> Rm = quat2rot(qn);
+            if (surface) {
+                const real nw[3] = {Rm.c[0][2], Rm.c[1][2], Rm.c[2][2]};
+                const real a0w[3] = {Rm.c[0][0], Rm.c[1][0], Rm.c[2][0]};
+                const real a1w[3] = {Rm.c[0][1], Rm.c[1][1], Rm.c[2][1]};
+                real nv[3], a0[3], a1[3];
+                xvec4x3(nw, view, nv); xvec4x3(a0w, view, a0); xvec4x3(a1w, view, a1);
+                const real dot = pv[0] * nv[0] + pv[1] * nv[1] + pv[2] * nv[2];
+                if ((double)dot > -0.01) continue;  // auxiliary.h:173-208 (compared in double)
+                viewCos[idx] = dot;
+                for (int i = 0; i < 3; i++) normal[3 * idx + i] = nv[i];
+                if (pix_depth) {
+                    real J[10];
+                    if (local_homo(pv, nv, a0, a1, J)) continue;
+                    for (int i = 0; i < 10; i++) Jinv[10 * idx + i] = J[i];
+                }
+            }
+            const real* c3;
+            if (cov3D_pre) c3 = cov3D_pre + 6 * idx;
+            else { cov3d_fwd(scales + 3 * idx, Rm, &cov3D[6 * idx]); c3 = &cov3D[6 * idx]; }
+            real cov[3];
+            cov2d_fwd(pv, c3, cov);
+            const real det = cov[0] * cov[2] - cov[1] * cov[1];
+            if (det == 0) continue;
+            const real det_inv = lit(1.f) / det;
+            const real conic[3] = {cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv};
+            const real mid = lit(0.5f) * (cov[0] + cov[2]);
+            const real l1 = mid + std::sqrt(std::max(lit(0.1f), mid * mid - det));
+            const real l2 = mid - std::sqrt(std::max(lit(0.1f), mid * mid - det));
+            const real my_radius = std::ceil(lit(3.f) * std::sqrt(std::max(l1, l2)));
+            uint32_t rmin[2], rmax[2];
+            get_rect(pix[0], pix[1], (int)my_radius, rmin, rmax);
+            if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
+            if (!colors_precomp) sh_fwd(idx, &rgb[3 * idx]);
+            depths[idx] = pv[2];
+            radii[idx] = (int)my_radius;
+            means2D[2 * idx] = pix[0]; means2D[2 * idx + 1] = pix[1];
+            conic_opacity[4 * idx] = conic[0]; conic_opacity[4 * idx + 1] = conic[1];
+            conic_opacity[4 * idx + 2] = conic[2]; conic_opacity[4 * idx + 3] = opac[idx];
+            tiles_touched[idx] = (rmax[1] - rmin[1]) * (rmax[0] - rmin[0]);
+            if (svgss && scales) { lambda[2 * idx] = scales[3 * idx]; lambda[2 * idx + 1] = scales[3 * idx + 1]; }
+        }
+    }
+
+    // ---- binning (rasterizer_impl.cu:70-138, 307-347) -------------------------------------------------------
+    void bin() {
+        point_offsets.assign(P, 0);
+        uint32_t acc = 0;
+        for (int i = 0; i < P; i++) { acc += tiles_touched[i]; point_offsets[i] = acc; }
+        R = (int)acc;
+        keys_unsorted.assign(R, 0); vals_unsorted.assign(R, 0);
+        for (int idx = 0; idx < P; idx++) {
+            if (radii[idx] <= 0) continue;
+            uint32_t off = idx == 0 ? 0 : point_offsets[idx - 1];
+            uint32_t rmin[2], rmax[2];
+            get_rect(means2D[2 * idx], means2D[2 * idx + 1], radii[idx], rmin, rmax);
+            // the key always carries the fp32 bit pattern of the depth, as the reference does
+            const float df = (float)depths[idx];
+            uint32_t dbits; std::memcpy(&dbits, &df, 4);
+            for (uint32_t y = rmin[1]; y < rmax[1]; y++)
+                for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
+                    uint64_t key = (uint64_t)(y * (uint32_t)gx + x);
+                    key <<= 32; key |= dbits;
+                    keys_unsorted[off] = key; vals_unsorted[off] = (uint32_t)idx; off++;
+                }
+        }
+        // stable sort by key (cub::DeviceRadixSort is a stable LSD sort, Q12)
+        std::vector<uint32_t> order(R);
+        for (int i = 0; i < R; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](uint32_t a, uint32_t b) { return keys_unsorted[a] < keys_unsorted[b]; });
+        keys.resize(R); point_list.resize(R);
+        for (int i = 0; i < R; i++) { keys[i] = keys_unsorted[order[i]]; point_list[i] = vals_unsorted[order[i]]; }
+        ranges.assign((size_t)T * 2, 0);
+        for (int i = 0; i < R; i++) {
+            const uint32_t cur = (uint32_t)(keys[i] >> 32);
+            if (i == 0) ranges[2 * cur] = 0;
+            else {
+                const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+                if (cur != prev) { ranges[2 * prev + 1] = i; ranges[2 * cur] = i; }
+            }
+            if (i == R - 1) ranges[2 * cur + 1] = R;
+        }
+    }
+
+    // Per-pixel blend state shared by forward and backward: everything the pair (pixel, splat) needs.
+    struct Pair {
+        real dx, dy, power, G, alpha;
+    };
+    inline bool pair_alpha(const real* xy, const real* co, real pxf, real pyf, Pair& q) const {
+        q.dx = xy[0] - pxf; q.dy = xy[1] - pyf;
+        if (svgss) {  // svgss forward.cu:534-535
+            const real dist = (co[0] * q.dx * q.dx + co[2] * q.dy * q.dy) + 2 * co[1] * q.dx * q.dy;
+            q.power = lit(-0.5f) * dist;
+        } else {  // rgss forward.cu:430
+            q.power = lit(-0.5f) * (co[0] * q.dx * q.dx + co[2] * q.dy * q.dy) - co[1] * q.dx * q.dy;
+        }
+        if (q.power > 0) return false;
+        q.G = std::exp(q.power);
+        q.alpha = std::min(lit(0.99f), co[3] * q.G);
+        if (q.alpha < lit(1.0f) / lit(255.0f)) return false;
+        return true;
+    }
+    inline void corner_weights(const Pair& q, const real* J, const real* lbd, real* w) const {
+        // svgss forward.cu:604-617
+        const real dtx = q.dx * J[0] + q.dy * J[1], dty = q.dx * J[2] + q.dy * J[3];
+        const real umx = (real)(0.5 * (double)lbd[0] + 0.1), umy = (real)(0.5 * (double)lbd[1] + 0.1);
+        real u = dtx / umx * lit(0.5f) + lit(0.5f), v = dty / umy * lit(0.5f) + lit(0.5f);
+        u = std::min(lit(0.999f), std::max(lit(0.001f), u));
+        v = std::min(lit(0.999f), std::max(lit(0.001f), v));
+        w[0] = (1 - u) * (1 - v); w[1] = u * (1 - v); w[2] = (1 - u) * v; w[3] = u * v;
+    }
+    inline real depth_dif_z(const Pair& q, const real* J) const {  // auxiliary.h:390-397 (.z only)
+        const real d0 = q.dx * J[0] + q.dy * J[1], d1 = q.dx * J[2] + q.dy * J[3];
+        return d0 * J[6] + d1 * J[9];
+    }
+
+    // ---- forward composite (svgss forward.cu:401-750, rgss forward.cu:323-535) ------------------------------
+    void render() {
+        const size_t N = (size_t)W * H;
+        const int VC = VS / 4;
+        final_T.assign(N, 0); final_D.assign(N, 0); n_contrib.assign(N, 0);
+        out_color.assign(3 * N, 0); out_normal.assign(3 * N, 0); out_depth.assign(N, 0); out_opac.assign(N, 0);
+        out_feature.assign((size_t)S * N, 0); out_vfeature.assign((size_t)VC * N, 0);
+        std::vector<double> wacc(P, 0.0);
+        const real* colors = colors_precomp ? colors_precomp : rgb.data();
+#pragma omp parallel
+        {
+            std::vector<real> F(S > 0 ? S : 1), VF(VC > 0 ? VC : 1);
+#pragma omp for schedule(dynamic, 4)
+            for (int tile = 0; tile < T; tile++) {
+                const int tx = tile % gx, ty = tile / gx;
+                const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+                for (int ly = 0; ly < TILE; ly++)
+                    for (int lx = 0; lx < TILE; lx++) {
+                        const int px = tx * TILE + lx, py = ty * TILE + ly;
+                        if (px >= W || py >= H) continue;
+                        const size_t pix_id = (size_t)W * py + px;
+                        const real pxf = (real)px, pyf = (real)py;
+                        real Tr = 1, C[3] = {0, 0, 0}, Nn[3] = {0, 0, 0}, Dd = 0;
+                        std::fill(F.begin(), F.end(), (real)0); std::fill(VF.begin(), VF.end(), (real)0);
+                        uint32_t contributor = 0, last = 0;
+                        for (uint32_t k = r0; k < r1; k++) {
+                            contributor++;
+                            const uint32_t g = point_list[k];
+                            Pair q;
+                            if (!pair_alpha(&means2D[2 * g], &conic_opacity[4 * g], pxf, pyf, q)) continue;
+                            const real test_T = Tr * (1 - q.alpha);
+                            if (test_T < lit(0.0001f)) break;  // done = true
+                            const real w = q.alpha * Tr;
+                            real cw[4] = {0, 0, 0, 0};
+                            real dep = depths[g];
+                            if (surface && pix_depth) {
+                                dep -= depth_dif_z(q, &Jinv[10 * g]);
+                                if (svgss) corner_weights(q, &Jinv[10 * g], &lambda[2 * g], cw);
+                            }
+                            Dd += dep * w;
+                            for (int ch = 0; ch < 3; ch++) C[ch] += colors[3 * g + ch] * w;
+                            for (int ch = 0; ch < S; ch++) F[ch] += features[(size_t)g * S + ch] * w;
+                            for (int ch = 0; ch < VC; ch++) {
+                                const real* vf = vfeatures + (size_t)g * VS + 4 * ch;
+                                const real v0 = vf[0] * cw[0], v1 = vf[1] * cw[1], v2 = vf[2] * cw[2],
+                                           v3 = vf[3] * cw[3];
+                                VF[ch] += w * (v0 + v1 + v2 + v3);
+                            }
+                            if (surface) for (int ch = 0; ch < 3; ch++) Nn[ch] += normal[3 * g + ch] * w;
+                            Tr = test_T;
+#pragma omp atomic
+                            wacc[g] += (double)w;
+                            last = contributor;
+                        }
+                        Tr = std::min((real)(1 - 0.000001), Tr);  // forward.cu:671
+                        final_T[pix_id] = Tr;
+                        n_contrib[pix_id] = last;
+                        for (int ch = 0; ch < 3; ch++) out_color[ch * N + pix_id] = C[ch] + Tr * bg[ch];
+                        for (int ch = 0; ch < S; ch++) out_feature[ch * N + pix_id] = F[ch];
+                        for (int ch = 0; ch < VC; ch++) out_vfeature[ch * N + pix_id] = VF[ch];
+                        for (int ch = 0; ch < 3; ch++) out_normal[ch * N + pix_id] = surface ? Nn[ch] : (real)0;
+                        out_depth[pix_id] = normalize_depth ? Dd / (1 - Tr) : Dd + Tr * 10;
+                        out_opac[pix_id] = 1 - Tr;
+                        if (normalize_depth) final_D[pix_id] = Dd;
+                    }
+            }
+        }
+        out_weights.resize(P);
+        for (int i = 0; i < P; i++) out_weights[i] = (real)wacc[i];
+        if (!svgss) image_kernels();
+    }
+
+    // rgss forward.cu:538-631 (only when computer_pseudo_normal)
+    void image_kernels() {
+        const size_t N = (size_t)W * H;
+        out_pseudo_normal.assign(3 * N, 0); out_surface_xyz.assign(3 * N, 0);
+        if (!p.computer_pseudo_normal) return;
+        const real cx = (real)p.cx, cy = (real)p.cy;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const size_t id = (size_t)W * y + x;
+                const real d = out_depth[id] / std::max(out_opac[id], lit(0.0000001f));
+                out_surface_xyz[id] = ((real)x - cx) / focal_x * d;
+                out_surface_xyz[N + id] = ((real)y - cy) / focal_y * d;
+                out_surface_xyz[2 * N + id] = d;
+            }
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const int ym = y == 0 ? 0 : y - 1, yp = y == H - 1 ? H - 1 : y + 1;
+                const int xm = x == 0 ? 0 : x - 1, xp = x == W - 1 ? W - 1 : x + 1;
+                auto at = [&](int yy, int xx, int c) { return out_surface_xyz[c * N + (size_t)W * yy + xx]; };
+                real ga[3], gb[3];
+                for (int i = 0; i < 3; i++) {
+                    ga[i] = lit(-0.125f) * at(ym, xm, i) + lit(0.125f) * at(ym, xp, i) - lit(0.25f) * at(y, xm, i) +
+                            lit(0.25f) * at(y, xp, i) - lit(0.125f) * at(yp, xm, i) + lit(0.125f) * at(yp, xp, i);
+                    gb[i] = lit(-0.125f) * at(ym, xm, i) - lit(0.25f) * at(ym, x, i) - lit(0.125f) * at(ym, xp, i) +
+                            lit(0.125f) * at(yp, xm, i) + lit(0.25f) * at(yp, x, i) + lit(0.125f) * at(yp, xp, i);
+                }
+                real n[3] = {ga[1] * gb[2] - ga[2] * gb[1], -ga[0] * gb[2] + ga[2] * gb[0],
+                             ga[0] * gb[1] - ga[1] * gb[0]};
+                const real nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                if (nn <= 0) continue;
+                for (int i = 0; i < 3; i++) n[i] = -n[i] / nn;
+                const size_t id = (size_t)W * y + x;
+                out_pseudo_normal[id] = view[0] * n[0] + view[1] * n[1] + view[2] * n[2];
+                out_pseudo_normal[N + id] = view[4] * n[0] + view[5] * n[1] + view[6] * n[2];
+                out_pseudo_normal[2 * N + id] = view[8] * n[0] + view[9] * n[1] + view[10] * n[2];
+            }
+    }
+
+    // ---- backward composite (svgss backward.cu:529-934, rgss backward.cu:431-757) ---------------------------
+    void render_backward() {
+        const size_t N = (size_t)W * H;
+        const int VC = VS / 4;
+        // per-Gaussian accumulators in double: stands in for the reference's order-dependent float atomics
+        std::vector<double> a_mean2D((size_t)P * 2, 0), a_conic((size_t)P * 3, 0), a_opac(P, 0), a_color((size_t)P * 3, 0),
+            a_feat((size_t)P * S, 0), a_vfeat((size_t)P * VS, 0), a_normal((size_t)P * 3, 0), a_depth(P, 0);
+        const real* colors = colors_precomp ? colors_precomp : rgb.data();
+        const real ddelx_dx = (real)(0.5 * W), ddely_dy = (real)(0.5 * H);
+        const bool bgeom = svgss ? true : (p.backward_geometry != 0);
+#pragma omp parallel
+        {
+            std::vector<real> acc_f(S + 1), last_f(S + 1), gF(S + 1), acc_vf(VC + 1), last_vf(VC + 1), gVF(VC + 1);
+            // tile-local accumulators: [splat in range][channel]
+            std::vector<double> loc;
+            const int NCH = 2 + 3 + 1 + 3 + 3 + 1 + S + VS;
+#pragma omp for schedule(dynamic, 4)
+            for (int tile = 0; tile < T; tile++) {
+                const int tx = tile % gx, ty = tile / gx;
+                const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+                const uint32_t len = r1 - r0;
+                if (len == 0) continue;
+                loc.assign((size_t)len * NCH, 0.0);
+                for (int ly = 0; ly < TILE; ly++)
+                    for (int lx = 0; lx < TILE; lx++) {
+                        const int px = tx * TILE + lx, py = ty * TILE + ly;
+                        if (px >= W || py >= H) continue;
+                        const size_t pix_id = (size_t)W * py + px;
+                        const real pxf = (real)px, pyf = (real)py;
+                        const real T_final = final_T[pix_id];
+                        const real D_final = normalize_depth ? final_D[pix_id] : (real)0;
+                        real Tr = T_final;
+                        const uint32_t last_contributor = n_contrib[pix_id];
+                        real gC[3], gN[3];
+                        for (int i = 0; i < 3; i++) { gC[i] = g_color[i * N + pix_id]; gN[i] = g_normal[i * N + pix_id]; }
+                        for (int i = 0; i < S; i++) gF[i] = g_feature[i * N + pix_id];
+                        for (int i = 0; i < VC; i++) gVF[i] = g_vfeature[i * N + pix_id];
+                        const real gD = g_depth[pix_id], gO = g_opac[pix_id];
+                        real acc_c[3] = {0, 0, 0}, acc_n[3] = {0, 0, 0}, acc_d = 0;
+                        real last_c[3] = {0, 0, 0}, last_n[3] = {0, 0, 0}, last_d = 0, last_alpha = 0;
+                        std::fill(acc_f.begin(), acc_f.end(), (real)0); std::fill(last_f.begin(), last_f.end(), (real)0);
+                        std::fill(acc_vf.begin(), acc_vf.end(), (real)0); std::fill(last_vf.begin(), last_vf.end(), (real)0);
+                        uint32_t contributor = len;
+                        for (uint32_t kk = 0; kk < len; kk++) {
+                            contributor--;
+                            if (contributor >= last_contributor) continue;
+                            const uint32_t slot = len - 1 - kk;  // index within the tile range
+                            const uint32_t g = point_list[r0 + slot];
+                            const real* co = &conic_opacity[4 * g];
+                            Pair q;
+                            if (!pair_alpha(&means2D[2 * g], co, pxf, pyf, q)) continue;
+                            Tr = Tr / (lit(1.f) - q.alpha);
+                            const real dch = q.alpha * Tr;
+                            real cw[4] = {0, 0, 0, 0};
+                            const real* J = &Jinv[10 * g];
+                            const bool sp = surface && pix_depth;
+                            if (sp && svgss) corner_weights(q, J, &lambda[2 * g], cw);
+                            double* L = &loc[(size_t)slot * NCH];
+                            real dL_dalpha = 0;
+                            // colour
+                            for (int ch = 0; ch < 3; ch++) {
+                                const real c = colors[3 * g + ch];
+                                acc_c[ch] = last_alpha * last_c[ch] + (lit(1.f) - last_alpha) * acc_c[ch];
+                                last_c[ch] = c;
+                                dL_dalpha += (c - acc_c[ch]) * gC[ch];
+                                L[6 + ch] += (double)(dch * gC[ch]);
+                            }
+                            auto do_normal = [&]() {
+                                if (!surface) return;
+                                for (int ch = 0; ch < 3; ch++) {
+                                    const real n = normal[3 * g + ch];
+                                    acc_n[ch] = last_alpha * last_n[ch] + (lit(1.f) - last_alpha) * acc_n[ch];
+                                    last_n[ch] = n;
+                                    dL_dalpha += (n - acc_n[ch]) * gN[ch];
+                                    L[9 + ch] += (double)(dch * gN[ch] * 10);  // Q4
+                                }
+                            };
+                            auto do_feature = [&]() {
+                                for (int ch = 0; ch < S; ch++) {
+                                    const real f = features[(size_t)g * S + ch];
+                                    acc_f[ch] = last_alpha * last_f[ch] + (lit(1.f) - last_alpha) * acc_f[ch];
+                                    last_f[ch] = f;
+                                    if (bgeom) dL_dalpha += (f - acc_f[ch]) * gF[ch];
+                                    L[13 + ch] += (double)(dch * gF[ch]);
+                                }
+                            };
+                            if (svgss) {
+                                do_feature();
+                                for (int ch = 0; ch < VC; ch++) {
+                                    const real* vf = vfeatures + (size_t)g * VS + 4 * ch;
+                                    const real v0 = vf[0] * cw[0], v1 = vf[1] * cw[1], v2 = vf[2] * cw[2],
+                                               v3 = vf[3] * cw[3];
+                                    const real v = v0 + v1 + v2 + v3;
+                                    acc_vf[ch] = last_alpha * last_vf[ch] + (lit(1.f) - last_alpha) * acc_vf[ch];
+                                    last_vf[ch] = v;
+                                    for (int k = 0; k < 4; k++) L[13 + S + 4 * ch + k] += (double)(cw[k] * dch * gVF[ch]);
+                                    dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
+                                }
+                                do_normal();
+                            } else {
+                                do_normal();
+                                do_feature();
+                            }
+                            {  // depth
+                                real d_cur = depths[g];
+                                if (sp) d_cur -= depth_dif_z(q, J);
+                                acc_d = last_alpha * last_d + (lit(1.f) - last_alpha) * acc_d;
+                                last_d = d_cur;
+                                real dch_d = gD, da = 0;
+                                if (normalize_depth) {
+                                    dch_d /= (lit(1.f) - T_final);
+                                    da += gD * D_final / (lit(1.f) - T_final) / (lit(1.f) - T_final) * -T_final /
+                                          (1 - q.alpha) / Tr;
+                                }
+                                da += (d_cur - acc_d) * dch_d;
+                                L[12] += (double)(dch * dch_d * 1);
+                                dL_dalpha += da;
+                            }
+                            dL_dalpha *= Tr;
+                            dL_dalpha += gO * T_final / (1 - q.alpha);
+                            last_alpha = q.alpha;
+                            real bgdot = 0;
+                            for (int i = 0; i < 3; i++) bgdot += bg[i] * gC[i];
+                            dL_dalpha += (-T_final / (lit(1.f) - q.alpha)) * bgdot;
+                            if (!normalize_depth) dL_dalpha += (-T_final / (lit(1.f) - q.alpha)) * (10 * gD);
+                            real dL_ddist = 0;
+                            dL_ddist += dL_dalpha * co[3] * lit(-0.5f) * q.G;
+                            real ndc_x = dL_ddist * 2 * (co[0] * q.dx + co[1] * q.dy) * ddelx_dx;
+                            real ndc_y = dL_ddist * 2 * (co[2] * q.dy + co[1] * q.dx) * ddely_dy;
+                            if (sp) {  // Q5
+                                ndc_x += 1 * -gD * (J[6] * J[0] + J[9] * J[2]);
+                                ndc_y += 1 * -gD * (J[6] * J[1] + J[9] * J[3]);
+                            }
+                            L[0] += (double)ndc_x; L[1] += (double)ndc_y;
+                            L[2] += (double)(dL_ddist * (q.dx * q.dx));
+                            L[3] += (double)(dL_ddist * (1 * q.dx * q.dy));
+                            L[4] += (double)(dL_ddist * (q.dy * q.dy));
+                            L[5] += (double)(q.G * dL_dalpha);
+                        }
+                    }
+                for (uint32_t s = 0; s < len; s++) {
+                    const uint32_t g = point_list[r0 + s];
+                    const double* L = &loc[(size_t)s * NCH];
+                    auto add = [](double& dst, double v) {
+                        if (v != 0.0) {
+#pragma omp atomic
+                            dst += v;
+                        }
+                    };
+                    add(a_mean2D[2 * g], L[0]); add(a_mean2D[2 * g + 1], L[1]);
+                    add(a_conic[3 * g], L[2]); add(a_conic[3 * g + 1], L[3]); add(a_conic[3 * g + 2], L[4]);
+                    add(a_opac[g], L[5]);
+                    for (int c = 0; c < 3; c++) { add(a_color[3 * g + c], L[6 + c]); add(a_normal[3 * g + c], L[9 + c]); }
+                    add(a_depth[g], L[12]);
+                    for (int c = 0; c < S; c++) add(a_feat[(size_t)g * S + c], L[13 + c]);
+                    for (int c = 0; c < VS; c++) add(a_vfeat[(size_t)g * VS + c], L[13 + S + c]);
+                }
+            }
+        }
+        dL_dmean2D.assign((size_t)P * 3, 0); dL_dconic.assign((size_t)P * 4, 0); dL_dopacity.assign(P, 0);
+        dL_dcolor.assign((size_t)P * 3, 0); dL_dfeature.assign((size_t)P * S, 0); dL_dvfeature.assign((size_t)P * VS, 0);
+        dL_dnormal.assign((size_t)P * 3, 0); dL_ddepth.assign(P, 0);
+        for (int g = 0; g < P; g++) {
+            dL_dmean2D[3 * g] = (real)a_mean2D[2 * g]; dL_dmean2D[3 * g + 1] = (real)a_mean2D[2 * g + 1];
+            dL_dconic[4 * g] = (real)a_conic[3 * g]; dL_dconic[4 * g + 1] = (real)a_conic[3 * g + 1];
+            dL_dconic[4 * g + 3] = (real)a_conic[3 * g + 2];
+            dL_dopacity[g] = (real)a_opac[g]; dL_ddepth[g] = (real)a_depth[g];
+            for (int c = 0; c < 3; c++) { dL_dcolor[3 * g + c] = (real)a_color[3 * g + c]; dL_dnormal[3 * g + c] = (real)a_normal[3 * g + c]; }
+            for (int c = 0; c < S; c++) dL_dfeature[(size_t)g * S + c] = (real)a_feat[(size_t)g * S + c];
+            for (int c = 0; c < VS; c++) dL_dvfeature[(size_t)g * VS + c] = (real)a_vfeat[(size_t)g * VS + c];
+        }
+    }
+
+    // ---- backward per-Gaussian ------------------------------------------------------------------------------
+    // svgss backward.cu:163-322 / rgss :144-276
+    void cov2d_backward(int idx) {
+        const real* c3 = (cov3D_pre ? cov3D_pre : cov3D.data()) + 6 * idx;
+        const real* mean = means3D + 3 * idx;
+        const real dcon[3] = {dL_dconic[4 * idx], dL_dconic[4 * idx + 1], dL_dconic[4 * idx + 3]};
+        real t[3];
+        xform4x3(mean, view, t);
+        const real limx = lit(1.3f) * tanx, limy = lit(1.3f) * tany;
+        const real txtz = t[0] / t[2], tytz = t[1] / t[2];
+        t[0] = std::min(limx, std::max(-limx, txtz)) * t[2];
+        t[1] = std::min(limy, std::max(-limy, tytz)) * t[2];
+        const real xgm = (txtz < -limx || txtz > limx) ? (real)0 : (real)1;
+        const real ygm = (tytz < -limy || tytz > limy) ? (real)0 : (real)1;
+        const real hx = focal_x, hy = focal_y;
+        const real J0 = hx / t[2], J1 = -(hx * t[0]) / (t[2] * t[2]), J2 = hy / t[2], J3 = -(hy * t[1]) / (t[2] * t[2]);
+        M3<real> J(J0, 0, J1, 0, J2, J3, 0, 0, 0);
+        M3<real> Wm(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+        M3<real> V(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+        M3<real> Tm = mul(Wm, J);
+        M3<real> cov = mul(mul(tr(Tm), tr(V)), Tm);
+        const real a = cov.c[0][0] + lit(0.3f), b = cov.c[0][1], c = cov.c[1][1] + lit(0.3f);
+        const real denom = a * c - b * b;
+        real da = 0, db = 0, dc = 0;
+        const real d2i = lit(1.0f) / ((denom * denom) + lit(0.0000001f));
+        real* dcv = &dL_dcov3D[6 * idx];
+        auto Tc = [&](int i, int j) { return Tm.c[i][j]; };
+        auto Vc = [&](int i, int j) { return V.c[i][j]; };
+        if (d2i != 0) {
+            da = d2i * (-c * c * dcon[0] + 2 * b * c * dcon[1] + (denom - a * c) * dcon[2]);
+            dc = d2i * (-a * a * dcon[2] + 2 * a * b * dcon[1] + (denom - a * c) * dcon[0]);
+            db = d2i * 2 * (b * c * dcon[0] - (denom + 2 * b * b) * dcon[1] + a * b * dcon[2]);
+            dcv[0] = (Tc(0, 0) * Tc(0, 0) * da + Tc(0, 0) * Tc(1, 0) * db + Tc(1, 0) * Tc(1, 0) * dc);
+            dcv[3] = (Tc(0, 1) * Tc(0, 1) * da + Tc(0, 1) * Tc(1, 1) * db + Tc(1, 1) * Tc(1, 1) * dc);
+            dcv[5] = (Tc(0, 2) * Tc(0, 2) * da + Tc(0, 2) * Tc(1, 2) * db + Tc(1, 2) * Tc(1, 2) * dc);
+            dcv[1] = 2 * Tc(0, 0) * Tc(0, 1) * da + (Tc(0, 0) * Tc(1, 1) + Tc(0, 1) * Tc(1, 0)) * db + 2 * Tc(1, 0) * Tc(1, 1) * dc;
+            dcv[2] = 2 * Tc(0, 0) * Tc(0, 2) * da + (Tc(0, 0) * Tc(1, 2) + Tc(0, 2) * Tc(1, 0)) * db + 2 * Tc(1, 0) * Tc(1, 2) * dc;
+            dcv[4] = 2 * Tc(0, 2) * Tc(0, 1) * da + (Tc(0, 1) * Tc(1, 2) + Tc(0, 2) * Tc(1, 1)) * db + 2 * Tc(1, 1) * Tc(1, 2) * dc;
+        } else {
+            for (int i = 0; i < 6; i++) dcv[i] = 0;
+        }
+        const real dT00 = 2 * (Tc(0, 0) * Vc(0, 0) + Tc(0, 1) * Vc(0, 1) + Tc(0, 2) * Vc(0, 2)) * da +
+                          (Tc(1, 0) * Vc(0, 0) + Tc(1, 1) * Vc(0, 1) + Tc(1, 2) * Vc(0, 2)) * db;
+        const real dT01 = 2 * (Tc(0, 0) * Vc(1, 0) + Tc(0, 1) * Vc(1, 1) + Tc(0, 2) * Vc(1, 2)) * da +
+                          (Tc(1, 0) * Vc(1, 0) + Tc(1, 1) * Vc(1, 1) + Tc(1, 2) * Vc(1, 2)) * db;
+        const real dT02 = 2 * (Tc(0, 0) * Vc(2, 0) + Tc(0, 1) * Vc(2, 1) + Tc(0, 2) * Vc(2, 2)) * da +
+                          (Tc(1, 0) * Vc(2, 0) + Tc(1, 1) * Vc(2, 1) + Tc(1, 2) * Vc(2, 2)) * db;
+        const real dT10 = 2 * (Tc(1, 0) * Vc(0, 0) + Tc(1, 1) * Vc(0, 1) + Tc(1, 2) * Vc(0, 2)) * dc +
+                          (Tc(0, 0) * Vc(0, 0) + Tc(0, 1) * Vc(0, 1) + Tc(0, 2) * Vc(0, 2)) * db;
+        const real dT11 = 2 * (Tc(1, 0) * Vc(1, 0) + Tc(1, 1) * Vc(1, 1) + Tc(1, 2) * Vc(1, 2)) * dc +
+                          (Tc(0, 0) * Vc(1, 0) + Tc(0, 1) * Vc(1, 1) + Tc(0, 2) * Vc(1, 2)) * db;
+        const real dT12 = 2 * (Tc(1, 0) * Vc(2, 0) + Tc(1, 1) * Vc(2, 1) + Tc(1, 2) * Vc(2, 2)) * dc +
+                          (Tc(0, 0) * Vc(2, 0) + Tc(0, 1) * Vc(2, 1) + Tc(0, 2) * Vc(2, 2)) * db;
+        const real dJ00 = Wm.c[0][0] * dT00 + Wm.c[0][1] * dT01 + Wm.c[0][2] * dT02;
+        const real dJ02 = Wm.c[2][0] * dT00 + Wm.c[2][1] * dT01 + Wm.c[2][2] * dT02;
+        const real dJ11 = Wm.c[1][0] * dT10 + Wm.c[1][1] * dT11 + Wm.c[1][2] * dT12;
+        const real dJ12 = Wm.c[2][0] * dT10 + Wm.c[2][1] * dT11 + Wm.c[2][2] * dT12;
+        const real tz = lit(1.f) / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        if (svgss && lrn_cam) {
+            const real dW[16] = {dT00 * J0, dT10 * J2, dT00 * J1 + dT10 * J3, 0, dT01 * J0, dT11 * J2,
+                                 dT01 * J1 + dT11 * J3, 0, dT02 * J0, dT12 * J2, dT02 * J1 + dT12 * J3, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 16; i++) {
+#pragma omp atomic
+                dL_dviewmat[i] += dW[i];
+            }
+        }
+        const real dtx = xgm * -hx * tz2 * dJ02;
+        const real dty = ygm * -hy * tz2 * dJ12;
+        const real dtz = -hx * tz2 * dJ00 - hy * tz2 * dJ11 + (2 * hx * t[0]) * tz3 * dJ02 + (2 * hy * t[1]) * tz3 * dJ12;
+        // auxiliary.h:96-104 (transpose transform)
+        dL_dmean3D[3 * idx + 0] = view[0] * dtx + view[1] * dty + view[2] * dtz;
+        dL_dmean3D[3 * idx + 1] = view[4] * dtx + view[5] * dty + view[6] * dtz;
+        dL_dmean3D[3 * idx + 2] = view[8] * dtx + view[9] * dty + view[10] * dtz;
+    }
+
+    // svgss backward.cu:20-158 / rgss :20-142
+    void sh_backward(int idx) {
+        const real* pos = means3D + 3 * idx;
+        const real dor[3] = {pos[0] - campos[0], pos[1] - campos[1], pos[2] - campos[2]};
+        const real len = std::sqrt(dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2]);
+        const real x = dor[0] / len, y = dor[1] / len, z = dor[2] / len;
+        const real* sh = shs + (size_t)idx * M * 3;
+        real g[3];
+        for (int c = 0; c < 3; c++) g[c] = dL_dcolor[3 * idx + c] * (clamped[3 * idx + c] ? (real)0 : (real)1);
+        real* dsh = &dL_dsh[(size_t)idx * M * 3];
+        real dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+        auto set = [&](int k, real coef) { for (int c = 0; c < 3; c++) dsh[3 * k + c] = coef * g[c]; };
+        auto h = [&](int k, int c) { return sh[3 * k + c]; };
+        set(0, lit(kC0));
+        if (D > 0) {
+            set(1, -lit(kC1) * y); set(2, lit(kC1) * z); set(3, -lit(kC1) * x);
+            for (int c = 0; c < 3; c++) { dx[c] = -lit(kC1) * h(3, c); dy[c] = -lit(kC1) * h(1, c); dz[c] = lit(kC1) * h(2, c); }
+            if (D > 1) {
+                const real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                set(4, lit(kC2[0]) * xy); set(5, lit(kC2[1]) * yz); set(6, lit(kC2[2]) * (lit(2.f) * zz - xx - yy));
+                set(7, lit(kC2[3]) * xz); set(8, lit(kC2[4]) * (xx - yy));
+                for (int c = 0; c < 3; c++) {
+                    dx[c] += lit(kC2[0]) * y * h(4, c) + lit(kC2[2]) * lit(2.f) * -x * h(6, c) + lit(kC2[3]) * z * h(7, c) +
+                             lit(kC2[4]) * lit(2.f) * x * h(8, c);
+                    dy[c] += lit(kC2[0]) * x * h(4, c) + lit(kC2[1]) * z * h(5, c) + lit(kC2[2]) * lit(2.f) * -y * h(6, c) +
+                             lit(kC2[4]) * lit(2.f) * -y * h(8, c);
+                    dz[c] += lit(kC2[1]) * y * h(5, c) + lit(kC2[2]) * lit(2.f) * lit(2.f) * z * h(6, c) + lit(kC2[3]) * x * h(7, c);
+                }
+                if (D > 2) {
+                    set(9, lit(kC3[0]) * y * (lit(3.f) * xx - yy)); set(10, lit(kC3[1]) * xy * z);
+                    set(11, lit(kC3[2]) * y * (lit(4.f) * zz - xx - yy));
+                    set(12, lit(kC3[3]) * z * (lit(2.f) * zz - lit(3.f) * xx - lit(3.f) * yy));
+                    set(13, lit(kC3[4]) * x * (lit(4.f) * zz - xx - yy)); set(14, lit(kC3[5]) * z * (xx - yy));
+                    set(15, lit(kC3[6]) * x * (xx - lit(3.f) * yy));
+                    for (int c = 0; c < 3; c++) {
+                        dx[c] += (lit(kC3[0]) * h(9, c) * lit(3.f) * lit(2.f) * xy + lit(kC3[1]) * h(10, c) * yz +
+                                  lit(kC3[2]) * h(11, c) * lit(-2.f) * xy + lit(kC3[3]) * h(12, c) * lit(-3.f) * lit(2.f) * xz +
+                                  lit(kC3[4]) * h(13, c) * (lit(-3.f) * xx + lit(4.f) * zz - yy) +
+                                  lit(kC3[5]) * h(14, c) * lit(2.f) * xz + lit(kC3[6]) * h(15, c) * lit(3.f) * (xx - yy));
+                        dy[c] += (lit(kC3[0]) * h(9, c) * lit(3.f) * (xx - yy) + lit(kC3[1]) * h(10, c) * xz +
+                                  lit(kC3[2]) * h(11, c) * (lit(-3.f) * yy + lit(4.f) * zz - xx) +
+                                  lit(kC3[3]) * h(12, c) * lit(-3.f) * lit(2.f) * yz + lit(kC3[4]) * h(13, c) * lit(-2.f) * xy +
+                                  lit(kC3[5]) * h(14, c) * lit(-2.f) * yz + lit(kC3[6]) * h(15, c) * lit(-3.f) * lit(2.f) * xy);
+                        dz[c] += (lit(kC3[1]) * h(10, c) * xy + lit(kC3[2]) * h(11, c) * lit(4.f) * lit(2.f) * yz +
+                                  lit(kC3[3]) * h(12, c) * lit(3.f) * (lit(2.f) * zz - xx - yy) +
+                                  lit(kC3[4]) * h(13, c) * lit(4.f) * lit(2.f) * xz + lit(kC3[5]) * h(14, c) * (xx - yy));
+                    }
+                }
+            }
+        }
+        const real ddir[3] = {dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
+                              dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]};
+        // auxiliary.h:114-124
+        const real s2 = dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2];
+        const real i32 = lit(1.0f) / std::sqrt(s2 * s2 * s2);
+        const real dm[3] = {((+s2 - dor[0] * dor[0]) * ddir[0] - dor[1] * dor[0] * ddir[1] - dor[2] * dor[0] * ddir[2]) * i32,
+                            (-dor[0] * dor[1] * ddir[0] + (s2 - dor[1] * dor[1]) * ddir[1] - dor[2] * dor[1] * ddir[2]) * i32,
+                            (-dor[0] * dor[2] * ddir[0] - dor[1] * dor[2] * ddir[1] + (s2 - dor[2] * dor[2]) * ddir[2]) * i32};
+        if (svgss && lrn_cam)
+            for (int i = 0; i < 3; i++) {
+#pragma omp atomic
+                dL_dcampos[i] += -dm[i];
+            }
+        for (int i = 0; i < 3; i++) dL_dmean3D[3 * idx + i] += dm[i];
+    }
+
+    // svgss backward.cu:326-432 / rgss :280-364 (incl. the s.z != 0 half of quirk Q1)
+    void cov3d_backward(int idx) {
+        const real* q = rots + 4 * idx;
+        const real r = q[0], x = q[1], y = q[2], z = q[3];
+        const M3<real> Rm = quat2rot(q);
+        const real s[3] = {smod * scales[3 * idx], smod * scales[3 * idx + 1], smod * scales[3 * idx + 2]};
+        M3<real> Sm(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        Sm.c[0][0] = s[0]; Sm.c[1][1] = s[1]; Sm.c[2][2] = s[2];
+        const M3<real> Mm = mul(Sm, Rm);
+        const real* dc = &dL_dcov3D[6 * idx];
+        const real hf = lit(0.5f);
+        M3<real> dSig(dc[0], hf * dc[1], hf * dc[2], hf * dc[1], dc[3], hf * dc[4], hf * dc[2], hf * dc[4], dc[5]);
+        M3<real> twoM;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) twoM.c[a][b] = lit(2.0f) * Mm.c[a][b];
+        const M3<real> dM = mul(twoM, dSig);
+        const M3<real> Rt = tr(Rm), dMt = tr(dM);
+        auto dot = [](const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+        dL_dscale[3 * idx + 0] = dot(Rt.c[0], dMt.c[0]);
+        dL_dscale[3 * idx + 1] = dot(Rt.c[1], dMt.c[1]);
+        dL_dscale[3 * idx + 2] = surface ? (real)0 : dot(Rt.c[2], dMt.c[2]);
+        M3<real> dRt = dMt;
+        for (int k = 0; k < 3; k++) { dRt.c[0][k] *= s[0]; dRt.c[1][k] *= s[1]; dRt.c[2][k] *= s[2]; }
+        const real* gn = &dL_dnormal[3 * idx];
+        const real wn[3] = {gn[0] * view[0] + gn[1] * view[1] + gn[2] * view[2],
+                            gn[0] * view[4] + gn[1] * view[5] + gn[2] * view[6],
+                            gn[0] * view[8] + gn[1] * view[9] + gn[2] * view[10]};
+        dRt.c[2][0] += wn[0]; dRt.c[2][1] += wn[1]; dRt.c[2][2] += wn[2];
+        if (svgss && lrn_cam) {
+            const real wN[3] = {Rm.c[0][2], Rm.c[1][2], Rm.c[2][2]};
+            const real dv[16] = {gn[0] * wN[0], gn[1] * wN[0], gn[2] * wN[0], 0, gn[0] * wN[1], gn[1] * wN[1], gn[2] * wN[1], 0,
+                                 gn[0] * wN[2], gn[1] * wN[2], gn[2] * wN[2], 0, 0, 0, 0, 0};
+            for (int i = 0; i < 16; i++) {
+#pragma omp atomic
+                dL_dviewmat[i] += dv[i];
+            }
+        }
+        auto d = [&](int a, int b) { return dRt.c[a][b]; };
+        real* o = &dL_drot[4 * idx];
+        o[0] = 2 * z * (d(0, 1) - d(1, 0)) + 2 * y * (d(2, 0) - d(0, 2)) + 2 * x * (d(1, 2) - d(2, 1));
+        o[1] = 2 * y * (d(1, 0) + d(0, 1)) + 2 * z * (d(2, 0) + d(0, 2)) + 2 * r * (d(1, 2) - d(2, 1)) - 4 * x * (d(2, 2) + d(1, 1));
+        o[2] = 2 * x * (d(1, 0) + d(0, 1)) + 2 * r * (d(2, 0) - d(0, 2)) + 2 * z * (d(1, 2) + d(2, 1)) - 4 * y * (d(2, 2) + d(0, 0));
+        o[3] = 2 * r * (d(0, 1) - d(1, 0)) + 2 * x * (d(2, 0) + d(0, 2)) + 2 * y * (d(1, 2) + d(2, 1)) - 4 * z * (d(1, 1) + d(0, 0));
+    }
+
+    // svgss backward.cu:437-526 / rgss :369-428
+    void preprocess_backward() {
+        dL_dmean3D.assign((size_t)P * 3, 0); dL_dcov3D.assign((size_t)P * 6, 0); dL_dsh.assign((size_t)P * M * 3, 0);
+        dL_dscale.assign((size_t)P * 3, 0); dL_drot.assign((size_t)P * 4, 0);
+        dL_dviewmat.assign(16, 0); dL_dprojmat.assign(16, 0); dL_dcampos.assign(3, 0);
+#pragma omp parallel for schedule(static)
+        for (int idx = 0; idx < P; idx++) {
+            if (!(radii[idx] > 0)) continue;
+            cov2d_backward(idx);
+            const real* m = means3D + 3 * idx;
+            real mh[4];
+            xform4x4(m, proj, mh);
+            const real mw = lit(1.0f) / (mh[3] + lit(0.0000001f));
+            const real mul1 = (proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12]) * mw * mw;
+            const real mul2 = (proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13]) * mw * mw;
+            const real g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
+            real dm[3];
+            dm[0] = (proj[0] * mw - proj[3] * mul1) * g2x + (proj[1] * mw - proj[3] * mul2) * g2y;
+            dm[1] = (proj[4] * mw - proj[7] * mul1) * g2x + (proj[5] * mw - proj[7] * mul2) * g2y;
+            dm[2] = (proj[8] * mw - proj[11] * mul1) * g2x + (proj[9] * mw - proj[11] * mul2) * g2y;
+            const real dd = dL_ddepth[idx];
+            const real fd[3] = {dd * view[2], dd * view[6], dd * view[10]};
+            for (int i = 0; i < 3; i++) dL_dmean3D[3 * idx + i] += dm[i] + fd[i];
+            if (svgss && lrn_cam) {
+                const real pm[16] = {g2x * m[0] * mw, g2y * m[0] * mw, 0, g2x * -mul1 * m[0] + g2y * -mul2 * m[0],
+                                     g2x * m[1] * mw, g2y * m[1] * mw, 0, g2x * -mul1 * m[1] + g2y * -mul2 * m[1],
+                                     g2x * m[2] * mw, g2y * m[2] * mw, 0, g2x * -mul1 * m[2] + g2y * -mul2 * m[2],
+                                     g2x * mw, g2y * mw, 0, g2x * -mul1 + g2y * -mul2};
+                const real vd[16] = {0, 0, dd * m[0], 0, 0, 0, dd * m[1], 0, 0, 0, dd * m[2], 0, 0, 0, dd, 0};
+                for (int i = 0; i < 16; i++) {
+#pragma omp atomic
+                    dL_dprojmat[i] += pm[i];
+#pragma omp atomic
+                    dL_dviewmat[i] += vd[i];
+                }
+            }
+            if (shs) sh_backward(idx);
+            if (scales) cov3d_backward(idx);
+        }
+    }
+
+    static double now() {
+#if defined(_OPENMP)
+        return omp_get_wtime();
+#else
+        return 0;
+#endif
+    }
+    void forward() {
+        double t0 = now(); preprocess();
+        double t1 = now(); bin();
+        double t2 = now(); render();
+        double t3 = now();
+        t_pre = t1 - t0; t_bin = t2 - t1; t_render = t3 - t2;
+    }
+    void backward(const void* gc, const void* gn, const void* gd, const void* go, const void* gf, const void* gvf) {
+        g_color = (const real*)gc; g_normal = (const real*)gn; g_depth = (const real*)gd; g_opac = (const real*)go;
+        g_feature = (const real*)gf; g_vfeature = (const real*)gvf;
+        double t0 = now(); render_backward();
+        double t1 = now(); preprocess_backward();
+        double t2 = now();
+        t_brender = t1 - t0; t_bpre = t2 - t1;
+    }
+    // svgss: no-op kernel => all false (Q14); rgss rasterizer_impl.cu:54-66 + auxiliary.h:146-170
+    void mark_visible() {
+        present.assign(P, 0);
+        if (svgss) return;
+        for (int i = 0; i < P; i++) {
+            real pv[3];
+            xform4x3(means3D + 3 * i, view, pv);
+            present[i] = pv[2] <= lit(0.2f) ? 0 : 1;
+        }
+    }
+};
+
+struct Handle {
+    int fp64;
+    Oracle<float>* f = nullptr;
+    Oracle<double>* d = nullptr;
+};
+
+template <typename real, typename V>
+bool pick(const char* want, const char* name, const std::vector<V>& v, const void** ptr, long long* n, int* dtype) {
+    if (std::strcmp(want, name) != 0) return false;
+    *ptr = v.data(); *n = (long long)v.size();
+    // dtype codes: 0 f32, 1 f64, 2 i32, 3 u32, 4 u64, 5 u8
+    if (std::is_same<V, float>::value) *dtype = 0;
+    else if (std::is_same<V, double>::value) *dtype = 1;
+    else if (std::is_same<V, int32_t>::value) *dtype = 2;
+    else if (std::is_same<V, uint32_t>::value) *dtype = 3;
+    else if (std::is_same<V, uint64_t>::value) *dtype = 4;
+    else *dtype = 5;
+    return true;
+}
+
+template <typename real>
+int get_field(Oracle<real>* o, const char* w, const void** ptr, long long* n, int* dt) {
+#define F(name) if (pick<real>(w, #name, o->name, ptr, n, dt)) return 0;
+    F(depths) F(means2D) F(cov3D) F(conic_opacity) F(rgb) F(normal) F(Jinv) F(viewCos) F(lambda) F(clamped) F(radii)
+    F(tiles_touched) F(point_offsets) F(keys_unsorted) F(keys) F(vals_unsorted) F(point_list) F(ranges) F(final_T)
+    F(final_D) F(n_contrib) F(out_color) F(out_normal) F(out_depth) F(out_opac) F(out_feature) F(out_vfeature)
+    F(out_weights) F(out_pseudo_normal) F(out_surface_xyz) F(dL_dmean2D) F(dL_dconic) F(dL_dopacity) F(dL_dcolor)
+    F(dL_dfeature) F(dL_dvfeature) F(dL_dnormal) F(dL_ddepth) F(dL_dmean3D) F(dL_dcov3D) F(dL_dsh) F(dL_dscale)
+    F(dL_drot) F(dL_dviewmat) F(dL_dprojmat) F(dL_dcampos) F(present)
+#undef F
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* orc_create(const orc_params* p) {
+    Handle* h = new Handle();
+    h->fp64 = p->fp64;
+    if (p->fp64) h->d = new Oracle<double>(*p);
+    else h->f = new Oracle<float>(*p);
+    return h;
+}
+void orc_destroy(void* hh) {
+    Handle* h = (Handle*)hh;
+    delete h->f; delete h->d; delete h;
+}
+int orc_forward(void* hh) {
+    Handle* h = (Handle*)hh;
+    if (h->fp64) { h->d->forward(); return h->d->R; }
+    h->f->forward(); return h->f->R;
+}
+void orc_backward(void* hh, const void* gc, const void* gn, const void* gd, const void* go, const void* gf,
+                  const void* gvf) {
+    Handle* h = (Handle*)hh;
+    if (h->fp64) h->d->backward(gc, gn, gd, go, gf, gvf);
+    else h->f->backward(gc, gn, gd, go, gf, gvf);
+}
+void orc_mark_visible(void* hh) {
+    Handle* h = (Handle*)hh;
+    if (h->fp64) h->d->mark_visible(); else h->f->mark_visible();
+}
+int orc_get(void* hh, const char* name, const void** ptr, long long* n, int* dtype) {
+    Handle* h = (Handle*)hh;
+    return h->fp64 ? get_field(h->d, name, ptr, n, dtype) : get_field(h->f, name, ptr, n, dtype);
+}
+void orc_timings(void* hh, double* out5) {
+    Handle* h = (Handle*)hh;
+    if (h->fp64) { out5[0] = h->d->t_pre; out5[1] = h->d->t_bin; out5[2] = h->d->t_render; out5[3] = h->d->t_brender; out5[4] = h->d->t_bpre; }
+    else { out5[0] = h->f->t_pre; out5[1] = h->f->t_bin; out5[2] = h->f->t_render; out5[3] = h->f->t_brender; out5[4] = h->f->t_bpre; }
+}
+int orc_max_threads(void) {
+#if defined(_OPENMP)
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"
