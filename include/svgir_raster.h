@@ -1,0 +1,166 @@
+/* include/svgir_raster.h -- C ABI of libsvgir_raster.so (MI355X / gfx950 surfel rasterizer).
+ *
+ * This is the drop-in boundary for the hot path of learner-shx/SVG-IR: it replaces the two
+ * `CudaRasterizer::Rasterizer` classes that the reference's torch glue binds
+ *     svgss_rasterization/cuda_rasterizer/rasterizer.h:24-115   (forward / backward / markVisible, "svgss")
+ *     rgss-rasterization/cuda_rasterizer/rasterizer.h:24-104    (same, "rgss")
+ * and that `svgss_rasterization/rasterize_points.cu:35-286` / `rgss-rasterization/rasterize_points.cu:36-264`
+ * call with raw device pointers.  No torch, HIP or C++ types appear in the signatures: plain pointers, sizes and
+ * a `void*` stream (a hipStream_t).  All pointers are DEVICE pointers unless stated otherwise.  All arithmetic
+ * is fp32; images are CHW row-major; per-Gaussian tensors are row-major [P,k] exactly as the reference's.
+ *
+ * Errors: every entry point returns a negative svgir_status on failure and sets a thread-local message
+ * retrievable with svgir_last_error() (the reference throws std::runtime_error / AT_ERROR instead,
+ * rasterize_points.cu:65-67, rasterizer_impl.cu:264-267; the host bindings convert the code to RuntimeError).
+ */
+#ifndef SVGIR_RASTER_H_
+#define SVGIR_RASTER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVGIR_ABI_VERSION 1
+
+enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
+
+enum svgir_status {
+    SVGIR_OK = 0,
+    SVGIR_ERR_INVALID = -1,  /* bad shapes / missing inputs / unsupported channel counts */
+    SVGIR_ERR_HIP = -2,      /* a HIP runtime call or kernel launch failed */
+    SVGIR_ERR_ALLOC = -3     /* a blob allocation callback returned NULL */
+};
+
+/* Blob allocator: must return a device pointer to at least `bytes` bytes (256-byte aligned), valid until the
+ * matching backward has run.  Replaces the reference's std::function<char*(size_t)> resize lambdas
+ * (rasterize_points.cu:27-33). */
+typedef char* (*svgir_alloc_fn)(size_t bytes, void* ctx);
+
+/* Inputs of one view.  Field-for-field the arguments of Rasterizer::forward
+ * (svgss rasterizer_impl.cu:209-242, rgss :209-241). */
+typedef struct svgir_params {
+    int32_t variant;            /* svgir_variant */
+    int32_t P;                  /* #Gaussians */
+    int32_t S;                  /* #feature channels (svgss <= 50, rgss <= 33; Q9) */
+    int32_t VS;                 /* #vfeature channels, multiple of 4, VS/4 <= 20 (svgss only) */
+    int32_t D;                  /* active SH degree 0..3 */
+    int32_t M;                  /* SH coefficients per colour channel in `shs` */
+    int32_t W, H;               /* image size */
+    const float* background;    /* [3] */
+    const float* means3D;       /* [P,3] */
+    const float* shs;           /* [P,M,3] or NULL */
+    const float* colors_precomp;/* [P,3] or NULL (exactly one of shs / colors_precomp) */
+    const float* features;      /* [P,S] or NULL when S == 0 */
+    const float* vfeatures;     /* [P,VS] or NULL when VS == 0 */
+    const float* opacities;     /* [P] */
+    const float* scales;        /* [P,3] or NULL */
+    const float* rotations;     /* [P,4] (r,x,y,z), NOT normalised in-kernel (Q3), or NULL */
+    const float* cov3D_precomp; /* [P,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
+    const float* viewmatrix;    /* [16] = W2C transposed (column-major W2C) */
+    const float* projmatrix;    /* [16] = full projection, same convention */
+    const float* cam_pos;       /* [3] */
+    const float* prcppoint;     /* [2]  svgss; carried for API parity, unused by the arithmetic (Q11) */
+    const float* patchbbox;     /* [4]  svgss: h0,w0,h1,w1 in pixels */
+    const float* config;        /* HOST pointer, [config_len] floats; svgss: surface, normalize_depth,
+                                   per_pixel_depth, (lrn_cam).  Entries >= config_len read as 0 (Q7).
+                                   rgss ignores it (compile-time {1,1,1} in the reference). */
+    int32_t config_len;
+    float scale_modifier;
+    float tan_fovx, tan_fovy;
+    float cx, cy;               /* rgss: principal point for surface_xyz */
+    int32_t prefiltered;
+    int32_t computer_pseudo_normal; /* rgss */
+    int32_t backward_geometry;      /* rgss */
+    int32_t debug;                  /* synchronise + check after every kernel (reference CHECK_CUDA) */
+} svgir_params;
+
+/* Outputs of forward.  Every buffer is written completely (no need to pre-zero) except where noted. */
+typedef struct svgir_outputs {
+    float* out_color;         /* [3,H,W] */
+    float* out_normal;        /* [3,H,W] */
+    float* out_depth;         /* [1,H,W] */
+    float* out_opacity;       /* [1,H,W] */
+    float* out_feature;       /* [S,H,W] */
+    float* out_vfeature;      /* [VS/4,H,W]  svgss */
+    float* out_pseudo_normal; /* [3,H,W]     rgss; must be zero-filled by the caller (pixels with a
+                                 degenerate stencil are left untouched, forward.cu:620-622) */
+    float* out_surface_xyz;   /* [3,H,W]     rgss */
+    float* out_weights;       /* [P]   must be zero-filled by the caller (accumulated atomically) */
+    int32_t* radii;           /* [P] */
+} svgir_outputs;
+
+/* Upstream gradients and gradient outputs of backward (Rasterizer::backward, svgss rasterizer_impl.cu:386-432,
+ * rgss :411-449).  All dL_d* outputs must be zero-filled by the caller (as the reference's glue does,
+ * rasterize_points.cu:195-211). */
+typedef struct svgir_grads {
+    const float* dL_dout_color;    /* [3,H,W] */
+    const float* dL_dout_normal;   /* [3,H,W] */
+    const float* dL_dout_depth;    /* [1,H,W] */
+    const float* dL_dout_opacity;  /* [1,H,W] */
+    const float* dL_dout_feature;  /* [S,H,W] */
+    const float* dL_dout_vfeature; /* [VS/4,H,W] svgss */
+    float* dL_dmeans2D;   /* [P,3] (x,y used) */
+    float* dL_dconic;     /* [P,4] (x,y,w used) */
+    float* dL_dopacity;   /* [P] */
+    float* dL_dcolors;    /* [P,3] */
+    float* dL_dfeatures;  /* [P,S] */
+    float* dL_dvfeatures; /* [P,VS] svgss */
+    float* dL_dnormal;    /* [P,3] */
+    float* dL_ddepth;     /* [P] */
+    float* dL_dmeans3D;   /* [P,3] */
+    float* dL_dcov3D;     /* [P,6] */
+    float* dL_dsh;        /* [P,M,3] */
+    float* dL_dscales;    /* [P,3] */
+    float* dL_drotations; /* [P,4] */
+    float* dL_dviewmat;   /* [16] svgss (only written when config[3] > 0) */
+    float* dL_dprojmat;   /* [16] svgss */
+    float* dL_dcampos;    /* [3]  svgss */
+} svgir_grads;
+
+int svgir_abi_version(void);
+
+/* Sizes of the three opaque scratch blobs (the reference's required<GeometryState/ImageState/BinningState>,
+ * rasterizer_impl.h:73-84). */
+size_t svgir_geom_bytes(int32_t P);
+size_t svgir_image_bytes(int32_t W, int32_t H);
+size_t svgir_binning_bytes(int32_t num_rendered);
+/* Byte offset of the int32 n_contrib[H*W] plane inside the image blob (rgss returns a view of it, Q10). */
+size_t svgir_image_ncontrib_offset(int32_t W, int32_t H);
+
+/* Forward pass.  Replaces CudaRasterizer::Rasterizer::forward (svgss rasterizer_impl.cu:209-382,
+ * rgss :209-407).  Calls geom(), image() and -- after one 4-byte device->host read of the instance count --
+ * binning().  Returns num_rendered (R >= 0) or a negative svgir_status. */
+int svgir_forward(const svgir_params* p, const svgir_outputs* o,
+                  svgir_alloc_fn geom, void* geom_ctx,
+                  svgir_alloc_fn binning, void* binning_ctx,
+                  svgir_alloc_fn image, void* image_ctx,
+                  void* stream);
+
+/* Backward pass.  Replaces CudaRasterizer::Rasterizer::backward (svgss rasterizer_impl.cu:386-523,
+ * rgss :411-535).  `R` and the three blobs are what the matching svgir_forward produced; `radii` is its
+ * radii output. */
+int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii,
+                   char* geom_blob, char* binning_blob, char* image_blob, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:141-153).  `present` is a byte per
+ * Gaussian.  svgss: the reference kernel body is commented out, so `present` is left untouched (all false, Q14);
+ * rgss: present = view-space z > 0.2. */
+int svgir_mark_visible(int32_t variant, int32_t P, const float* means3D, const float* viewmatrix,
+                       const float* projmatrix, uint8_t* present, void* stream);
+
+/* Per-kernel timing of the most recent forward/backward on this thread (milliseconds, HIP events on the given
+ * stream).  Enabled with svgir_set_profiling(1); costs one stream synchronisation per call when enabled.
+ * names: "preprocess","sort_depth","scan","emit","sort_tile","ranges","render","image",
+ *        "render_bwd","geom_bwd". Returns the number of entries written (<= cap). */
+void svgir_set_profiling(int enabled);
+int svgir_last_timings(const char** names, float* ms, int cap);
+
+const char* svgir_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVGIR_RASTER_H_ */

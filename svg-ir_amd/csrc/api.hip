@@ -1,0 +1,324 @@
+// svg-ir_amd/csrc/api.hip -- C ABI (include/svgir_raster.h) and host-side orchestration of the kernels.
+//
+// Host counterpart of CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (svgss rasterizer_impl.cu:141-153, 209-382, 386-523; rgss :141-153, 209-407, 411-535).
+// Every kernel is launched on the caller's stream (the reference uses the legacy default stream); the only
+// host synchronisation is the 4-byte read of the instance count R that sizes the binning blob -- the same one
+// the reference has at rasterizer_impl.cu:311 -- plus, when svgir_set_profiling(1), one sync per call to read
+// the HIP event timings.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace svgir;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local bool g_prof = false;
+thread_local std::vector<std::pair<const char*, float>> g_times;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(SVGIR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Stage timer: HIP events on the launch stream, resolved after the call's final synchronisation.
+struct StageTimer {
+    hipStream_t s;
+    bool on;
+    std::vector<hipEvent_t> ev;
+    std::vector<const char*> names;
+    StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
+        if (on) mark(nullptr);
+    }
+    void mark(const char* name) {
+        if (!on) return;
+        hipEvent_t e;
+        hipEventCreate(&e);
+        hipEventRecord(e, s);
+        ev.push_back(e);
+        names.push_back(name);
+    }
+    void resolve(bool append) {
+        if (!on) return;
+        hipStreamSynchronize(s);
+        if (!append) g_times.clear();
+        for (size_t i = 1; i < ev.size(); i++) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            g_times.push_back({names[i], ms});
+        }
+        for (auto e : ev) hipEventDestroy(e);
+        ev.clear();
+    }
+};
+
+struct Flags {
+    bool svgss, surface, normalize_depth, pix_depth, lrn_cam;
+};
+Flags read_flags(const svgir_params* p) {
+    Flags f;
+    f.svgss = p->variant == SVGIR_SVGSS;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f.svgss) {
+        for (int i = 0; i < 4 && i < p->config_len; i++) c[i] = p->config ? p->config[i] : 0.f;  // Q7
+    } else {
+        c[0] = c[1] = c[2] = 1.f;  // rgss auxiliary.h:41-46
+    }
+    f.surface = c[0] > 0;
+    f.normalize_depth = c[1] > 0;
+    f.pix_depth = c[2] > 0;
+    f.lrn_cam = f.svgss && c[3] > 0;
+    return f;
+}
+
+int validate(const svgir_params* p, bool fwd) {
+    if (!p) return fail(SVGIR_ERR_INVALID, "params is NULL");
+    if (p->variant != SVGIR_RGSS && p->variant != SVGIR_SVGSS) return fail(SVGIR_ERR_INVALID, "unknown variant %d", p->variant);
+    if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(SVGIR_ERR_INVALID, "bad sizes P=%d W=%d H=%d", p->P, p->W, p->H);
+    if (p->P == 0) return 0;
+    if (!p->means3D || !p->viewmatrix || !p->projmatrix || !p->background)
+        return fail(SVGIR_ERR_INVALID, "means3D/viewmatrix/projmatrix/background must be provided");
+    if (fwd && !p->opacities) return fail(SVGIR_ERR_INVALID, "opacities must be provided");
+    if (!p->colors_precomp && !p->shs)
+        return fail(SVGIR_ERR_INVALID, "For non-RGB, provide precomputed Gaussian colors!");  // rasterizer_impl.cu:264-267
+    if (p->shs && (p->D < 0 || p->D > 3 || p->M < (p->D + 1) * (p->D + 1)))
+        return fail(SVGIR_ERR_INVALID, "SH degree %d needs M >= %d coefficients (M=%d)", p->D, (p->D + 1) * (p->D + 1), p->M);
+    if (p->shs && !p->cam_pos) return fail(SVGIR_ERR_INVALID, "cam_pos is required with SHs");
+    if (!p->cov3D_precomp && !(p->scales && p->rotations))
+        return fail(SVGIR_ERR_INVALID, "provide scales+rotations or cov3D_precomp");
+    if (p->S < 0 || (p->S > 0 && !p->features)) return fail(SVGIR_ERR_INVALID, "features missing for S=%d", p->S);
+    if (p->variant == SVGIR_SVGSS) {
+        if (p->VS < 0 || p->VS % 4 != 0) return fail(SVGIR_ERR_INVALID, "VS=%d must be a non-negative multiple of 4", p->VS);
+        if (p->VS > 0 && !p->vfeatures) return fail(SVGIR_ERR_INVALID, "vfeatures missing for VS=%d", p->VS);
+        if (!p->patchbbox) return fail(SVGIR_ERR_INVALID, "patchbbox is required for svgss");
+        if (p->S > 50 || p->VS / 4 > 20) return fail(SVGIR_ERR_INVALID, "svgss supports S<=50, VS/4<=20 (Q9)");
+    } else {
+        if (p->VS != 0) return fail(SVGIR_ERR_INVALID, "rgss has no vfeatures");
+        if (p->S > 33) return fail(SVGIR_ERR_INVALID, "rgss supports S<=33 (Q9)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svgir_abi_version(void) { return SVGIR_ABI_VERSION; }
+size_t svgir_geom_bytes(int32_t P) { return geom_layout(nullptr, P).bytes; }
+size_t svgir_image_bytes(int32_t W, int32_t H) { return image_layout(nullptr, W, H).bytes; }
+size_t svgir_binning_bytes(int32_t R) { return bin_layout(nullptr, R).bytes; }
+size_t svgir_image_ncontrib_offset(int32_t W, int32_t H) { return image_layout(nullptr, W, H).ncontrib_off; }
+const char* svgir_last_error(void) { return g_err.c_str(); }
+void svgir_set_profiling(int enabled) { g_prof = enabled != 0; }
+int svgir_last_timings(const char** names, float* ms, int cap) {
+    int n = 0;
+    for (auto& kv : g_times) {
+        if (n >= cap) break;
+        names[n] = kv.first;
+        ms[n] = kv.second;
+        n++;
+    }
+    return n;
+}
+
+int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
+                  svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream) {
+    if (int rc = validate(p, true)) return rc;
+    if (!o || !geom || !binning || !image) return fail(SVGIR_ERR_INVALID, "outputs / allocators must be provided");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = p->P, W = p->W, H = p->H;
+    const size_t N = (size_t)W * H;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
+    const Flags f = read_flags(p);
+    if (P == 0) {  // rasterize_points.cu:100: nothing runs, outputs stay zero
+        HIP_OK(hipMemsetAsync(o->out_color, 0, 3 * N * 4, s));
+        HIP_OK(hipMemsetAsync(o->out_normal, 0, 3 * N * 4, s));
+        HIP_OK(hipMemsetAsync(o->out_depth, 0, N * 4, s));
+        HIP_OK(hipMemsetAsync(o->out_opacity, 0, N * 4, s));
+        if (p->S) HIP_OK(hipMemsetAsync(o->out_feature, 0, (size_t)p->S * N * 4, s));
+        if (f.svgss && p->VS) HIP_OK(hipMemsetAsync(o->out_vfeature, 0, (size_t)(p->VS / 4) * N * 4, s));
+        return 0;
+    }
+    const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
+
+    char* gblob = geom(geom_layout(nullptr, P).bytes, geom_ctx);
+    char* iblob = image(image_layout(nullptr, W, H).bytes, image_ctx);
+    if (!gblob || !iblob) return fail(SVGIR_ERR_ALLOC, "geometry/image blob allocation failed");
+    const GeomLayout G = geom_layout(gblob, P);
+    const ImageLayout I = image_layout(iblob, W, H);
+
+    StageTimer tm(s, g_prof);
+    auto check = [&](const char* what) -> int {
+        if (!p->debug) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+            return 0;
+        }
+        hipError_t e = hipStreamSynchronize(s);  // reference CHECK_CUDA(debug), auxiliary.h:425-432
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        return 0;
+    };
+
+    PreArgs pa;
+    pa.P = P; pa.D = p->D; pa.M = p->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
+    pa.means3D = p->means3D; pa.shs = p->colors_precomp ? nullptr : p->shs; pa.colors_precomp = p->colors_precomp;
+    pa.opacities = p->opacities; pa.scales = p->scales; pa.rotations = p->rotations; pa.cov3D_precomp = p->cov3D_precomp;
+    pa.view = p->viewmatrix; pa.proj = p->projmatrix; pa.campos = p->cam_pos; pa.patchbbox = p->patchbbox;
+    pa.scale_modifier = p->scale_modifier; pa.tanx = p->tan_fovx; pa.tany = p->tan_fovy;
+    pa.focal_x = focal_x; pa.focal_y = focal_y; pa.surface = f.surface; pa.pix_depth = f.pix_depth;
+    pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
+    pa.radii = o->radii;
+    launch_preprocess(pa, f.svgss, s);
+    if (int rc = check("preprocess")) return rc;
+    tm.mark("preprocess");
+
+    // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in slot 0
+    for (int pass = 0; pass < 4; pass++)
+        launch_radix_pass(G.key[pass & 1], G.idx[pass & 1], G.key[(pass + 1) & 1], G.idx[(pass + 1) & 1], P, 8 * pass, 8,
+                          G.radix_tbl, s);
+    if (int rc = check("depth sort")) return rc;
+    tm.mark("sort_depth");
+
+    launch_offsets_scan(G.tiles, G.idx[0], G.offsets, G.scan_tmp, P, G.counters, s);
+    if (int rc = check("offsets scan")) return rc;
+    uint32_t R_host = 0;
+    HIP_OK(hipMemcpyAsync(&R_host, G.counters, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    tm.mark("scan");
+    if (R_host > 0x7fffffffu) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
+    const int R = (int)R_host;
+
+    char* bblob = binning(bin_layout(nullptr, R).bytes, binning_ctx);
+    if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
+    const BinLayout B = bin_layout(bblob, R);
+    const TileSortPlan plan = tile_sort_plan(T);
+
+    if (R > 0) {
+        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], s);
+        if (int rc = check("emit")) return rc;
+    }
+    tm.mark("emit");
+    for (int pass = 0; pass < plan.passes; pass++) {
+        const int lo = pass * plan.bits_per_pass;
+        const int nb = std::min(plan.bits_per_pass, plan.bits - lo);
+        launch_radix_pass(B.key[pass & 1], B.val[pass & 1], B.key[(pass + 1) & 1], B.val[(pass + 1) & 1], R, lo, nb,
+                          B.radix_tbl, s);
+    }
+    if (int rc = check("tile sort")) return rc;
+    tm.mark("sort_tile");
+    const int fin = plan.passes & 1;
+    launch_ranges(R, B.key[fin], I.ranges, T, s);
+    if (int rc = check("ranges")) return rc;
+    tm.mark("ranges");
+
+    RenderArgs ra;
+    ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = f.svgss ? p->VS : 0;
+    ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
+    ra.bg = p->background;
+    ra.surface = f.surface; ra.normalize_depth = f.normalize_depth; ra.pix_depth = f.pix_depth;
+    ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
+    ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
+    ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
+    if (launch_render_fwd(ra, f.svgss, s) < 0)
+        return fail(SVGIR_ERR_INVALID, "no forward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ra.VS,
+                    f.svgss ? "svgss" : "rgss");
+    if (int rc = check("render")) return rc;
+    tm.mark("render");
+
+    if (!f.svgss && p->computer_pseudo_normal) {
+        launch_image_ops(W, H, p->viewmatrix, focal_x, focal_y, p->cx, p->cy, o->out_opacity, o->out_depth,
+                         o->out_pseudo_normal, o->out_surface_xyz, s);
+        if (int rc = check("image ops")) return rc;
+        tm.mark("image");
+    }
+    tm.resolve(false);
+    return R;
+}
+
+int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii, char* geom_blob,
+                   char* binning_blob, char* image_blob, void* stream) {
+    if (int rc = validate(p, false)) return rc;
+    if (p->P == 0) return 0;
+    if (!g || !radii || !geom_blob || !binning_blob || !image_blob)
+        return fail(SVGIR_ERR_INVALID, "grads / radii / blobs must be provided");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = p->P, W = p->W, H = p->H;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
+    const Flags f = read_flags(p);
+    const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
+    const GeomLayout G = geom_layout(geom_blob, P);
+    const ImageLayout I = image_layout(image_blob, W, H);
+    const BinLayout B = bin_layout(binning_blob, R);
+    const int fin = tile_sort_plan(T).passes & 1;
+    StageTimer tm(s, g_prof);
+
+    RenderBwdArgs ba;
+    ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = f.svgss ? p->VS : 0;
+    ba.ranges = I.ranges; ba.point_list = B.val[fin]; ba.rec = G.rec; ba.features = p->features; ba.vfeatures = p->vfeatures;
+    ba.bg = p->background;
+    ba.surface = f.surface; ba.normalize_depth = f.normalize_depth; ba.pix_depth = f.pix_depth;
+    ba.backward_geometry = p->backward_geometry;
+    ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;
+    ba.g_color = g->dL_dout_color; ba.g_normal = g->dL_dout_normal; ba.g_depth = g->dL_dout_depth;
+    ba.g_opacity = g->dL_dout_opacity; ba.g_feature = g->dL_dout_feature; ba.g_vfeature = g->dL_dout_vfeature;
+    ba.dL_dmean2D = g->dL_dmeans2D; ba.dL_dconic = g->dL_dconic; ba.dL_dopacity = g->dL_dopacity; ba.dL_dcolor = g->dL_dcolors;
+    ba.dL_dfeature = g->dL_dfeatures; ba.dL_dvfeature = g->dL_dvfeatures; ba.dL_dnormal = g->dL_dnormal; ba.dL_ddepth = g->dL_ddepth;
+    if (R > 0) {
+        if (launch_render_bwd(ba, f.svgss, s) < 0)
+            return fail(SVGIR_ERR_INVALID, "no backward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ba.VS,
+                        f.svgss ? "svgss" : "rgss");
+    }
+    tm.mark("render_bwd");
+
+    GeomBwdArgs ga;
+    ga.P = P; ga.D = p->D; ga.M = p->M;
+    ga.means3D = p->means3D; ga.shs = p->colors_precomp ? nullptr : p->shs; ga.scales = p->scales; ga.rotations = p->rotations;
+    ga.cov3D = p->cov3D_precomp ? p->cov3D_precomp : G.cov3D; ga.view = p->viewmatrix; ga.proj = p->projmatrix; ga.campos = p->cam_pos;
+    ga.radii = radii; ga.clamped = G.clamped;
+    ga.scale_modifier = p->scale_modifier; ga.tanx = p->tan_fovx; ga.tany = p->tan_fovy; ga.focal_x = focal_x; ga.focal_y = focal_y;
+    ga.surface = f.surface; ga.lrn_cam = f.lrn_cam; ga.svgss = f.svgss;
+    ga.dL_dmean2D = g->dL_dmeans2D; ga.dL_dconic = g->dL_dconic; ga.dL_dcolor = g->dL_dcolors; ga.dL_dnormal = g->dL_dnormal;
+    ga.dL_ddepth = g->dL_ddepth;
+    ga.dL_dmean3D = g->dL_dmeans3D; ga.dL_dcov3D = g->dL_dcov3D; ga.dL_dsh = g->dL_dsh; ga.dL_dscale = g->dL_dscales;
+    ga.dL_drot = g->dL_drotations; ga.dL_dviewmat = g->dL_dviewmat; ga.dL_dprojmat = g->dL_dprojmat; ga.dL_dcampos = g->dL_dcampos;
+    if (ga.scales && !ga.rotations) return fail(SVGIR_ERR_INVALID, "rotations missing");
+    launch_geom_bwd(ga, s);
+    tm.mark("geom_bwd");
+    hipError_t e = p->debug ? hipStreamSynchronize(s) : hipSuccess;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "backward failed: %s", hipGetErrorString(e));
+    tm.resolve(false);
+    return 0;
+}
+
+int svgir_mark_visible(int32_t variant, int32_t P, const float* means3D, const float* viewmatrix,
+                       const float* projmatrix, uint8_t* present, void* stream) {
+    (void)projmatrix;
+    if (P < 0) return fail(SVGIR_ERR_INVALID, "P < 0");
+    if (P == 0 || variant == SVGIR_SVGSS) return 0;  // svgss: kernel body is a no-op in the reference (Q14)
+    if (!means3D || !viewmatrix || !present) return fail(SVGIR_ERR_INVALID, "NULL pointer");
+    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "mark_visible failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// svg-ir_amd/csrc/common.hpp -- shared declarations of the gfx950 surfel rasterizer (product code).
+//
+// HBM layout (all blobs are opaque to the callers; only the sizes are part of the C ABI):
+//   geometry blob  : per-Gaussian "splat record" (24 floats = 96 B, one gather unit for the composite kernels),
+//                    cov3D, SH clamp mask, tiles_touched, depth-sort ping/pong (key, id), instance offsets,
+//                    scan / radix scratch, device instance counter.
+//   image blob     : final_T, final_D, n_contrib (int32) planes + per-tile ranges (uint2).
+//   binning blob   : tile-key and Gaussian-id ping/pong buffers of R entries + radix scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/svgir_raster.h"
+
+namespace svgir {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = 256;
+constexpr int REC = 24;  // floats per splat record
+
+// Record field offsets (floats).  First 6 floats = the "header" the composite kernels stage in LDS.
+enum RecField {
+    R_X = 0, R_Y = 1, R_CX = 2, R_CY = 3,      // float4 #0: mean2D, conic.x, conic.y
+    R_CZ = 4, R_OP = 5, R_DEPTH = 6, R_J6 = 7, // float4 #1: conic.z, opacity, view depth, ax0.z
+    R_J0 = 8, R_J1 = 9, R_J2 = 10, R_J3 = 11,  // float4 #2: screen->tangent 2x2
+    R_J9 = 12, R_R = 13, R_G = 14, R_B = 15,   // float4 #3: ax1.z, rgb
+    R_NX = 16, R_NY = 17, R_NZ = 18, R_IU = 19,// float4 #4: view normal, 1/(0.5*scale.x+0.1)
+    R_IV = 20, R_PAD0 = 21, R_PAD1 = 22, R_PAD2 = 23  // float4 #5: 1/(0.5*scale.y+0.1)
+};
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- radix sort geometry -----------------------------------------------------------------------------------
+constexpr int SORT_ITEMS = 16;                      // elements per thread per block
+constexpr int SORT_BLOCK_ELEMS = BLOCK * SORT_ITEMS;  // 4096
+inline int sort_blocks(int n) { return n <= 0 ? 1 : (n + SORT_BLOCK_ELEMS - 1) / SORT_BLOCK_ELEMS; }
+constexpr int SCAN_BLOCK_ELEMS = 2048;
+inline int scan_blocks(int n) { return n <= 0 ? 1 : (n + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS; }
+
+struct GeomLayout {
+    float* rec;            // [P*24]
+    float* cov3D;          // [P*6]
+    uint32_t* clamped;     // [P] bit c set => SH colour channel c was clamped
+    uint32_t* tiles;       // [P] tiles touched (0 => culled)
+    uint32_t* key[2];      // [P] depth keys ping/pong
+    uint32_t* idx[2];      // [P] Gaussian ids ping/pong (idx[final] = depth-sorted order)
+    uint32_t* offsets;     // [P] exclusive scan of tiles in depth-sorted order
+    uint32_t* scan_tmp;    // [scan_blocks(P)+1]
+    uint32_t* radix_tbl;   // [256 * sort_blocks(P)]
+    uint32_t* counters;    // [4]: [0] = R
+    size_t bytes;
+};
+inline GeomLayout geom_layout(char* base, int P) {
+    GeomLayout g;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    const size_t p = (size_t)(P > 0 ? P : 1);
+    g.rec = (float*)take(p * REC * 4);
+    g.cov3D = (float*)take(p * 6 * 4);
+    g.clamped = (uint32_t*)take(p * 4);
+    g.tiles = (uint32_t*)take(p * 4);
+    g.key[0] = (uint32_t*)take(p * 4);
+    g.key[1] = (uint32_t*)take(p * 4);
+    g.idx[0] = (uint32_t*)take(p * 4);
+    g.idx[1] = (uint32_t*)take(p * 4);
+    g.offsets = (uint32_t*)take(p * 4);
+    g.scan_tmp = (uint32_t*)take(((size_t)scan_blocks(P) + 1) * 4);
+    g.radix_tbl = (uint32_t*)take((size_t)256 * sort_blocks(P) * 4);
+    g.counters = (uint32_t*)take(16);
+    g.bytes = off;
+    return g;
+}
+
+struct ImageLayout {
+    float* final_T;      // [N]
+    float* final_D;      // [N]
+    int32_t* n_contrib;  // [N]
+    uint32_t* ranges;    // [2*T]
+    size_t ncontrib_off;
+    size_t bytes;
+};
+inline ImageLayout image_layout(char* base, int W, int H) {
+    ImageLayout im;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    const size_t N = (size_t)W * H;
+    const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    im.final_T = (float*)take(N * 4);
+    im.final_D = (float*)take(N * 4);
+    im.ncontrib_off = off;
+    im.n_contrib = (int32_t*)take(N * 4);
+    im.ranges = (uint32_t*)take(T * 8);
+    im.bytes = off;
+    return im;
+}
+
+struct BinLayout {
+    uint32_t* key[2];  // [R] tile ids ping/pong
+    uint32_t* val[2];  // [R] Gaussian ids ping/pong
+    uint32_t* radix_tbl;
+    size_t bytes;
+};
+inline BinLayout bin_layout(char* base, int R) {
+    BinLayout b;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    const size_t r = (size_t)(R > 0 ? R : 1);
+    b.key[0] = (uint32_t*)take(r * 4);
+    b.key[1] = (uint32_t*)take(r * 4);
+    b.val[0] = (uint32_t*)take(r * 4);
+    b.val[1] = (uint32_t*)take(r * 4);
+    b.radix_tbl = (uint32_t*)take((size_t)256 * sort_blocks(R) * 4);
+    b.bytes = off;
+    return b;
+}
+
+// Tile-sort plan: #bits of the tile id split into equal passes of <= 8 bits (both fwd and bwd derive the final
+// ping/pong slot from it).
+struct TileSortPlan { int bits, passes, bits_per_pass; };
+inline TileSortPlan tile_sort_plan(int T) {
+    int bits = 1;
+    while ((1 << bits) < T) bits++;
+    TileSortPlan p;
+    p.bits = bits;
+    p.passes = (bits + 7) / 8;
+    p.bits_per_pass = (bits + p.passes - 1) / p.passes;
+    return p;
+}
+
+// ---- kernel argument blocks --------------------------------------------------------------------------------
+struct PreArgs {
+    int P, D, M, W, H, gx, gy;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *view, *proj, *campos, *patchbbox;
+    float scale_modifier, tanx, tany, focal_x, focal_y;
+    int surface, pix_depth;
+    float* rec; float* cov3D; uint32_t* clamped; uint32_t* tiles; uint32_t* key; uint32_t* idx; int32_t* radii;
+};
+
+struct RenderArgs {
+    int W, H, gx, gy, S, VS;
+    const uint32_t* ranges; const uint32_t* point_list;
+    const float* rec; const float* features; const float* vfeatures;
+    const float* bg;
+    int surface, normalize_depth, pix_depth;
+    float *final_T, *final_D; int32_t* n_contrib;
+    float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
+};
+
+struct RenderBwdArgs {
+    int W, H, gx, gy, S, VS;
+    const uint32_t* ranges; const uint32_t* point_list;
+    const float* rec; const float* features; const float* vfeatures;
+    const float* bg;
+    int surface, normalize_depth, pix_depth, backward_geometry;
+    const float *final_T, *final_D; const int32_t* n_contrib;
+    const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
+};
+
+struct GeomBwdArgs {
+    int P, D, M;
+    const float *means3D, *shs, *scales, *rotations, *cov3D, *view, *proj, *campos;
+    const int32_t* radii; const uint32_t* clamped;
+    float scale_modifier, tanx, tany, focal_x, focal_y;
+    int surface, lrn_cam, svgss;
+    const float *dL_dmean2D, *dL_dconic, *dL_dcolor, *dL_dnormal, *dL_ddepth;
+    float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot, *dL_dviewmat, *dL_dprojmat, *dL_dcampos;
+};
+
+// ---- host-side launchers (one per .hip file) ---------------------------------------------------------------
+void launch_preprocess(const PreArgs& a, bool svgss, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+// stable LSD radix sort of (u32 key, u32 value) pairs on bits [bit_lo, bit_lo + nbits); in -> out
+void launch_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int bit_lo,
+                       int nbits, uint32_t* table, hipStream_t s);
+// offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
+void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
+                         uint32_t* total_out, hipStream_t s);
+void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
+                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, hipStream_t s);
+void launch_ranges(int R, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
+int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 if (S,VS) unsupported
+int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 if (S,VS) unsupported
+void launch_geom_bwd(const GeomBwdArgs& a, hipStream_t s);
+void launch_image_ops(int W, int H, const float* view, float focal_x, float focal_y, float cx, float cy,
+                      const float* opacity, const float* depth, float* pseudo_normal, float* surface_xyz,
+                      hipStream_t s);
+
+#if defined(__HIPCC__)
+// ---- device helpers ----------------------------------------------------------------------------------------
+// Wave64 sum with DPP row shifts + row broadcasts (gfx9 family); the total lands in lane 63.  All 64 lanes must
+// be active.
+__device__ __forceinline__ float wave_scan_last(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {  // uniform result
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_last(v)), 63));
+}
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+#endif
+
+}  // namespace svgir

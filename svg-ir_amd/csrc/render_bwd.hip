@@ -1,0 +1,272 @@
+// svg-ir_amd/csrc/render_bwd.hip -- backward per-tile alpha compositing.
+//
+// Replaces the backward renderCUDA (svgss backward.cu:529-934, rgss backward.cu:431-757): back-to-front replay
+// of each tile's splat list (T <- T / (1 - alpha) starting from final_T), gradients of every blended quantity
+// w.r.t. the per-Gaussian colour / feature / vfeature (x corner weight) / normal (x10, Q4) / depth, and through
+// alpha to conic, mean2D (incl. the un-weighted depth-differencing term, Q5) and opacity.
+//
+// CDNA4 mapping
+//   * same tile/wave/pixel mapping and LDS header staging as render_fwd.hip, walked in reverse; the replay starts
+//     at the tile's deepest contributor (block max of n_contrib) instead of the end of the list;
+//   * per-pixel replay state (running accumulators, last values, upstream gradients) lives in VGPRs thanks to
+//     compile-time channel counts (the reference keeps ~330 floats per thread in scratch, backward.cu:617-635);
+//   * the reference issues 13 + S + VS global float atomics per (pixel, splat) pair (18 / 69 / 84).  Here each
+//     wave reduces every channel over its 64 pixels with DPP row shifts/broadcasts, parks channel c's total in
+//     lane c, and issues ONE global atomic instruction per 64 channels whose lanes hit consecutive addresses of
+//     the Gaussian's gradient rows: <= 2 atomic instructions per (wave, splat) instead of up to 64 x 84;
+//   * splats that no pixel of the wave blends are skipped after the 6-float header test (wave ballot).
+#include "common.hpp"
+
+namespace svgir {
+
+namespace {
+
+template <int S, int VC, bool SVGSS>
+__global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a) {
+    constexpr int VS = VC * 4;
+    constexpr int NCH = 13 + S + VS;
+    constexpr int NV = (NCH + 63) / 64;
+    constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
+
+    __shared__ float4 sA[BLOCK];
+    __shared__ float2 sB[BLOCK];
+    __shared__ int sId[BLOCK];
+    __shared__ uint32_t sMax[4];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+    if (r1 <= r0) return;  // uniform: empty tile
+    const float* __restrict__ rec = a.rec;
+    const float* __restrict__ feat = a.features;
+    const float* __restrict__ vfeat = a.vfeatures;
+    const bool sp = a.surface && a.pix_depth;
+    const bool bgeom = SVGSS ? true : (a.backward_geometry != 0);
+    const size_t N_ = (size_t)a.W * a.H;
+    const size_t pid = inside ? (size_t)a.W * py + px : 0;
+
+    const float T_final = inside ? a.final_T[pid] : 0.f;
+    const float D_final = (inside && a.normalize_depth) ? a.final_D[pid] : 0.f;
+    const uint32_t last_contributor = inside ? (uint32_t)a.n_contrib[pid] : 0u;
+    float gC[3], gN[3], gF[SS], gVF[VV], gD = 0.f, gO = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { gC[i] = inside ? a.g_color[i * N_ + pid] : 0.f; gN[i] = inside ? a.g_normal[i * N_ + pid] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < SS; i++) gF[i] = (inside && i < S) ? a.g_feature[i * N_ + pid] : 0.f;
+#pragma unroll
+    for (int i = 0; i < VV; i++) gVF[i] = (inside && i < VC) ? a.g_vfeature[i * N_ + pid] : 0.f;
+    if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
+    const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
+    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+
+    // deepest contributor of the wave / of the tile
+    uint32_t wmax = last_contributor;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
+    if (lane == 0) sMax[wave] = wmax;
+    __syncthreads();
+    const uint32_t bmax = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+
+    // per-lane destination of channel (lane + 64 k): base pointer and per-Gaussian stride
+    float* dbase[NV];
+    int dstride[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int ci = lane + 64 * k;
+        float* b = nullptr; int st = 0;
+        if (ci < 2) { b = a.dL_dmean2D + ci; st = 3; }
+        else if (ci < 5) { b = a.dL_dconic + (ci == 4 ? 3 : ci - 2); st = 4; }
+        else if (ci < 6) { b = a.dL_dopacity; st = 1; }
+        else if (ci < 9) { b = a.dL_dcolor + (ci - 6); st = 3; }
+        else if (ci < 12) { b = a.dL_dnormal + (ci - 9); st = 3; }
+        else if (ci < 13) { b = a.dL_ddepth; st = 1; }
+        else if (ci < 13 + S) { b = a.dL_dfeature + (ci - 13); st = S; }
+        else if (ci < NCH) { b = a.dL_dvfeature + (ci - 13 - S); st = VS; }
+        dbase[k] = b; dstride[k] = st;
+    }
+
+    float T = T_final;
+    float last_alpha = 0.f;
+    float acc_c[3] = {0.f, 0.f, 0.f}, last_c[3] = {0.f, 0.f, 0.f};
+    float acc_n[3] = {0.f, 0.f, 0.f}, last_n[3] = {0.f, 0.f, 0.f};
+    float acc_d = 0.f, last_d = 0.f;
+    float acc_f[SS], last_f[SS], acc_vf[VV], last_vf[VV];
+#pragma unroll
+    for (int i = 0; i < SS; i++) { acc_f[i] = 0.f; last_f[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < VV; i++) { acc_vf[i] = 0.f; last_vf[i] = 0.f; }
+
+    for (int top = (int)bmax; top > 0; top -= BLOCK) {  // this batch covers slots [top - n, top)
+        const int n = min((int)BLOCK, top);
+        __syncthreads();
+        if (t < n) {
+            const int id = (int)a.point_list[r0 + (uint32_t)(top - 1 - t)];
+            const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+            const float4 h0 = r[0];
+            const float4 h1 = r[1];
+            sA[t] = h0;
+            sB[t] = make_float2(h1.x, h1.y);
+            sId[t] = id;
+        }
+        __syncthreads();
+        for (int j = 0; j < n; j++) {
+            const uint32_t slot = (uint32_t)(top - 1 - j);
+            if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
+            const float4 A = sA[j];
+            const float2 B = sB[j];
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            float power;
+            if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
+            else power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, B.y * G);
+            const bool pass = slot < last_contributor && power <= 0.0f && alpha >= (1.0f / 255.0f);
+            if (__ballot(pass) == 0ull) continue;
+
+            const int gid = __builtin_amdgcn_readfirstlane(sId[j]);
+            const float* __restrict__ r = rec + (size_t)gid * REC;
+            float cb[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; i++) cb[i] = 0.f;
+
+            if (pass) {
+                const float oma = 1.f - alpha;
+                T = T / oma;
+                const float dch = alpha * T;
+                const float inv_keep = 1.f - last_alpha;
+                float dL_dalpha = 0.f;
+                float J0 = 0.f, J1 = 0.f, J2 = 0.f, J3 = 0.f, J6 = 0.f, J9 = 0.f;
+                float du = 0.f, dv = 0.f;
+                float cw[4] = {0.f, 0.f, 0.f, 0.f};
+                if (sp) {
+                    J0 = r[R_J0]; J1 = r[R_J1]; J2 = r[R_J2]; J3 = r[R_J3]; J6 = r[R_J6]; J9 = r[R_J9];
+                    du = dx * J0 + dy * J1; dv = dx * J2 + dy * J3;
+                    if (SVGSS && VC > 0) {
+                        float u = du * r[R_IU] * 0.5f + 0.5f, v = dv * r[R_IV] * 0.5f + 0.5f;
+                        u = fminf(0.999f, fmaxf(0.001f, u));
+                        v = fminf(0.999f, fmaxf(0.001f, v));
+                        cw[0] = (1.f - u) * (1.f - v); cw[1] = u * (1.f - v); cw[2] = (1.f - u) * v; cw[3] = u * v;
+                    }
+                }
+                // colour
+                const float col[3] = {r[R_R], r[R_G], r[R_B]};
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    acc_c[ch] = last_alpha * last_c[ch] + inv_keep * acc_c[ch];
+                    last_c[ch] = col[ch];
+                    dL_dalpha += (col[ch] - acc_c[ch]) * gC[ch];
+                    cb[6 + ch] = dch * gC[ch];
+                }
+                if (S > 0) {
+                    const float* __restrict__ f = feat + (size_t)gid * S;
+#pragma unroll
+                    for (int ch = 0; ch < S; ch++) {
+                        const float fv = f[ch];
+                        acc_f[ch] = last_alpha * last_f[ch] + inv_keep * acc_f[ch];
+                        last_f[ch] = fv;
+                        if (bgeom) dL_dalpha += (fv - acc_f[ch]) * gF[ch];
+                        cb[13 + ch] = dch * gF[ch];
+                    }
+                }
+                if (VC > 0) {
+                    const float* __restrict__ vf = vfeat + (size_t)gid * VS;
+#pragma unroll
+                    for (int ch = 0; ch < VC; ch++) {
+                        const float v = vf[4 * ch] * cw[0] + vf[4 * ch + 1] * cw[1] + vf[4 * ch + 2] * cw[2] + vf[4 * ch + 3] * cw[3];
+                        acc_vf[ch] = last_alpha * last_vf[ch] + inv_keep * acc_vf[ch];
+                        last_vf[ch] = v;
+                        const float gw = dch * gVF[ch];
+                        cb[13 + S + 4 * ch + 0] = cw[0] * gw;
+                        cb[13 + S + 4 * ch + 1] = cw[1] * gw;
+                        cb[13 + S + 4 * ch + 2] = cw[2] * gw;
+                        cb[13 + S + 4 * ch + 3] = cw[3] * gw;
+                        dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
+                    }
+                }
+                if (a.surface) {
+                    const float nn[3] = {r[R_NX], r[R_NY], r[R_NZ]};
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        acc_n[ch] = last_alpha * last_n[ch] + inv_keep * acc_n[ch];
+                        last_n[ch] = nn[ch];
+                        dL_dalpha += (nn[ch] - acc_n[ch]) * gN[ch];
+                        cb[9 + ch] = dch * gN[ch] * 10.f;  // Q4
+                    }
+                }
+                {  // depth
+                    float d_cur = r[R_DEPTH];
+                    if (sp) d_cur -= du * J6 + dv * J9;
+                    acc_d = last_alpha * last_d + inv_keep * acc_d;
+                    last_d = d_cur;
+                    float dch_d = gD, da = 0.f;
+                    if (a.normalize_depth) {
+                        const float omt = 1.f - T_final;
+                        dch_d = gD / omt;
+                        da = gD * D_final / omt / omt * -T_final / oma / T;
+                    }
+                    da += (d_cur - acc_d) * dch_d;
+                    cb[12] = dch * dch_d;
+                    dL_dalpha += da;
+                }
+                dL_dalpha *= T;
+                const float tf_oma = T_final / oma;
+                dL_dalpha += gO * tf_oma;
+                last_alpha = alpha;
+                dL_dalpha -= tf_oma * bgdot;
+                if (!a.normalize_depth) dL_dalpha -= tf_oma * (10.f * gD);
+                const float dL_ddist = dL_dalpha * B.y * -0.5f * G;
+                float ndc_x = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx;
+                float ndc_y = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy;
+                if (sp) {  // Q5
+                    ndc_x += -gD * (J6 * J0 + J9 * J2);
+                    ndc_y += -gD * (J6 * J1 + J9 * J3);
+                }
+                cb[0] = ndc_x; cb[1] = ndc_y;
+                cb[2] = dL_ddist * (dx * dx);
+                cb[3] = dL_ddist * (dx * dy);
+                cb[4] = dL_ddist * (dy * dy);
+                cb[5] = G * dL_dalpha;
+            }
+
+            // wave reduction of every channel; channel ci's total is parked in lane ci % 64 of outv[ci / 64]
+            int outv[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) outv[k] = 0;
+#pragma unroll
+            for (int ci = 0; ci < NCH; ci++) {
+                const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_last(cb[ci])), 63);
+                outv[ci >> 6] = (lane == (ci & 63)) ? tot : outv[ci >> 6];
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if (lane + 64 * k < NCH) {
+                    const float v = __builtin_bit_cast(float, outv[k]);
+                    if (v != 0.f) atomic_add_f32(dbase[k] + (size_t)gid * dstride[k], v);
+                }
+            }
+        }
+    }
+}
+
+template <int S, int VC, bool SVGSS>
+void launch(const RenderBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+}
+
+}  // namespace
+
+int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s) {
+    const int VC = a.VS / 4;
+#define CASE(SV, VCV, SG) if (a.S == SV && VC == VCV && svgss == SG) { launch<SV, VCV, SG>(a, s); return 0; }
+    CASE(0, 0, true) CASE(4, 13, true) CASE(7, 16, true) CASE(3, 2, true) CASE(1, 1, true) CASE(5, 0, true)
+    CASE(0, 0, false) CASE(5, 0, false) CASE(3, 0, false) CASE(1, 0, false)
+#undef CASE
+    return -1;
+}
+
+}  // namespace svgir

@@ -1,0 +1,172 @@
+"""ctypes bridge to libsvgir_raster.so (the C ABI declared in include/svgir_raster.h).
+
+PyTorch is used only for device memory and the current HIP stream; the library sees raw device pointers.
+There is NO fallback: if the shared library is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
+
+RGSS, SVGSS = 0, 1
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("P", C.c_int32), ("S", C.c_int32), ("VS", C.c_int32), ("D", C.c_int32),
+        ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("features", C.c_void_p), ("vfeatures", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+        ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+        ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p), ("prcppoint", C.c_void_p), ("patchbbox", C.c_void_p),
+        ("config", C.POINTER(C.c_float)), ("config_len", C.c_int32),
+        ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("cx", C.c_float),
+        ("cy", C.c_float),
+        ("prefiltered", C.c_int32), ("computer_pseudo_normal", C.c_int32), ("backward_geometry", C.c_int32),
+        ("debug", C.c_int32),
+    ]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "out_color", "out_normal", "out_depth", "out_opacity", "out_feature", "out_vfeature", "out_pseudo_normal",
+        "out_surface_xyz", "out_weights", "radii")]
+
+
+class Grads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "dL_dout_color", "dL_dout_normal", "dL_dout_depth", "dL_dout_opacity", "dL_dout_feature", "dL_dout_vfeature",
+        "dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dfeatures", "dL_dvfeatures", "dL_dnormal",
+        "dL_ddepth", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dviewmat",
+        "dL_dprojmat", "dL_dcampos")]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or make -C svg-ir_amd/csrc). There is no CPU / PyTorch fallback for the rasterizer.")
+    lib = C.CDLL(LIB_PATH)
+    lib.svgir_abi_version.restype = C.c_int
+    lib.svgir_geom_bytes.restype = C.c_size_t
+    lib.svgir_geom_bytes.argtypes = [C.c_int32]
+    lib.svgir_image_bytes.restype = C.c_size_t
+    lib.svgir_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.svgir_binning_bytes.restype = C.c_size_t
+    lib.svgir_binning_bytes.argtypes = [C.c_int32]
+    lib.svgir_image_ncontrib_offset.restype = C.c_size_t
+    lib.svgir_image_ncontrib_offset.argtypes = [C.c_int32, C.c_int32]
+    lib.svgir_forward.restype = C.c_int
+    lib.svgir_forward.argtypes = [C.POINTER(Params), C.POINTER(Outputs), ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+                                  ALLOC_FN, C.c_void_p, C.c_void_p]
+    lib.svgir_backward.restype = C.c_int
+    lib.svgir_backward.argtypes = [C.POINTER(Params), C.POINTER(Grads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    lib.svgir_mark_visible.restype = C.c_int
+    lib.svgir_mark_visible.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svgir_set_profiling.argtypes = [C.c_int]
+    lib.svgir_last_timings.restype = C.c_int
+    lib.svgir_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.svgir_last_error.restype = C.c_char_p
+    if lib.svgir_abi_version() != 1:
+        raise ImportError("libsvgir_raster.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_binning_bytes",
+           "svgir_image_ncontrib_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
+           "svgir_set_profiling", "svgir_last_timings", "svgir_last_error")
+
+
+def last_error():
+    return (lib.svgir_last_error() or b"").decode()
+
+
+def check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"svgir {what} failed ({rc}): {last_error()}")
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a contiguous float/int tensor, or None for empty/absent tensors (the reference passes
+    `torch.Tensor([])` whose data pointer is null, rasterize_points.cu:111-119)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def f32c(t, device):
+    """Contiguous fp32 copy/view on `device` (the reference calls .contiguous() on every argument)."""
+    if t is None:
+        return None
+    if t.numel() == 0:
+        return t
+    if t.device != device or t.dtype != torch.float32:
+        t = t.to(device=device, dtype=torch.float32)
+    return t.contiguous()
+
+
+class BlobAllocator:
+    """The three resizable byte blobs of the reference glue (rasterize_points.cu:27-33) as torch uint8 tensors."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensors = {}
+        self._fns = {}
+
+    def fn(self, name):
+        def alloc(nbytes, _ctx):
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self.tensors[name] = t
+            return t.data_ptr()
+
+        f = ALLOC_FN(alloc)
+        self._fns[name] = f  # keep the thunk alive
+        return f
+
+    def get(self, name):
+        t = self.tensors.get(name)
+        if t is None:
+            t = torch.empty(0, dtype=torch.uint8, device=self.device)
+        return t
+
+
+_config_cache = {}
+
+
+def host_config(cfg):
+    """Host copy of the tiny `config` tensor (one device->host read per distinct tensor version)."""
+    if cfg is None:
+        return (C.c_float * 1)(), 0
+    key = (cfg.data_ptr(), cfg._version, cfg.numel(), str(cfg.device))
+    hit = _config_cache.get(key)
+    if hit is None:
+        vals = [float(v) for v in cfg.detach().reshape(-1).tolist()]
+        hit = ((C.c_float * max(1, len(vals)))(*vals), len(vals))
+        if len(_config_cache) > 64:
+            _config_cache.clear()
+        _config_cache[key] = hit
+    return hit
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def set_profiling(on):
+    lib.svgir_set_profiling(1 if on else 0)
+
+
+def last_timings():
+    names = (C.c_char_p * 16)()
+    ms = (C.c_float * 16)()
+    n = lib.svgir_last_timings(names, ms, 16)
+    return [(names[i].decode(), float(ms[i])) for i in range(n)]

@@ -1,0 +1,314 @@
+"""Drop-in for the reference's `gaussian_renderer.svgss_rasterization` (stage-2, spatially-varying surfels).
+
+Same public names, argument order, return tuples and gradient tuples as
+/root/reference/gaussian_renderer/svgss_rasterization.py:
+  * GaussianRasterizationSettings (15 fields, :331-346)
+  * GaussianRasterizer(raster_settings).forward(...) -> 9-tuple (:365-411, :183); .markVisible (:354-363)
+  * _RasterizeGaussians autograd.Function: grads for (means3D, means2D, features, vfeatures, sh, colors_precomp,
+    opacities, scales, rotations, cov3Ds_precomp, viewmatrix, projmatrix, campos, None) (:293-308)
+  * `_C` with rasterize_gaussians / rasterize_gaussians_backward / mark_visible in the pybind argument order of
+    svgss_rasterization/rasterize_points.h:18-82 (24 args -> 12-tuple, 31 args -> 13-tuple).
+The compute runs in libsvgir_raster.so (hand-written HIP for gfx950) through the C ABI of include/svgir_raster.h.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+class _CBinding:
+    """Same three entry points as the reference's pybind module (svgss_rasterization/ext.cpp:15-19)."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, features, vfeatures, colors, opacity, scales, rotations,
+                            scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx,
+                            tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, config):
+        if means3D.ndimension() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:65-67
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("svgss rasterizer: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
+        P = means3D.size(0)
+        S = features.size(1) if features.dim() == 2 else 0
+        VS = vfeatures.size(1) if vfeatures.dim() == 2 else 0
+        H, W = int(image_height), int(image_width)
+        f32 = dict(dtype=torch.float32, device=dev)
+        out_color = torch.empty((3, H, W), **f32)
+        out_normal = torch.empty((3, H, W), **f32)
+        out_depth = torch.empty((1, H, W), **f32)
+        out_opac = torch.empty((1, H, W), **f32)
+        out_feature = torch.empty((S, H, W), **f32)
+        out_vfeature = torch.empty((VS // 4, H, W), **f32)
+        out_weights = torch.zeros((P, 1), **f32)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        blobs = N.BlobAllocator(dev)
+        rendered = 0
+        if P != 0:
+            keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, vfeatures, opacity, scales,
+                                              rotations, cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint,
+                                              patchbbox)]
+            (bg, m3, shc, col, fe, vf, op, sc, ro, cv, vm, pm, cp, pr, pb) = keep
+            cfg, cfg_len = N.host_config(config)
+            p = N.Params()
+            p.variant, p.P, p.S, p.VS, p.D, p.W, p.H = N.SVGSS, P, S, VS, int(degree), W, H
+            p.M = shc.size(1) if (shc is not None and shc.numel() != 0) else 0
+            p.background, p.means3D, p.shs, p.colors_precomp = N.ptr(bg), N.ptr(m3), N.ptr(shc), N.ptr(col)
+            p.features, p.vfeatures, p.opacities = N.ptr(fe), N.ptr(vf), N.ptr(op)
+            p.scales, p.rotations, p.cov3D_precomp = N.ptr(sc), N.ptr(ro), N.ptr(cv)
+            p.viewmatrix, p.projmatrix, p.cam_pos = N.ptr(vm), N.ptr(pm), N.ptr(cp)
+            p.prcppoint, p.patchbbox = N.ptr(pr), N.ptr(pb)
+            p.config, p.config_len = cfg, cfg_len
+            p.scale_modifier, p.tan_fovx, p.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
+            p.cx, p.cy = W / 2.0, H / 2.0
+            p.prefiltered, p.debug = int(bool(prefiltered)), int(bool(debug))
+            o = N.Outputs()
+            o.out_color, o.out_normal, o.out_depth, o.out_opacity = (out_color.data_ptr(), out_normal.data_ptr(),
+                                                                     out_depth.data_ptr(), out_opac.data_ptr())
+            o.out_feature, o.out_vfeature = N.ptr(out_feature), N.ptr(out_vfeature)
+            o.out_weights, o.radii = out_weights.data_ptr(), radii.data_ptr()
+            rendered = N.check(N.lib.svgir_forward(p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
+                                                   blobs.fn("image"), None, N.stream_ptr(dev)), "forward")
+        # note: C++ order is (..., depth, opac, ...) -- the Python wrapper re-orders (svgss_rasterization.py:175,183)
+        return (rendered, out_color, out_normal, out_depth, out_opac, out_feature, out_vfeature, out_weights, radii,
+                blobs.get("geom"), blobs.get("binning"), blobs.get("image"))
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, features, vfeatures, radii, colors, scales, rotations,
+                                     scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox,
+                                     tan_fovx, tan_fovy, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac,
+                                     dL_dout_feature, dL_dout_vfeature, sh, degree, campos, geomBuffer, R,
+                                     binningBuffer, imageBuffer, debug, config):
+        dev = means3D.device
+        P = means3D.size(0)
+        S = features.size(1) if features.dim() == 2 else 0
+        VS = vfeatures.size(1) if vfeatures.dim() == 2 else 0
+        H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+        M = sh.size(1) if sh.numel() != 0 else 0
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        dL_dmeans3D, dL_dmeans2D = z(P, 3), z(P, 3)
+        dL_dfeatures, dL_dvfeatures = z(P, S), z(P, VS)
+        dL_dcolors, dL_dnormal, dL_ddepth = z(P, 3), z(P, 3), z(P, 1)
+        dL_dconic, dL_dopacity = z(P, 2, 2), z(P, 1)
+        dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
+        dL_dviewmat, dL_dprojmat, dL_dcampos = z(4, 4), z(4, 4), z(3)
+        if P != 0:
+            keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, vfeatures, scales, rotations,
+                                              cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint, patchbbox,
+                                              dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac,
+                                              dL_dout_feature, dL_dout_vfeature)]
+            (bg, m3, shc, col, fe, vf, sc, ro, cv, vm, pm, cp, pr, pb, gc, gn, gd, go, gf, gvf) = keep
+            cfg, cfg_len = N.host_config(config)
+            p = N.Params()
+            p.variant, p.P, p.S, p.VS, p.D, p.M, p.W, p.H = N.SVGSS, P, S, VS, int(degree), M, W, H
+            p.background, p.means3D, p.shs, p.colors_precomp = N.ptr(bg), N.ptr(m3), N.ptr(shc), N.ptr(col)
+            p.features, p.vfeatures = N.ptr(fe), N.ptr(vf)
+            p.scales, p.rotations, p.cov3D_precomp = N.ptr(sc), N.ptr(ro), N.ptr(cv)
+            p.viewmatrix, p.projmatrix, p.cam_pos = N.ptr(vm), N.ptr(pm), N.ptr(cp)
+            p.prcppoint, p.patchbbox = N.ptr(pr), N.ptr(pb)
+            p.config, p.config_len = cfg, cfg_len
+            p.scale_modifier, p.tan_fovx, p.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
+            p.debug = int(bool(debug))
+            g = N.Grads()
+            g.dL_dout_color, g.dL_dout_normal, g.dL_dout_depth = N.ptr(gc), N.ptr(gn), N.ptr(gd)
+            g.dL_dout_opacity, g.dL_dout_feature, g.dL_dout_vfeature = N.ptr(go), N.ptr(gf), N.ptr(gvf)
+            g.dL_dmeans2D, g.dL_dconic, g.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr()
+            g.dL_dcolors, g.dL_dfeatures, g.dL_dvfeatures = dL_dcolors.data_ptr(), N.ptr(dL_dfeatures), N.ptr(dL_dvfeatures)
+            g.dL_dnormal, g.dL_ddepth, g.dL_dmeans3D = dL_dnormal.data_ptr(), dL_ddepth.data_ptr(), dL_dmeans3D.data_ptr()
+            g.dL_dcov3D, g.dL_dsh, g.dL_dscales = dL_dcov3D.data_ptr(), N.ptr(dL_dsh), dL_dscales.data_ptr()
+            g.dL_drotations = dL_drotations.data_ptr()
+            g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
+            rad = radii.contiguous()
+            N.check(N.lib.svgir_backward(p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                                         imageBuffer.data_ptr(), N.stream_ptr(dev)), "backward")
+        return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dvfeatures, dL_dcov3D, dL_dsh,
+                dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos)
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        P = means3D.size(0)
+        present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+        if P != 0:
+            m3, vm, pm = (N.f32c(t, means3D.device) for t in (means3D, viewmatrix, projmatrix))
+            N.check(N.lib.svgir_mark_visible(N.SVGSS, P, m3.data_ptr(), vm.data_ptr(), pm.data_ptr(),
+                                             present.data_ptr(), N.stream_ptr(means3D.device)), "mark_visible")
+        return present
+
+
+_C = _CBinding()
+
+
+def rasterize_gaussians(
+    means3D,
+    means2D,
+    sh,
+    features,
+    vfeatures,
+    colors_precomp,
+    opacities,
+    scales,
+    rotations,
+    cov3Ds_precomp,
+    viewmatrix,
+    projmatrix,
+    campos,
+    raster_settings,
+):
+    # Parameter names are mislabelled in the reference too (Q13); the positional pass-through is what matters.
+    return _RasterizeGaussians.apply(
+        means3D, means2D, sh, features, vfeatures, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+        viewmatrix, projmatrix, campos, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, features, vfeatures, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, viewmatrix, projmatrix, campos, raster_settings):
+        args = (
+            raster_settings.bg, means3D, features, vfeatures, colors_precomp, opacities, scales, rotations,
+            raster_settings.scale_modifier, cov3Ds_precomp, viewmatrix, projmatrix, raster_settings.prcppoint,
+            raster_settings.patch_bbox, raster_settings.tanfovx, raster_settings.tanfovy,
+            raster_settings.image_height, raster_settings.image_width, sh, raster_settings.sh_degree, campos,
+            raster_settings.prefiltered, raster_settings.debug, raster_settings.config)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+            try:
+                out = _C.rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            out = _C.rasterize_gaussians(*args)
+        (num_rendered, color, normal, depth, opacity, feature, vfeature, weights, radii, geomBuffer, binningBuffer,
+         imgBuffer) = out
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, features, vfeatures, scales, rotations, cov3Ds_precomp, radii,
+                              sh, geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(weights, radii)
+        return num_rendered, color, normal, opacity, depth, feature, vfeature, weights, radii
+
+    @staticmethod
+    def backward(ctx, grad_num_rendered, grad_out_color, grad_out_normal, grad_out_opacity, grad_out_depth,
+                 grad_out_feature, grad_out_vfeature, grad_out_weights, grad_out_radii):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        (colors_precomp, means3D, features, vfeatures, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+         binningBuffer, imgBuffer) = ctx.saved_tensors
+        H, W = raster_settings.image_height, raster_settings.image_width
+
+        def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss
+            return g if g is not None else torch.zeros((ch, H, W), dtype=torch.float32, device=means3D.device)
+
+        args = (raster_settings.bg, means3D, features, vfeatures, radii, colors_precomp, scales, rotations,
+                raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,
+                raster_settings.projmatrix, raster_settings.prcppoint, raster_settings.patch_bbox,
+                raster_settings.tanfovx, raster_settings.tanfovy, _g(grad_out_color, 3), _g(grad_out_normal, 3),
+                _g(grad_out_depth, 1), _g(grad_out_opacity, 1),
+                _g(grad_out_feature, features.size(1) if features.dim() == 2 else 0),
+                _g(grad_out_vfeature, (vfeatures.size(1) if vfeatures.dim() == 2 else 0) // 4),
+                sh, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer,
+                imgBuffer, raster_settings.debug, raster_settings.config)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                res = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            res = _C.rasterize_gaussians_backward(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_features, grad_vfeatures,
+         grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations, grad_viewmat, grad_projmat, grad_campos) = res
+
+        def _m(g, like):  # grads of inputs that were passed as empty placeholders
+            return g if (like is not None and like.numel() != 0) else None
+
+        grads = (
+            grad_means3D,
+            grad_means2D,
+            _m(grad_features, features),
+            _m(grad_vfeatures, vfeatures),
+            _m(grad_sh, sh),
+            _m(grad_colors_precomp, colors_precomp),
+            grad_opacities,
+            _m(grad_scales, scales),
+            _m(grad_rotations, rotations),
+            _m(grad_cov3Ds_precomp, cov3Ds_precomp),
+            grad_viewmat,
+            grad_projmat,
+            grad_campos,
+            None,
+        )
+        return grads
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    patch_bbox: torch.Tensor
+    prcppoint: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    config: torch.Tensor
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # Mark visible points (based on frustum culling for camera) with a boolean
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, features=None, vfeatures=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+        if features is None:
+            features = torch.empty_like(means3D[..., :0])
+        if vfeatures is None:
+            vfeatures = torch.empty_like(means3D[..., :0])
+
+        # Invoke the HIP rasterization routine
+        return rasterize_gaussians(
+            means3D, means2D, features, vfeatures, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+            raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.campos, raster_settings)
