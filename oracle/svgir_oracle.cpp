@@ -95,12 +95,12 @@ M3<T> tr(const M3<T>& A) {
 }
 
 // SH basis constants (svgss auxiliary.h:23-40)
-const float kC0 = 0.28209479177387814f;
-const float kC1 = 0.4886025119029199f;
-const float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
-                      0.5462742152960396f};
-const float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
-                      -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+const double kC0 = 0.28209479177387814;
+const double kC1 = 0.4886025119029199;
+const double kC2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792,
+                       0.5462742152960396};
+const double kC3[7] = {-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+                       -0.4570457994644658, 1.445305721320277, -0.5900435899266435};
 
 template <typename real>
 struct Oracle {
@@ -140,7 +140,7 @@ struct Oracle {
     std::vector<real> present;  // mark_visible result as 0/1
     double t_pre = 0, t_bin = 0, t_render = 0, t_brender = 0, t_bpre = 0;
 
-    static real lit(float f) { return (real)f; }
+    static real lit(double f) { return (real)f; }  // decimal literal -> working precision (fp32: same as an f-suffixed literal)
 
     explicit Oracle(const orc_params& pp) : p(pp) {
         P = p.P; S = p.S; VS = p.VS; D = p.D; M = p.M; W = p.W; H = p.H;
@@ -162,8 +162,8 @@ struct Oracle {
         surface = cfg[0] > 0; normalize_depth = cfg[1] > 0; pix_depth = cfg[2] > 0; lrn_cam = cfg[3] > 0;
         tanx = (real)p.tan_fovx; tany = (real)p.tan_fovy; smod = (real)p.scale_modifier;
         // rasterizer_impl.cu:244-245
-        focal_y = (real)H / (lit(2.0f) * tany);
-        focal_x = (real)W / (lit(2.0f) * tanx);
+        focal_y = (real)H / (lit(2.0) * tany);
+        focal_x = (real)W / (lit(2.0) * tanx);
 #if defined(_OPENMP)
         if (p.num_threads > 0) omp_set_num_threads(p.num_threads);
 #endif
@@ -197,7 +197,7 @@ struct Oracle {
         rmax[1] = (uint32_t)std::min(gy, std::max(0, (int)((py + r + TILE - 1) / TILE)));
     }
     static real norm3_inplace(real* v) {  // auxiliary.h:236-242
-        real mod = std::max((real)std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), lit((float)0.00000001));
+        real mod = std::max((real)std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), lit(0.00000001));
         v[0] /= mod; v[1] /= mod; v[2] /= mod;
         return mod;
     }
@@ -209,7 +209,7 @@ struct Oracle {
         const real m0 = norm3_inplace(d0);
         real d1[3] = {qx, qy + 1 / S_fix, 1};
         const real m1 = norm3_inplace(d1);
-        const real thr = lit(0.01f);
+        const real thr = lit(0.01);
         const real c0 = d0[0] * nv[0] + d0[1] * nv[1] + d0[2] * nv[2];
         const real c1 = d1[0] * nv[0] + d1[1] * nv[1] + d1[2] * nv[2];
         if (std::fabs(c0 / m0) < thr || std::fabs(c1 / m1) < thr) return true;
@@ -248,7 +248,7 @@ struct Oracle {
     // forward.cu:74-139.  `t` is the view-space mean (Q2).
     void cov2d_fwd(const real* tv, const real* c3, real* out, M3<real>* Tout = nullptr, real* tcl = nullptr) const {
         real t[3] = {tv[0], tv[1], tv[2]};
-        const real limx = lit(1.3f) * tanx, limy = lit(1.3f) * tany;
+        const real limx = lit(1.3) * tanx, limy = lit(1.3) * tany;
         const real txtz = t[0] / t[2], tytz = t[1] / t[2];
         t[0] = std::min(limx, std::max(-limx, txtz)) * t[2];
         t[1] = std::min(limy, std::max(-limy, tytz)) * t[2];
@@ -258,9 +258,9 @@ struct Oracle {
         M3<real> Tm = mul(Wm, J);
         M3<real> V(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
         M3<real> cov = mul(mul(tr(Tm), tr(V)), Tm);
-        out[0] = cov.c[0][0] + lit(0.3f);
+        out[0] = cov.c[0][0] + lit(0.3);
         out[1] = cov.c[0][1];
-        out[2] = cov.c[1][1] + lit(0.3f);
+        out[2] = cov.c[1][1] + lit(0.3);
         if (Tout) *Tout = Tm;
         if (tcl) { tcl[0] = t[0]; tcl[1] = t[1]; tcl[2] = t[2]; }
     }
@@ -280,18 +280,18 @@ struct Oracle {
                 if (D > 1) {
                     const real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                     res = res + lit(kC2[0]) * xy * h(4) + lit(kC2[1]) * yz * h(5) +
-                          lit(kC2[2]) * (lit(2.0f) * zz - xx - yy) * h(6) + lit(kC2[3]) * xz * h(7) +
+                          lit(kC2[2]) * (lit(2.0) * zz - xx - yy) * h(6) + lit(kC2[3]) * xz * h(7) +
                           lit(kC2[4]) * (xx - yy) * h(8);
                     if (D > 2) {
-                        res = res + lit(kC3[0]) * y * (lit(3.0f) * xx - yy) * h(9) + lit(kC3[1]) * xy * z * h(10) +
-                              lit(kC3[2]) * y * (lit(4.0f) * zz - xx - yy) * h(11) +
-                              lit(kC3[3]) * z * (lit(2.0f) * zz - lit(3.0f) * xx - lit(3.0f) * yy) * h(12) +
-                              lit(kC3[4]) * x * (lit(4.0f) * zz - xx - yy) * h(13) +
-                              lit(kC3[5]) * z * (xx - yy) * h(14) + lit(kC3[6]) * x * (xx - lit(3.0f) * yy) * h(15);
+                        res = res + lit(kC3[0]) * y * (lit(3.0) * xx - yy) * h(9) + lit(kC3[1]) * xy * z * h(10) +
+                              lit(kC3[2]) * y * (lit(4.0) * zz - xx - yy) * h(11) +
+                              lit(kC3[3]) * z * (lit(2.0) * zz - lit(3.0) * xx - lit(3.0) * yy) * h(12) +
+                              lit(kC3[4]) * x * (lit(4.0) * zz - xx - yy) * h(13) +
+                              lit(kC3[5]) * z * (xx - yy) * h(14) + lit(kC3[6]) * x * (xx - lit(3.0) * yy) * h(15);
                     }
                 }
             }
-            res += lit(0.5f);
+            res += lit(0.5);
             clamped[3 * idx + c] = res < 0;
             out[c] = std::max(res, (real)0);
         }
@@ -308,18 +308,18 @@ struct Oracle {
             const real* po = means3D + 3 * idx;
             real ph[4], pv[3];
             xform4x4(po, proj, ph);
-            const real pw = lit(1.0f) / (ph[3] + lit(0.0000001f));
+            const real pw = lit(1.0) / (ph[3] + lit(0.0000001));
             const real pp[3] = {ph[0] * pw, ph[1] * pw, ph[2] * pw};
             xform4x3(po, view, pv);
             const real pix[2] = {ndc2pix(pp[0], W), ndc2pix(pp[1], H)};
             if (svgss) {  // svgss auxiliary.h:146-171
                 const real x0 = patchbbox[1], y0 = patchbbox[0], x1 = patchbbox[3], y1 = patchbbox[2];
-                const real w = x1 - x0, h = y1 - y0, e = lit((float)0.2);
+                const real w = x1 - x0, h = y1 - y0, e = lit(0.2);
                 if (pv[2] < 0 || pix[0] < x0 - w * e || pix[0] >= x1 + w * e || pix[1] < y0 - h * e ||
                     pix[1] >= y1 + h * e)
                     continue;
             } else {  // rgss auxiliary.h:146-170
-                if (pv[2] <= lit(0.2f)) continue;
+                if (pv[2] <= lit(0.2)) continue;
             }
             real qn[4] = {1, 0, 0, 0};
             if (rots) for (int i = 0; i < 4; i++) qn[i] = rots[4 * idx + i];
@@ -347,12 +347,12 @@ struct Oracle {
             cov2d_fwd(pv, c3, cov);
             const real det = cov[0] * cov[2] - cov[1] * cov[1];
             if (det == 0) continue;
-            const real det_inv = lit(1.f) / det;
+            const real det_inv = lit(1.) / det;
             const real conic[3] = {cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv};
-            const real mid = lit(0.5f) * (cov[0] + cov[2]);
-            const real l1 = mid + std::sqrt(std::max(lit(0.1f), mid * mid - det));
-            const real l2 = mid - std::sqrt(std::max(lit(0.1f), mid * mid - det));
-            const real my_radius = std::ceil(lit(3.f) * std::sqrt(std::max(l1, l2)));
+            const real mid = lit(0.5) * (cov[0] + cov[2]);
+            const real l1 = mid + std::sqrt(std::max(lit(0.1), mid * mid - det));
+            const real l2 = mid - std::sqrt(std::max(lit(0.1), mid * mid - det));
+            const real my_radius = std::ceil(lit(3.) * std::sqrt(std::max(l1, l2)));
             uint32_t rmin[2], rmax[2];
             get_rect(pix[0], pix[1], (int)my_radius, rmin, rmax);
             if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
@@ -416,23 +416,23 @@ struct Oracle {
         q.dx = xy[0] - pxf; q.dy = xy[1] - pyf;
         if (svgss) {  // svgss forward.cu:534-535
             const real dist = (co[0] * q.dx * q.dx + co[2] * q.dy * q.dy) + 2 * co[1] * q.dx * q.dy;
-            q.power = lit(-0.5f) * dist;
+            q.power = lit(-0.5) * dist;
         } else {  // rgss forward.cu:430
-            q.power = lit(-0.5f) * (co[0] * q.dx * q.dx + co[2] * q.dy * q.dy) - co[1] * q.dx * q.dy;
+            q.power = lit(-0.5) * (co[0] * q.dx * q.dx + co[2] * q.dy * q.dy) - co[1] * q.dx * q.dy;
         }
         if (q.power > 0) return false;
         q.G = std::exp(q.power);
-        q.alpha = std::min(lit(0.99f), co[3] * q.G);
-        if (q.alpha < lit(1.0f) / lit(255.0f)) return false;
+        q.alpha = std::min(lit(0.99), co[3] * q.G);
+        if (q.alpha < lit(1.0) / lit(255.0)) return false;
         return true;
     }
     inline void corner_weights(const Pair& q, const real* J, const real* lbd, real* w) const {
         // svgss forward.cu:604-617
         const real dtx = q.dx * J[0] + q.dy * J[1], dty = q.dx * J[2] + q.dy * J[3];
         const real umx = (real)(0.5 * (double)lbd[0] + 0.1), umy = (real)(0.5 * (double)lbd[1] + 0.1);
-        real u = dtx / umx * lit(0.5f) + lit(0.5f), v = dty / umy * lit(0.5f) + lit(0.5f);
-        u = std::min(lit(0.999f), std::max(lit(0.001f), u));
-        v = std::min(lit(0.999f), std::max(lit(0.001f), v));
+        real u = dtx / umx * lit(0.5) + lit(0.5), v = dty / umy * lit(0.5) + lit(0.5);
+        u = std::min(lit(0.999), std::max(lit(0.001), u));
+        v = std::min(lit(0.999), std::max(lit(0.001), v));
         w[0] = (1 - u) * (1 - v); w[1] = u * (1 - v); w[2] = (1 - u) * v; w[3] = u * v;
     }
     inline real depth_dif_z(const Pair& q, const real* J) const {  // auxiliary.h:390-397 (.z only)
@@ -471,7 +471,7 @@ struct Oracle {
                             Pair q;
                             if (!pair_alpha(&means2D[2 * g], &conic_opacity[4 * g], pxf, pyf, q)) continue;
                             const real test_T = Tr * (1 - q.alpha);
-                            if (test_T < lit(0.0001f)) break;  // done = true
+                            if (test_T < lit(0.0001)) break;  // done = true
                             const real w = q.alpha * Tr;
                             real cw[4] = {0, 0, 0, 0};
                             real dep = depths[g];
@@ -521,7 +521,7 @@ struct Oracle {
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
                 const size_t id = (size_t)W * y + x;
-                const real d = out_depth[id] / std::max(out_opac[id], lit(0.0000001f));
+                const real d = out_depth[id] / std::max(out_opac[id], lit(0.0000001));
                 out_surface_xyz[id] = ((real)x - cx) / focal_x * d;
                 out_surface_xyz[N + id] = ((real)y - cy) / focal_y * d;
                 out_surface_xyz[2 * N + id] = d;
@@ -533,10 +533,10 @@ struct Oracle {
                 auto at = [&](int yy, int xx, int c) { return out_surface_xyz[c * N + (size_t)W * yy + xx]; };
                 real ga[3], gb[3];
                 for (int i = 0; i < 3; i++) {
-                    ga[i] = lit(-0.125f) * at(ym, xm, i) + lit(0.125f) * at(ym, xp, i) - lit(0.25f) * at(y, xm, i) +
-                            lit(0.25f) * at(y, xp, i) - lit(0.125f) * at(yp, xm, i) + lit(0.125f) * at(yp, xp, i);
-                    gb[i] = lit(-0.125f) * at(ym, xm, i) - lit(0.25f) * at(ym, x, i) - lit(0.125f) * at(ym, xp, i) +
-                            lit(0.125f) * at(yp, xm, i) + lit(0.25f) * at(yp, x, i) + lit(0.125f) * at(yp, xp, i);
+                    ga[i] = lit(-0.125) * at(ym, xm, i) + lit(0.125) * at(ym, xp, i) - lit(0.25) * at(y, xm, i) +
+                            lit(0.25) * at(y, xp, i) - lit(0.125) * at(yp, xm, i) + lit(0.125) * at(yp, xp, i);
+                    gb[i] = lit(-0.125) * at(ym, xm, i) - lit(0.25) * at(ym, x, i) - lit(0.125) * at(ym, xp, i) +
+                            lit(0.125) * at(yp, xm, i) + lit(0.25) * at(yp, x, i) + lit(0.125) * at(yp, xp, i);
                 }
                 real n[3] = {ga[1] * gb[2] - ga[2] * gb[1], -ga[0] * gb[2] + ga[2] * gb[0],
                              ga[0] * gb[1] - ga[1] * gb[0]};
@@ -601,7 +601,7 @@ struct Oracle {
                             const real* co = &conic_opacity[4 * g];
                             Pair q;
                             if (!pair_alpha(&means2D[2 * g], co, pxf, pyf, q)) continue;
-                            Tr = Tr / (lit(1.f) - q.alpha);
+                            Tr = Tr / (lit(1.) - q.alpha);
                             const real dch = q.alpha * Tr;
                             real cw[4] = {0, 0, 0, 0};
                             const real* J = &Jinv[10 * g];
@@ -612,7 +612,7 @@ struct Oracle {
                             // colour
                             for (int ch = 0; ch < 3; ch++) {
                                 const real c = colors[3 * g + ch];
-                                acc_c[ch] = last_alpha * last_c[ch] + (lit(1.f) - last_alpha) * acc_c[ch];
+                                acc_c[ch] = last_alpha * last_c[ch] + (lit(1.) - last_alpha) * acc_c[ch];
                                 last_c[ch] = c;
                                 dL_dalpha += (c - acc_c[ch]) * gC[ch];
                                 L[6 + ch] += (double)(dch * gC[ch]);
@@ -621,7 +621,7 @@ struct Oracle {
                                 if (!surface) return;
                                 for (int ch = 0; ch < 3; ch++) {
                                     const real n = normal[3 * g + ch];
-                                    acc_n[ch] = last_alpha * last_n[ch] + (lit(1.f) - last_alpha) * acc_n[ch];
+                                    acc_n[ch] = last_alpha * last_n[ch] + (lit(1.) - last_alpha) * acc_n[ch];
                                     last_n[ch] = n;
                                     dL_dalpha += (n - acc_n[ch]) * gN[ch];
                                     L[9 + ch] += (double)(dch * gN[ch] * 10);  // Q4
@@ -630,7 +630,7 @@ struct Oracle {
                             auto do_feature = [&]() {
                                 for (int ch = 0; ch < S; ch++) {
                                     const real f = features[(size_t)g * S + ch];
-                                    acc_f[ch] = last_alpha * last_f[ch] + (lit(1.f) - last_alpha) * acc_f[ch];
+                                    acc_f[ch] = last_alpha * last_f[ch] + (lit(1.) - last_alpha) * acc_f[ch];
                                     last_f[ch] = f;
                                     if (bgeom) dL_dalpha += (f - acc_f[ch]) * gF[ch];
                                     L[13 + ch] += (double)(dch * gF[ch]);
@@ -643,7 +643,7 @@ struct Oracle {
                                     const real v0 = vf[0] * cw[0], v1 = vf[1] * cw[1], v2 = vf[2] * cw[2],
                                                v3 = vf[3] * cw[3];
                                     const real v = v0 + v1 + v2 + v3;
-                                    acc_vf[ch] = last_alpha * last_vf[ch] + (lit(1.f) - last_alpha) * acc_vf[ch];
+                                    acc_vf[ch] = last_alpha * last_vf[ch] + (lit(1.) - last_alpha) * acc_vf[ch];
                                     last_vf[ch] = v;
                                     for (int k = 0; k < 4; k++) L[13 + S + 4 * ch + k] += (double)(cw[k] * dch * gVF[ch]);
                                     dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
@@ -656,12 +656,12 @@ struct Oracle {
                             {  // depth
                                 real d_cur = depths[g];
                                 if (sp) d_cur -= depth_dif_z(q, J);
-                                acc_d = last_alpha * last_d + (lit(1.f) - last_alpha) * acc_d;
+                                acc_d = last_alpha * last_d + (lit(1.) - last_alpha) * acc_d;
                                 last_d = d_cur;
                                 real dch_d = gD, da = 0;
                                 if (normalize_depth) {
-                                    dch_d /= (lit(1.f) - T_final);
-                                    da += gD * D_final / (lit(1.f) - T_final) / (lit(1.f) - T_final) * -T_final /
+                                    dch_d /= (lit(1.) - T_final);
+                                    da += gD * D_final / (lit(1.) - T_final) / (lit(1.) - T_final) * -T_final /
                                           (1 - q.alpha) / Tr;
                                 }
                                 da += (d_cur - acc_d) * dch_d;
@@ -673,10 +673,10 @@ struct Oracle {
                             last_alpha = q.alpha;
                             real bgdot = 0;
                             for (int i = 0; i < 3; i++) bgdot += bg[i] * gC[i];
-                            dL_dalpha += (-T_final / (lit(1.f) - q.alpha)) * bgdot;
-                            if (!normalize_depth) dL_dalpha += (-T_final / (lit(1.f) - q.alpha)) * (10 * gD);
+                            dL_dalpha += (-T_final / (lit(1.) - q.alpha)) * bgdot;
+                            if (!normalize_depth) dL_dalpha += (-T_final / (lit(1.) - q.alpha)) * (10 * gD);
                             real dL_ddist = 0;
-                            dL_ddist += dL_dalpha * co[3] * lit(-0.5f) * q.G;
+                            dL_ddist += dL_dalpha * co[3] * lit(-0.5) * q.G;
                             real ndc_x = dL_ddist * 2 * (co[0] * q.dx + co[1] * q.dy) * ddelx_dx;
                             real ndc_y = dL_ddist * 2 * (co[2] * q.dy + co[1] * q.dx) * ddely_dy;
                             if (sp) {  // Q5
@@ -731,7 +731,7 @@ struct Oracle {
         const real dcon[3] = {dL_dconic[4 * idx], dL_dconic[4 * idx + 1], dL_dconic[4 * idx + 3]};
         real t[3];
         xform4x3(mean, view, t);
-        const real limx = lit(1.3f) * tanx, limy = lit(1.3f) * tany;
+        const real limx = lit(1.3) * tanx, limy = lit(1.3) * tany;
         const real txtz = t[0] / t[2], tytz = t[1] / t[2];
         t[0] = std::min(limx, std::max(-limx, txtz)) * t[2];
         t[1] = std::min(limy, std::max(-limy, tytz)) * t[2];
@@ -744,10 +744,10 @@ struct Oracle {
         M3<real> V(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
         M3<real> Tm = mul(Wm, J);
         M3<real> cov = mul(mul(tr(Tm), tr(V)), Tm);
-        const real a = cov.c[0][0] + lit(0.3f), b = cov.c[0][1], c = cov.c[1][1] + lit(0.3f);
+        const real a = cov.c[0][0] + lit(0.3), b = cov.c[0][1], c = cov.c[1][1] + lit(0.3);
         const real denom = a * c - b * b;
         real da = 0, db = 0, dc = 0;
-        const real d2i = lit(1.0f) / ((denom * denom) + lit(0.0000001f));
+        const real d2i = lit(1.0) / ((denom * denom) + lit(0.0000001));
         real* dcv = &dL_dcov3D[6 * idx];
         auto Tc = [&](int i, int j) { return Tm.c[i][j]; };
         auto Vc = [&](int i, int j) { return V.c[i][j]; };
@@ -780,7 +780,7 @@ struct Oracle {
         const real dJ02 = Wm.c[2][0] * dT00 + Wm.c[2][1] * dT01 + Wm.c[2][2] * dT02;
         const real dJ11 = Wm.c[1][0] * dT10 + Wm.c[1][1] * dT11 + Wm.c[1][2] * dT12;
         const real dJ12 = Wm.c[2][0] * dT10 + Wm.c[2][1] * dT11 + Wm.c[2][2] * dT12;
-        const real tz = lit(1.f) / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const real tz = lit(1.) / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
         if (svgss && lrn_cam) {
             const real dW[16] = {dT00 * J0, dT10 * J2, dT00 * J1 + dT10 * J3, 0, dT01 * J0, dT11 * J2,
                                  dT01 * J1 + dT11 * J3, 0, dT02 * J0, dT12 * J2, dT02 * J1 + dT12 * J3, 0, 0, 0, 0, 0};
@@ -817,33 +817,33 @@ struct Oracle {
             for (int c = 0; c < 3; c++) { dx[c] = -lit(kC1) * h(3, c); dy[c] = -lit(kC1) * h(1, c); dz[c] = lit(kC1) * h(2, c); }
             if (D > 1) {
                 const real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                set(4, lit(kC2[0]) * xy); set(5, lit(kC2[1]) * yz); set(6, lit(kC2[2]) * (lit(2.f) * zz - xx - yy));
+                set(4, lit(kC2[0]) * xy); set(5, lit(kC2[1]) * yz); set(6, lit(kC2[2]) * (lit(2.) * zz - xx - yy));
                 set(7, lit(kC2[3]) * xz); set(8, lit(kC2[4]) * (xx - yy));
                 for (int c = 0; c < 3; c++) {
-                    dx[c] += lit(kC2[0]) * y * h(4, c) + lit(kC2[2]) * lit(2.f) * -x * h(6, c) + lit(kC2[3]) * z * h(7, c) +
-                             lit(kC2[4]) * lit(2.f) * x * h(8, c);
-                    dy[c] += lit(kC2[0]) * x * h(4, c) + lit(kC2[1]) * z * h(5, c) + lit(kC2[2]) * lit(2.f) * -y * h(6, c) +
-                             lit(kC2[4]) * lit(2.f) * -y * h(8, c);
-                    dz[c] += lit(kC2[1]) * y * h(5, c) + lit(kC2[2]) * lit(2.f) * lit(2.f) * z * h(6, c) + lit(kC2[3]) * x * h(7, c);
+                    dx[c] += lit(kC2[0]) * y * h(4, c) + lit(kC2[2]) * lit(2.) * -x * h(6, c) + lit(kC2[3]) * z * h(7, c) +
+                             lit(kC2[4]) * lit(2.) * x * h(8, c);
+                    dy[c] += lit(kC2[0]) * x * h(4, c) + lit(kC2[1]) * z * h(5, c) + lit(kC2[2]) * lit(2.) * -y * h(6, c) +
+                             lit(kC2[4]) * lit(2.) * -y * h(8, c);
+                    dz[c] += lit(kC2[1]) * y * h(5, c) + lit(kC2[2]) * lit(2.) * lit(2.) * z * h(6, c) + lit(kC2[3]) * x * h(7, c);
                 }
                 if (D > 2) {
-                    set(9, lit(kC3[0]) * y * (lit(3.f) * xx - yy)); set(10, lit(kC3[1]) * xy * z);
-                    set(11, lit(kC3[2]) * y * (lit(4.f) * zz - xx - yy));
-                    set(12, lit(kC3[3]) * z * (lit(2.f) * zz - lit(3.f) * xx - lit(3.f) * yy));
-                    set(13, lit(kC3[4]) * x * (lit(4.f) * zz - xx - yy)); set(14, lit(kC3[5]) * z * (xx - yy));
-                    set(15, lit(kC3[6]) * x * (xx - lit(3.f) * yy));
+                    set(9, lit(kC3[0]) * y * (lit(3.) * xx - yy)); set(10, lit(kC3[1]) * xy * z);
+                    set(11, lit(kC3[2]) * y * (lit(4.) * zz - xx - yy));
+                    set(12, lit(kC3[3]) * z * (lit(2.) * zz - lit(3.) * xx - lit(3.) * yy));
+                    set(13, lit(kC3[4]) * x * (lit(4.) * zz - xx - yy)); set(14, lit(kC3[5]) * z * (xx - yy));
+                    set(15, lit(kC3[6]) * x * (xx - lit(3.) * yy));
                     for (int c = 0; c < 3; c++) {
-                        dx[c] += (lit(kC3[0]) * h(9, c) * lit(3.f) * lit(2.f) * xy + lit(kC3[1]) * h(10, c) * yz +
-                                  lit(kC3[2]) * h(11, c) * lit(-2.f) * xy + lit(kC3[3]) * h(12, c) * lit(-3.f) * lit(2.f) * xz +
-                                  lit(kC3[4]) * h(13, c) * (lit(-3.f) * xx + lit(4.f) * zz - yy) +
-                                  lit(kC3[5]) * h(14, c) * lit(2.f) * xz + lit(kC3[6]) * h(15, c) * lit(3.f) * (xx - yy));
-                        dy[c] += (lit(kC3[0]) * h(9, c) * lit(3.f) * (xx - yy) + lit(kC3[1]) * h(10, c) * xz +
-                                  lit(kC3[2]) * h(11, c) * (lit(-3.f) * yy + lit(4.f) * zz - xx) +
-                                  lit(kC3[3]) * h(12, c) * lit(-3.f) * lit(2.f) * yz + lit(kC3[4]) * h(13, c) * lit(-2.f) * xy +
-                                  lit(kC3[5]) * h(14, c) * lit(-2.f) * yz + lit(kC3[6]) * h(15, c) * lit(-3.f) * lit(2.f) * xy);
-                        dz[c] += (lit(kC3[1]) * h(10, c) * xy + lit(kC3[2]) * h(11, c) * lit(4.f) * lit(2.f) * yz +
-                                  lit(kC3[3]) * h(12, c) * lit(3.f) * (lit(2.f) * zz - xx - yy) +
-                                  lit(kC3[4]) * h(13, c) * lit(4.f) * lit(2.f) * xz + lit(kC3[5]) * h(14, c) * (xx - yy));
+                        dx[c] += (lit(kC3[0]) * h(9, c) * lit(3.) * lit(2.) * xy + lit(kC3[1]) * h(10, c) * yz +
+                                  lit(kC3[2]) * h(11, c) * lit(-2.) * xy + lit(kC3[3]) * h(12, c) * lit(-3.) * lit(2.) * xz +
+                                  lit(kC3[4]) * h(13, c) * (lit(-3.) * xx + lit(4.) * zz - yy) +
+                                  lit(kC3[5]) * h(14, c) * lit(2.) * xz + lit(kC3[6]) * h(15, c) * lit(3.) * (xx - yy));
+                        dy[c] += (lit(kC3[0]) * h(9, c) * lit(3.) * (xx - yy) + lit(kC3[1]) * h(10, c) * xz +
+                                  lit(kC3[2]) * h(11, c) * (lit(-3.) * yy + lit(4.) * zz - xx) +
+                                  lit(kC3[3]) * h(12, c) * lit(-3.) * lit(2.) * yz + lit(kC3[4]) * h(13, c) * lit(-2.) * xy +
+                                  lit(kC3[5]) * h(14, c) * lit(-2.) * yz + lit(kC3[6]) * h(15, c) * lit(-3.) * lit(2.) * xy);
+                        dz[c] += (lit(kC3[1]) * h(10, c) * xy + lit(kC3[2]) * h(11, c) * lit(4.) * lit(2.) * yz +
+                                  lit(kC3[3]) * h(12, c) * lit(3.) * (lit(2.) * zz - xx - yy) +
+                                  lit(kC3[4]) * h(13, c) * lit(4.) * lit(2.) * xz + lit(kC3[5]) * h(14, c) * (xx - yy));
                     }
                 }
             }
@@ -852,7 +852,7 @@ struct Oracle {
                               dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]};
         // auxiliary.h:114-124
         const real s2 = dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2];
-        const real i32 = lit(1.0f) / std::sqrt(s2 * s2 * s2);
+        const real i32 = lit(1.0) / std::sqrt(s2 * s2 * s2);
         const real dm[3] = {((+s2 - dor[0] * dor[0]) * ddir[0] - dor[1] * dor[0] * ddir[1] - dor[2] * dor[0] * ddir[2]) * i32,
                             (-dor[0] * dor[1] * ddir[0] + (s2 - dor[1] * dor[1]) * ddir[1] - dor[2] * dor[1] * ddir[2]) * i32,
                             (-dor[0] * dor[2] * ddir[0] - dor[1] * dor[2] * ddir[1] + (s2 - dor[2] * dor[2]) * ddir[2]) * i32};
@@ -874,10 +874,10 @@ struct Oracle {
         Sm.c[0][0] = s[0]; Sm.c[1][1] = s[1]; Sm.c[2][2] = s[2];
         const M3<real> Mm = mul(Sm, Rm);
         const real* dc = &dL_dcov3D[6 * idx];
-        const real hf = lit(0.5f);
+        const real hf = lit(0.5);
         M3<real> dSig(dc[0], hf * dc[1], hf * dc[2], hf * dc[1], dc[3], hf * dc[4], hf * dc[2], hf * dc[4], dc[5]);
         M3<real> twoM;
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) twoM.c[a][b] = lit(2.0f) * Mm.c[a][b];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) twoM.c[a][b] = lit(2.0) * Mm.c[a][b];
         const M3<real> dM = mul(twoM, dSig);
         const M3<real> Rt = tr(Rm), dMt = tr(dM);
         auto dot = [](const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
@@ -920,7 +920,7 @@ struct Oracle {
             const real* m = means3D + 3 * idx;
             real mh[4];
             xform4x4(m, proj, mh);
-            const real mw = lit(1.0f) / (mh[3] + lit(0.0000001f));
+            const real mw = lit(1.0) / (mh[3] + lit(0.0000001));
             const real mul1 = (proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12]) * mw * mw;
             const real mul2 = (proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13]) * mw * mw;
             const real g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
@@ -978,7 +978,7 @@ struct Oracle {
         for (int i = 0; i < P; i++) {
             real pv[3];
             xform4x3(means3D + 3 * i, view, pv);
-            present[i] = pv[2] <= lit(0.2f) ? 0 : 1;
+            present[i] = pv[2] <= lit(0.2) ? 0 : 1;
         }
     }
 };

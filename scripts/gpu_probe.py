@@ -79,7 +79,7 @@ def main():
                   features="features", means2D="means2D")
         if variant == "svgss":
             gm["vfeatures"] = "vfeatures"
-        r["bwd"] = {k: stats(leaves[k].grad.detach().cpu().numpy(), gr[v]) for k, v in gm.items()}
+        r["bwd"] = {k: stats(leaves[k].grad.detach().cpu().numpy(), gr[v]) for k, v in gm.items() if leaves[k].grad is not None}
         res[name] = r
         print(json.dumps({name: r}, indent=1))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -1,0 +1,121 @@
+"""Generates tests/golden/*.npz by importing the REFERENCE's importable Python helpers from /root/reference.
+
+Runs only in the authoring container (the reference tree is absent on the GPU box); the fixtures are data
+(inputs + expected outputs), no reference source is copied.  Heavy / CUDA-only reference dependencies are
+replaced by inert stubs just so that the modules import.
+
+    python scripts/make_golden.py
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import inspect
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+STUBS = {"plyfile", "simple_knn", "custom_knn", "kornia", "torchvision", "cv2", "imageio", "nvdiffrast", "slangtorch",
+         "pyexr", "submodules", "pbgi", "svgss_rasterization", "rgss_rasterization", "lpipsPyTorch", "dearpygui",
+         "tqdm", "PIL", "matplotlib", "skimage", "scipy", "open3d", "trimesh", "bvh"}
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        m = _Stub(self.__name__ + "." + name)
+        sys.modules[m.__name__] = m
+        return m
+
+    def __call__(self, *a, **k):
+        return _Stub("stubcall")
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in STUBS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _Stub(spec.name)
+
+    def exec_module(self, module):
+        module.__path__ = []
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sys.meta_path.insert(0, _Finder())
+    sys.path.insert(0, REF)
+    import torch.utils.cpp_extension as cpp
+    cpp.load = lambda *a, **k: _Stub("_C")
+    rng = np.random.default_rng(1234)
+
+    # ---- SH evaluation (utils/sh_utils.py:71-128 as used at gaussian_renderer/svgss.py:92-96) ----
+    from utils.sh_utils import eval_sh
+    n = 257
+    pos = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    campos = np.array([0.3, -2.5, 1.1], dtype=np.float32)
+    sh = rng.normal(0, 0.6, size=(n, 16, 3)).astype(np.float32)
+    d = torch.from_numpy(pos) - torch.from_numpy(campos)[None]
+    d = d / d.norm(dim=-1, keepdim=True)
+    cols = {}
+    for deg in range(4):
+        shs_view = torch.from_numpy(sh).transpose(1, 2).reshape(-1, 3, 16)
+        rgb = torch.clamp_min(eval_sh(deg, shs_view, d) + 0.5, 0.0)
+        cols[f"rgb_deg{deg}"] = rgb.numpy().astype(np.float32)
+    np.savez(os.path.join(OUT, "sh_eval.npz"), pos=pos, campos=campos, sh=sh, **cols)
+
+    # ---- quaternion -> rotation (utils/general_utils.py:231-239) ----
+    from utils.general_utils import quaternion2rotmat
+    q = rng.normal(size=(129, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    Rm = quaternion2rotmat(torch.from_numpy(q)).numpy().astype(np.float32)
+    np.savez(os.path.join(OUT, "quat_rot.npz"), q=q, R=Rm)
+
+    # ---- camera matrices (utils/graphics_utils.py:136-168, scene/cameras.py:69-80) ----
+    from utils.graphics_utils import getProjectionMatrix, getWorld2View2
+    cams = {}
+    for i in range(4):
+        A = rng.normal(size=(3, 3))
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] *= -1
+        t = rng.normal(size=3)
+        fovx, fovy = float(rng.uniform(0.4, 1.2)), float(rng.uniform(0.4, 1.2))
+        w2c = getWorld2View2(Q, t)
+        wvt = torch.tensor(w2c).transpose(0, 1)
+        P = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy)
+        full = (wvt.unsqueeze(0).bmm(P.transpose(0, 1).unsqueeze(0))).squeeze(0)
+        center = wvt.inverse()[3, :3]
+        cams[f"R{i}"], cams[f"t{i}"] = Q.astype(np.float64), t.astype(np.float64)
+        cams[f"fov{i}"] = np.array([fovx, fovy])
+        cams[f"w2c{i}"], cams[f"P{i}"] = np.asarray(w2c, dtype=np.float32), P.numpy().astype(np.float32)
+        cams[f"full{i}"], cams[f"center{i}"] = full.numpy().astype(np.float32), center.numpy().astype(np.float32)
+    np.savez(os.path.join(OUT, "cameras.npz"), **cams)
+
+    # ---- binding API surface (gaussian_renderer/{svgss,rgss}_rasterization.py) ----
+    api = {}
+    for mod in ("svgss_rasterization", "rgss_rasterization"):
+        m = importlib.import_module("gaussian_renderer." + mod)
+        api[mod + ".settings_fields"] = np.array(m.GaussianRasterizationSettings._fields)
+        api[mod + ".forward_args"] = np.array(list(inspect.signature(m.GaussianRasterizer.forward).parameters))
+        api[mod + ".function_forward_args"] = np.array(list(inspect.signature(m._RasterizeGaussians.forward).parameters))
+        api[mod + ".function_backward_args"] = np.array(list(inspect.signature(m._RasterizeGaussians.backward).parameters))
+        api[mod + ".public"] = np.array(sorted(k for k in vars(m) if k in (
+            "GaussianRasterizationSettings", "GaussianRasterizer", "_RasterizeGaussians", "rasterize_gaussians", "_C",
+            "cpu_deep_copy_tuple")))
+    np.savez(os.path.join(OUT, "binding_api.npz"), **api)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()

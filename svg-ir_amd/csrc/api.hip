@@ -8,7 +8,9 @@
 // the HIP event timings.
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,8 +21,10 @@ using namespace svgir;
 namespace {
 
 thread_local std::string g_err;
-thread_local bool g_prof = false;
-thread_local std::vector<std::pair<const char*, float>> g_times;
+// profiling state is process-wide: the autograd engine runs backward on its own thread
+std::atomic<bool> g_prof{false};
+std::mutex g_times_mu;
+std::vector<std::pair<const char*, float>> g_times;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -58,6 +62,7 @@ struct StageTimer {
     void resolve(bool append) {
         if (!on) return;
         hipStreamSynchronize(s);
+        std::lock_guard<std::mutex> lk(g_times_mu);
         if (!append) g_times.clear();
         for (size_t i = 1; i < ev.size(); i++) {
             float ms = 0.f;
@@ -126,8 +131,9 @@ size_t svgir_image_bytes(int32_t W, int32_t H) { return image_layout(nullptr, W,
 size_t svgir_binning_bytes(int32_t R) { return bin_layout(nullptr, R).bytes; }
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H) { return image_layout(nullptr, W, H).ncontrib_off; }
 const char* svgir_last_error(void) { return g_err.c_str(); }
-void svgir_set_profiling(int enabled) { g_prof = enabled != 0; }
+void svgir_set_profiling(int enabled) { g_prof.store(enabled != 0); }
 int svgir_last_timings(const char** names, float* ms, int cap) {
+    std::lock_guard<std::mutex> lk(g_times_mu);
     int n = 0;
     for (auto& kv : g_times) {
         if (n >= cap) break;
@@ -164,7 +170,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     const GeomLayout G = geom_layout(gblob, P);
     const ImageLayout I = image_layout(iblob, W, H);
 
-    StageTimer tm(s, g_prof);
+    StageTimer tm(s, g_prof.load());
     auto check = [&](const char* what) -> int {
         if (!p->debug) {
             hipError_t e = hipGetLastError();
@@ -268,7 +274,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     const ImageLayout I = image_layout(image_blob, W, H);
     const BinLayout B = bin_layout(binning_blob, R);
     const int fin = tile_sort_plan(T).passes & 1;
-    StageTimer tm(s, g_prof);
+    StageTimer tm(s, g_prof.load());
 
     RenderBwdArgs ba;
     ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = f.svgss ? p->VS : 0;

@@ -1,0 +1,113 @@
+"""CPU-only checks of the C-ABI shared library and the drop-in Python surface (no GPU compute is launched)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_symbol_of_the_header(built):
+    from gaussian_renderer import _native
+    hdr = open(os.path.join(ROOT, "include", "svgir_raster.h")).read()
+    declared = set(re.findall(r"\b(svgir_[a-z_]+)\s*\(", hdr))
+    declared -= {"svgir_alloc_fn"}
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    lib = C.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.svgir_abi_version() == 1
+
+
+def test_struct_layouts_match_header_field_order(built):
+    """The ctypes mirrors must list the same fields, in the same order, as the C structs."""
+    from gaussian_renderer import _native
+    hdr = open(os.path.join(ROOT, "include", "svgir_raster.h")).read()
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.replace("*", " ").split(None, 1)[1] if not decl.startswith("const") else decl.replace("*", " ").split(None, 2)[2]
+            out += [n.strip() for n in names.split(",")]
+        return out
+
+    assert fields("svgir_params") == [f[0] for f in _native.Params._fields_]
+    assert fields("svgir_outputs") == [f[0] for f in _native.Outputs._fields_]
+    assert fields("svgir_grads") == [f[0] for f in _native.Grads._fields_]
+
+
+def test_blob_sizes_and_error_reporting(built):
+    from gaussian_renderer import _native as N
+    lib = N.lib
+    assert lib.svgir_geom_bytes(1000) > 1000 * 96
+    assert lib.svgir_geom_bytes(2000) > lib.svgir_geom_bytes(1000)
+    assert lib.svgir_image_bytes(800, 800) >= 800 * 800 * 12
+    off = lib.svgir_image_ncontrib_offset(800, 800)
+    assert off % 256 == 0 and off + 800 * 800 * 4 <= lib.svgir_image_bytes(800, 800)
+    assert lib.svgir_binning_bytes(0) > 0 and lib.svgir_binning_bytes(10 ** 6) >= 16 * 10 ** 6
+    # invalid parameter blocks are rejected before any HIP call, with a message
+    p = N.Params()
+    p.variant, p.P, p.W, p.H = 7, 10, 16, 16
+    rc = lib.svgir_forward(p, N.Outputs(), N.ALLOC_FN(lambda n, c: 0), None, N.ALLOC_FN(lambda n, c: 0), None,
+                           N.ALLOC_FN(lambda n, c: 0), None, None)
+    assert rc == -1 and "variant" in N.last_error()
+    p.variant = N.SVGSS
+    rc = lib.svgir_forward(p, N.Outputs(), N.ALLOC_FN(lambda n, c: 0), None, N.ALLOC_FN(lambda n, c: 0), None,
+                           N.ALLOC_FN(lambda n, c: 0), None, None)
+    assert rc == -1 and "must be provided" in N.last_error()
+    with pytest.raises(RuntimeError):
+        N.check(rc, "forward")
+
+
+@pytest.mark.parametrize("mod", ["svgss_rasterization", "rgss_rasterization"])
+def test_binding_surface_matches_reference_module(built, mod):
+    """Field names / argument orders captured from the reference's own modules (scripts/make_golden.py)."""
+    import importlib
+    import inspect
+    g = np.load(os.path.join(GOLD, "binding_api.npz"))
+    m = importlib.import_module("gaussian_renderer." + mod)
+    assert list(m.GaussianRasterizationSettings._fields) == list(g[mod + ".settings_fields"])
+    assert list(inspect.signature(m.GaussianRasterizer.forward).parameters) == list(g[mod + ".forward_args"])
+    assert list(inspect.signature(m._RasterizeGaussians.forward).parameters) == list(g[mod + ".function_forward_args"])
+    assert list(inspect.signature(m._RasterizeGaussians.backward).parameters) == list(g[mod + ".function_backward_args"])
+    for name in g[mod + ".public"]:
+        assert hasattr(m, str(name)), name
+    for fn in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"):
+        assert hasattr(m._C, fn)
+
+
+@pytest.mark.parametrize("mod", ["svgss_rasterization", "rgss_rasterization"])
+def test_argument_validation_like_reference(built, mod):
+    import importlib
+    m = importlib.import_module("gaussian_renderer." + mod)
+    rast = m.GaussianRasterizer(raster_settings=None)
+    x = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(means3D=x, means2D=x, opacities=x[:, :1])
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(means3D=x, means2D=x, opacities=x[:, :1], shs=x, colors_precomp=x)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=x, means2D=x, opacities=x[:, :1], shs=x, scales=x)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=x, means2D=x, opacities=x[:, :1], shs=x, scales=x, rotations=x, cov3D_precomp=x)
+
+
+def test_cpu_tensors_fail_loudly_no_fallback(built):
+    """There is no CPU / eager fallback behind the bindings: CPU tensors are rejected."""
+    from svgir_harness import runner, scenes
+    sc = scenes.random_cloud(P=16, W=32, H=32, variant="svgss")
+    sct = runner.to_torch(sc, torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        runner.render(sct, "svgss")
+    sc = scenes.random_cloud(P=16, W=32, H=32, variant="rgss")
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        runner.render(runner.to_torch(sc, torch.device("cpu")), "rgss")
