@@ -64,8 +64,9 @@ typedef struct svgir_params {
     const float* cam_pos;       /* [3] */
     const float* prcppoint;     /* [2]  svgss; carried for API parity, unused by the arithmetic (Q11) */
     const float* patchbbox;     /* [4]  svgss: h0,w0,h1,w1 in pixels */
-    const float* config;        /* HOST pointer, [config_len] floats; svgss: surface, normalize_depth,
-                                   per_pixel_depth, (lrn_cam).  Entries >= config_len read as 0 (Q7).
+    const float* config;        /* [config_len] floats ON THE DEVICE, read by the kernels like the reference does;
+                                   svgss: surface, normalize_depth, per_pixel_depth, (lrn_cam).  Entries >=
+                                   config_len read as 0 (Q7: the reference reads config[3] out of bounds).
                                    rgss ignores it (compile-time {1,1,1} in the reference). */
     int32_t config_len;
     float scale_modifier;

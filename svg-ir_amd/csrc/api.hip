@@ -74,23 +74,11 @@ struct StageTimer {
     }
 };
 
-struct Flags {
-    bool svgss, surface, normalize_depth, pix_depth, lrn_cam;
-};
-Flags read_flags(const svgir_params* p) {
-    Flags f;
-    f.svgss = p->variant == SVGIR_SVGSS;
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
-    if (f.svgss) {
-        for (int i = 0; i < 4 && i < p->config_len; i++) c[i] = p->config ? p->config[i] : 0.f;  // Q7
-    } else {
-        c[0] = c[1] = c[2] = 1.f;  // rgss auxiliary.h:41-46
-    }
-    f.surface = c[0] > 0;
-    f.normalize_depth = c[1] > 0;
-    f.pix_depth = c[2] > 0;
-    f.lrn_cam = f.svgss && c[3] > 0;
-    return f;
+CfgRef cfg_ref(const svgir_params* p) {
+    CfgRef c;
+    if (p->variant == SVGIR_SVGSS) { c.ptr = p->config; c.len = p->config ? p->config_len : 0; }
+    else { c.ptr = nullptr; c.len = -1; }
+    return c;
 }
 
 int validate(const svgir_params* p, bool fwd) {
@@ -152,14 +140,15 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     const int P = p->P, W = p->W, H = p->H;
     const size_t N = (size_t)W * H;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
-    const Flags f = read_flags(p);
+    const bool svgss = p->variant == SVGIR_SVGSS;
+    const CfgRef cfg = cfg_ref(p);
     if (P == 0) {  // rasterize_points.cu:100: nothing runs, outputs stay zero
         HIP_OK(hipMemsetAsync(o->out_color, 0, 3 * N * 4, s));
         HIP_OK(hipMemsetAsync(o->out_normal, 0, 3 * N * 4, s));
         HIP_OK(hipMemsetAsync(o->out_depth, 0, N * 4, s));
         HIP_OK(hipMemsetAsync(o->out_opacity, 0, N * 4, s));
         if (p->S) HIP_OK(hipMemsetAsync(o->out_feature, 0, (size_t)p->S * N * 4, s));
-        if (f.svgss && p->VS) HIP_OK(hipMemsetAsync(o->out_vfeature, 0, (size_t)(p->VS / 4) * N * 4, s));
+        if (svgss && p->VS) HIP_OK(hipMemsetAsync(o->out_vfeature, 0, (size_t)(p->VS / 4) * N * 4, s));
         return 0;
     }
     const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
@@ -189,10 +178,10 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     pa.opacities = p->opacities; pa.scales = p->scales; pa.rotations = p->rotations; pa.cov3D_precomp = p->cov3D_precomp;
     pa.view = p->viewmatrix; pa.proj = p->projmatrix; pa.campos = p->cam_pos; pa.patchbbox = p->patchbbox;
     pa.scale_modifier = p->scale_modifier; pa.tanx = p->tan_fovx; pa.tany = p->tan_fovy;
-    pa.focal_x = focal_x; pa.focal_y = focal_y; pa.surface = f.surface; pa.pix_depth = f.pix_depth;
+    pa.focal_x = focal_x; pa.focal_y = focal_y; pa.cfg = cfg;
     pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
     pa.radii = o->radii;
-    launch_preprocess(pa, f.svgss, s);
+    launch_preprocess(pa, svgss, s);
     if (int rc = check("preprocess")) return rc;
     tm.mark("preprocess");
 
@@ -236,20 +225,20 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     tm.mark("ranges");
 
     RenderArgs ra;
-    ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = f.svgss ? p->VS : 0;
+    ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = svgss ? p->VS : 0;
     ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
     ra.bg = p->background;
-    ra.surface = f.surface; ra.normalize_depth = f.normalize_depth; ra.pix_depth = f.pix_depth;
+    ra.cfg = cfg;
     ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
     ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
     ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
-    if (launch_render_fwd(ra, f.svgss, s) < 0)
+    if (launch_render_fwd(ra, svgss, s) < 0)
         return fail(SVGIR_ERR_INVALID, "no forward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ra.VS,
-                    f.svgss ? "svgss" : "rgss");
+                    svgss ? "svgss" : "rgss");
     if (int rc = check("render")) return rc;
     tm.mark("render");
 
-    if (!f.svgss && p->computer_pseudo_normal) {
+    if (!svgss && p->computer_pseudo_normal) {
         launch_image_ops(W, H, p->viewmatrix, focal_x, focal_y, p->cx, p->cy, o->out_opacity, o->out_depth,
                          o->out_pseudo_normal, o->out_surface_xyz, s);
         if (int rc = check("image ops")) return rc;
@@ -268,7 +257,8 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     hipStream_t s = (hipStream_t)stream;
     const int P = p->P, W = p->W, H = p->H;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
-    const Flags f = read_flags(p);
+    const bool svgss = p->variant == SVGIR_SVGSS;
+    const CfgRef cfg = cfg_ref(p);
     const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
     const GeomLayout G = geom_layout(geom_blob, P);
     const ImageLayout I = image_layout(image_blob, W, H);
@@ -277,10 +267,10 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     StageTimer tm(s, g_prof.load());
 
     RenderBwdArgs ba;
-    ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = f.svgss ? p->VS : 0;
+    ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = svgss ? p->VS : 0;
     ba.ranges = I.ranges; ba.point_list = B.val[fin]; ba.rec = G.rec; ba.features = p->features; ba.vfeatures = p->vfeatures;
     ba.bg = p->background;
-    ba.surface = f.surface; ba.normalize_depth = f.normalize_depth; ba.pix_depth = f.pix_depth;
+    ba.cfg = cfg;
     ba.backward_geometry = p->backward_geometry;
     ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;
     ba.g_color = g->dL_dout_color; ba.g_normal = g->dL_dout_normal; ba.g_depth = g->dL_dout_depth;
@@ -288,9 +278,9 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.dL_dmean2D = g->dL_dmeans2D; ba.dL_dconic = g->dL_dconic; ba.dL_dopacity = g->dL_dopacity; ba.dL_dcolor = g->dL_dcolors;
     ba.dL_dfeature = g->dL_dfeatures; ba.dL_dvfeature = g->dL_dvfeatures; ba.dL_dnormal = g->dL_dnormal; ba.dL_ddepth = g->dL_ddepth;
     if (R > 0) {
-        if (launch_render_bwd(ba, f.svgss, s) < 0)
+        if (launch_render_bwd(ba, svgss, s) < 0)
             return fail(SVGIR_ERR_INVALID, "no backward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ba.VS,
-                        f.svgss ? "svgss" : "rgss");
+                        svgss ? "svgss" : "rgss");
     }
     tm.mark("render_bwd");
 
@@ -300,7 +290,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ga.cov3D = p->cov3D_precomp ? p->cov3D_precomp : G.cov3D; ga.view = p->viewmatrix; ga.proj = p->projmatrix; ga.campos = p->cam_pos;
     ga.radii = radii; ga.clamped = G.clamped;
     ga.scale_modifier = p->scale_modifier; ga.tanx = p->tan_fovx; ga.tany = p->tan_fovy; ga.focal_x = focal_x; ga.focal_y = focal_y;
-    ga.surface = f.surface; ga.lrn_cam = f.lrn_cam; ga.svgss = f.svgss;
+    ga.cfg = cfg; ga.svgss = svgss;
     ga.dL_dmean2D = g->dL_dmeans2D; ga.dL_dconic = g->dL_dconic; ga.dL_dcolor = g->dL_dcolors; ga.dL_dnormal = g->dL_dnormal;
     ga.dL_ddepth = g->dL_ddepth;
     ga.dL_dmean3D = g->dL_dmeans3D; ga.dL_dcov3D = g->dL_dcov3D; ga.dL_dsh = g->dL_dsh; ga.dL_dscale = g->dL_dscales;

@@ -128,13 +128,24 @@ inline TileSortPlan tile_sort_plan(int T) {
     return p;
 }
 
+// The svgss `config` tensor ([surface, normalize_depth, per_pixel_depth, (lrn_cam)]) stays on the device, exactly as
+// in the reference (kernels read config[i] > 0); entries >= len read as false (quirk Q7).  rgss uses the
+// compile-time constant {1,1,1} of its auxiliary.h:41-46, encoded as len < 0.
+struct CfgRef { const float* ptr; int len; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool cfg_flag(const CfgRef& c, int i) {
+    if (c.len < 0) return i < 3;
+    return i < c.len && c.ptr[i] > 0.f;
+}
+#endif
+
 // ---- kernel argument blocks --------------------------------------------------------------------------------
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos, *patchbbox;
     float scale_modifier, tanx, tany, focal_x, focal_y;
-    int surface, pix_depth;
+    CfgRef cfg;
     float* rec; float* cov3D; uint32_t* clamped; uint32_t* tiles; uint32_t* key; uint32_t* idx; int32_t* radii;
 };
 
@@ -143,7 +154,7 @@ struct RenderArgs {
     const uint32_t* ranges; const uint32_t* point_list;
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
-    int surface, normalize_depth, pix_depth;
+    CfgRef cfg;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
 };
@@ -153,7 +164,7 @@ struct RenderBwdArgs {
     const uint32_t* ranges; const uint32_t* point_list;
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
-    int surface, normalize_depth, pix_depth, backward_geometry;
+    CfgRef cfg; int backward_geometry;
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
@@ -164,7 +175,7 @@ struct GeomBwdArgs {
     const float *means3D, *shs, *scales, *rotations, *cov3D, *view, *proj, *campos;
     const int32_t* radii; const uint32_t* clamped;
     float scale_modifier, tanx, tany, focal_x, focal_y;
-    int surface, lrn_cam, svgss;
+    CfgRef cfg; int svgss;
     const float *dL_dmean2D, *dL_dconic, *dL_dcolor, *dL_dnormal, *dL_ddepth;
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot, *dL_dviewmat, *dL_dprojmat, *dL_dcampos;
 };

@@ -45,6 +45,8 @@ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    const bool surface = cfg_flag(a.cfg, 0);
+    const bool lrn_cam = a.svgss && a.cfg.len >= 0 && cfg_flag(a.cfg, 3);
     const float* V = a.view;
     const float* PR = a.proj;
     const float mean[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         const float dJ11 = Wm.m[1][0] * dT10 + Wm.m[1][1] * dT11 + Wm.m[1][2] * dT12;
         const float dJ12 = Wm.m[2][0] * dT10 + Wm.m[2][1] * dT11 + Wm.m[2][2] * dT12;
         const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-        if (a.lrn_cam) {
+        if (lrn_cam) {
             const float dW[16] = {dT00 * J0, dT10 * J2, dT00 * J1 + dT10 * J3, 0, dT01 * J0, dT11 * J2,
                                   dT01 * J1 + dT11 * J3, 0, dT02 * J0, dT12 * J2, dT02 * J1 + dT12 * J3, 0, 0, 0, 0, 0};
             for (int i = 0; i < 16; i++) if (dW[i] != 0.f) atomic_add_f32(&a.dL_dviewmat[i], dW[i]);
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         const float fd[3] = {dd * V[2], dd * V[6], dd * V[10]};
 #pragma unroll
         for (int i = 0; i < 3; i++) dmean[i] += dm[i] + fd[i];
-        if (a.lrn_cam) {
+        if (lrn_cam) {
             const float pm[16] = {g2x * mean[0] * mw, g2y * mean[0] * mw, 0, g2x * -mul1 * mean[0] + g2y * -mul2 * mean[0],
                                   g2x * mean[1] * mw, g2y * mean[1] * mw, 0, g2x * -mul1 * mean[1] + g2y * -mul2 * mean[1],
                                   g2x * mean[2] * mw, g2y * mean[2] * mw, 0, g2x * -mul1 * mean[2] + g2y * -mul2 * mean[2],
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         const float dm[3] = {((+s2 - dor[0] * dor[0]) * ddir[0] - dor[1] * dor[0] * ddir[1] - dor[2] * dor[0] * ddir[2]) * i32,
                              (-dor[0] * dor[1] * ddir[0] + (s2 - dor[1] * dor[1]) * ddir[1] - dor[2] * dor[1] * ddir[2]) * i32,
                              (-dor[0] * dor[2] * ddir[0] - dor[1] * dor[2] * ddir[1] + (s2 - dor[2] * dor[2]) * ddir[2]) * i32};
-        if (a.lrn_cam)
+        if (lrn_cam)
             for (int i = 0; i < 3; i++) if (dm[i] != 0.f) atomic_add_f32(&a.dL_dcampos[i], -dm[i]);
 #pragma unroll
         for (int i = 0; i < 3; i++) dmean[i] += dm[i];
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         float* dsc = a.dL_dscale + 3 * idx;
         dsc[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
         dsc[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
-        dsc[2] = a.surface ? 0.f : (Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2]);
+        dsc[2] = surface ? 0.f : (Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2]);
         Mat3 dRt = dMt;
 #pragma unroll
         for (int k = 0; k < 3; k++) { dRt.m[0][k] *= s[0]; dRt.m[1][k] *= s[1]; dRt.m[2][k] *= s[2]; }
@@ -261,7 +263,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         dRt.m[2][0] += gn[0] * V[0] + gn[1] * V[1] + gn[2] * V[2];
         dRt.m[2][1] += gn[0] * V[4] + gn[1] * V[5] + gn[2] * V[6];
         dRt.m[2][2] += gn[0] * V[8] + gn[1] * V[9] + gn[2] * V[10];
-        if (a.lrn_cam) {
+        if (lrn_cam) {
             const float wN[3] = {Rm.m[0][2], Rm.m[1][2], Rm.m[2][2]};
             const float dv[16] = {gn[0] * wN[0], gn[1] * wN[0], gn[2] * wN[0], 0, gn[0] * wN[1], gn[1] * wN[1], gn[2] * wN[1], 0,
                                   gn[0] * wN[2], gn[1] * wN[2], gn[2] * wN[2], 0, 0, 0, 0, 0};

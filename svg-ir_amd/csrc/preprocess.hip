@@ -106,6 +106,7 @@ template <bool SVGSS>
 __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.P) return;
+    const bool surface = cfg_flag(a.cfg, 0), pix_depth = cfg_flag(a.cfg, 2);
     // defaults for a culled Gaussian
     a.radii[idx] = 0;
     a.tiles[idx] = 0;
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     float nv[3] = {0, 0, 0}, J[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) J[i] = 0;
-    if (a.surface) {
+    if (surface) {
         const float nw[3] = {Rm.m[0][2], Rm.m[1][2], Rm.m[2][2]};
         const float a0w[3] = {Rm.m[0][0], Rm.m[1][0], Rm.m[2][0]};
         const float a1w[3] = {Rm.m[0][1], Rm.m[1][1], Rm.m[2][1]};
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
         }
         const float dot = pv[0] * nv[0] + pv[1] * nv[1] + pv[2] * nv[2];
         if ((double)dot > -0.01) return;  // back-facing
-        if (a.pix_depth) {
+        if (pix_depth) {
             // local homography between the screen and the tangent plane (auxiliary.h:291-388)
             const float qx = pv[0] / pv[2], qy = pv[1] / pv[2];
             const float S_fix = 1000, Svp = (a.focal_x + a.focal_y) / 2;
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
             for (int rr = 0; rr < 3; rr++) Sm.m[c][rr] = 0.f;
         Sm.m[0][0] = a.scale_modifier * a.scales[3 * idx];
         Sm.m[1][1] = a.scale_modifier * a.scales[3 * idx + 1];
-        Sm.m[2][2] = (a.scale_modifier * (a.surface ? 1.0f : 0.0f)) != 0.0f ? 0.0f : a.scales[3 * idx + 2];
+        Sm.m[2][2] = (a.scale_modifier * (surface ? 1.0f : 0.0f)) != 0.0f ? 0.0f : a.scales[3 * idx + 2];
         const Mat3 Mm = mmul(Sm, Rm);
         const Mat3 Sg = mmul(mtr(Mm), Mm);
         c3[0] = Sg.m[0][0]; c3[1] = Sg.m[0][1]; c3[2] = Sg.m[0][2];

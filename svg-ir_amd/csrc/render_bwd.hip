@@ -45,13 +45,14 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
     const float* __restrict__ rec = a.rec;
     const float* __restrict__ feat = a.features;
     const float* __restrict__ vfeat = a.vfeatures;
-    const bool sp = a.surface && a.pix_depth;
+    const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
+    const bool sp = surface && cfg_flag(a.cfg, 2);
     const bool bgeom = SVGSS ? true : (a.backward_geometry != 0);
     const size_t N_ = (size_t)a.W * a.H;
     const size_t pid = inside ? (size_t)a.W * py + px : 0;
 
     const float T_final = inside ? a.final_T[pid] : 0.f;
-    const float D_final = (inside && a.normalize_depth) ? a.final_D[pid] : 0.f;
+    const float D_final = (inside && normalize_depth) ? a.final_D[pid] : 0.f;
     const uint32_t last_contributor = inside ? (uint32_t)a.n_contrib[pid] : 0u;
     float gC[3], gN[3], gF[SS], gVF[VV], gD = 0.f, gO = 0.f;
 #pragma unroll
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                         dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
                     }
                 }
-                if (a.surface) {
+                if (surface) {
                     const float nn[3] = {r[R_NX], r[R_NY], r[R_NZ]};
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                     acc_d = last_alpha * last_d + inv_keep * acc_d;
                     last_d = d_cur;
                     float dch_d = gD, da = 0.f;
-                    if (a.normalize_depth) {
+                    if (normalize_depth) {
                         const float omt = 1.f - T_final;
                         dch_d = gD / omt;
                         da = gD * D_final / omt / omt * -T_final / oma / T;
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                 dL_dalpha += gO * tf_oma;
                 last_alpha = alpha;
                 dL_dalpha -= tf_oma * bgdot;
-                if (!a.normalize_depth) dL_dalpha -= tf_oma * (10.f * gD);
+                if (!normalize_depth) dL_dalpha -= tf_oma * (10.f * gD);
                 const float dL_ddist = dL_dalpha * B.y * -0.5f * G;
                 float ndc_x = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx;
                 float ndc_y = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy;

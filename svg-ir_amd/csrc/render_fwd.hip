@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
     const float* __restrict__ rec = a.rec;
     const float* __restrict__ feat = a.features;
     const float* __restrict__ vfeat = a.vfeatures;
-    const bool sp = a.surface && a.pix_depth;
+    const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
+    const bool sp = surface && cfg_flag(a.cfg, 2);
 
     bool done = !inside;
     float T = 1.0f, D = 0.f;
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
             }
             D += dep * w;
             C[0] += r[R_R] * w; C[1] += r[R_G] * w; C[2] += r[R_B] * w;
-            if (a.surface) { N[0] += r[R_NX] * w; N[1] += r[R_NY] * w; N[2] += r[R_NZ] * w; }
+            if (surface) { N[0] += r[R_NX] * w; N[1] += r[R_NY] * w; N[2] += r[R_NZ] * w; }
             if (S > 0) {
                 const float* __restrict__ f = feat + (size_t)gid * S;
 #pragma unroll
@@ -137,10 +138,10 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
         for (int ch = 0; ch < S; ch++) a.out_feature[ch * N_ + pid] = F[ch];
 #pragma unroll
         for (int ch = 0; ch < VC; ch++) a.out_vfeature[ch * N_ + pid] = VF[ch];
-        a.out_normal[pid] = a.surface ? N[0] : 0.f;
-        a.out_normal[N_ + pid] = a.surface ? N[1] : 0.f;
-        a.out_normal[2 * N_ + pid] = a.surface ? N[2] : 0.f;
-        a.out_depth[pid] = a.normalize_depth ? D / (1.f - T) : D + T * 10.f;
+        a.out_normal[pid] = surface ? N[0] : 0.f;
+        a.out_normal[N_ + pid] = surface ? N[1] : 0.f;
+        a.out_normal[2 * N_ + pid] = surface ? N[2] : 0.f;
+        a.out_depth[pid] = normalize_depth ? D / (1.f - T) : D + T * 10.f;
         a.out_opacity[pid] = 1.f - T;
         a.final_D[pid] = D;
     }

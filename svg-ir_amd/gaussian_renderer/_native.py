@@ -24,7 +24,7 @@ class Params(C.Structure):
         ("features", C.c_void_p), ("vfeatures", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
         ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p), ("prcppoint", C.c_void_p), ("patchbbox", C.c_void_p),
-        ("config", C.POINTER(C.c_float)), ("config_len", C.c_int32),
+        ("config", C.c_void_p), ("config_len", C.c_int32),
         ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("cx", C.c_float),
         ("cy", C.c_float),
         ("prefiltered", C.c_int32), ("computer_pseudo_normal", C.c_int32), ("backward_geometry", C.c_int32),
@@ -137,24 +137,6 @@ class BlobAllocator:
         if t is None:
             t = torch.empty(0, dtype=torch.uint8, device=self.device)
         return t
-
-
-_config_cache = {}
-
-
-def host_config(cfg):
-    """Host copy of the tiny `config` tensor (one device->host read per distinct tensor version)."""
-    if cfg is None:
-        return (C.c_float * 1)(), 0
-    key = (cfg.data_ptr(), cfg._version, cfg.numel(), str(cfg.device))
-    hit = _config_cache.get(key)
-    if hit is None:
-        vals = [float(v) for v in cfg.detach().reshape(-1).tolist()]
-        hit = ((C.c_float * max(1, len(vals)))(*vals), len(vals))
-        if len(_config_cache) > 64:
-            _config_cache.clear()
-        _config_cache[key] = hit
-    return hit
 
 
 def stream_ptr(device):

@@ -53,9 +53,8 @@ class _CBinding:
         if P != 0:
             keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, vfeatures, opacity, scales,
                                               rotations, cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint,
-                                              patchbbox)]
-            (bg, m3, shc, col, fe, vf, op, sc, ro, cv, vm, pm, cp, pr, pb) = keep
-            cfg, cfg_len = N.host_config(config)
+                                              patchbbox, config)]
+            (bg, m3, shc, col, fe, vf, op, sc, ro, cv, vm, pm, cp, pr, pb, cfg) = keep
             p = N.Params()
             p.variant, p.P, p.S, p.VS, p.D, p.W, p.H = N.SVGSS, P, S, VS, int(degree), W, H
             p.M = shc.size(1) if (shc is not None and shc.numel() != 0) else 0
@@ -64,7 +63,7 @@ class _CBinding:
             p.scales, p.rotations, p.cov3D_precomp = N.ptr(sc), N.ptr(ro), N.ptr(cv)
             p.viewmatrix, p.projmatrix, p.cam_pos = N.ptr(vm), N.ptr(pm), N.ptr(cp)
             p.prcppoint, p.patchbbox = N.ptr(pr), N.ptr(pb)
-            p.config, p.config_len = cfg, cfg_len
+            p.config, p.config_len = N.ptr(cfg), (cfg.numel() if cfg is not None else 0)
             p.scale_modifier, p.tan_fovx, p.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
             p.cx, p.cy = W / 2.0, H / 2.0
             p.prefiltered, p.debug = int(bool(prefiltered)), int(bool(debug))
@@ -102,9 +101,8 @@ class _CBinding:
             keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, vfeatures, scales, rotations,
                                               cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint, patchbbox,
                                               dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac,
-                                              dL_dout_feature, dL_dout_vfeature)]
-            (bg, m3, shc, col, fe, vf, sc, ro, cv, vm, pm, cp, pr, pb, gc, gn, gd, go, gf, gvf) = keep
-            cfg, cfg_len = N.host_config(config)
+                                              dL_dout_feature, dL_dout_vfeature, config)]
+            (bg, m3, shc, col, fe, vf, sc, ro, cv, vm, pm, cp, pr, pb, gc, gn, gd, go, gf, gvf, cfg) = keep
             p = N.Params()
             p.variant, p.P, p.S, p.VS, p.D, p.M, p.W, p.H = N.SVGSS, P, S, VS, int(degree), M, W, H
             p.background, p.means3D, p.shs, p.colors_precomp = N.ptr(bg), N.ptr(m3), N.ptr(shc), N.ptr(col)
@@ -112,7 +110,7 @@ class _CBinding:
             p.scales, p.rotations, p.cov3D_precomp = N.ptr(sc), N.ptr(ro), N.ptr(cv)
             p.viewmatrix, p.projmatrix, p.cam_pos = N.ptr(vm), N.ptr(pm), N.ptr(cp)
             p.prcppoint, p.patchbbox = N.ptr(pr), N.ptr(pb)
-            p.config, p.config_len = cfg, cfg_len
+            p.config, p.config_len = N.ptr(cfg), (cfg.numel() if cfg is not None else 0)
             p.scale_modifier, p.tan_fovx, p.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
             p.debug = int(bool(debug))
             g = N.Grads()
