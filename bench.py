@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Gaussian-surfels/s, forward + backward, one 800x800 view per step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3_train|...]
+
+One process per GPU (launched by torchrun for N > 1).  A "step" is one forward+backward pass of the rasterizer
+over one synthetic view (inputs resident in HBM before the timed region), through the drop-in binding layer
+(`_C.rasterize_gaussians` + `_C.rasterize_gaussians_backward` -> C ABI -> HIP kernels).  For N > 1 the views are
+sharded (each rank renders its own camera; weak scaling) and the only collective is one fused all_gather of a
+3-float metrics vector per step (RCCL over xGMI).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     dominant kernel (backward composite): algorithmic bytes (SURVEY 8d formula with the measured R)
+                  / average kernel time from HIP events recorded on the launch stream DURING the timed steps,
+                  against the 8 TB/s HBM peak;
+  "cpu_baseline": the CPU oracle (port of the reference kernels; the reference has no CPU path) timed on the host
+                  cores on a bounded number of the same steps (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "svg-ir_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(P, R, W, H, S, VS, svgss):
+    """per-instance gather G and the forward/backward composite byte models."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    G = 8 + 16 + 12 + 4 + 12 + 40 + (8 if svgss else 0) + 4 * S + 4 * VS
+    pix = W * H * (44 + 4 * S + VS)
+    fwd = 8 * T + R * (4 + G) + pix + 4 * P
+    bwd = 8 * T + R * (4 + G) + 2 * R * (52 + 4 * S + 4 * VS) + pix
+    return dict(G=G, fwd=fwd, bwd=bwd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    args = ap.parse_args()
+
+    from svgir_harness import cameras, runner, scenes, view_parallel as vp
+    rank, world, local = vp.init_from_env()
+    assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the rasterizer has no CPU path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    from gaussian_renderer import _native
+
+    gen_kw = dict(scenes.CONFIGS[args.workload][1])
+    variant = gen_kw["variant"]
+    sc = scenes.make(args.workload)
+    # every rank renders its own view of the (replicated) scene: azimuth 30 + 45*rank degrees
+    sc.update(cameras.make_camera(sc["W"], sc["H"], cameras.orbit_eye(4.0, 30.0 + 45.0 * rank, 25.0)))
+    grads = scenes.upstream_grads(sc, variant)
+    sct = runner.to_torch(sc, dev)
+    per_gaussian = {k: sct[k] for k in ("means3D", "scales", "rotations", "opacities", "shs", "features") if k in sct}
+    if variant == "svgss":
+        per_gaussian["vfeatures"] = sct["vfeatures"]
+    vp.broadcast_scene(per_gaussian)  # one-time replication (identical seeds already; exercised for N > 1)
+    gt = {k: torch.from_numpy(v).to(dev) for k, v in grads.items()}
+    P, W, H = int(sc["means3D"].shape[0]), sc["W"], sc["H"]
+    S = int(sc["features"].shape[1])
+    VS = int(sc["vfeatures"].shape[1]) if variant == "svgss" else 0
+
+    if variant == "svgss":
+        from gaussian_renderer.svgss_rasterization import _C
+    else:
+        from gaussian_renderer.rgss_rasterization import _C
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+    st = runner.settings(sct, variant)
+
+    def step():
+        """One forward + backward through the binding layer; returns (R, checksum tensor)."""
+        if variant == "svgss":
+            out = _C.rasterize_gaussians(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], empty,
+                                         sct["opacities"], sct["scales"], sct["rotations"], st.scale_modifier, empty,
+                                         st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
+                                         st.tanfovy, st.image_height, st.image_width, sct["shs"], st.sh_degree,
+                                         st.campos, False, False, st.config)
+            (R, color, normal, depth, opac, feat, vfeat, weights, radii, gb, bb, ib) = out
+            g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], radii, empty,
+                                                sct["scales"], sct["rotations"], st.scale_modifier, empty,
+                                                st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
+                                                st.tanfovy, gt["color"], gt["normal"], gt["depth"], gt["opacity"],
+                                                gt["feature"], gt["vfeature"], sct["shs"], st.sh_degree, st.campos,
+                                                gb, R, bb, ib, False, st.config)
+        else:
+            out = _C.rasterize_gaussians(st.bg, sct["means3D"], sct["features"], empty, sct["opacities"],
+                                         sct["scales"], sct["rotations"], st.scale_modifier, empty, st.viewmatrix,
+                                         st.projmatrix, st.tanfovx, st.tanfovy, st.cx, st.cy, st.image_height,
+                                         st.image_width, sct["shs"], st.sh_degree, st.campos, False, False, False)
+            (R, ncontrib, color, normal, opac, depth, feat, pn, sx, weights, radii, gb, bb, ib) = out
+            g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], radii, empty, sct["scales"],
+                                                sct["rotations"], st.scale_modifier, empty, st.viewmatrix,
+                                                st.projmatrix, st.tanfovx, st.tanfovy, gt["color"], gt["normal"],
+                                                gt["opacity"], gt["depth"], gt["feature"], sct["shs"], st.sh_degree,
+                                                st.campos, gb, R, bb, ib, True, False)
+        return R, color, g[3]
+
+    def metrics(R, color, gmean):
+        # "loss"-like scalars gathered across ranks with ONE collective per step
+        return torch.stack([color.sum(), gmean.abs().sum(), torch.tensor(float(R), device=dev)])
+
+    for _ in range(args.warmup):
+        R, color, gm = step()
+        vp.gather_metrics(metrics(R, color, gm))
+    vp.barrier()
+    torch.cuda.synchronize()
+    _native.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        R, color, gm = step()
+        allm = vp.gather_metrics(metrics(R, color, gm))
+    vp.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stage = {n: (ms, cnt) for n, ms, cnt in _native.last_timings(with_counts=True)}
+    _native.set_profiling(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank != 0:
+        return
+    value = world * P * args.steps / elapsed
+    ab = algorithmic_bytes(P, R, W, H, S, VS, variant == "svgss")
+    dom = "render_bwd"
+    dom_ms = stage[dom][0]
+    achieved = ab["bwd"] / (dom_ms * 1e-3) / 1e9
+    fwd_ms = stage["render"][0]
+    res = {
+        "metric": "Gaussian-surfels/sec fwd+bwd @800x800 (1 view)",
+        "value": value, "unit": "surfels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {variant} path, P={P} surfels, {W}x{H}, SH degree {sc['sh_degree']}, "
+                               f"S={S}, VS={VS}, fwd+bwd, one view per step per GPU (BASELINE.json configs[1] for cfg2)",
+                   "num_rendered": int(R), "views_per_step": world, "parallelism": f"view-parallel x{world}"},
+        "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel (backward composite)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": ab["bwd"], "avg_launch_ms": dom_ms, "launches": stage[dom][1],
+                     "fwd_composite": {"achieved": ab["fwd"] / (fwd_ms * 1e-3) / 1e9, "avg_launch_ms": fwd_ms,
+                                       "algorithmic_bytes_per_launch": ab["fwd"]}},
+        "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        var_id = orc.SVGSS if variant == "svgss" else orc.RGSS
+        cores = orc.max_threads()
+        o = orc.OracleRun(sc, var_id)
+        o.forward()  # warm-up (thread pool, page faults)
+        tc = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            o.forward()
+            o.backward(grads["color"], grads["normal"], grads["depth"], grads["opacity"], grads["feature"],
+                       grads.get("vfeature"))
+        cpu_el = time.perf_counter() - tc
+        res["cpu_baseline"] = {"value": P * args.cpu_steps / cpu_el, "unit": "surfels/s", "cores": cores, "kind": "port",
+                               "sample": f"{args.cpu_steps} fwd+bwd steps of the same {args.workload} view "
+                                         f"({cpu_el:.1f} s, OpenMP oracle/svgir_oracle.cpp, {cores} threads)"}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -152,12 +152,13 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
 int svgir_mark_visible(int32_t variant, int32_t P, const float* means3D, const float* viewmatrix,
                        const float* projmatrix, uint8_t* present, void* stream);
 
-/* Per-kernel timing of the most recent forward/backward on this thread (milliseconds, HIP events on the given
- * stream).  Enabled with svgir_set_profiling(1); costs one stream synchronisation per call when enabled.
- * names: "preprocess","sort_depth","scan","emit","sort_tile","ranges","render","image",
- *        "render_bwd","geom_bwd". Returns the number of entries written (<= cap). */
+/* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
+ * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,
+ * the AVERAGE duration in milliseconds and the number of samples since profiling was (re-)enabled.
+ * Stage names: "preprocess","sort_depth","scan","emit","sort_tile","ranges","render","image",
+ *              "render_bwd","geom_bwd".  Returns the number of entries written (<= cap); `counts` may be NULL. */
 void svgir_set_profiling(int enabled);
-int svgir_last_timings(const char** names, float* ms, int cap);
+int svgir_last_timings(const char** names, float* avg_ms, int* counts, int cap);
 
 const char* svgir_last_error(void);
 

@@ -21,10 +21,15 @@ using namespace svgir;
 namespace {
 
 thread_local std::string g_err;
-// profiling state is process-wide: the autograd engine runs backward on its own thread
+// Profiling state is process-wide (the autograd engine runs backward on its own thread).  Stage boundaries are
+// HIP events recorded on the launch stream; they are resolved lazily (svgir_last_timings), so enabling profiling
+// adds no synchronisation to forward/backward.
 std::atomic<bool> g_prof{false};
 std::mutex g_times_mu;
-std::vector<std::pair<const char*, float>> g_times;
+struct Pending { hipEvent_t a, b; const char* name; };
+std::vector<Pending> g_pending;
+struct Accum { const char* name; double sum_ms; int count; };
+std::vector<Accum> g_accum;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -42,37 +47,55 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(SVGIR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-// Stage timer: HIP events on the launch stream, resolved after the call's final synchronisation.
+// Stage timer: one event per stage boundary; consecutive pairs are queued for lazy resolution.
 struct StageTimer {
     hipStream_t s;
     bool on;
-    std::vector<hipEvent_t> ev;
-    std::vector<const char*> names;
+    hipEvent_t prev = nullptr;
     StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
         if (on) mark(nullptr);
     }
     void mark(const char* name) {
         if (!on) return;
         hipEvent_t e;
-        hipEventCreate(&e);
-        hipEventRecord(e, s);
-        ev.push_back(e);
-        names.push_back(name);
-    }
-    void resolve(bool append) {
-        if (!on) return;
-        hipStreamSynchronize(s);
-        std::lock_guard<std::mutex> lk(g_times_mu);
-        if (!append) g_times.clear();
-        for (size_t i = 1; i < ev.size(); i++) {
-            float ms = 0.f;
-            hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
-            g_times.push_back({names[i], ms});
+        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e, s);
+        if (prev && name) {
+            std::lock_guard<std::mutex> lk(g_times_mu);
+            g_pending.push_back({prev, e, name});
         }
-        for (auto e : ev) hipEventDestroy(e);
-        ev.clear();
+        prev = e;  // events are destroyed when the pair that ends with them is resolved (the first one leaks into
+                   // the pair as `a`; every event is destroyed exactly once in resolve_pending)
     }
 };
+
+// Resolve queued event pairs into per-stage sums.  Each event appears as `b` of one pair and possibly `a` of the
+// next; destroy an event after its last use.
+void resolve_pending() {
+    std::vector<Pending> todo;
+    {
+        std::lock_guard<std::mutex> lk(g_times_mu);
+        todo.swap(g_pending);
+    }
+    std::vector<hipEvent_t> seen;
+    for (auto& p : todo) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_times_mu);
+            bool found = false;
+            for (auto& acc : g_accum)
+                if (acc.name == p.name) { acc.sum_ms += ms; acc.count++; found = true; break; }
+            if (!found) g_accum.push_back({p.name, (double)ms, 1});
+        }
+        for (hipEvent_t e : {p.a, p.b}) {
+            bool dup = false;
+            for (auto x : seen) if (x == e) dup = true;
+            if (!dup) seen.push_back(e);
+        }
+    }
+    for (auto e : seen) (void)hipEventDestroy(e);
+}
 
 CfgRef cfg_ref(const svgir_params* p) {
     CfgRef c;
@@ -119,14 +142,23 @@ size_t svgir_image_bytes(int32_t W, int32_t H) { return image_layout(nullptr, W,
 size_t svgir_binning_bytes(int32_t R) { return bin_layout(nullptr, R).bytes; }
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H) { return image_layout(nullptr, W, H).ncontrib_off; }
 const char* svgir_last_error(void) { return g_err.c_str(); }
-void svgir_set_profiling(int enabled) { g_prof.store(enabled != 0); }
-int svgir_last_timings(const char** names, float* ms, int cap) {
+void svgir_set_profiling(int enabled) {
+    resolve_pending();
+    if (enabled) {
+        std::lock_guard<std::mutex> lk(g_times_mu);
+        g_accum.clear();
+    }
+    g_prof.store(enabled != 0);
+}
+int svgir_last_timings(const char** names, float* avg_ms, int* counts, int cap) {
+    resolve_pending();
     std::lock_guard<std::mutex> lk(g_times_mu);
     int n = 0;
-    for (auto& kv : g_times) {
+    for (auto& acc : g_accum) {
         if (n >= cap) break;
-        names[n] = kv.first;
-        ms[n] = kv.second;
+        names[n] = acc.name;
+        avg_ms[n] = (float)(acc.sum_ms / (acc.count > 0 ? acc.count : 1));
+        if (counts) counts[n] = acc.count;
         n++;
     }
     return n;
@@ -244,7 +276,6 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         if (int rc = check("image ops")) return rc;
         tm.mark("image");
     }
-    tm.resolve(false);
     return R;
 }
 
@@ -301,7 +332,6 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     hipError_t e = p->debug ? hipStreamSynchronize(s) : hipSuccess;
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "backward failed: %s", hipGetErrorString(e));
-    tm.resolve(false);
     return 0;
 }
 

@@ -71,7 +71,7 @@ def _load():
     lib.svgir_mark_visible.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svgir_set_profiling.argtypes = [C.c_int]
     lib.svgir_last_timings.restype = C.c_int
-    lib.svgir_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.svgir_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     lib.svgir_last_error.restype = C.c_char_p
     if lib.svgir_abi_version() != 1:
         raise ImportError("libsvgir_raster.so ABI version mismatch")
@@ -147,8 +147,12 @@ def set_profiling(on):
     lib.svgir_set_profiling(1 if on else 0)
 
 
-def last_timings():
+def last_timings(with_counts=False):
+    """Average milliseconds per stage since profiling was enabled (resolves the recorded HIP events)."""
     names = (C.c_char_p * 16)()
     ms = (C.c_float * 16)()
-    n = lib.svgir_last_timings(names, ms, 16)
+    cnt = (C.c_int * 16)()
+    n = lib.svgir_last_timings(names, ms, cnt, 16)
+    if with_counts:
+        return [(names[i].decode(), float(ms[i]), int(cnt[i])) for i in range(n)]
     return [(names[i].decode(), float(ms[i])) for i in range(n)]

@@ -1,0 +1,79 @@
+"""View-parallel execution: independent camera views are sharded across ranks (one process per GPU).
+
+The reference is single-GPU; views are its natural independent unit (one camera per training
+iteration, train.py:127-135; independent frames in eval, eval_relighting_tensoIR.py:303-378).  All per-Gaussian
+arrays are replicated on every rank (one broadcast), rank r renders views {v : v mod world == r}, and there is
+NO collective inside forward/backward.  The only data-path-adjacent collective is one fused all_gather of a small
+fp32 metrics vector per step (loss / checksum / timings) -- RCCL over xGMI on GPUs, gloo in the CPU tests;
+latency-bound (tens of bytes), so it is a single call, never one call per metric.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_views(num_views, rank, world):
+    """Round-robin ownership: view v belongs to rank v % world."""
+    return [v for v in range(num_views) if v % world == rank]
+
+
+def broadcast_scene(tensors, src=0):
+    """One-time replication of the per-Gaussian arrays (dict name -> tensor), in place."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensors
+    for k in sorted(tensors):
+        if torch.is_tensor(tensors[k]):
+            dist.broadcast(tensors[k], src=src)
+    return tensors
+
+
+def gather_metrics(vec):
+    """vec: 1-D fp32 tensor of k per-rank scalars -> [world, k] on every rank with ONE all_gather."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return vec.reshape(1, -1).clone()
+    world = dist.get_world_size()
+    out = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
+    dist.all_gather_into_tensor(out, vec.contiguous().reshape(-1))
+    return out.reshape(world, vec.numel())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def run_views(render_view, num_views, rank, world, device, metrics_dim):
+    """Renders this rank's share of `num_views` with render_view(v) -> 1-D fp32 tensor[metrics_dim]; returns the
+    [num_views, metrics_dim] table assembled from all ranks (rows of views no rank owns stay NaN)."""
+    mine = shard_views(num_views, rank, world)
+    rounds = (num_views + world - 1) // world
+    table = torch.full((num_views, metrics_dim), float("nan"), dtype=torch.float32, device=device)
+    for r in range(rounds):
+        v = r * world + rank
+        if v < num_views:
+            assert v in mine
+            m = render_view(v).to(device=device, dtype=torch.float32).reshape(-1)
+            payload = torch.cat([torch.tensor([float(v)], device=device), m])
+        else:
+            payload = torch.cat([torch.tensor([-1.0], device=device), torch.zeros(metrics_dim, device=device)])
+        allm = gather_metrics(payload)
+        for row in allm:
+            vi = int(row[0].item())
+            if vi >= 0:
+                table[vi] = row[1:]
+    return table
