@@ -16,6 +16,7 @@
 //     the Gaussian's gradient rows: <= 2 atomic instructions per (wave, splat) instead of up to 64 x 84;
 //   * splats that no pixel of the wave blends are skipped after the 6-float header test (wave ballot).
 #include "common.hpp"
+#include "stage.hpp"
 
 namespace svgir {
 
@@ -28,9 +29,10 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
     constexpr int NV = (NCH + 63) / 64;
     constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
 
-    __shared__ float4 sA[BLOCK];
-    __shared__ float2 sB[BLOCK];
-    __shared__ int sId[BLOCK];
+    using SG = StageGeom<S, VC>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sD = reinterpret_cast<float*>(smem);                               // [BATCH][NF]
+    int* sId = reinterpret_cast<int*>(smem + (size_t)SG::BATCH * SG::NF * 4);  // [BATCH]
     __shared__ uint32_t sMax[4];
 
     const int tile = blockIdx.x;
@@ -42,9 +44,6 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     if (r1 <= r0) return;  // uniform: empty tile
-    const float* __restrict__ rec = a.rec;
-    const float* __restrict__ feat = a.features;
-    const float* __restrict__ vfeat = a.vfeatures;
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
     const bool sp = surface && cfg_flag(a.cfg, 2);
     const bool bgeom = SVGSS ? true : (a.backward_geometry != 0);
@@ -102,24 +101,19 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
 #pragma unroll
     for (int i = 0; i < VV; i++) { acc_vf[i] = 0.f; last_vf[i] = 0.f; }
 
-    for (int top = (int)bmax; top > 0; top -= BLOCK) {  // this batch covers slots [top - n, top)
-        const int n = min((int)BLOCK, top);
+    for (int top = (int)bmax; top > 0; top -= SG::BATCH) {  // this batch covers slots [top - n, top)
+        const int n = min((int)SG::BATCH, top);
         __syncthreads();
-        if (t < n) {
-            const int id = (int)a.point_list[r0 + (uint32_t)(top - 1 - t)];
-            const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
-            const float4 h0 = r[0];
-            const float4 h1 = r[1];
-            sA[t] = h0;
-            sB[t] = make_float2(h1.x, h1.y);
-            sId[t] = id;
-        }
+        if (t < n) sId[t] = (int)a.point_list[r0 + (uint32_t)(top - 1 - t)];
+        __syncthreads();
+        stage_batch<S, VC>(sD, sId, n, a.rec, a.features, a.vfeatures);
         __syncthreads();
         for (int j = 0; j < n; j++) {
             const uint32_t slot = (uint32_t)(top - 1 - j);
             if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
-            const float4 A = sA[j];
-            const float2 B = sB[j];
+            const float4* q = reinterpret_cast<const float4*>(sD + j * SG::NF);
+            const float4 A = q[0];   // x, y, conic.x, conic.y
+            const float4 B = q[1];   // conic.z, opacity, depth, J6
             const float dx = A.x - pxf, dy = A.y - pyf;
             float power;
             if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
@@ -129,8 +123,8 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
             const bool pass = slot < last_contributor && power <= 0.0f && alpha >= (1.0f / 255.0f);
             if (__ballot(pass) == 0ull) continue;
 
-            const int gid = __builtin_amdgcn_readfirstlane(sId[j]);
-            const float* __restrict__ r = rec + (size_t)gid * REC;
+            const int gid = sId[j];
+            const float* r = sD + j * SG::NF;
             float cb[NCH];
 #pragma unroll
             for (int i = 0; i < NCH; i++) cb[i] = 0.f;
@@ -164,7 +158,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                     cb[6 + ch] = dch * gC[ch];
                 }
                 if (S > 0) {
-                    const float* __restrict__ f = feat + (size_t)gid * S;
+                    const float* f = sD + j * SG::NF + SG::F_OFF;
 #pragma unroll
                     for (int ch = 0; ch < S; ch++) {
                         const float fv = f[ch];
@@ -175,7 +169,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                     }
                 }
                 if (VC > 0) {
-                    const float* __restrict__ vf = vfeat + (size_t)gid * VS;
+                    const float* vf = sD + j * SG::NF + SG::V_OFF;
 #pragma unroll
                     for (int ch = 0; ch < VC; ch++) {
                         const float v = vf[4 * ch] * cw[0] + vf[4 * ch + 1] * cw[1] + vf[4 * ch + 2] * cw[2] + vf[4 * ch + 3] * cw[3];
@@ -256,7 +250,8 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
 
 template <int S, int VC, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+    using SG = StageGeom<S, VC>;
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(a.gx * a.gy), dim3(BLOCK), SG::lds_bytes(), s, a);
 }
 
 }  // namespace

@@ -7,16 +7,20 @@
 // CDNA4 mapping
 //   * one 256-thread workgroup per tile = 4 wave64, each wave owns an 8x8 pixel quadrant (compact footprint =>
 //     more wave-level culling than the reference's 16x2 warp rows);
-//   * per batch of 256 splats only the 24-byte "header" (mean2D, conic, opacity) + id is staged in LDS with one
-//     coalesced-by-record gather per thread; every wave walks the batch reading headers as LDS broadcasts;
-//   * a wave ballot decides whether ANY of its 64 pixels blends the splat; only then is the rest of the 96-byte
-//     record and the S + VS feature floats fetched -- with wave-uniform addresses, i.e. scalar loads through
-//     the constant cache into SGPRs, so the blend is `v_fmac vacc, s_feature, v_weight` with no LDS/VGPR staging;
+//   * the splat list is consumed in batches; for each batch ALL per-splat data -- the 96-byte record written by the
+//     preprocess stage plus the S feature and VS vfeature floats -- is gathered into LDS once per tile with 16-byte
+//     loads issued by all 256 threads (one latency exposure per batch, every byte of the algorithmic gather
+//     R*(4+G) is touched exactly once per tile).  The reference stages only the geometry and re-reads
+//     features/vfeatures from global memory per (pixel, splat) (forward.cu:635-646);
+//   * every wave walks the staged batch reading wave-uniform LDS addresses (broadcast ds_read_b128, no bank
+//     conflicts); a wave ballot on the 8-float header decides whether ANY of its 64 pixels blends the splat before
+//     the remaining floats are read;
 //   * channel counts are template parameters: accumulators live in VGPRs (the reference spills >640 floats of
 //     per-thread arrays to scratch, forward.cu:483-493);
 //   * the per-(pixel,splat) out_weights atomic of the reference (forward.cu:653) becomes one DPP wave reduction
 //     + one atomic per (wave, splat).
 #include "common.hpp"
+#include "stage.hpp"
 
 namespace svgir {
 
@@ -24,9 +28,10 @@ namespace {
 
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
-    __shared__ float4 sA[BLOCK];  // x, y, conic.x, conic.y
-    __shared__ float2 sB[BLOCK];  // conic.z, opacity
-    __shared__ int sId[BLOCK];
+    using SG = StageGeom<S, VC>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sD = reinterpret_cast<float*>(smem);                               // [BATCH][NF]
+    int* sId = reinterpret_cast<int*>(smem + (size_t)SG::BATCH * SG::NF * 4);  // [BATCH]
 
     const int tile = blockIdx.x;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -36,9 +41,6 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
-    const float* __restrict__ rec = a.rec;
-    const float* __restrict__ feat = a.features;
-    const float* __restrict__ vfeat = a.vfeatures;
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
     const bool sp = surface && cfg_flag(a.cfg, 2);
 
@@ -53,25 +55,20 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
     for (int i = 0; i < (VC > 0 ? VC : 1); i++) VF[i] = 0.f;
     uint32_t last_contributor = 0;
 
-    for (uint32_t base = r0; base < r1; base += BLOCK) {
+    for (uint32_t base = r0; base < r1; base += SG::BATCH) {
         // all four waves finished => stop fetching (forward.cu:499-501); also the barrier that frees the LDS batch
         if (__syncthreads_and(done)) break;
-        const int n = min((int)BLOCK, (int)(r1 - base));
-        if (t < n) {
-            const int id = (int)a.point_list[base + t];
-            const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
-            const float4 h0 = r[0];
-            const float4 h1 = r[1];
-            sA[t] = h0;
-            sB[t] = make_float2(h1.x, h1.y);
-            sId[t] = id;
-        }
+        const int n = min((int)SG::BATCH, (int)(r1 - base));
+        if (t < n) sId[t] = (int)a.point_list[base + t];
+        __syncthreads();
+        stage_batch<S, VC>(sD, sId, n, a.rec, a.features, a.vfeatures);
         __syncthreads();
         if (__all(done)) continue;  // this wave is finished; keep taking part in the barriers
 
         for (int j = 0; j < n; j++) {
-            const float4 A = sA[j];
-            const float2 B = sB[j];
+            const float4* q = reinterpret_cast<const float4*>(sD + j * SG::NF);
+            const float4 A = q[0];   // x, y, conic.x, conic.y
+            const float4 B = q[1];   // conic.z, opacity, depth, J6
             const float dx = A.x - pxf, dy = A.y - pyf;
             float power;
             if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
@@ -84,18 +81,19 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
                 if (__all(done)) break;
                 continue;
             }
-            // wave-uniform fetch of the rest of the record
-            const int gid = __builtin_amdgcn_readfirstlane(sId[j]);
-            const float* __restrict__ r = rec + (size_t)gid * REC;
             const float w = pass ? alpha * T : 0.f;
-            float dep = r[R_DEPTH];
+            const float4 J = q[2];   // J0..J3
+            const float4 E = q[3];   // J9, r, g, b
+            const float4 Nn = q[4];  // nx, ny, nz, 1/umax
+            float dep = B.z;
             float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
             if (sp) {
-                const float du = dx * r[R_J0] + dy * r[R_J1];
-                const float dv = dx * r[R_J2] + dy * r[R_J3];
-                dep -= du * r[R_J6] + dv * r[R_J9];
+                const float du = dx * J.x + dy * J.y;
+                const float dv = dx * J.z + dy * J.w;
+                dep -= du * B.w + dv * E.x;
                 if (SVGSS && VC > 0) {
-                    float u = du * r[R_IU] * 0.5f + 0.5f, v = dv * r[R_IV] * 0.5f + 0.5f;
+                    const float iv = q[5].x;
+                    float u = du * Nn.w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
                     u = fminf(0.999f, fmaxf(0.001f, u));
                     v = fminf(0.999f, fmaxf(0.001f, v));
                     // pre-multiplied by the blend weight
@@ -103,25 +101,27 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
                 }
             }
             D += dep * w;
-            C[0] += r[R_R] * w; C[1] += r[R_G] * w; C[2] += r[R_B] * w;
-            if (surface) { N[0] += r[R_NX] * w; N[1] += r[R_NY] * w; N[2] += r[R_NZ] * w; }
+            C[0] += E.y * w; C[1] += E.z * w; C[2] += E.w * w;
+            if (surface) { N[0] += Nn.x * w; N[1] += Nn.y * w; N[2] += Nn.z * w; }
             if (S > 0) {
-                const float* __restrict__ f = feat + (size_t)gid * S;
+                const float* f = sD + j * SG::NF + SG::F_OFF;
 #pragma unroll
                 for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w;
             }
             if (VC > 0) {
-                const float* __restrict__ vf = vfeat + (size_t)gid * (VC * 4);
+                const float4* vf = reinterpret_cast<const float4*>(sD + j * SG::NF + SG::V_OFF);
 #pragma unroll
-                for (int ch = 0; ch < VC; ch++)
-                    VF[ch] += vf[4 * ch] * w0 + vf[4 * ch + 1] * w1 + vf[4 * ch + 2] * w2 + vf[4 * ch + 3] * w3;
+                for (int ch = 0; ch < VC; ch++) {
+                    const float4 c4 = vf[ch];
+                    VF[ch] += c4.x * w0 + c4.y * w1 + c4.z * w2 + c4.w * w3;
+                }
             }
             if (pass) {
                 T = test_T;
                 last_contributor = (base - r0) + (uint32_t)j + 1u;
             }
             const float wsum = wave_scan_last(w);
-            if (lane == 63) atomic_add_f32(&a.out_weights[gid], wsum);
+            if (lane == 63) atomic_add_f32(&a.out_weights[sId[j]], wsum);
         }
     }
 
@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
 
 template <int S, int VC, bool SVGSS>
 void launch(const RenderArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+    using SG = StageGeom<S, VC>;
+    hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(a.gx * a.gy), dim3(BLOCK), SG::lds_bytes(), s, a);
 }
 
 }  // namespace
