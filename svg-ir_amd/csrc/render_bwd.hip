@@ -14,7 +14,8 @@
 //     wave reduces every channel over its 64 pixels with DPP row shifts/broadcasts, parks channel c's total in
 //     lane c, and issues ONE global atomic instruction per 64 channels whose lanes hit consecutive addresses of
 //     the Gaussian's gradient rows: <= 2 atomic instructions per (wave, splat) instead of up to 64 x 84;
-//   * splats that no pixel of the wave blends are skipped after the 6-float header test (wave ballot).
+//   * splats that cannot touch the wave's 8x8 pixel block are culled lane-parallel (64 splats per instruction,
+//     stage.hpp) and the surviving ballot mask is walked with scalar bit scans.
 #include "common.hpp"
 #include "stage.hpp"
 
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
     const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
+    const float wx0 = (float)(tx * TILE + (wave & 1) * 8), wy0 = (float)(ty * TILE + (wave >> 1) * 8);
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     if (r1 <= r0) return;  // uniform: empty tile
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
@@ -108,9 +110,21 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
         __syncthreads();
         stage_batch<S, VC>(sD, sId, n, a.rec, a.features, a.vfeatures);
         __syncthreads();
-        for (int j = 0; j < n; j++) {
+        for (int rnd = 0; rnd * 64 < n; rnd++) {
+          // lane-parallel conservative cull of 64 staged splats against this wave's 8x8 pixel block (stage.hpp)
+          const int js = rnd * 64 + lane;
+          bool cand = false;
+          if (js < n && (uint32_t)(top - 1 - js) < wmax) {
+              const float4* qs = reinterpret_cast<const float4*>(sD + js * SG::NF);
+              const float4 A = qs[0];
+              const float4 B = qs[1];
+              cand = splat_may_touch(A.x, A.y, A.z, A.w, B.x, B.y, wx0, wy0, wx0 + 7.f, wy0 + 7.f);
+          }
+          unsigned long long mask = __ballot(cand);
+          while (mask) {
+            const int j = rnd * 64 + __builtin_ctzll(mask);
+            mask &= mask - 1;
             const uint32_t slot = (uint32_t)(top - 1 - j);
-            if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
             const float4* q = reinterpret_cast<const float4*>(sD + j * SG::NF);
             const float4 A = q[0];   // x, y, conic.x, conic.y
             const float4 B = q[1];   // conic.z, opacity, depth, J6
@@ -244,6 +258,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                     if (v != 0.f) atomic_add_f32(dbase[k] + (size_t)gid * dstride[k], v);
                 }
             }
+          }
         }
     }
 }

@@ -13,8 +13,10 @@
 //     R*(4+G) is touched exactly once per tile).  The reference stages only the geometry and re-reads
 //     features/vfeatures from global memory per (pixel, splat) (forward.cu:635-646);
 //   * every wave walks the staged batch reading wave-uniform LDS addresses (broadcast ds_read_b128, no bank
-//     conflicts); a wave ballot on the 8-float header decides whether ANY of its 64 pixels blends the splat before
-//     the remaining floats are read;
+//     conflicts).  Before that, the wave culls the batch LANE-PARALLEL: each lane tests one staged splat against the
+//     wave's 8x8 pixel rectangle (exact minimum of the conic form over the rectangle vs. the 1/255 alpha threshold,
+//     stage.hpp) and the ballot mask is then walked with scalar bit scans, so splats that cannot touch the wave
+//     cost 1/64 of an iteration instead of one;
 //   * channel counts are template parameters: accumulators live in VGPRs (the reference spills >640 floats of
 //     per-thread arrays to scratch, forward.cu:483-493);
 //   * the per-(pixel,splat) out_weights atomic of the reference (forward.cu:653) becomes one DPP wave reduction
@@ -40,6 +42,7 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
     const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
+    const float wx0 = (float)(tx * TILE + (wave & 1) * 8), wy0 = (float)(ty * TILE + (wave >> 1) * 8);
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
     const bool sp = surface && cfg_flag(a.cfg, 2);
@@ -65,63 +68,80 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
         __syncthreads();
         if (__all(done)) continue;  // this wave is finished; keep taking part in the barriers
 
-        for (int j = 0; j < n; j++) {
-            const float4* q = reinterpret_cast<const float4*>(sD + j * SG::NF);
-            const float4 A = q[0];   // x, y, conic.x, conic.y
-            const float4 B = q[1];   // conic.z, opacity, depth, J6
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            float power;
-            if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
-            else power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-            const float alpha = fminf(0.99f, B.y * __expf(power));
-            bool pass = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-            const float test_T = T * (1.f - alpha);
-            if (pass && test_T < 0.0001f) { done = true; pass = false; }
-            if (__ballot(pass) == 0ull) {
-                if (__all(done)) break;
-                continue;
+        bool wave_done = false;
+        for (int rnd = 0; rnd * 64 < n && !wave_done; rnd++) {
+            // lane-parallel conservative cull of 64 staged splats against this wave's 8x8 pixel block
+            const int js = rnd * 64 + lane;
+            bool cand = false;
+            if (js < n) {
+                const float4* qs = reinterpret_cast<const float4*>(sD + js * SG::NF);
+                const float4 A = qs[0];
+                const float4 B = qs[1];
+                cand = splat_may_touch(A.x, A.y, A.z, A.w, B.x, B.y, wx0, wy0, wx0 + 7.f, wy0 + 7.f);
             }
-            const float w = pass ? alpha * T : 0.f;
-            const float4 J = q[2];   // J0..J3
-            const float4 E = q[3];   // J9, r, g, b
-            const float4 Nn = q[4];  // nx, ny, nz, 1/umax
-            float dep = B.z;
-            float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-            if (sp) {
-                const float du = dx * J.x + dy * J.y;
-                const float dv = dx * J.z + dy * J.w;
-                dep -= du * B.w + dv * E.x;
-                if (SVGSS && VC > 0) {
-                    const float iv = q[5].x;
-                    float u = du * Nn.w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
-                    u = fminf(0.999f, fmaxf(0.001f, u));
-                    v = fminf(0.999f, fmaxf(0.001f, v));
-                    // pre-multiplied by the blend weight
-                    w0 = (1.f - u) * (1.f - v) * w; w1 = u * (1.f - v) * w; w2 = (1.f - u) * v * w; w3 = u * v * w;
+            unsigned long long mask = __ballot(cand);
+            while (mask) {
+                const int j = rnd * 64 + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float4* q = reinterpret_cast<const float4*>(sD + j * SG::NF);
+                const float4 A = q[0];   // x, y, conic.x, conic.y
+                const float4 B = q[1];   // conic.z, opacity, depth, J6
+                const float dx = A.x - pxf, dy = A.y - pyf;
+                float power;
+                if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
+                else power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                const float alpha = fminf(0.99f, B.y * __expf(power));
+                bool pass = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                const float test_T = T * (1.f - alpha);
+                bool newly_done = false;
+                if (pass && test_T < 0.0001f) { done = true; pass = false; newly_done = true; }
+                if (__ballot(pass) == 0ull) {
+                    if (__any(newly_done) && __all(done)) { wave_done = true; break; }
+                    continue;
                 }
-            }
-            D += dep * w;
-            C[0] += E.y * w; C[1] += E.z * w; C[2] += E.w * w;
-            if (surface) { N[0] += Nn.x * w; N[1] += Nn.y * w; N[2] += Nn.z * w; }
-            if (S > 0) {
-                const float* f = sD + j * SG::NF + SG::F_OFF;
-#pragma unroll
-                for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w;
-            }
-            if (VC > 0) {
-                const float4* vf = reinterpret_cast<const float4*>(sD + j * SG::NF + SG::V_OFF);
-#pragma unroll
-                for (int ch = 0; ch < VC; ch++) {
-                    const float4 c4 = vf[ch];
-                    VF[ch] += c4.x * w0 + c4.y * w1 + c4.z * w2 + c4.w * w3;
+                const float w = pass ? alpha * T : 0.f;
+                const float4 J = q[2];   // J0..J3
+                const float4 E = q[3];   // J9, r, g, b
+                const float4 Nn = q[4];  // nx, ny, nz, 1/umax
+                float dep = B.z;
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+                if (sp) {
+                    const float du = dx * J.x + dy * J.y;
+                    const float dv = dx * J.z + dy * J.w;
+                    dep -= du * B.w + dv * E.x;
+                    if (SVGSS && VC > 0) {
+                        const float iv = q[5].x;
+                        float u = du * Nn.w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
+                        u = fminf(0.999f, fmaxf(0.001f, u));
+                        v = fminf(0.999f, fmaxf(0.001f, v));
+                        // pre-multiplied by the blend weight
+                        w0 = (1.f - u) * (1.f - v) * w; w1 = u * (1.f - v) * w; w2 = (1.f - u) * v * w; w3 = u * v * w;
+                    }
                 }
+                D += dep * w;
+                C[0] += E.y * w; C[1] += E.z * w; C[2] += E.w * w;
+                if (surface) { N[0] += Nn.x * w; N[1] += Nn.y * w; N[2] += Nn.z * w; }
+                if (S > 0) {
+                    const float* f = sD + j * SG::NF + SG::F_OFF;
+#pragma unroll
+                    for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w;
+                }
+                if (VC > 0) {
+                    const float4* vf = reinterpret_cast<const float4*>(sD + j * SG::NF + SG::V_OFF);
+#pragma unroll
+                    for (int ch = 0; ch < VC; ch++) {
+                        const float4 c4 = vf[ch];
+                        VF[ch] += c4.x * w0 + c4.y * w1 + c4.z * w2 + c4.w * w3;
+                    }
+                }
+                if (pass) {
+                    T = test_T;
+                    last_contributor = (base - r0) + (uint32_t)j + 1u;
+                }
+                const float wsum = wave_scan_last(w);
+                if (lane == 63) atomic_add_f32(&a.out_weights[sId[j]], wsum);
+                if (__any(newly_done) && __all(done)) { wave_done = true; break; }
             }
-            if (pass) {
-                T = test_T;
-                last_contributor = (base - r0) + (uint32_t)j + 1u;
-            }
-            const float wsum = wave_scan_last(w);
-            if (lane == 63) atomic_add_f32(&a.out_weights[sId[j]], wsum);
         }
     }
 

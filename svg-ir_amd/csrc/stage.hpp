@@ -12,8 +12,11 @@ namespace svgir {
 template <int S, int VC>
 struct StageGeom {
     static constexpr int S4 = (S + 3) / 4 * 4;      // feature slots padded to a float4 boundary
-    static constexpr int NF = REC + S4 + VC * 4;     // floats per staged splat
-    static constexpr int NF4 = NF / 4;
+    static constexpr int NFD = REC + S4 + VC * 4;    // floats of data per staged splat
+    // slot stride: an ODD number of float4s, so that 64 lanes reading the headers of 64 consecutive slots with
+    // ds_read_b128 fall on distinct 16-byte LDS slots (bank-conflict free), while a wave-uniform read broadcasts
+    static constexpr int NF4 = (NFD / 4) | 1;
+    static constexpr int NF = NF4 * 4;
     static constexpr int C4 = 6 + VC;                // float4 chunks gathered with 16-byte loads (record + vfeatures)
     static constexpr int BATCH = NF <= 32 ? 256 : (NF <= 64 ? 192 : 128);  // <= 48 KB of LDS per workgroup
     static constexpr int F_OFF = REC;                // features
@@ -22,6 +25,31 @@ struct StageGeom {
 };
 
 #if defined(__HIPCC__)
+// Conservative wave-level cull.  Lane-parallel over splats: does the splat with mean (mx,my), conic (a,b,c) and
+// opacity `op` reach alpha >= 1/255 anywhere inside the pixel rectangle [X0,X1]x[Y0,Y1]?  The per-pixel test is
+// q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 op); the minimum of the convex form over the rectangle is 0 when
+// the mean is inside, else it lies on one of the four edges.  A slack absorbs fp32 rounding of the per-pixel
+// evaluation, so a splat is only ever dropped when no pixel of the rectangle can pass the exact test.
+__device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, float b, float c, float op, float X0,
+                                                float Y0, float X1, float Y1) {
+    const float u0 = mx - X1, u1 = mx - X0, v0 = my - Y1, v1 = my - Y0;  // ranges of dx, dy
+    const float tau2 = 2.f * __logf(255.f * op);                         // NaN / -inf for op <= 0 => never passes
+    if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f)) return tau2 == tau2;  // degenerate conic: keep
+    float qmin = 0.f;
+    const bool in = (u0 <= 0.f) && (u1 >= 0.f) && (v0 <= 0.f) && (v1 >= 0.f);
+    if (!in) {
+        const float ic = 1.f / c, ia = 1.f / a;
+        float v, u, q;
+        v = fminf(v1, fmaxf(v0, -b * u0 * ic)); qmin = a * u0 * u0 + 2.f * b * u0 * v + c * v * v;
+        v = fminf(v1, fmaxf(v0, -b * u1 * ic)); q = a * u1 * u1 + 2.f * b * u1 * v + c * v * v; qmin = fminf(qmin, q);
+        u = fminf(u1, fmaxf(u0, -b * v0 * ia)); q = a * u * u + 2.f * b * u * v0 + c * v0 * v0; qmin = fminf(qmin, q);
+        u = fminf(u1, fmaxf(u0, -b * v1 * ia)); q = a * u * u + 2.f * b * u * v1 + c * v1 * v1; qmin = fminf(qmin, q);
+    }
+    const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
+    const float slack = 0.02f + 4e-5f * (a * um * um + 2.f * fabsf(b) * um * vm + c * vm * vm);
+    return qmin <= tau2 + slack;
+}
+
 // Gathers splats [0, n) of the current batch into LDS.  ids[s] must already hold the Gaussian id of slot s
 // (written before a barrier).  All 256 threads take part; loads are 16 bytes wide except the S feature floats
 // (rows of S floats are not 16-byte aligned in the caller's [P,S] tensor).
