@@ -77,6 +77,7 @@ struct ImageLayout {
     float* final_D;      // [N]
     int32_t* n_contrib;  // [N]
     uint32_t* ranges;    // [2*T]
+    uint32_t* sub_count; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the forward)
     size_t ncontrib_off;
     size_t bytes;
 };
@@ -91,6 +92,7 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.ncontrib_off = off;
     im.n_contrib = (int32_t*)take(N * 4);
     im.ranges = (uint32_t*)take(T * 8);
+    im.sub_count = (uint32_t*)take(T * 4 * 4);
     im.bytes = off;
     return im;
 }
@@ -99,6 +101,8 @@ struct BinLayout {
     uint32_t* key[2];  // [R] tile ids ping/pong
     uint32_t* val[2];  // [R] Gaussian ids ping/pong
     uint32_t* radix_tbl;
+    uint2* sub_list;   // [4*R] compact per-sub-tile candidate lists {Gaussian id, slot in the tile list}; sub-tile w
+                       // of a tile with range [r0,r1) owns entries [4*r0 + w*(r1-r0), 4*r0 + (w+1)*(r1-r0))
     size_t bytes;
 };
 inline BinLayout bin_layout(char* base, int R) {
@@ -111,6 +115,7 @@ inline BinLayout bin_layout(char* base, int R) {
     b.val[0] = (uint32_t*)take(r * 4);
     b.val[1] = (uint32_t*)take(r * 4);
     b.radix_tbl = (uint32_t*)take((size_t)256 * sort_blocks(R) * 4);
+    b.sub_list = (uint2*)take(r * 4 * 8);
     b.bytes = off;
     return b;
 }
@@ -155,6 +160,7 @@ struct RenderArgs {
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
     CfgRef cfg;
+    uint2* sub_list; uint32_t* sub_count;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
 };
@@ -165,6 +171,7 @@ struct RenderBwdArgs {
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
     CfgRef cfg; int backward_geometry;
+    const uint2* sub_list; const uint32_t* sub_count;
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;

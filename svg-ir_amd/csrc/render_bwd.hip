@@ -1,21 +1,21 @@
-// svg-ir_amd/csrc/render_bwd.hip -- backward per-tile alpha compositing.
+// svg-ir_amd/csrc/render_bwd.hip -- backward alpha compositing.
 //
 // Replaces the backward renderCUDA (svgss backward.cu:529-934, rgss backward.cu:431-757): back-to-front replay
-// of each tile's splat list (T <- T / (1 - alpha) starting from final_T), gradients of every blended quantity
+// of each pixel's blended splats (T <- T / (1 - alpha) starting from final_T), gradients of every blended quantity
 // w.r.t. the per-Gaussian colour / feature / vfeature (x corner weight) / normal (x10, Q4) / depth, and through
 // alpha to conic, mean2D (incl. the un-weighted depth-differencing term, Q5) and opacity.
 //
 // CDNA4 mapping
-//   * same tile/wave/pixel mapping and LDS header staging as render_fwd.hip, walked in reverse; the replay starts
-//     at the tile's deepest contributor (block max of n_contrib) instead of the end of the list;
+//   * one wave64 per 8x8-pixel sub-tile (one wave per workgroup, no barriers across waves), walking -- in reverse --
+//     the compact candidate list {Gaussian id, slot} that the forward kernel wrote for this sub-tile, so nothing is
+//     culled twice; the replay starts at the wave's deepest contributor (max n_contrib over its 64 pixels);
+//   * candidates are staged CH at a time into LDS exactly like in the forward (stage.hpp);
 //   * per-pixel replay state (running accumulators, last values, upstream gradients) lives in VGPRs thanks to
 //     compile-time channel counts (the reference keeps ~330 floats per thread in scratch, backward.cu:617-635);
 //   * the reference issues 13 + S + VS global float atomics per (pixel, splat) pair (18 / 69 / 84).  Here each
 //     wave reduces every channel over its 64 pixels with DPP row shifts/broadcasts, parks channel c's total in
 //     lane c, and issues ONE global atomic instruction per 64 channels whose lanes hit consecutive addresses of
-//     the Gaussian's gradient rows: <= 2 atomic instructions per (wave, splat) instead of up to 64 x 84;
-//   * splats that cannot touch the wave's 8x8 pixel block are culled lane-parallel (64 splats per instruction,
-//     stage.hpp) and the surviving ballot mask is walked with scalar bit scans.
+//     the Gaussian's gradient rows: <= 2 atomic instructions per (wave, splat) instead of up to 64 x 84.
 #include "common.hpp"
 #include "stage.hpp"
 
@@ -24,28 +24,29 @@ namespace svgir {
 namespace {
 
 template <int S, int VC, bool SVGSS>
-__global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a) {
+__global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int VS = VC * 4;
     constexpr int NCH = 13 + S + VS;
     constexpr int NV = (NCH + 63) / 64;
     constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
-
     using SG = StageGeom<S, VC>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sD = reinterpret_cast<float*>(smem);                               // [BATCH][NF]
-    int* sId = reinterpret_cast<int*>(smem + (size_t)SG::BATCH * SG::NF * 4);  // [BATCH]
-    __shared__ uint32_t sMax[4];
+    float* sD = reinterpret_cast<float*>(smem);                              // [CH][NF]
+    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);  // [CH] {gid, slot} of the batch
 
-    const int tile = blockIdx.x;
+    int tile, sub;
+    sub_tile_of_block(blockIdx.x, a.gx * a.gy, tile, sub);
+    if (tile < 0) return;
+    const int count = (int)a.sub_count[4 * tile + sub];
+    if (count == 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int lane = threadIdx.x;
+    const int px = tx * TILE + (sub & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (sub >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float wx0 = (float)(tx * TILE + (wave & 1) * 8), wy0 = (float)(ty * TILE + (wave >> 1) * 8);
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
-    if (r1 <= r0) return;  // uniform: empty tile
+    const uint2* __restrict__ sub_in = a.sub_list + (size_t)4 * r0 + (size_t)sub * (r1 - r0);
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
     const bool sp = surface && cfg_flag(a.cfg, 2);
     const bool bgeom = SVGSS ? true : (a.backward_geometry != 0);
@@ -66,13 +67,11 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
     const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
-    // deepest contributor of the wave / of the tile
+    // deepest contributor of the wave
     uint32_t wmax = last_contributor;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
-    if (lane == 0) sMax[wave] = wmax;
-    __syncthreads();
-    const uint32_t bmax = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+    if (wmax == 0) return;
 
     // per-lane destination of channel (lane + 64 k): base pointer and per-Gaussian stride
     float* dbase[NV];
@@ -103,29 +102,23 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
 #pragma unroll
     for (int i = 0; i < VV; i++) { acc_vf[i] = 0.f; last_vf[i] = 0.f; }
 
-    for (int top = (int)bmax; top > 0; top -= SG::BATCH) {  // this batch covers slots [top - n, top)
-        const int n = min((int)SG::BATCH, top);
+    for (int top = count; top > 0; top -= SG::CH) {  // this batch covers list entries [top - m, top), in reverse
+        const int m = min((int)SG::CH, top);
+        uint2 e = make_uint2(0u, 0xFFFFFFFFu);
+        if (lane < m) e = sub_in[top - 1 - lane];
+        // entries are ordered by slot: if even the shallowest entry of the batch is behind every pixel, skip it
+        if (__ballot(e.y < wmax) == 0ull) continue;
+        __syncthreads();  // previous batch fully consumed
+        if (lane < m) sQ[lane] = e;
         __syncthreads();
-        if (t < n) sId[t] = (int)a.point_list[r0 + (uint32_t)(top - 1 - t)];
+        stage_candidates<S, VC>(sD, m, [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
         __syncthreads();
-        stage_batch<S, VC>(sD, sId, n, a.rec, a.features, a.vfeatures);
-        __syncthreads();
-        for (int rnd = 0; rnd * 64 < n; rnd++) {
-          // lane-parallel conservative cull of 64 staged splats against this wave's 8x8 pixel block (stage.hpp)
-          const int js = rnd * 64 + lane;
-          bool cand = false;
-          if (js < n && (uint32_t)(top - 1 - js) < wmax) {
-              const float4* qs = reinterpret_cast<const float4*>(sD + js * SG::NF);
-              const float4 A = qs[0];
-              const float4 B = qs[1];
-              cand = splat_may_touch(A.x, A.y, A.z, A.w, B.x, B.y, wx0, wy0, wx0 + 7.f, wy0 + 7.f);
-          }
-          unsigned long long mask = __ballot(cand);
-          while (mask) {
-            const int j = rnd * 64 + __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const uint32_t slot = (uint32_t)(top - 1 - j);
-            const float4* q = reinterpret_cast<const float4*>(sD + j * SG::NF);
+        for (int c = 0; c < m; c++) {
+            const uint2 ec = sQ[c];
+            const uint32_t slot = ec.y;
+            if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
+            const float* r = sD + c * SG::NF;
+            const float4* q = reinterpret_cast<const float4*>(r);
             const float4 A = q[0];   // x, y, conic.x, conic.y
             const float4 B = q[1];   // conic.z, opacity, depth, J6
             const float dx = A.x - pxf, dy = A.y - pyf;
@@ -137,8 +130,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
             const bool pass = slot < last_contributor && power <= 0.0f && alpha >= (1.0f / 255.0f);
             if (__ballot(pass) == 0ull) continue;
 
-            const int gid = sId[j];
-            const float* r = sD + j * SG::NF;
+            const int gid = (int)ec.x;
             float cb[NCH];
 #pragma unroll
             for (int i = 0; i < NCH; i++) cb[i] = 0.f;
@@ -172,7 +164,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                     cb[6 + ch] = dch * gC[ch];
                 }
                 if (S > 0) {
-                    const float* f = sD + j * SG::NF + SG::F_OFF;
+                    const float* f = r + SG::F_OFF;
 #pragma unroll
                     for (int ch = 0; ch < S; ch++) {
                         const float fv = f[ch];
@@ -183,7 +175,7 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                     }
                 }
                 if (VC > 0) {
-                    const float* vf = sD + j * SG::NF + SG::V_OFF;
+                    const float* vf = r + SG::V_OFF;
 #pragma unroll
                     for (int ch = 0; ch < VC; ch++) {
                         const float v = vf[4 * ch] * cw[0] + vf[4 * ch + 1] * cw[1] + vf[4 * ch + 2] * cw[2] + vf[4 * ch + 3] * cw[3];
@@ -258,7 +250,6 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
                     if (v != 0.f) atomic_add_f32(dbase[k] + (size_t)gid * dstride[k], v);
                 }
             }
-          }
         }
     }
 }
@@ -266,7 +257,8 @@ __global__ void __launch_bounds__(BLOCK) render_bwd_kernel(const RenderBwdArgs a
 template <int S, int VC, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
     using SG = StageGeom<S, VC>;
-    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(a.gx * a.gy), dim3(BLOCK), SG::lds_bytes(), s, a);
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), SG::lds_bytes(),
+                       s, a);
 }
 
 }  // namespace

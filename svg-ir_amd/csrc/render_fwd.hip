@@ -1,24 +1,20 @@
-// svg-ir_amd/csrc/render_fwd.hip -- forward per-tile alpha compositing.
+// svg-ir_amd/csrc/render_fwd.hip -- forward alpha compositing.
 //
 // Replaces renderCUDA (svgss forward.cu:401-750, rgss forward.cu:323-535): front-to-back blending of the
 // depth-ordered splat list of each 16x16 tile; per-pixel depth by depth differencing; svgss additionally blends
 // VS/4 "vfeature" channels, each the bilinear interpolation of 4 corner values in the surfel's tangent plane.
 //
-// CDNA4 mapping
-//   * one 256-thread workgroup per tile = 4 wave64, each wave owns an 8x8 pixel quadrant (compact footprint =>
-//     more wave-level culling than the reference's 16x2 warp rows);
-//   * the splat list is consumed in batches; for each batch ALL per-splat data -- the 96-byte record written by the
-//     preprocess stage plus the S feature and VS vfeature floats -- is gathered into LDS once per tile with 16-byte
-//     loads issued by all 256 threads (one latency exposure per batch, every byte of the algorithmic gather
-//     R*(4+G) is touched exactly once per tile).  The reference stages only the geometry and re-reads
-//     features/vfeatures from global memory per (pixel, splat) (forward.cu:635-646);
-//   * every wave walks the staged batch reading wave-uniform LDS addresses (broadcast ds_read_b128, no bank
-//     conflicts).  Before that, the wave culls the batch LANE-PARALLEL: each lane tests one staged splat against the
-//     wave's 8x8 pixel rectangle (exact minimum of the conic form over the rectangle vs. the 1/255 alpha threshold,
-//     stage.hpp) and the ballot mask is then walked with scalar bit scans, so splats that cannot touch the wave
-//     cost 1/64 of an iteration instead of one;
-//   * channel counts are template parameters: accumulators live in VGPRs (the reference spills >640 floats of
-//     per-thread arrays to scratch, forward.cu:483-493);
+// CDNA4 mapping (see stage.hpp for the staging details)
+//   * one wave64 per 8x8-pixel sub-tile, one wave per workgroup: 4x more independent work items than the
+//     reference's 256-thread tile blocks, no workgroup barriers, and a compact pixel footprint so that a splat is
+//     only visited by the waves it can actually touch (measured: ~17 % of the (wave, splat) pairs of a tile list);
+//   * the wave scans the tile list 64 entries per step, one splat per lane: coalesced id load, 32-byte header
+//     gather, exact minimum of the conic form over the 8x8 rectangle against the 1/255 alpha threshold; survivors are
+//     compacted with a ballot + popcount into an LDS ring and -- with their slot in the tile list -- into a global
+//     per-sub-tile list that the backward kernel reuses (it never re-culls);
+//   * candidates are staged CH at a time into LDS (record + features + vfeatures, 16-byte loads, all in flight
+//     together) and consumed with wave-uniform broadcast reads; channel counts are template parameters so every
+//     accumulator lives in a VGPR (the reference keeps >640 floats per thread in scratch, forward.cu:483-493);
 //   * the per-(pixel,splat) out_weights atomic of the reference (forward.cu:653) becomes one DPP wave reduction
 //     + one atomic per (wave, splat).
 #include "common.hpp"
@@ -29,23 +25,29 @@ namespace svgir {
 namespace {
 
 template <int S, int VC, bool SVGSS>
-__global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
+__global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
     using SG = StageGeom<S, VC>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sD = reinterpret_cast<float*>(smem);                               // [BATCH][NF]
-    int* sId = reinterpret_cast<int*>(smem + (size_t)SG::BATCH * SG::NF * 4);  // [BATCH]
+    float* sD = reinterpret_cast<float*>(smem);                              // [CH][NF]
+    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);  // [QN] {gid, slot}
 
-    const int tile = blockIdx.x;
+    int tile, sub;
+    sub_tile_of_block(blockIdx.x, a.gx * a.gy, tile, sub);
+    if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int lane = threadIdx.x;
+    const int bx = tx * TILE + (sub & 1) * 8, by = ty * TILE + (sub >> 1) * 8;
+    const int px = bx + (lane & 7), py = by + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float wx0 = (float)(tx * TILE + (wave & 1) * 8), wy0 = (float)(ty * TILE + (wave >> 1) * 8);
+    const float wx0 = (float)bx, wy0 = (float)by;
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+    const int len = (int)(r1 - r0);
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
     const bool sp = surface && cfg_flag(a.cfg, 2);
+    const float4* __restrict__ rec4 = reinterpret_cast<const float4*>(a.rec);
+    uint2* __restrict__ sub_out = a.sub_list + (size_t)4 * r0 + (size_t)sub * len;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     bool done = !inside;
     float T = 1.0f, D = 0.f;
@@ -58,34 +60,43 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
     for (int i = 0; i < (VC > 0 ? VC : 1); i++) VF[i] = 0.f;
     uint32_t last_contributor = 0;
 
-    for (uint32_t base = r0; base < r1; base += SG::BATCH) {
-        // all four waves finished => stop fetching (forward.cu:499-501); also the barrier that frees the LDS batch
-        if (__syncthreads_and(done)) break;
-        const int n = min((int)SG::BATCH, (int)(r1 - base));
-        if (t < n) sId[t] = (int)a.point_list[base + t];
-        __syncthreads();
-        stage_batch<S, VC>(sD, sId, n, a.rec, a.features, a.vfeatures);
-        __syncthreads();
-        if (__all(done)) continue;  // this wave is finished; keep taking part in the barriers
+    uint32_t head = 0, tail = 0;  // candidate ring indices (wave-uniform)
+    bool wave_done = __all(done);
+    for (int scan = 0; scan < len && !wave_done; scan += 64) {
+        // ---- lane-parallel cull of 64 list entries ----
+        const int i = scan + lane;
+        bool cand = false;
+        uint32_t gid = 0;
+        if (i < len) {
+            gid = a.point_list[r0 + i];
+            const float4 A = rec4[(size_t)gid * 6];
+            const float4 B = rec4[(size_t)gid * 6 + 1];
+            cand = splat_may_touch(A.x, A.y, A.z, A.w, B.x, B.y, wx0, wy0, wx0 + 7.f, wy0 + 7.f);
+        }
+        const unsigned long long mask = __ballot(cand);
+        if (cand) {
+            const uint32_t pos = tail + (uint32_t)__popcll(mask & lt_mask);
+            const uint2 e = make_uint2(gid, (uint32_t)i);
+            sQ[pos & (SG::QN - 1)] = e;
+            sub_out[pos] = e;
+        }
+        tail += (uint32_t)__popcll(mask);
+        const bool last_scan = scan + 64 >= len;
 
-        bool wave_done = false;
-        for (int rnd = 0; rnd * 64 < n && !wave_done; rnd++) {
-            // lane-parallel conservative cull of 64 staged splats against this wave's 8x8 pixel block
-            const int js = rnd * 64 + lane;
-            bool cand = false;
-            if (js < n) {
-                const float4* qs = reinterpret_cast<const float4*>(sD + js * SG::NF);
-                const float4 A = qs[0];
-                const float4 B = qs[1];
-                cand = splat_may_touch(A.x, A.y, A.z, A.w, B.x, B.y, wx0, wy0, wx0 + 7.f, wy0 + 7.f);
-            }
-            unsigned long long mask = __ballot(cand);
-            while (mask) {
-                const int j = rnd * 64 + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float4* q = reinterpret_cast<const float4*>(sD + j * SG::NF);
+        // ---- stage + blend queued candidates, CH at a time ----
+        while (!wave_done && (tail - head >= (uint32_t)SG::CH || (last_scan && tail != head))) {
+            const int m = min((int)SG::CH, (int)(tail - head));
+            __syncthreads();  // ring writes visible; previous batch fully consumed
+            stage_candidates<S, VC>(sD, m, [&](int s) { return sQ[(head + s) & (SG::QN - 1)].x; }, lane, a.rec,
+                                    a.features, a.vfeatures);
+            __syncthreads();
+            for (int c = 0; c < m; c++) {
+                const float4* q = reinterpret_cast<const float4*>(sD + c * SG::NF);
                 const float4 A = q[0];   // x, y, conic.x, conic.y
                 const float4 B = q[1];   // conic.z, opacity, depth, J6
+                const float4 J = q[2];   // J0..J3
+                const float4 E = q[3];   // J9, r, g, b
+                const float4 Nn = q[4];  // nx, ny, nz, 1/umax
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 float power;
                 if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
@@ -95,55 +106,53 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
                 const float test_T = T * (1.f - alpha);
                 bool newly_done = false;
                 if (pass && test_T < 0.0001f) { done = true; pass = false; newly_done = true; }
-                if (__ballot(pass) == 0ull) {
-                    if (__any(newly_done) && __all(done)) { wave_done = true; break; }
-                    continue;
-                }
-                const float w = pass ? alpha * T : 0.f;
-                const float4 J = q[2];   // J0..J3
-                const float4 E = q[3];   // J9, r, g, b
-                const float4 Nn = q[4];  // nx, ny, nz, 1/umax
-                float dep = B.z;
-                float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-                if (sp) {
-                    const float du = dx * J.x + dy * J.y;
-                    const float dv = dx * J.z + dy * J.w;
-                    dep -= du * B.w + dv * E.x;
-                    if (SVGSS && VC > 0) {
-                        const float iv = q[5].x;
-                        float u = du * Nn.w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
-                        u = fminf(0.999f, fmaxf(0.001f, u));
-                        v = fminf(0.999f, fmaxf(0.001f, v));
-                        // pre-multiplied by the blend weight
-                        w0 = (1.f - u) * (1.f - v) * w; w1 = u * (1.f - v) * w; w2 = (1.f - u) * v * w; w3 = u * v * w;
+                if (__ballot(pass) != 0ull) {
+                    const float w = pass ? alpha * T : 0.f;
+                    float dep = B.z;
+                    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+                    if (sp) {
+                        const float du = dx * J.x + dy * J.y;
+                        const float dv = dx * J.z + dy * J.w;
+                        dep -= du * B.w + dv * E.x;
+                        if (SVGSS && VC > 0) {
+                            const float iv = q[5].x;
+                            float u = du * Nn.w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
+                            u = fminf(0.999f, fmaxf(0.001f, u));
+                            v = fminf(0.999f, fmaxf(0.001f, v));
+                            // pre-multiplied by the blend weight
+                            w0 = (1.f - u) * (1.f - v) * w; w1 = u * (1.f - v) * w; w2 = (1.f - u) * v * w; w3 = u * v * w;
+                        }
                     }
-                }
-                D += dep * w;
-                C[0] += E.y * w; C[1] += E.z * w; C[2] += E.w * w;
-                if (surface) { N[0] += Nn.x * w; N[1] += Nn.y * w; N[2] += Nn.z * w; }
-                if (S > 0) {
-                    const float* f = sD + j * SG::NF + SG::F_OFF;
+                    D += dep * w;
+                    C[0] += E.y * w; C[1] += E.z * w; C[2] += E.w * w;
+                    if (surface) { N[0] += Nn.x * w; N[1] += Nn.y * w; N[2] += Nn.z * w; }
+                    if (S > 0) {
+                        const float* f = sD + c * SG::NF + SG::F_OFF;
 #pragma unroll
-                    for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w;
-                }
-                if (VC > 0) {
-                    const float4* vf = reinterpret_cast<const float4*>(sD + j * SG::NF + SG::V_OFF);
-#pragma unroll
-                    for (int ch = 0; ch < VC; ch++) {
-                        const float4 c4 = vf[ch];
-                        VF[ch] += c4.x * w0 + c4.y * w1 + c4.z * w2 + c4.w * w3;
+                        for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w;
                     }
+                    if (VC > 0) {
+                        const float4* vf = reinterpret_cast<const float4*>(sD + c * SG::NF + SG::V_OFF);
+#pragma unroll
+                        for (int ch = 0; ch < VC; ch++) {
+                            const float4 c4 = vf[ch];
+                            VF[ch] += c4.x * w0 + c4.y * w1 + c4.z * w2 + c4.w * w3;
+                        }
+                    }
+                    const uint2 e = sQ[(head + c) & (SG::QN - 1)];
+                    if (pass) {
+                        T = test_T;
+                        last_contributor = e.y + 1u;
+                    }
+                    const float wsum = wave_scan_last(w);
+                    if (lane == 63) atomic_add_f32(&a.out_weights[e.x], wsum);
                 }
-                if (pass) {
-                    T = test_T;
-                    last_contributor = (base - r0) + (uint32_t)j + 1u;
-                }
-                const float wsum = wave_scan_last(w);
-                if (lane == 63) atomic_add_f32(&a.out_weights[sId[j]], wsum);
                 if (__any(newly_done) && __all(done)) { wave_done = true; break; }
             }
+            head += (uint32_t)m;
         }
     }
+    if (lane == 0) a.sub_count[4 * tile + sub] = tail;
 
     if (inside) {
         const size_t N_ = (size_t)a.W * a.H;
@@ -170,7 +179,8 @@ __global__ void __launch_bounds__(BLOCK) render_fwd_kernel(const RenderArgs a) {
 template <int S, int VC, bool SVGSS>
 void launch(const RenderArgs& a, hipStream_t s) {
     using SG = StageGeom<S, VC>;
-    hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(a.gx * a.gy), dim3(BLOCK), SG::lds_bytes(), s, a);
+    hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), SG::lds_bytes(),
+                       s, a);
 }
 
 }  // namespace

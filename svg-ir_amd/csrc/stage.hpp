@@ -1,9 +1,15 @@
-// svg-ir_amd/csrc/stage.hpp -- LDS staging of a batch of splats, shared by the forward and backward composite
+// svg-ir_amd/csrc/stage.hpp -- wave-level culling and LDS staging shared by the forward and backward composite
 // kernels.
 //
-// Staged layout of one splat (floats):  [0,24) the record written by preprocess.hip (common.hpp RecField),
-// [24, 24+S4) the S feature floats padded to a float4 boundary, [24+S4, NF) the VS vfeature floats.
-// Every slot starts on a 16-byte boundary, so the walking waves read it with broadcast ds_read_b128.
+// Work decomposition: ONE wave64 per 8x8-pixel sub-tile (4 per 16x16 tile), no workgroup barriers.  A wave scans its
+// tile's depth-ordered splat list 64 entries at a time, culls lane-parallel (one splat per lane) against its 8x8
+// pixel rectangle, and queues the survivors ("candidates") in a small LDS ring.  Candidates are then staged CH at a
+// time: the 96-byte record written by preprocess.hip plus the S feature and VS vfeature floats are gathered into LDS
+// with 16-byte loads (all loads of a batch in flight before the first LDS store) and every candidate is then consumed
+// with wave-uniform (broadcast) ds_read_b128.
+//
+// Staged layout of one candidate (floats):  [0,24) the record (common.hpp RecField), [24, 24+S4) the S feature
+// floats padded to a float4 boundary, [24+S4, NFD) the VS vfeature floats; slot stride NF = an odd number of float4s.
 #pragma once
 #include "common.hpp"
 
@@ -11,17 +17,18 @@ namespace svgir {
 
 template <int S, int VC>
 struct StageGeom {
-    static constexpr int S4 = (S + 3) / 4 * 4;      // feature slots padded to a float4 boundary
-    static constexpr int NFD = REC + S4 + VC * 4;    // floats of data per staged splat
-    // slot stride: an ODD number of float4s, so that 64 lanes reading the headers of 64 consecutive slots with
-    // ds_read_b128 fall on distinct 16-byte LDS slots (bank-conflict free), while a wave-uniform read broadcasts
-    static constexpr int NF4 = (NFD / 4) | 1;
+    static constexpr int S4 = (S + 3) / 4 * 4;
+    static constexpr int NFD = REC + S4 + VC * 4;    // floats of data per staged candidate
+    static constexpr int NF4 = (NFD / 4) | 1;        // slot stride in float4 (odd => conflict-free column access)
     static constexpr int NF = NF4 * 4;
-    static constexpr int C4 = 6 + VC;                // float4 chunks gathered with 16-byte loads (record + vfeatures)
-    static constexpr int BATCH = NF <= 32 ? 256 : (NF <= 64 ? 192 : 128);  // <= 48 KB of LDS per workgroup
-    static constexpr int F_OFF = REC;                // features
-    static constexpr int V_OFF = REC + S4;           // vfeatures
-    static constexpr size_t lds_bytes() { return (size_t)BATCH * NF * 4 + (size_t)BATCH * 4; }
+    static constexpr int C4 = 6 + VC;                // 16-byte chunks gathered per candidate (record + vfeatures)
+    static constexpr int CH = NF <= 48 ? 64 : 32;    // candidates staged per batch (<= ~13 KB of LDS per wave)
+    static constexpr int QN = 128;                   // candidate ring (>= CH + 64)
+    static constexpr int F_OFF = REC;
+    static constexpr int V_OFF = REC + S4;
+    static constexpr int KV = (CH * C4 + 63) / 64;   // 16-byte loads per lane per batch
+    static constexpr int KF = (CH * S + 63) / 64;    // feature floats per lane per batch
+    static constexpr size_t lds_bytes() { return (size_t)CH * NF * 4 + (size_t)QN * 8; }
 };
 
 #if defined(__HIPCC__)
@@ -50,32 +57,69 @@ __device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, flo
     return qmin <= tau2 + slack;
 }
 
-// Gathers splats [0, n) of the current batch into LDS.  ids[s] must already hold the Gaussian id of slot s
-// (written before a barrier).  All 256 threads take part; loads are 16 bytes wide except the S feature floats
-// (rows of S floats are not 16-byte aligned in the caller's [P,S] tensor).
-template <int S, int VC>
-__device__ __forceinline__ void stage_batch(float* __restrict__ sD, const int* __restrict__ ids, int n,
-                                            const float* __restrict__ rec, const float* __restrict__ feat,
-                                            const float* __restrict__ vfeat) {
+// Wave-level gather of m (<= CH) candidates into LDS slots [0, m).  `gid_of(s)` returns the Gaussian id of the
+// candidate that goes to slot s (a wave-uniform-free LDS read).  All global loads of the batch are issued before
+// the first LDS store.  The caller separates the stores from the subsequent LDS reads with a workgroup barrier
+// (one wave per workgroup => s_barrier is only an ordering point).
+template <int S, int VC, typename GidOf>
+__device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, GidOf gid_of, int lane,
+                                                 const float* __restrict__ rec, const float* __restrict__ feat,
+                                                 const float* __restrict__ vfeat) {
     using SG = StageGeom<S, VC>;
     float4* sD4 = reinterpret_cast<float4*>(sD);
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
     const float4* vf4 = reinterpret_cast<const float4*>(vfeat);
-    const int total = n * SG::C4;
-    for (int k = threadIdx.x; k < total; k += BLOCK) {
+    const int total = m * SG::C4;  // >= C4 (m >= 1)
+    // Loads are unconditional (index clamped), only the LDS stores are predicated: keeps everything in registers.
+    float4 v[SG::KV];
+#pragma unroll
+    for (int u = 0; u < SG::KV; u++) {
+        const int k = min(u * 64 + lane, total - 1);
         const int s = k / SG::C4, part = k - s * SG::C4;
-        const size_t id = (size_t)ids[s];
-        if (part < 6) sD4[s * SG::NF4 + part] = rec4[id * 6 + part];
-        else sD4[s * SG::NF4 + SG::V_OFF / 4 + (part - 6)] = vf4[id * VC + (part - 6)];
+        const size_t id = (size_t)gid_of(s);
+        const float4* src = part < 6 ? rec4 + id * 6 + part : vf4 + id * VC + (part - 6);
+        v[u] = *src;
+    }
+    float fv[SG::KF > 0 ? SG::KF : 1];
+    if (S > 0) {
+        const int totf = m * S;
+#pragma unroll
+        for (int u = 0; u < SG::KF; u++) {
+            const int k = min(u * 64 + lane, totf - 1);
+            const int s = k / S, c = k - s * S;
+            fv[u] = feat[(size_t)gid_of(s) * S + c];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SG::KV; u++) {
+        const int k = u * 64 + lane;
+        if (k < total) {
+            const int s = k / SG::C4, part = k - s * SG::C4;
+            sD4[s * SG::NF4 + (part < 6 ? part : SG::V_OFF / 4 + (part - 6))] = v[u];
+        }
     }
     if (S > 0) {
-        const int totf = n * S;
-        for (int k = threadIdx.x; k < totf; k += BLOCK) {
-            const int s = k / S, c = k - s * S;
-            sD[s * SG::NF + SG::F_OFF + c] = feat[(size_t)ids[s] * S + c];
+        const int totf = m * S;
+#pragma unroll
+        for (int u = 0; u < SG::KF; u++) {
+            const int k = u * 64 + lane;
+            if (k < totf) {
+                const int s = k / S, c = k - s * S;
+                sD[s * SG::NF + SG::F_OFF + c] = fv[u];
+            }
         }
     }
 }
+
+// Block -> (tile, sub-tile) mapping: the four waves of a tile get block ids congruent mod 8, i.e. they run on the
+// same XCD (blocks are dispatched round-robin over the 8 XCDs) and share that XCD's L2 for the records they gather.
+__device__ __forceinline__ void sub_tile_of_block(int b, int T, int& tile, int& sub) {
+    const int grp = b >> 5, r = b & 31;  // 32 blocks = 8 tiles x 4 sub-tiles
+    tile = grp * 8 + (r & 7);
+    sub = r >> 3;
+    if (tile >= T) tile = -1;
+}
+inline int sub_tile_grid(int T) { return ((T + 7) / 8) * 32; }
 #endif
 
 }  // namespace svgir
