@@ -39,11 +39,15 @@ class _CBinding:
         S = features.size(1) if features.dim() == 2 else 0
         H, W = int(image_height), int(image_width)
         f32 = dict(dtype=torch.float32, device=dev)
-        out_color = torch.empty((3, H, W), **f32)
-        out_normal = torch.empty((3, H, W), **f32)
-        out_opacity = torch.empty((1, H, W), **f32)
-        out_depth = torch.empty((1, H, W), **f32)
-        out_feature = torch.empty((S, H, W), **f32)
+        if P == 0:  # nothing is launched: the reference returns its zero-initialised outputs (rasterize_points.cu:100)
+            torch_empty = torch.zeros
+        else:
+            torch_empty = torch.empty  # every pixel is written by the composite kernel
+        out_color = torch_empty((3, H, W), **f32)
+        out_normal = torch_empty((3, H, W), **f32)
+        out_opacity = torch_empty((1, H, W), **f32)
+        out_depth = torch_empty((1, H, W), **f32)
+        out_feature = torch_empty((S, H, W), **f32)
         out_pseudo_normal = torch.zeros((3, H, W), **f32)
         out_surface_xyz = torch.zeros((3, H, W), **f32)
         out_weights = torch.zeros((P, 1), **f32)
