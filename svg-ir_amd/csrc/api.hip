@@ -253,6 +253,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     tm.mark("sort_tile");
     const int fin = plan.passes & 1;
     launch_ranges(R, B.key[fin], I.ranges, T, s);
+    launch_tile_order(I.ranges, T, I.tile_order, s);
     if (int rc = check("ranges")) return rc;
     tm.mark("ranges");
 
@@ -260,7 +261,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = svgss ? p->VS : 0;
     ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
     ra.bg = p->background;
-    ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_count = I.sub_count;
+    ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_count = I.sub_count; ra.tile_order = I.tile_order;
     ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
     ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
     ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
@@ -301,7 +302,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = svgss ? p->VS : 0;
     ba.ranges = I.ranges; ba.point_list = B.val[fin]; ba.rec = G.rec; ba.features = p->features; ba.vfeatures = p->vfeatures;
     ba.bg = p->background;
-    ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count;
+    ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count; ba.tile_order = I.tile_order;
     ba.backward_geometry = p->backward_geometry;
     ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;
     ba.g_color = g->dL_dout_color; ba.g_normal = g->dL_dout_normal; ba.g_depth = g->dL_dout_depth;

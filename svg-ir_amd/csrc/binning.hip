@@ -195,7 +195,54 @@ __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R, const uint32_t* __
     if (i == R - 1) ranges[2 * cur + 1] = (uint32_t)R;
 }
 
+// One-block counting sort of the T tiles by descending list length (1024 length buckets).
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ ranges, int T,
+                                                          uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t maxlen_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    hist[t] = 0;
+    if (t == 0) maxlen_s = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int i = t; i < T; i += 1024) mx = max(mx, ranges[2 * i + 1] - ranges[2 * i]);
+    atomicMax(&maxlen_s, mx);
+    __syncthreads();
+    const uint32_t maxlen = maxlen_s + 1;
+    for (int i = t; i < T; i += 1024) {
+        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
+        const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
+        atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of hist over the 1024 threads
+    const uint32_t v = hist[t];
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    __syncthreads();
+    hist[t] = woff + incl - v;  // becomes the bucket cursor
+    __syncthreads();
+    for (int i = t; i < T; i += 1024) {
+        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
+        const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
+        order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
+    }
+}
+
 }  // namespace
+
+void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, T, order);
+}
 
 void launch_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int bit_lo,
                        int nbits, uint32_t* table, hipStream_t s) {

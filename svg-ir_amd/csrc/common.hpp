@@ -77,6 +77,7 @@ struct ImageLayout {
     float* final_D;      // [N]
     int32_t* n_contrib;  // [N]
     uint32_t* ranges;    // [2*T]
+    uint32_t* tile_order; // [T] tiles sorted by descending list length (heaviest work is dispatched first)
     uint32_t* sub_count; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the forward)
     size_t ncontrib_off;
     size_t bytes;
@@ -92,6 +93,7 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.ncontrib_off = off;
     im.n_contrib = (int32_t*)take(N * 4);
     im.ranges = (uint32_t*)take(T * 8);
+    im.tile_order = (uint32_t*)take(T * 4);
     im.sub_count = (uint32_t*)take(T * 4 * 4);
     im.bytes = off;
     return im;
@@ -160,7 +162,7 @@ struct RenderArgs {
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
     CfgRef cfg;
-    uint2* sub_list; uint32_t* sub_count;
+    uint2* sub_list; uint32_t* sub_count; const uint32_t* tile_order;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
 };
@@ -171,7 +173,7 @@ struct RenderBwdArgs {
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
     CfgRef cfg; int backward_geometry;
-    const uint2* sub_list; const uint32_t* sub_count;
+    const uint2* sub_list; const uint32_t* sub_count; const uint32_t* tile_order;
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
@@ -199,6 +201,8 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, hipStream_t s);
 void launch_ranges(int R, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
+// order[] = tile ids sorted by descending list length (longest-processing-time-first dispatch of the composite waves)
+void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 if (S,VS) unsupported
 int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 if (S,VS) unsupported
 void launch_geom_bwd(const GeomBwdArgs& a, hipStream_t s);

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);  // [CH] {gid, slot} of the batch
 
     int tile, sub;
-    sub_tile_of_block(blockIdx.x, a.gx * a.gy, tile, sub);
+    sub_tile_of_block(blockIdx.x, a.gx * a.gy, a.tile_order, tile, sub);
     if (tile < 0) return;
     const int count = (int)a.sub_count[4 * tile + sub];
     if (count == 0) return;

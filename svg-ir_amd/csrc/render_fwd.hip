@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
     uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);  // [QN] {gid, slot}
 
     int tile, sub;
-    sub_tile_of_block(blockIdx.x, a.gx * a.gy, tile, sub);
+    sub_tile_of_block(blockIdx.x, a.gx * a.gy, a.tile_order, tile, sub);
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int lane = threadIdx.x;

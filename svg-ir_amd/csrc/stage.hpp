@@ -113,11 +113,14 @@ __device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, 
 
 // Block -> (tile, sub-tile) mapping: the four waves of a tile get block ids congruent mod 8, i.e. they run on the
 // same XCD (blocks are dispatched round-robin over the 8 XCDs) and share that XCD's L2 for the records they gather.
-__device__ __forceinline__ void sub_tile_of_block(int b, int T, int& tile, int& sub) {
+// Tiles are taken in descending order of their list length (tile_order), so the longest sequential walks start
+// first and the short ones fill the tail of the launch.
+__device__ __forceinline__ void sub_tile_of_block(int b, int T, const uint32_t* __restrict__ tile_order, int& tile,
+                                                  int& sub) {
     const int grp = b >> 5, r = b & 31;  // 32 blocks = 8 tiles x 4 sub-tiles
-    tile = grp * 8 + (r & 7);
+    const int k = grp * 8 + (r & 7);
     sub = r >> 3;
-    if (tile >= T) tile = -1;
+    tile = k < T ? (int)tile_order[k] : -1;
 }
 inline int sub_tile_grid(int T) { return ((T + 7) / 8) * 32; }
 #endif
