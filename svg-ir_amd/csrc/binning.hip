@@ -19,25 +19,29 @@ namespace svgir {
 namespace {
 
 // ---- radix pass --------------------------------------------------------------------------------------------
+// ITEMS keys per thread (1024 or 4096 keys per block).  FUSED: the digit table is [block][256] and the scatter kernel
+// derives its own output cursors from it (no separate scan launch); otherwise the table is [digit][block] and a
+// one-block scan kernel turns it into exclusive offsets (very large inputs).
+template <int ITEMS, bool FUSED>
 __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int bit_lo,
                                                            uint32_t mask, int nblocks, uint32_t* __restrict__ table) {
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
-    const int base = blockIdx.x * SORT_BLOCK_ELEMS;
-#pragma unroll 4
-    for (int i = 0; i < SORT_ITEMS; i++) {
+    const int base = blockIdx.x * (BLOCK * ITEMS);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
         const int e = base + i * BLOCK + threadIdx.x;
         if (e < n) atomicAdd(&hist[(keys[e] >> bit_lo) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+    if (FUSED) table[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
+    else if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 
 // One-block exclusive scan of `count` uint32 values, in place.
 __global__ void __launch_bounds__(1024) table_scan_kernel(uint32_t* __restrict__ table, int count) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (count + 1023) / 1024;
     const int lo = min(count, t * per), hi = min(count, lo + per);
@@ -55,13 +59,13 @@ __global__ void __launch_bounds__(1024) table_scan_kernel(uint32_t* __restrict__
     if (t == 0) {
         uint32_t acc = 0;
         for (int w = 0; w < 16; w++) { const uint32_t v = wsum[w]; wsum[w] = acc; acc += v; }
-        carry_s = acc;
     }
     __syncthreads();
     uint32_t run = wsum[wave] + incl - s;
     for (int i = lo; i < hi; i++) { const uint32_t v = table[i]; table[i] = run; run += v; }
 }
 
+template <int ITEMS, bool FUSED>
 __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __restrict__ kin,
                                                               const uint32_t* __restrict__ vin,
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -69,12 +73,34 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ table) {
     __shared__ uint32_t running[256];     // global output cursor per digit for this block
     __shared__ uint32_t wave_cnt[4][256];  // per-wave digit counts of the current chunk
+    __shared__ uint32_t wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t mask = (1u << nbits) - 1;
-    running[t] = (t <= (int)mask) ? table[(size_t)t * nblocks + blockIdx.x] : 0;
-    const int base = blockIdx.x * SORT_BLOCK_ELEMS;
+    if (FUSED) {
+        // cursor[d] = sum over digits d' < d of (count of d' in all blocks) + count of d in the blocks before this one
+        uint32_t before = 0, total = 0;
+        for (int b = 0; b < nblocks; b++) {
+            const uint32_t c = table[(size_t)b * 256 + t];
+            total += c;
+            if (b < (int)blockIdx.x) before += c;
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        running[t] = woff + incl - total + before;
+    } else {
+        running[t] = (t <= (int)mask) ? table[(size_t)t * nblocks + blockIdx.x] : 0;
+    }
+    const int base = blockIdx.x * (BLOCK * ITEMS);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int c = 0; c < SORT_ITEMS; c++) {
+    for (int c = 0; c < ITEMS; c++) {
 #pragma unroll
         for (int w = 0; w < 4; w++) wave_cnt[w][t] = 0;
         __syncthreads();
@@ -244,15 +270,25 @@ void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, T, order);
 }
 
+template <int ITEMS, bool FUSED>
+static void radix_pass_impl(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int bit_lo,
+                            int nbits, uint32_t* table, hipStream_t s) {
+    const int per = BLOCK * ITEMS;
+    const int nb = (n + per - 1) / per;
+    const uint32_t mask = (1u << nbits) - 1;
+    hipLaunchKernelGGL((radix_hist_kernel<ITEMS, FUSED>), dim3(nb), dim3(BLOCK), 0, s, kin, n, bit_lo, mask, nb, table);
+    if (!FUSED) hipLaunchKernelGGL(table_scan_kernel, dim3(1), dim3(1024), 0, s, table, (int)((mask + 1) * nb));
+    hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, FUSED>), dim3(nb), dim3(BLOCK), 0, s, kin, vin, kout, vout, n,
+                       bit_lo, nbits, nb, table);
+}
+
 void launch_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int bit_lo,
                        int nbits, uint32_t* table, hipStream_t s) {
     if (n <= 0) return;
-    const int nb = sort_blocks(n);
-    const uint32_t mask = (1u << nbits) - 1;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(BLOCK), 0, s, kin, n, bit_lo, mask, nb, table);
-    hipLaunchKernelGGL(table_scan_kernel, dim3(1), dim3(1024), 0, s, table, (int)((mask + 1) * nb));
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(BLOCK), 0, s, kin, vin, kout, vout, n, bit_lo, nbits, nb,
-                       table);
+    // small inputs: 1024 keys per block for parallelism; medium: 4096; both with the scan fused into the scatter.
+    if (n <= 256 * 1024) radix_pass_impl<4, true>(kin, vin, kout, vout, n, bit_lo, nbits, table, s);
+    else if (n <= 512 * 4096) radix_pass_impl<16, true>(kin, vin, kout, vout, n, bit_lo, nbits, table, s);
+    else radix_pass_impl<16, false>(kin, vin, kout, vout, n, bit_lo, nbits, table, s);
 }
 
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,

@@ -34,7 +34,8 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // ---- radix sort geometry -----------------------------------------------------------------------------------
 constexpr int SORT_ITEMS = 16;                      // elements per thread per block
 constexpr int SORT_BLOCK_ELEMS = BLOCK * SORT_ITEMS;  // 4096
-inline int sort_blocks(int n) { return n <= 0 ? 1 : (n + SORT_BLOCK_ELEMS - 1) / SORT_BLOCK_ELEMS; }
+// upper bound of the number of radix blocks for n keys (1024 keys per block for small inputs)
+inline int sort_blocks(int n) { return n <= 0 ? 1 : (n + 1023) / 1024; }
 constexpr int SCAN_BLOCK_ELEMS = 2048;
 inline int scan_blocks(int n) { return n <= 0 ? 1 : (n + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS; }
 

@@ -12,10 +12,17 @@
 //   * candidates are staged CH at a time into LDS exactly like in the forward (stage.hpp);
 //   * per-pixel replay state (running accumulators, last values, upstream gradients) lives in VGPRs thanks to
 //     compile-time channel counts (the reference keeps ~330 floats per thread in scratch, backward.cu:617-635);
-//   * the reference issues 13 + S + VS global float atomics per (pixel, splat) pair (18 / 69 / 84).  Here each
-//     wave reduces every channel over its 64 pixels with DPP row shifts/broadcasts, parks channel c's total in
-//     lane c, and issues ONE global atomic instruction per 64 channels whose lanes hit consecutive addresses of
-//     the Gaussian's gradient rows: <= 2 atomic instructions per (wave, splat) instead of up to 64 x 84.
+//   * gradient accumulation.  The reference issues 13 + S + VS global float atomics per (pixel, splat) pair
+//     (18 / 69 / 84).  All per-Gaussian gradients except the 6 geometric ones have the form
+//         dL/dq[g][ch] = sum over pixels of  a_v[pixel] * G[pixel][ch]
+//     with a per-tile-constant matrix G (upstream image gradients) and only 1 (+4 for the bilinear corners) per-pair
+//     scalars a_v.  So the replay is split in two phases per sub-batch of SB = 8 candidates:
+//       phase A (lane = pixel): replay, alpha gradient, and the 1+4+6 per-pair scalars written to an LDS panel
+//                [candidate][vector][pixel];
+//       phase B (lane = candidate x pixel-octant): every lane contracts 8 pixels of its candidate's panel rows with
+//                the matching rows of G (LDS), a 3-step DPP butterfly over the 8 octant lanes finishes the sums, and
+//                each lane then issues the atomics of the channels it owns (channel mod 8 == octant): ~9 atomic
+//                instructions per 8 candidates, and ~1/6 of the VALU work of reducing every channel across the wave.
 #include "common.hpp"
 #include "stage.hpp"
 
@@ -23,16 +30,34 @@ namespace svgir {
 
 namespace {
 
+constexpr int SB = 8;      // candidates per phase-A/phase-B sub-batch
+constexpr int PROW = 65;   // panel row stride (floats): 64 pixels + 1 pad => conflict-free rows
+
+// sum over the 8 lanes of an aligned octant (lanes differing in their low 3 bits); result in all 8 lanes
+__device__ __forceinline__ float octant_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return v;
+}
+
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int VS = VC * 4;
-    constexpr int NCH = 13 + S + VS;
-    constexpr int NV = (NCH + 63) / 64;
+    constexpr int NCH = 13 + S + VS;        // gradient channels per Gaussian
+    constexpr int NC0 = 7 + S;              // channels fed by the plain blend weight: colour3, normal3, depth, feature S
+    constexpr int NG = NC0 + VC;            // columns of the per-pixel upstream-gradient matrix G
+    constexpr int GROW = NG + 1;            // G row stride (floats)
+    constexpr int NVEC = 1 + (VC > 0 ? 4 : 0) + 6;  // panel vectors: w, w*corner[4], geometry[6]
+    constexpr int VGEO = NVEC - 6;
+    constexpr int NK = (NCH + 7) / 8;       // atomic instructions per sub-batch
     constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
     using SG = StageGeom<S, VC>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sD = reinterpret_cast<float*>(smem);                              // [CH][NF]
-    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);  // [CH] {gid, slot} of the batch
+    float* sD = reinterpret_cast<float*>(smem);                                // [CH][NF] staged candidates
+    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);    // [CH] {gid, slot} of the batch
+    float* sG = reinterpret_cast<float*>(smem + SG::lds_bytes());               // [64][GROW] upstream gradients
+    float* sP = sG + 64 * GROW;                                                 // [SB][NVEC][PROW] panel
 
     int tile, sub;
     sub_tile_of_block(blockIdx.x, a.gx * a.gy, a.tile_order, tile, sub);
@@ -66,6 +91,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
     const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    const float gDn = normalize_depth ? gD / (1.f - T_final) : gD;  // depth gradient seen by the blended depth
 
     // deepest contributor of the wave
     uint32_t wmax = last_contributor;
@@ -73,21 +99,34 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
     if (wmax == 0) return;
 
-    // per-lane destination of channel (lane + 64 k): base pointer and per-Gaussian stride
-    float* dbase[NV];
-    int dstride[NV];
+    // G matrix of this sub-tile: row = pixel (lane), columns = [colour3 | normal3 x10 (Q4) | depth | feature S | vfeature VC]
+    {
+        float* g = sG + lane * GROW;
+        g[0] = gC[0]; g[1] = gC[1]; g[2] = gC[2];
+        g[3] = surface ? gN[0] * 10.f : 0.f; g[4] = surface ? gN[1] * 10.f : 0.f; g[5] = surface ? gN[2] * 10.f : 0.f;
+        g[6] = gDn;
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        const int ci = lane + 64 * k;
+        for (int i = 0; i < S; i++) g[7 + i] = gF[i];
+#pragma unroll
+        for (int i = 0; i < VC; i++) g[NC0 + i] = gVF[i];
+    }
+
+    // phase-B role of this lane: candidate cB of the sub-batch, pixel octant oB; it owns channels ci = 8k + oB
+    const int cB = lane >> 3, oB = lane & 7;
+    float* dbase[NK];
+    int dstride[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int ci = 8 * k + oB;
         float* b = nullptr; int st = 0;
-        if (ci < 2) { b = a.dL_dmean2D + ci; st = 3; }
-        else if (ci < 5) { b = a.dL_dconic + (ci == 4 ? 3 : ci - 2); st = 4; }
-        else if (ci < 6) { b = a.dL_dopacity; st = 1; }
-        else if (ci < 9) { b = a.dL_dcolor + (ci - 6); st = 3; }
-        else if (ci < 12) { b = a.dL_dnormal + (ci - 9); st = 3; }
-        else if (ci < 13) { b = a.dL_ddepth; st = 1; }
-        else if (ci < 13 + S) { b = a.dL_dfeature + (ci - 13); st = S; }
-        else if (ci < NCH) { b = a.dL_dvfeature + (ci - 13 - S); st = VS; }
+        if (ci < 3) { b = a.dL_dcolor + ci; st = 3; }
+        else if (ci < 6) { b = a.dL_dnormal + (ci - 3); st = 3; }
+        else if (ci < 7) { b = a.dL_ddepth; st = 1; }
+        else if (ci < 7 + S) { b = a.dL_dfeature + (ci - 7); st = S; }
+        else if (ci < 7 + S + VS) { b = a.dL_dvfeature + (ci - 7 - S); st = VS; }
+        else if (ci < 7 + S + VS + 2) { b = a.dL_dmean2D + (ci - 7 - S - VS); st = 3; }
+        else if (ci < 7 + S + VS + 5) { const int j = ci - 7 - S - VS - 2; b = a.dL_dconic + (j == 2 ? 3 : j); st = 4; }
+        else if (ci < NCH) { b = a.dL_dopacity; st = 1; }
         dbase[k] = b; dstride[k] = st;
     }
 
@@ -113,143 +152,171 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
         __syncthreads();
         stage_candidates<S, VC>(sD, m, [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
         __syncthreads();
-        for (int c = 0; c < m; c++) {
-            const uint2 ec = sQ[c];
-            const uint32_t slot = ec.y;
-            if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
-            const float* r = sD + c * SG::NF;
-            const float4* q = reinterpret_cast<const float4*>(r);
-            const float4 A = q[0];   // x, y, conic.x, conic.y
-            const float4 B = q[1];   // conic.z, opacity, depth, J6
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            float power;
-            if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
-            else power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, B.y * G);
-            const bool pass = slot < last_contributor && power <= 0.0f && alpha >= (1.0f / 255.0f);
-            if (__ballot(pass) == 0ull) continue;
 
-            const int gid = (int)ec.x;
-            float cb[NCH];
-#pragma unroll
-            for (int i = 0; i < NCH; i++) cb[i] = 0.f;
+        for (int c0 = 0; c0 < m; c0 += SB) {
+            const int nsub = min(SB, m - c0);
+            uint32_t live = 0;  // bit cs set: candidate c0+cs has at least one blending pixel (wave-uniform)
+            // ---------------- phase A: lane = pixel ----------------
+            for (int cs = 0; cs < nsub; cs++) {
+                const int c = c0 + cs;
+                const uint32_t slot = sQ[c].y;
+                if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
+                const float* r = sD + c * SG::NF;
+                const float4* q = reinterpret_cast<const float4*>(r);
+                const float4 A = q[0];   // x, y, conic.x, conic.y
+                const float4 B = q[1];   // conic.z, opacity, depth, J6
+                const float dx = A.x - pxf, dy = A.y - pyf;
+                float power;
+                if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
+                else power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, B.y * G);
+                const bool pass = slot < last_contributor && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                if (__ballot(pass) == 0ull) continue;
+                live |= 1u << cs;
 
-            if (pass) {
-                const float oma = 1.f - alpha;
-                T = T / oma;
-                const float dch = alpha * T;
-                const float inv_keep = 1.f - last_alpha;
-                float dL_dalpha = 0.f;
-                float J0 = 0.f, J1 = 0.f, J2 = 0.f, J3 = 0.f, J6 = 0.f, J9 = 0.f;
-                float du = 0.f, dv = 0.f;
-                float cw[4] = {0.f, 0.f, 0.f, 0.f};
-                if (sp) {
-                    J0 = r[R_J0]; J1 = r[R_J1]; J2 = r[R_J2]; J3 = r[R_J3]; J6 = r[R_J6]; J9 = r[R_J9];
-                    du = dx * J0 + dy * J1; dv = dx * J2 + dy * J3;
-                    if (SVGSS && VC > 0) {
-                        float u = du * r[R_IU] * 0.5f + 0.5f, v = dv * r[R_IV] * 0.5f + 0.5f;
-                        u = fminf(0.999f, fmaxf(0.001f, u));
-                        v = fminf(0.999f, fmaxf(0.001f, v));
-                        cw[0] = (1.f - u) * (1.f - v); cw[1] = u * (1.f - v); cw[2] = (1.f - u) * v; cw[3] = u * v;
+                float vw = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
+                float ge[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (pass) {
+                    const float oma = 1.f - alpha;
+                    T = T / oma;
+                    const float dch = alpha * T;
+                    const float inv_keep = 1.f - last_alpha;
+                    float dL_dalpha = 0.f;
+                    float J0 = 0.f, J1 = 0.f, J2 = 0.f, J3 = 0.f, J6 = 0.f, J9 = 0.f;
+                    float du = 0.f, dv = 0.f;
+                    float cw[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (sp) {
+                        J0 = r[R_J0]; J1 = r[R_J1]; J2 = r[R_J2]; J3 = r[R_J3]; J6 = r[R_J6]; J9 = r[R_J9];
+                        du = dx * J0 + dy * J1; dv = dx * J2 + dy * J3;
+                        if (SVGSS && VC > 0) {
+                            float u = du * r[R_IU] * 0.5f + 0.5f, v = dv * r[R_IV] * 0.5f + 0.5f;
+                            u = fminf(0.999f, fmaxf(0.001f, u));
+                            v = fminf(0.999f, fmaxf(0.001f, v));
+                            cw[0] = (1.f - u) * (1.f - v); cw[1] = u * (1.f - v); cw[2] = (1.f - u) * v; cw[3] = u * v;
+                        }
                     }
-                }
-                // colour
-                const float col[3] = {r[R_R], r[R_G], r[R_B]};
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    acc_c[ch] = last_alpha * last_c[ch] + inv_keep * acc_c[ch];
-                    last_c[ch] = col[ch];
-                    dL_dalpha += (col[ch] - acc_c[ch]) * gC[ch];
-                    cb[6 + ch] = dch * gC[ch];
-                }
-                if (S > 0) {
-                    const float* f = r + SG::F_OFF;
-#pragma unroll
-                    for (int ch = 0; ch < S; ch++) {
-                        const float fv = f[ch];
-                        acc_f[ch] = last_alpha * last_f[ch] + inv_keep * acc_f[ch];
-                        last_f[ch] = fv;
-                        if (bgeom) dL_dalpha += (fv - acc_f[ch]) * gF[ch];
-                        cb[13 + ch] = dch * gF[ch];
-                    }
-                }
-                if (VC > 0) {
-                    const float* vf = r + SG::V_OFF;
-#pragma unroll
-                    for (int ch = 0; ch < VC; ch++) {
-                        const float v = vf[4 * ch] * cw[0] + vf[4 * ch + 1] * cw[1] + vf[4 * ch + 2] * cw[2] + vf[4 * ch + 3] * cw[3];
-                        acc_vf[ch] = last_alpha * last_vf[ch] + inv_keep * acc_vf[ch];
-                        last_vf[ch] = v;
-                        const float gw = dch * gVF[ch];
-                        cb[13 + S + 4 * ch + 0] = cw[0] * gw;
-                        cb[13 + S + 4 * ch + 1] = cw[1] * gw;
-                        cb[13 + S + 4 * ch + 2] = cw[2] * gw;
-                        cb[13 + S + 4 * ch + 3] = cw[3] * gw;
-                        dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
-                    }
-                }
-                if (surface) {
-                    const float nn[3] = {r[R_NX], r[R_NY], r[R_NZ]};
+                    const float col[3] = {r[R_R], r[R_G], r[R_B]};
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        acc_n[ch] = last_alpha * last_n[ch] + inv_keep * acc_n[ch];
-                        last_n[ch] = nn[ch];
-                        dL_dalpha += (nn[ch] - acc_n[ch]) * gN[ch];
-                        cb[9 + ch] = dch * gN[ch] * 10.f;  // Q4
+                        acc_c[ch] = last_alpha * last_c[ch] + inv_keep * acc_c[ch];
+                        last_c[ch] = col[ch];
+                        dL_dalpha += (col[ch] - acc_c[ch]) * gC[ch];
                     }
-                }
-                {  // depth
-                    float d_cur = r[R_DEPTH];
-                    if (sp) d_cur -= du * J6 + dv * J9;
-                    acc_d = last_alpha * last_d + inv_keep * acc_d;
-                    last_d = d_cur;
-                    float dch_d = gD, da = 0.f;
-                    if (normalize_depth) {
-                        const float omt = 1.f - T_final;
-                        dch_d = gD / omt;
-                        da = gD * D_final / omt / omt * -T_final / oma / T;
+                    if (S > 0) {
+                        const float* f = r + SG::F_OFF;
+#pragma unroll
+                        for (int ch = 0; ch < S; ch++) {
+                            const float fv = f[ch];
+                            acc_f[ch] = last_alpha * last_f[ch] + inv_keep * acc_f[ch];
+                            last_f[ch] = fv;
+                            if (bgeom) dL_dalpha += (fv - acc_f[ch]) * gF[ch];
+                        }
                     }
-                    da += (d_cur - acc_d) * dch_d;
-                    cb[12] = dch * dch_d;
-                    dL_dalpha += da;
+                    if (VC > 0) {
+                        const float* vf = r + SG::V_OFF;
+#pragma unroll
+                        for (int ch = 0; ch < VC; ch++) {
+                            const float v = vf[4 * ch] * cw[0] + vf[4 * ch + 1] * cw[1] + vf[4 * ch + 2] * cw[2] + vf[4 * ch + 3] * cw[3];
+                            acc_vf[ch] = last_alpha * last_vf[ch] + inv_keep * acc_vf[ch];
+                            last_vf[ch] = v;
+                            dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
+                        }
+                    }
+                    if (surface) {
+                        const float nn[3] = {r[R_NX], r[R_NY], r[R_NZ]};
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            acc_n[ch] = last_alpha * last_n[ch] + inv_keep * acc_n[ch];
+                            last_n[ch] = nn[ch];
+                            dL_dalpha += (nn[ch] - acc_n[ch]) * gN[ch];
+                        }
+                    }
+                    {  // depth
+                        float d_cur = r[R_DEPTH];
+                        if (sp) d_cur -= du * J6 + dv * J9;
+                        acc_d = last_alpha * last_d + inv_keep * acc_d;
+                        last_d = d_cur;
+                        float da = 0.f;
+                        if (normalize_depth) {
+                            const float omt = 1.f - T_final;
+                            da = gD * D_final / omt / omt * -T_final / oma / T;
+                        }
+                        da += (d_cur - acc_d) * gDn;
+                        dL_dalpha += da;
+                    }
+                    dL_dalpha *= T;
+                    const float tf_oma = T_final / oma;
+                    dL_dalpha += gO * tf_oma;
+                    last_alpha = alpha;
+                    dL_dalpha -= tf_oma * bgdot;
+                    if (!normalize_depth) dL_dalpha -= tf_oma * (10.f * gD);
+                    const float dL_ddist = dL_dalpha * B.y * -0.5f * G;
+                    float ndc_x = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx;
+                    float ndc_y = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy;
+                    if (sp) {  // Q5
+                        ndc_x += -gD * (J6 * J0 + J9 * J2);
+                        ndc_y += -gD * (J6 * J1 + J9 * J3);
+                    }
+                    vw = dch;
+                    vc0 = cw[0] * dch; vc1 = cw[1] * dch; vc2 = cw[2] * dch; vc3 = cw[3] * dch;
+                    ge[0] = ndc_x; ge[1] = ndc_y;
+                    ge[2] = dL_ddist * (dx * dx);
+                    ge[3] = dL_ddist * (dx * dy);
+                    ge[4] = dL_ddist * (dy * dy);
+                    ge[5] = G * dL_dalpha;
                 }
-                dL_dalpha *= T;
-                const float tf_oma = T_final / oma;
-                dL_dalpha += gO * tf_oma;
-                last_alpha = alpha;
-                dL_dalpha -= tf_oma * bgdot;
-                if (!normalize_depth) dL_dalpha -= tf_oma * (10.f * gD);
-                const float dL_ddist = dL_dalpha * B.y * -0.5f * G;
-                float ndc_x = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx;
-                float ndc_y = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy;
-                if (sp) {  // Q5
-                    ndc_x += -gD * (J6 * J0 + J9 * J2);
-                    ndc_y += -gD * (J6 * J1 + J9 * J3);
-                }
-                cb[0] = ndc_x; cb[1] = ndc_y;
-                cb[2] = dL_ddist * (dx * dx);
-                cb[3] = dL_ddist * (dx * dy);
-                cb[4] = dL_ddist * (dy * dy);
-                cb[5] = G * dL_dalpha;
+                float* pr = sP + cs * (NVEC * PROW) + lane;
+                pr[0] = vw;
+                if (VC > 0) { pr[1 * PROW] = vc0; pr[2 * PROW] = vc1; pr[3 * PROW] = vc2; pr[4 * PROW] = vc3; }
+#pragma unroll
+                for (int k = 0; k < 6; k++) pr[(VGEO + k) * PROW] = ge[k];
             }
+            if (live == 0) continue;  // uniform
+            __syncthreads();          // panel (and, the first time, G) visible to the phase-B lanes
 
-            // wave reduction of every channel; channel ci's total is parked in lane ci % 64 of outv[ci / 64]
-            int outv[NV];
+            // ---------------- phase B: lane = (candidate cB, pixel octant oB) ----------------
+            {
+                const bool mine = cB < nsub && ((live >> cB) & 1u);
+                float out[NCH];
 #pragma unroll
-            for (int k = 0; k < NV; k++) outv[k] = 0;
+                for (int i = 0; i < NCH; i++) out[i] = 0.f;
+                const float* prow = sP + cB * (NVEC * PROW) + oB * 8;
+                const float* grow = sG + (oB * 8) * GROW;
 #pragma unroll
-            for (int ci = 0; ci < NCH; ci++) {
-                const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_last(cb[ci])), 63);
-                outv[ci >> 6] = (lane == (ci & 63)) ? tot : outv[ci >> 6];
-            }
+                for (int i = 0; i < 8; i++) {
+                    const float w = prow[i];
+                    const float* g = grow + i * GROW;
 #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                if (lane + 64 * k < NCH) {
-                    const float v = __builtin_bit_cast(float, outv[k]);
-                    if (v != 0.f) atomic_add_f32(dbase[k] + (size_t)gid * dstride[k], v);
+                    for (int ch = 0; ch < NC0; ch++) out[ch] += w * g[ch];
+                    if (VC > 0) {
+                        const float w0 = prow[1 * PROW + i], w1 = prow[2 * PROW + i], w2 = prow[3 * PROW + i], w3 = prow[4 * PROW + i];
+#pragma unroll
+                        for (int ch = 0; ch < VC; ch++) {
+                            const float gv = g[NC0 + ch];
+                            out[NC0 + 4 * ch + 0] += w0 * gv;
+                            out[NC0 + 4 * ch + 1] += w1 * gv;
+                            out[NC0 + 4 * ch + 2] += w2 * gv;
+                            out[NC0 + 4 * ch + 3] += w3 * gv;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) out[NC0 + VS + k] += prow[(VGEO + k) * PROW + i];
+                }
+#pragma unroll
+                for (int i = 0; i < NCH; i++) out[i] = octant_sum(out[i]);
+                const int gidB = mine ? (int)sQ[c0 + cB].x : 0;
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    // pick out[8k + oB] (register index depends on the lane: 8-way select)
+                    float v = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (8 * k + j < NCH) v = (oB == j) ? out[8 * k + j] : v;
+                    if (mine && 8 * k + oB < NCH && v != 0.f) atomic_add_f32(dbase[k] + (size_t)gidB * dstride[k], v);
                 }
             }
+            __syncthreads();  // panel consumed before the next phase A overwrites it
         }
     }
 }
@@ -257,8 +324,10 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
 template <int S, int VC, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
     using SG = StageGeom<S, VC>;
-    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), SG::lds_bytes(),
-                       s, a);
+    constexpr int NG = 7 + S + VC;
+    constexpr int NVEC = 1 + (VC > 0 ? 4 : 0) + 6;
+    const size_t lds = SG::lds_bytes() + (size_t)64 * (NG + 1) * 4 + (size_t)SB * NVEC * PROW * 4;
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), lds, s, a);
 }
 
 }  // namespace
