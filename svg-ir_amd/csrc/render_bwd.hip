@@ -9,20 +9,21 @@
 //   * one wave64 per 8x8-pixel sub-tile (one wave per workgroup, no barriers across waves), walking -- in reverse --
 //     the compact candidate list {Gaussian id, slot} that the forward kernel wrote for this sub-tile, so nothing is
 //     culled twice; the replay starts at the wave's deepest contributor (max n_contrib over its 64 pixels);
-//   * candidates are staged CH at a time into LDS exactly like in the forward (stage.hpp);
+//   * candidates are staged CHB at a time into LDS like in the forward (stage.hpp); LDS per wave is kept small
+//     (9 KB rgss / 18 KB svgss-train) because the kernel is latency-bound and lives off waves per SIMD;
 //   * per-pixel replay state (running accumulators, last values, upstream gradients) lives in VGPRs thanks to
 //     compile-time channel counts (the reference keeps ~330 floats per thread in scratch, backward.cu:617-635);
 //   * gradient accumulation.  The reference issues 13 + S + VS global float atomics per (pixel, splat) pair
 //     (18 / 69 / 84).  All per-Gaussian gradients except the 6 geometric ones have the form
 //         dL/dq[g][ch] = sum over pixels of  a_v[pixel] * G[pixel][ch]
-//     with a per-tile-constant matrix G (upstream image gradients) and only 1 (+4 for the bilinear corners) per-pair
-//     scalars a_v.  So the replay is split in two phases per sub-batch of SB = 8 candidates:
-//       phase A (lane = pixel): replay, alpha gradient, and the 1+4+6 per-pair scalars written to an LDS panel
-//                [candidate][vector][pixel];
+//     with a per-sub-tile-constant matrix G (upstream image gradients) and only 1 (+4 for the bilinear corners)
+//     per-pair scalars a_v.  The replay is therefore split in two phases per sub-batch of SB candidates:
+//       phase A (lane = pixel): replay, alpha gradient; the 1+4 per-pair scalars go to an LDS panel
+//                [candidate][vector][pixel]; the 6 geometric gradients are pre-reduced over 8-lane octants with 3
+//                DPP steps and stored as [candidate][6][8];
 //       phase B (lane = candidate x pixel-octant): every lane contracts 8 pixels of its candidate's panel rows with
 //                the matching rows of G (LDS), a 3-step DPP butterfly over the 8 octant lanes finishes the sums, and
-//                each lane then issues the atomics of the channels it owns (channel mod 8 == octant): ~9 atomic
-//                instructions per 8 candidates, and ~1/6 of the VALU work of reducing every channel across the wave.
+//                each lane then issues the atomics of the channels it owns (channel mod 8 == octant).
 #include "common.hpp"
 #include "stage.hpp"
 
@@ -30,7 +31,6 @@ namespace svgir {
 
 namespace {
 
-constexpr int SB = 8;      // candidates per phase-A/phase-B sub-batch
 constexpr int PROW = 65;   // panel row stride (floats): 64 pixels + 1 pad => conflict-free rows
 
 // sum over the 8 lanes of an aligned octant (lanes differing in their low 3 bits); result in all 8 lanes
@@ -41,23 +41,39 @@ __device__ __forceinline__ float octant_sum(float v) {
     return v;
 }
 
+template <int S, int VC>
+struct BwdGeom {
+    using SG = StageGeom<S, VC>;
+    static constexpr int CHB = 16;                       // candidates staged per batch
+    static constexpr int SB = (VC > 8) ? 4 : 8;          // candidates per phase-A/phase-B sub-batch
+    static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S
+    static constexpr int NG = NC0 + VC;                  // columns of G
+    static constexpr int GROW = NG + 1;
+    static constexpr int NVW = 1 + (VC > 0 ? 4 : 0);     // panel vectors: w, w*corner[4]
+    static constexpr size_t off_q = (size_t)CHB * SG::NF * 4;
+    static constexpr size_t off_g = off_q + (size_t)CHB * 8;
+    static constexpr size_t off_p = off_g + (size_t)64 * GROW * 4;
+    static constexpr size_t off_pg = off_p + (size_t)SB * NVW * PROW * 4;
+    static constexpr size_t lds_bytes = off_pg + (size_t)SB * 6 * 8 * 4;
+};
+
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int VS = VC * 4;
-    constexpr int NCH = 13 + S + VS;        // gradient channels per Gaussian
-    constexpr int NC0 = 7 + S;              // channels fed by the plain blend weight: colour3, normal3, depth, feature S
-    constexpr int NG = NC0 + VC;            // columns of the per-pixel upstream-gradient matrix G
-    constexpr int GROW = NG + 1;            // G row stride (floats)
-    constexpr int NVEC = 1 + (VC > 0 ? 4 : 0) + 6;  // panel vectors: w, w*corner[4], geometry[6]
-    constexpr int VGEO = NVEC - 6;
-    constexpr int NK = (NCH + 7) / 8;       // atomic instructions per sub-batch
-    constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
     using SG = StageGeom<S, VC>;
+    using BG = BwdGeom<S, VC>;
+    constexpr int SB = BG::SB, NC0 = BG::NC0, GROW = BG::GROW, NVW = BG::NVW, CHB = BG::CHB;
+    constexpr int LPC = 64 / SB;            // phase-B lanes per candidate (8 or 16)
+    constexpr int PPL = 64 / LPC;           // pixels contracted per phase-B lane (8 or 4)
+    constexpr int NKP = (NC0 + LPC - 1) / LPC;   // ownership rounds for the plain channels
+    constexpr int NVG = (VC + 3) / 4;       // vfeature groups of 4 channels (16 outputs)
+    constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sD = reinterpret_cast<float*>(smem);                                // [CH][NF] staged candidates
-    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);    // [CH] {gid, slot} of the batch
-    float* sG = reinterpret_cast<float*>(smem + SG::lds_bytes());               // [64][GROW] upstream gradients
-    float* sP = sG + 64 * GROW;                                                 // [SB][NVEC][PROW] panel
+    float* sD = reinterpret_cast<float*>(smem);                    // [CHB][NF] staged candidates
+    uint2* sQ = reinterpret_cast<uint2*>(smem + BG::off_q);        // [CHB] {gid, slot} of the batch
+    float* sG = reinterpret_cast<float*>(smem + BG::off_g);        // [64][GROW] upstream gradients
+    float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [SB][NVW][PROW] blend-weight panel
+    float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [SB][6][8] octant-reduced geometric gradients
 
     int tile, sub;
     sub_tile_of_block(blockIdx.x, a.gx * a.gy, a.tile_order, tile, sub);
@@ -91,7 +107,12 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
     const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
-    const float gDn = normalize_depth ? gD / (1.f - T_final) : gD;  // depth gradient seen by the blended depth
+    const float omt = 1.f - T_final;
+    const float gDn = normalize_depth ? gD / omt : gD;  // depth gradient seen by the blended depth
+    // d(depth normalisation)/d alpha of the reference, gD*D_final/(1-Tf)^2 * -Tf/(1-alpha)/T_new, equals kdn / T_old
+    const float kdn = normalize_depth ? -gD * D_final * T_final / (omt * omt) : 0.f;
+    const float kbg = bgdot + (normalize_depth ? 0.f : 10.f * gD);   // background (+ un-normalised depth) term
+    const float q5 = sp ? -gD : 0.f;
 
     // deepest contributor of the wave
     uint32_t wmax = last_contributor;
@@ -111,23 +132,27 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
         for (int i = 0; i < VC; i++) g[NC0 + i] = gVF[i];
     }
 
-    // phase-B role of this lane: candidate cB of the sub-batch, pixel octant oB; it owns channels ci = 8k + oB
-    const int cB = lane >> 3, oB = lane & 7;
-    float* dbase[NK];
-    int dstride[NK];
+    // phase-B role of this lane: candidate cB of the sub-batch, pixel group oB
+    const int cB = lane / LPC, oB = lane % LPC;
+    float* pbase[NKP];   // destination of plain channel (LPC*k + oB)
+    int pstride[NKP];
 #pragma unroll
-    for (int k = 0; k < NK; k++) {
-        const int ci = 8 * k + oB;
+    for (int k = 0; k < NKP; k++) {
+        const int ci = LPC * k + oB;
         float* b = nullptr; int st = 0;
         if (ci < 3) { b = a.dL_dcolor + ci; st = 3; }
         else if (ci < 6) { b = a.dL_dnormal + (ci - 3); st = 3; }
         else if (ci < 7) { b = a.dL_ddepth; st = 1; }
-        else if (ci < 7 + S) { b = a.dL_dfeature + (ci - 7); st = S; }
-        else if (ci < 7 + S + VS) { b = a.dL_dvfeature + (ci - 7 - S); st = VS; }
-        else if (ci < 7 + S + VS + 2) { b = a.dL_dmean2D + (ci - 7 - S - VS); st = 3; }
-        else if (ci < 7 + S + VS + 5) { const int j = ci - 7 - S - VS - 2; b = a.dL_dconic + (j == 2 ? 3 : j); st = 4; }
-        else if (ci < NCH) { b = a.dL_dopacity; st = 1; }
-        dbase[k] = b; dstride[k] = st;
+        else if (ci < NC0) { b = a.dL_dfeature + (ci - 7); st = S; }
+        pbase[k] = b; pstride[k] = st;
+    }
+    // geometric channel owned by this lane in phase B (octant-partial index oB & 7 < 6 on the first 8 lanes per candidate)
+    float* gbase = nullptr; int gstride = 0;
+    {
+        const int j = oB;
+        if (j < 2) { gbase = a.dL_dmean2D + j; gstride = 3; }
+        else if (j < 5) { gbase = a.dL_dconic + (j == 4 ? 3 : j - 2); gstride = 4; }
+        else if (j < 6) { gbase = a.dL_dopacity; gstride = 1; }
     }
 
     float T = T_final;
@@ -141,8 +166,8 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < VV; i++) { acc_vf[i] = 0.f; last_vf[i] = 0.f; }
 
-    for (int top = count; top > 0; top -= SG::CH) {  // this batch covers list entries [top - m, top), in reverse
-        const int m = min((int)SG::CH, top);
+    for (int top = count; top > 0; top -= CHB) {  // this batch covers list entries [top - m, top), in reverse
+        const int m = min((int)CHB, top);
         uint2 e = make_uint2(0u, 0xFFFFFFFFu);
         if (lane < m) e = sub_in[top - 1 - lane];
         // entries are ordered by slot: if even the shallowest entry of the batch is behind every pixel, skip it
@@ -150,7 +175,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
         __syncthreads();  // previous batch fully consumed
         if (lane < m) sQ[lane] = e;
         __syncthreads();
-        stage_candidates<S, VC>(sD, m, [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
+        stage_candidates<S, VC, CHB>(sD, m, [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
         __syncthreads();
 
         for (int c0 = 0; c0 < m; c0 += SB) {
@@ -159,12 +184,20 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
             // ---------------- phase A: lane = pixel ----------------
             for (int cs = 0; cs < nsub; cs++) {
                 const int c = c0 + cs;
-                const uint32_t slot = sQ[c].y;
-                if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
                 const float* r = sD + c * SG::NF;
                 const float4* q = reinterpret_cast<const float4*>(r);
+                // all LDS reads of the candidate are issued up front (one latency exposure)
+                const uint32_t slot = sQ[c].y;
                 const float4 A = q[0];   // x, y, conic.x, conic.y
                 const float4 B = q[1];   // conic.z, opacity, depth, J6
+                const float4 Jv = q[2];  // J0..J3
+                const float4 E = q[3];   // J9, r, g, b
+                const float4 Nn = q[4];  // nx, ny, nz, 1/umax
+                const float ivm = q[5].x;
+                float fl[SS];
+#pragma unroll
+                for (int ch = 0; ch < S; ch++) fl[ch] = r[SG::F_OFF + ch];
+                if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 float power;
                 if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
@@ -179,24 +212,24 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                 float ge[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (pass) {
                     const float oma = 1.f - alpha;
-                    T = T / oma;
+                    const float inv_oma = __builtin_amdgcn_rcpf(oma);
+                    const float inv_Told = __builtin_amdgcn_rcpf(T);
+                    T = T * inv_oma;
                     const float dch = alpha * T;
                     const float inv_keep = 1.f - last_alpha;
                     float dL_dalpha = 0.f;
-                    float J0 = 0.f, J1 = 0.f, J2 = 0.f, J3 = 0.f, J6 = 0.f, J9 = 0.f;
                     float du = 0.f, dv = 0.f;
                     float cw[4] = {0.f, 0.f, 0.f, 0.f};
                     if (sp) {
-                        J0 = r[R_J0]; J1 = r[R_J1]; J2 = r[R_J2]; J3 = r[R_J3]; J6 = r[R_J6]; J9 = r[R_J9];
-                        du = dx * J0 + dy * J1; dv = dx * J2 + dy * J3;
+                        du = dx * Jv.x + dy * Jv.y; dv = dx * Jv.z + dy * Jv.w;
                         if (SVGSS && VC > 0) {
-                            float u = du * r[R_IU] * 0.5f + 0.5f, v = dv * r[R_IV] * 0.5f + 0.5f;
+                            float u = du * Nn.w * 0.5f + 0.5f, v = dv * ivm * 0.5f + 0.5f;
                             u = fminf(0.999f, fmaxf(0.001f, u));
                             v = fminf(0.999f, fmaxf(0.001f, v));
                             cw[0] = (1.f - u) * (1.f - v); cw[1] = u * (1.f - v); cw[2] = (1.f - u) * v; cw[3] = u * v;
                         }
                     }
-                    const float col[3] = {r[R_R], r[R_G], r[R_B]};
+                    const float col[3] = {E.y, E.z, E.w};
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
                         acc_c[ch] = last_alpha * last_c[ch] + inv_keep * acc_c[ch];
@@ -204,27 +237,26 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                         dL_dalpha += (col[ch] - acc_c[ch]) * gC[ch];
                     }
                     if (S > 0) {
-                        const float* f = r + SG::F_OFF;
 #pragma unroll
                         for (int ch = 0; ch < S; ch++) {
-                            const float fv = f[ch];
                             acc_f[ch] = last_alpha * last_f[ch] + inv_keep * acc_f[ch];
-                            last_f[ch] = fv;
-                            if (bgeom) dL_dalpha += (fv - acc_f[ch]) * gF[ch];
+                            last_f[ch] = fl[ch];
+                            if (bgeom) dL_dalpha += (fl[ch] - acc_f[ch]) * gF[ch];
                         }
                     }
                     if (VC > 0) {
-                        const float* vf = r + SG::V_OFF;
+                        const float4* vf = reinterpret_cast<const float4*>(r + SG::V_OFF);
 #pragma unroll
                         for (int ch = 0; ch < VC; ch++) {
-                            const float v = vf[4 * ch] * cw[0] + vf[4 * ch + 1] * cw[1] + vf[4 * ch + 2] * cw[2] + vf[4 * ch + 3] * cw[3];
+                            const float4 c4 = vf[ch];
+                            const float v = c4.x * cw[0] + c4.y * cw[1] + c4.z * cw[2] + c4.w * cw[3];
                             acc_vf[ch] = last_alpha * last_vf[ch] + inv_keep * acc_vf[ch];
                             last_vf[ch] = v;
                             dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
                         }
                     }
                     if (surface) {
-                        const float nn[3] = {r[R_NX], r[R_NY], r[R_NZ]};
+                        const float nn[3] = {Nn.x, Nn.y, Nn.z};
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
                             acc_n[ch] = last_alpha * last_n[ch] + inv_keep * acc_n[ch];
@@ -233,87 +265,119 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                         }
                     }
                     {  // depth
-                        float d_cur = r[R_DEPTH];
-                        if (sp) d_cur -= du * J6 + dv * J9;
+                        float d_cur = B.z;
+                        if (sp) d_cur -= du * B.w + dv * E.x;
                         acc_d = last_alpha * last_d + inv_keep * acc_d;
                         last_d = d_cur;
-                        float da = 0.f;
-                        if (normalize_depth) {
-                            const float omt = 1.f - T_final;
-                            da = gD * D_final / omt / omt * -T_final / oma / T;
-                        }
-                        da += (d_cur - acc_d) * gDn;
-                        dL_dalpha += da;
+                        dL_dalpha += kdn * inv_Told + (d_cur - acc_d) * gDn;
                     }
                     dL_dalpha *= T;
-                    const float tf_oma = T_final / oma;
-                    dL_dalpha += gO * tf_oma;
+                    const float tf_oma = T_final * inv_oma;
+                    dL_dalpha += (gO - kbg) * tf_oma;
                     last_alpha = alpha;
-                    dL_dalpha -= tf_oma * bgdot;
-                    if (!normalize_depth) dL_dalpha -= tf_oma * (10.f * gD);
                     const float dL_ddist = dL_dalpha * B.y * -0.5f * G;
-                    float ndc_x = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx;
-                    float ndc_y = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy;
-                    if (sp) {  // Q5
-                        ndc_x += -gD * (J6 * J0 + J9 * J2);
-                        ndc_y += -gD * (J6 * J1 + J9 * J3);
-                    }
                     vw = dch;
                     vc0 = cw[0] * dch; vc1 = cw[1] * dch; vc2 = cw[2] * dch; vc3 = cw[3] * dch;
-                    ge[0] = ndc_x; ge[1] = ndc_y;
+                    ge[0] = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx + q5 * (B.w * Jv.x + E.x * Jv.z);  // + Q5
+                    ge[1] = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy + q5 * (B.w * Jv.y + E.x * Jv.w);
                     ge[2] = dL_ddist * (dx * dx);
                     ge[3] = dL_ddist * (dx * dy);
                     ge[4] = dL_ddist * (dy * dy);
                     ge[5] = G * dL_dalpha;
                 }
-                float* pr = sP + cs * (NVEC * PROW) + lane;
+                float* pr = sP + cs * (NVW * PROW) + lane;
                 pr[0] = vw;
                 if (VC > 0) { pr[1 * PROW] = vc0; pr[2 * PROW] = vc1; pr[3 * PROW] = vc2; pr[4 * PROW] = vc3; }
 #pragma unroll
-                for (int k = 0; k < 6; k++) pr[(VGEO + k) * PROW] = ge[k];
+                for (int k = 0; k < 6; k++) {
+                    const float s8 = octant_sum(ge[k]);
+                    if ((lane & 7) == 0) sPg[(cs * 6 + k) * 8 + (lane >> 3)] = s8;
+                }
             }
             if (live == 0) continue;  // uniform
             __syncthreads();          // panel (and, the first time, G) visible to the phase-B lanes
 
-            // ---------------- phase B: lane = (candidate cB, pixel octant oB) ----------------
+            // ---------------- phase B: lane = (candidate cB, pixel group oB) ----------------
             {
                 const bool mine = cB < nsub && ((live >> cB) & 1u);
-                float out[NCH];
+                const int gidB = mine ? (int)sQ[c0 + cB].x : 0;
+                const float* prow = sP + cB * (NVW * PROW) + oB * PPL;
+                const float* grow = sG + (oB * PPL) * GROW;
+                // --- plain channels: colour, normal, depth, features (vector w) ---
+                {
+                    float out[NC0];
 #pragma unroll
-                for (int i = 0; i < NCH; i++) out[i] = 0.f;
-                const float* prow = sP + cB * (NVEC * PROW) + oB * 8;
-                const float* grow = sG + (oB * 8) * GROW;
+                    for (int i = 0; i < NC0; i++) out[i] = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float w = prow[i];
-                    const float* g = grow + i * GROW;
+                    for (int i = 0; i < PPL; i++) {
+                        const float w = prow[i];
+                        const float* g = grow + i * GROW;
 #pragma unroll
-                    for (int ch = 0; ch < NC0; ch++) out[ch] += w * g[ch];
-                    if (VC > 0) {
-                        const float w0 = prow[1 * PROW + i], w1 = prow[2 * PROW + i], w2 = prow[3 * PROW + i], w3 = prow[4 * PROW + i];
-#pragma unroll
-                        for (int ch = 0; ch < VC; ch++) {
-                            const float gv = g[NC0 + ch];
-                            out[NC0 + 4 * ch + 0] += w0 * gv;
-                            out[NC0 + 4 * ch + 1] += w1 * gv;
-                            out[NC0 + 4 * ch + 2] += w2 * gv;
-                            out[NC0 + 4 * ch + 3] += w3 * gv;
-                        }
+                        for (int ch = 0; ch < NC0; ch++) out[ch] += w * g[ch];
                     }
 #pragma unroll
-                    for (int k = 0; k < 6; k++) out[NC0 + VS + k] += prow[(VGEO + k) * PROW + i];
+                    for (int i = 0; i < NC0; i++) {
+                        out[i] = octant_sum(out[i]);
+                        if (LPC == 16)  // 16 lanes per candidate: fold the two octants (row_ror:8 within the 16-lane row)
+                            out[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, out[i]), 0x128, 0xf, 0xf, false));
+                    }
+#pragma unroll
+                    for (int k = 0; k < NKP; k++) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int j = 0; j < LPC; j++)
+                            if (LPC * k + j < NC0) v = (oB == j) ? out[LPC * k + j] : v;
+                        if (mine && LPC * k + oB < NC0 && v != 0.f) atomic_add_f32(pbase[k] + (size_t)gidB * pstride[k], v);
+                    }
                 }
+                // --- vfeature channels, 4 channels (16 outputs) at a time (vectors w*corner[k]) ---
+                if (VC > 0) {
 #pragma unroll
-                for (int i = 0; i < NCH; i++) out[i] = octant_sum(out[i]);
-                const int gidB = mine ? (int)sQ[c0 + cB].x : 0;
+                    for (int gq = 0; gq < NVG; gq++) {
+                        float out[16];
 #pragma unroll
-                for (int k = 0; k < NK; k++) {
-                    // pick out[8k + oB] (register index depends on the lane: 8-way select)
+                        for (int i = 0; i < 16; i++) out[i] = 0.f;
+#pragma unroll
+                        for (int i = 0; i < PPL; i++) {
+                            const float w0 = prow[1 * PROW + i], w1 = prow[2 * PROW + i], w2 = prow[3 * PROW + i], w3 = prow[4 * PROW + i];
+                            const float* g = grow + i * GROW + NC0 + 4 * gq;
+#pragma unroll
+                            for (int ch = 0; ch < 4; ch++) {
+                                if (4 * gq + ch < VC) {
+                                    const float gv = g[ch];
+                                    out[4 * ch + 0] += w0 * gv; out[4 * ch + 1] += w1 * gv;
+                                    out[4 * ch + 2] += w2 * gv; out[4 * ch + 3] += w3 * gv;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            out[i] = octant_sum(out[i]);
+                            if (LPC == 16)
+                                out[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, out[i]), 0x128, 0xf, 0xf, false));
+                        }
+                        // lane oB owns outputs j with j % LPC == oB
+#pragma unroll
+                        for (int k = 0; k < 16 / LPC; k++) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int j = 0; j < LPC; j++) v = (oB == j) ? out[LPC * k + j] : v;
+                            const int jj = LPC * k + oB;
+                            if (mine && 16 * gq + jj < VS && v != 0.f)
+                                atomic_add_f32(a.dL_dvfeature + (size_t)gidB * VS + 16 * gq + jj, v);
+                        }
+                    }
+                }
+                // --- geometric channels: finish the octant partials ---
+                {
+                    // lane (cB, oB): value index j = oB % 8 (< 6), partial p handled by ... all 8 partials summed here
                     float v = 0.f;
+                    const int j = oB & 7;
+                    if (j < 6) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (8 * k + j < NCH) v = (oB == j) ? out[8 * k + j] : v;
-                    if (mine && 8 * k + oB < NCH && v != 0.f) atomic_add_f32(dbase[k] + (size_t)gidB * dstride[k], v);
+                        for (int p = 0; p < 8; p++) v += sPg[(cB * 6 + j) * 8 + p];
+                    }
+                    if (mine && oB < 6 && v != 0.f) atomic_add_f32(gbase + (size_t)gidB * gstride, v);
                 }
             }
             __syncthreads();  // panel consumed before the next phase A overwrites it
@@ -323,11 +387,8 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
 
 template <int S, int VC, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
-    using SG = StageGeom<S, VC>;
-    constexpr int NG = 7 + S + VC;
-    constexpr int NVEC = 1 + (VC > 0 ? 4 : 0) + 6;
-    const size_t lds = SG::lds_bytes() + (size_t)64 * (NG + 1) * 4 + (size_t)SB * NVEC * PROW * 4;
-    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), lds, s, a);
+    using BG = BwdGeom<S, VC>;
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), BG::lds_bytes, s, a);
 }
 
 }  // namespace

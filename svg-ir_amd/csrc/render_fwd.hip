@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
         while (!wave_done && (tail - head >= (uint32_t)SG::CH || (last_scan && tail != head))) {
             const int m = min((int)SG::CH, (int)(tail - head));
             __syncthreads();  // ring writes visible; previous batch fully consumed
-            stage_candidates<S, VC>(sD, m, [&](int s) { return sQ[(head + s) & (SG::QN - 1)].x; }, lane, a.rec,
+            stage_candidates<S, VC, SG::CH>(sD, m, [&](int s) { return sQ[(head + s) & (SG::QN - 1)].x; }, lane, a.rec,
                                     a.features, a.vfeatures);
             __syncthreads();
             for (int c = 0; c < m; c++) {

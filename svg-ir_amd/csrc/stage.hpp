@@ -26,8 +26,6 @@ struct StageGeom {
     static constexpr int QN = 128;                   // candidate ring (>= CH + 64)
     static constexpr int F_OFF = REC;
     static constexpr int V_OFF = REC + S4;
-    static constexpr int KV = (CH * C4 + 63) / 64;   // 16-byte loads per lane per batch
-    static constexpr int KF = (CH * S + 63) / 64;    // feature floats per lane per batch
     static constexpr size_t lds_bytes() { return (size_t)CH * NF * 4 + (size_t)QN * 8; }
 };
 
@@ -61,37 +59,39 @@ __device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, flo
 // candidate that goes to slot s (a wave-uniform-free LDS read).  All global loads of the batch are issued before
 // the first LDS store.  The caller separates the stores from the subsequent LDS reads with a workgroup barrier
 // (one wave per workgroup => s_barrier is only an ordering point).
-template <int S, int VC, typename GidOf>
+template <int S, int VC, int CHN, typename GidOf>
 __device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, GidOf gid_of, int lane,
                                                  const float* __restrict__ rec, const float* __restrict__ feat,
                                                  const float* __restrict__ vfeat) {
     using SG = StageGeom<S, VC>;
+    constexpr int KV = (CHN * SG::C4 + 63) / 64;  // 16-byte loads per lane per batch
+    constexpr int KF = (CHN * S + 63) / 64;       // feature floats per lane per batch
     float4* sD4 = reinterpret_cast<float4*>(sD);
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
     const float4* vf4 = reinterpret_cast<const float4*>(vfeat);
     const int total = m * SG::C4;  // >= C4 (m >= 1)
     // Loads are unconditional (index clamped), only the LDS stores are predicated: keeps everything in registers.
-    float4 v[SG::KV];
+    float4 v[KV];
 #pragma unroll
-    for (int u = 0; u < SG::KV; u++) {
+    for (int u = 0; u < KV; u++) {
         const int k = min(u * 64 + lane, total - 1);
         const int s = k / SG::C4, part = k - s * SG::C4;
         const size_t id = (size_t)gid_of(s);
         const float4* src = part < 6 ? rec4 + id * 6 + part : vf4 + id * VC + (part - 6);
         v[u] = *src;
     }
-    float fv[SG::KF > 0 ? SG::KF : 1];
+    float fv[KF > 0 ? KF : 1];
     if (S > 0) {
         const int totf = m * S;
 #pragma unroll
-        for (int u = 0; u < SG::KF; u++) {
+        for (int u = 0; u < KF; u++) {
             const int k = min(u * 64 + lane, totf - 1);
             const int s = k / S, c = k - s * S;
             fv[u] = feat[(size_t)gid_of(s) * S + c];
         }
     }
 #pragma unroll
-    for (int u = 0; u < SG::KV; u++) {
+    for (int u = 0; u < KV; u++) {
         const int k = u * 64 + lane;
         if (k < total) {
             const int s = k / SG::C4, part = k - s * SG::C4;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, 
     if (S > 0) {
         const int totf = m * S;
 #pragma unroll
-        for (int u = 0; u < SG::KF; u++) {
+        for (int u = 0; u < KF; u++) {
             const int k = u * 64 + lane;
             if (k < totf) {
                 const int s = k / S, c = k - s * S;
