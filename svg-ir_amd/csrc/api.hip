@@ -218,9 +218,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     tm.mark("preprocess");
 
     // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in slot 0
-    for (int pass = 0; pass < 4; pass++)
-        launch_radix_pass(G.key[pass & 1], G.idx[pass & 1], G.key[(pass + 1) & 1], G.idx[(pass + 1) & 1], P, 8 * pass, 8,
-                          G.radix_tbl, s);
+    launch_radix_sort(G.key, G.idx, P, 32, 8, G.radix_tbl, s);
     if (int rc = check("depth sort")) return rc;
     tm.mark("sort_depth");
 
@@ -243,12 +241,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         if (int rc = check("emit")) return rc;
     }
     tm.mark("emit");
-    for (int pass = 0; pass < plan.passes; pass++) {
-        const int lo = pass * plan.bits_per_pass;
-        const int nb = std::min(plan.bits_per_pass, plan.bits - lo);
-        launch_radix_pass(B.key[pass & 1], B.val[pass & 1], B.key[(pass + 1) & 1], B.val[(pass + 1) & 1], R, lo, nb,
-                          B.radix_tbl, s);
-    }
+    launch_radix_sort(B.key, B.val, R, plan.bits, plan.bits_per_pass, B.radix_tbl, s);
     if (int rc = check("tile sort")) return rc;
     tm.mark("sort_tile");
     const int fin = plan.passes & 1;

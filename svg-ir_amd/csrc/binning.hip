@@ -12,6 +12,8 @@
 //
 // The radix pass is a hand-written stable LSD pass: per-block digit histogram -> one-block exclusive scan of the
 // [digit][block] table -> stable scatter using wave-level digit matching (ballots) for the in-wave rank.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace svgir {
@@ -19,12 +21,12 @@ namespace svgir {
 namespace {
 
 // ---- radix pass --------------------------------------------------------------------------------------------
-// ITEMS keys per thread (1024 or 4096 keys per block).  FUSED: the digit table is [block][256] and the scatter kernel
-// derives its own output cursors from it (no separate scan launch); otherwise the table is [digit][block] and a
-// one-block scan kernel turns it into exclusive offsets (very large inputs).
-template <int ITEMS, bool FUSED>
+// Digit table layout: [block][256] counts.  A pass is: (hist ->) column scan -> scatter.  The scatter of pass k also
+// accumulates the digit table of pass k+1 (it knows where every key lands), so only the first pass needs a histogram
+// kernel -- and the producers of the keys (preprocess / emit) could provide even that.
+template <int ITEMS>
 __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int bit_lo,
-                                                           uint32_t mask, int nblocks, uint32_t* __restrict__ table) {
+                                                           uint32_t mask, uint32_t* __restrict__ table) {
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -35,79 +37,84 @@ __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __res
         if (e < n) atomicAdd(&hist[(keys[e] >> bit_lo) & mask], 1u);
     }
     __syncthreads();
-    if (FUSED) table[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
-    else if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+    table[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 
-// One-block exclusive scan of `count` uint32 values, in place.
-__global__ void __launch_bounds__(1024) table_scan_kernel(uint32_t* __restrict__ table, int count) {
-    __shared__ uint32_t wsum[16];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (count + 1023) / 1024;
-    const int lo = min(count, t * per), hi = min(count, lo + per);
+// One block, 1024 threads: turns table[nb][256] (counts) into output cursors in place:
+//   cursor[b][d] = sum_{d' < d} total[d'] + sum_{b' < b} count[b'][d];  optionally zeroes `zero_tbl` (same shape).
+__global__ void __launch_bounds__(1024) column_scan_kernel(uint32_t* __restrict__ table, int nb,
+                                                           uint32_t* __restrict__ zero_tbl) {
+    __shared__ uint32_t partial[4][256];
+    __shared__ uint32_t wsum[4];
+    const int t = threadIdx.x, d = t & 255, part = t >> 8, lane = t & 63;
+    const int per = (nb + 3) / 4;
+    const int b0 = min(nb, part * per), b1 = min(nb, b0 + per);
     uint32_t s = 0;
-    for (int i = lo; i < hi; i++) s += table[i];
-    // block exclusive scan of s
-    uint32_t incl = s;
+    for (int b = b0; b < b1; b++) s += table[(size_t)b * 256 + d];
+    partial[part][d] = s;
+    __syncthreads();
+    uint32_t dbase = 0;
+    if (t < 256) {
+        const uint32_t tot = partial[0][t] + partial[1][t] + partial[2][t] + partial[3][t];
+        uint32_t incl = tot;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t acc = 0;
-        for (int w = 0; w < 16; w++) { const uint32_t v = wsum[w]; wsum[w] = acc; acc += v; }
+        for (int k = 1; k < 64; k <<= 1) {
+            const uint32_t o = __shfl_up(incl, k);
+            if (lane >= k) incl += o;
+        }
+        if (lane == 63) wsum[t >> 6] = incl;
+        dbase = incl - tot;
     }
     __syncthreads();
-    uint32_t run = wsum[wave] + incl - s;
-    for (int i = lo; i < hi; i++) { const uint32_t v = table[i]; table[i] = run; run += v; }
+    if (t < 256) {
+        for (int w = 0; w < (t >> 6); w++) dbase += wsum[w];
+        // reuse partial[][] as the per-part starting cursors
+        uint32_t run = dbase;
+        for (int p = 0; p < 4; p++) { const uint32_t c = partial[p][t]; partial[p][t] = run; run += c; }
+    }
+    __syncthreads();
+    uint32_t run = partial[part][d];
+    for (int b = b0; b < b1; b++) {
+        const size_t i = (size_t)b * 256 + d;
+        const uint32_t c = table[i];
+        table[i] = run;
+        run += c;
+        if (zero_tbl) zero_tbl[i] = 0;
+    }
 }
 
-template <int ITEMS, bool FUSED>
+template <int ITEMS>
 __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __restrict__ kin,
                                                               const uint32_t* __restrict__ vin,
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                              int n, int bit_lo, int nbits, int nblocks,
-                                                              const uint32_t* __restrict__ table) {
+                                                              int n, int bit_lo, int nbits,
+                                                              const uint32_t* __restrict__ table,
+                                                              uint32_t* __restrict__ next_table, int next_lo,
+                                                              uint32_t next_mask) {
     __shared__ uint32_t running[256];     // global output cursor per digit for this block
     __shared__ uint32_t wave_cnt[4][256];  // per-wave digit counts of the current chunk
-    __shared__ uint32_t wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t mask = (1u << nbits) - 1;
-    if (FUSED) {
-        // cursor[d] = sum over digits d' < d of (count of d' in all blocks) + count of d in the blocks before this one
-        uint32_t before = 0, total = 0;
-        for (int b = 0; b < nblocks; b++) {
-            const uint32_t c = table[(size_t)b * 256 + t];
-            total += c;
-            if (b < (int)blockIdx.x) before += c;
-        }
-        uint32_t incl = total;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wsum[w];
-        running[t] = woff + incl - total + before;
-    } else {
-        running[t] = (t <= (int)mask) ? table[(size_t)t * nblocks + blockIdx.x] : 0;
-    }
+    running[t] = table[(size_t)blockIdx.x * 256 + t];
     const int base = blockIdx.x * (BLOCK * ITEMS);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // all loads of the block up front
+    uint32_t ks[ITEMS], vs[ITEMS];
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+        const int e = base + c * BLOCK + t;
+        ks[c] = e < n ? kin[e] : 0u;
+        vs[c] = e < n ? vin[e] : 0u;
+    }
+#pragma unroll
     for (int c = 0; c < ITEMS; c++) {
 #pragma unroll
         for (int w = 0; w < 4; w++) wave_cnt[w][t] = 0;
         __syncthreads();
         const int e = base + c * BLOCK + t;
         const bool valid = e < n;
-        uint32_t k = 0, v = 0, d = 0;
-        if (valid) { k = kin[e]; v = vin[e]; d = (k >> bit_lo) & mask; }
+        const uint32_t k = ks[c], v = vs[c];
+        const uint32_t d = (k >> bit_lo) & mask;
         // lanes of this wave holding the same digit
         unsigned long long same = __ballot(valid);
         for (int b = 0; b < nbits; b++) {
@@ -124,9 +131,38 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
         }
         __syncthreads();
         if (t <= (int)mask) running[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
-        if (valid) { kout[pos] = k; vout[pos] = v; }
+        if (valid) {
+            kout[pos] = k;
+            vout[pos] = v;
+            if (next_table) atomicAdd(&next_table[(size_t)(pos / (BLOCK * ITEMS)) * 256 + ((k >> next_lo) & next_mask)], 1u);
+        }
         __syncthreads();
     }
+}
+
+// One-block exclusive scan of `count` uint32 values, in place.
+__global__ void __launch_bounds__(1024) table_scan_kernel(uint32_t* __restrict__ table, int count) {
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (count + 1023) / 1024;
+    const int lo = min(count, t * per), hi = min(count, lo + per);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += table[i];
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (int w = 0; w < 16; w++) { const uint32_t v = wsum[w]; wsum[w] = acc; acc += v; }
+    }
+    __syncthreads();
+    uint32_t run = wsum[wave] + incl - s;
+    for (int i = lo; i < hi; i++) { const uint32_t v = table[i]; table[i] = run; run += v; }
 }
 
 // ---- instance offsets: exclusive scan of tiles[order[i]] ---------------------------------------------------
@@ -270,25 +306,35 @@ void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, T, order);
 }
 
-template <int ITEMS, bool FUSED>
-static void radix_pass_impl(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int bit_lo,
-                            int nbits, uint32_t* table, hipStream_t s) {
+template <int ITEMS>
+static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
+                            uint32_t* tbl0, uint32_t* tbl1, hipStream_t s) {
     const int per = BLOCK * ITEMS;
     const int nb = (n + per - 1) / per;
-    const uint32_t mask = (1u << nbits) - 1;
-    hipLaunchKernelGGL((radix_hist_kernel<ITEMS, FUSED>), dim3(nb), dim3(BLOCK), 0, s, kin, n, bit_lo, mask, nb, table);
-    if (!FUSED) hipLaunchKernelGGL(table_scan_kernel, dim3(1), dim3(1024), 0, s, table, (int)((mask + 1) * nb));
-    hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, FUSED>), dim3(nb), dim3(BLOCK), 0, s, kin, vin, kout, vout, n,
-                       bit_lo, nbits, nb, table);
+    const int passes = (total_bits + bits_per_pass - 1) / bits_per_pass;
+    uint32_t* tbl[2] = {tbl0, tbl1};
+    for (int p = 0; p < passes; p++) {
+        const int lo = p * bits_per_pass, nbits = std::min(bits_per_pass, total_bits - lo);
+        const bool has_next = p + 1 < passes;
+        const int nlo = lo + nbits, nnb = has_next ? std::min(bits_per_pass, total_bits - nlo) : 0;
+        uint32_t* cur = tbl[p & 1];
+        uint32_t* nxt = has_next ? tbl[(p + 1) & 1] : nullptr;
+        if (p == 0)
+            hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[0], n, lo, (1u << nbits) - 1, cur);
+        hipLaunchKernelGGL(column_scan_kernel, dim3(1), dim3(1024), 0, s, cur, nb, nxt);
+        hipLaunchKernelGGL((radix_scatter_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], val[p & 1],
+                           key[(p + 1) & 1], val[(p + 1) & 1], n, lo, nbits, cur, nxt, nlo, (1u << nnb) - 1);
+    }
 }
 
-void launch_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int bit_lo,
-                       int nbits, uint32_t* table, hipStream_t s) {
+// Stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
+// the result lands in slot (passes & 1) of the ping/pong buffers.  `table` holds 2 x 256 x sort_blocks(n) counters.
+void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
+                       uint32_t* table, hipStream_t s) {
     if (n <= 0) return;
-    // small inputs: 1024 keys per block for parallelism; medium: 4096; both with the scan fused into the scatter.
-    if (n <= 256 * 1024) radix_pass_impl<4, true>(kin, vin, kout, vout, n, bit_lo, nbits, table, s);
-    else if (n <= 512 * 4096) radix_pass_impl<16, true>(kin, vin, kout, vout, n, bit_lo, nbits, table, s);
-    else radix_pass_impl<16, false>(kin, vin, kout, vout, n, bit_lo, nbits, table, s);
+    uint32_t* tbl1 = table + (size_t)256 * sort_blocks(n);
+    if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, total_bits, bits_per_pass, table, tbl1, s);
+    else radix_sort_impl<16>(key, val, n, total_bits, bits_per_pass, table, tbl1, s);
 }
 
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,

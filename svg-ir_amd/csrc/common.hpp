@@ -67,7 +67,7 @@ inline GeomLayout geom_layout(char* base, int P) {
     g.idx[1] = (uint32_t*)take(p * 4);
     g.offsets = (uint32_t*)take(p * 4);
     g.scan_tmp = (uint32_t*)take(((size_t)scan_blocks(P) + 1) * 4);
-    g.radix_tbl = (uint32_t*)take((size_t)256 * sort_blocks(P) * 4);
+    g.radix_tbl = (uint32_t*)take((size_t)2 * 256 * sort_blocks(P) * 4);
     g.counters = (uint32_t*)take(16);
     g.bytes = off;
     return g;
@@ -117,7 +117,7 @@ inline BinLayout bin_layout(char* base, int R) {
     b.key[1] = (uint32_t*)take(r * 4);
     b.val[0] = (uint32_t*)take(r * 4);
     b.val[1] = (uint32_t*)take(r * 4);
-    b.radix_tbl = (uint32_t*)take((size_t)256 * sort_blocks(R) * 4);
+    b.radix_tbl = (uint32_t*)take((size_t)2 * 256 * sort_blocks(R) * 4);
     b.sub_list = (uint2*)take(r * 4 * 8);
     b.bytes = off;
     return b;
@@ -193,9 +193,10 @@ struct GeomBwdArgs {
 // ---- host-side launchers (one per .hip file) ---------------------------------------------------------------
 void launch_preprocess(const PreArgs& a, bool svgss, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
-// stable LSD radix sort of (u32 key, u32 value) pairs on bits [bit_lo, bit_lo + nbits); in -> out
-void launch_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int bit_lo,
-                       int nbits, uint32_t* table, hipStream_t s);
+// stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
+// input in slot 0 of the ping/pong buffers, result in slot (passes & 1); table: 2 x 256 x sort_blocks(n) counters
+void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
+                       uint32_t* table, hipStream_t s);
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
                          uint32_t* total_out, hipStream_t s);
