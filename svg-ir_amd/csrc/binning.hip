@@ -26,7 +26,8 @@ namespace {
 // kernel -- and the producers of the keys (preprocess / emit) could provide even that.
 template <int ITEMS>
 __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int bit_lo,
-                                                           uint32_t mask, uint32_t* __restrict__ table) {
+                                                           uint32_t mask, uint32_t* __restrict__ table,
+                                                           uint32_t* __restrict__ totals) {
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -37,49 +38,40 @@ __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __res
         if (e < n) atomicAdd(&hist[(keys[e] >> bit_lo) & mask], 1u);
     }
     __syncthreads();
-    table[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
+    const uint32_t c = hist[threadIdx.x];
+    table[(size_t)blockIdx.x * 256 + threadIdx.x] = c;
+    if (c) atomicAdd(&totals[threadIdx.x], c);
 }
 
-// One block, 1024 threads: turns table[nb][256] (counts) into output cursors in place:
-//   cursor[b][d] = sum_{d' < d} total[d'] + sum_{b' < b} count[b'][d];  optionally zeroes `zero_tbl` (same shape).
+// 8 blocks x 1024 threads: turns table[nb][256] (counts) into output cursors in place:
+//   cursor[b][d] = sum_{d' < d} total[d'] + sum_{b' < b} count[b'][d].
+// Block g owns digits [32g, 32g+32): thread (digit j, segment sg) walks nb/32 consecutive table rows.  The per-digit
+// totals were accumulated by the histogram kernel (`totals`, 256 counters), so no block depends on another.
 __global__ void __launch_bounds__(1024) column_scan_kernel(uint32_t* __restrict__ table, int nb,
-                                                           uint32_t* __restrict__ zero_tbl) {
-    __shared__ uint32_t partial[4][256];
-    __shared__ uint32_t wsum[4];
-    const int t = threadIdx.x, d = t & 255, part = t >> 8, lane = t & 63;
-    const int per = (nb + 3) / 4;
-    const int b0 = min(nb, part * per), b1 = min(nb, b0 + per);
+                                                           const uint32_t* __restrict__ totals) {
+    __shared__ uint32_t partial[32][33];
+    __shared__ uint32_t dbase_s[32];
+    const int t = threadIdx.x, j = t & 31, sg = t >> 5;
+    const int d = blockIdx.x * 32 + j;
+    const int per = (nb + 31) / 32;
+    const int b0 = min(nb, sg * per), b1 = min(nb, b0 + per);
     uint32_t s = 0;
     for (int b = b0; b < b1; b++) s += table[(size_t)b * 256 + d];
-    partial[part][d] = s;
-    __syncthreads();
-    uint32_t dbase = 0;
-    if (t < 256) {
-        const uint32_t tot = partial[0][t] + partial[1][t] + partial[2][t] + partial[3][t];
-        uint32_t incl = tot;
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) {
-            const uint32_t o = __shfl_up(incl, k);
-            if (lane >= k) incl += o;
-        }
-        if (lane == 63) wsum[t >> 6] = incl;
-        dbase = incl - tot;
+    partial[sg][j] = s;
+    if (t < 32) {
+        // exclusive prefix of the digit totals up to digit d (256 values: plain loop, 8 blocks do it redundantly)
+        uint32_t acc = 0;
+        for (int dd = 0; dd < d; dd++) acc += totals[dd];
+        dbase_s[t] = acc;
     }
     __syncthreads();
-    if (t < 256) {
-        for (int w = 0; w < (t >> 6); w++) dbase += wsum[w];
-        // reuse partial[][] as the per-part starting cursors
-        uint32_t run = dbase;
-        for (int p = 0; p < 4; p++) { const uint32_t c = partial[p][t]; partial[p][t] = run; run += c; }
-    }
-    __syncthreads();
-    uint32_t run = partial[part][d];
+    uint32_t run = dbase_s[j];
+    for (int p = 0; p < sg; p++) run += partial[p][j];
     for (int b = b0; b < b1; b++) {
         const size_t i = (size_t)b * 256 + d;
         const uint32_t c = table[i];
         table[i] = run;
         run += c;
-        if (zero_tbl) zero_tbl[i] = 0;
     }
 }
 
@@ -88,9 +80,7 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ vin,
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                               int n, int bit_lo, int nbits,
-                                                              const uint32_t* __restrict__ table,
-                                                              uint32_t* __restrict__ next_table, int next_lo,
-                                                              uint32_t next_mask) {
+                                                              const uint32_t* __restrict__ table) {
     __shared__ uint32_t running[256];     // global output cursor per digit for this block
     __shared__ uint32_t wave_cnt[4][256];  // per-wave digit counts of the current chunk
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -134,7 +124,6 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
         if (valid) {
             kout[pos] = k;
             vout[pos] = v;
-            if (next_table) atomicAdd(&next_table[(size_t)(pos / (BLOCK * ITEMS)) * 256 + ((k >> next_lo) & next_mask)], 1u);
         }
         __syncthreads();
     }
@@ -308,33 +297,29 @@ void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream
 
 template <int ITEMS>
 static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
-                            uint32_t* tbl0, uint32_t* tbl1, hipStream_t s) {
+                            uint32_t* tbl, uint32_t* totals, hipStream_t s) {
     const int per = BLOCK * ITEMS;
     const int nb = (n + per - 1) / per;
     const int passes = (total_bits + bits_per_pass - 1) / bits_per_pass;
-    uint32_t* tbl[2] = {tbl0, tbl1};
+    (void)hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s);
     for (int p = 0; p < passes; p++) {
         const int lo = p * bits_per_pass, nbits = std::min(bits_per_pass, total_bits - lo);
-        const bool has_next = p + 1 < passes;
-        const int nlo = lo + nbits, nnb = has_next ? std::min(bits_per_pass, total_bits - nlo) : 0;
-        uint32_t* cur = tbl[p & 1];
-        uint32_t* nxt = has_next ? tbl[(p + 1) & 1] : nullptr;
-        if (p == 0)
-            hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[0], n, lo, (1u << nbits) - 1, cur);
-        hipLaunchKernelGGL(column_scan_kernel, dim3(1), dim3(1024), 0, s, cur, nb, nxt);
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], n, lo, (1u << nbits) - 1,
+                           tbl, totals + 256 * p);
+        hipLaunchKernelGGL(column_scan_kernel, dim3(8), dim3(1024), 0, s, tbl, nb, totals + 256 * p);
         hipLaunchKernelGGL((radix_scatter_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], val[p & 1],
-                           key[(p + 1) & 1], val[(p + 1) & 1], n, lo, nbits, cur, nxt, nlo, (1u << nnb) - 1);
+                           key[(p + 1) & 1], val[(p + 1) & 1], n, lo, nbits, tbl);
     }
 }
 
 // Stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
-// the result lands in slot (passes & 1) of the ping/pong buffers.  `table` holds 2 x 256 x sort_blocks(n) counters.
+// the result lands in slot (passes & 1) of the ping/pong buffers.  `table` holds 256 x sort_blocks(n) + 1024 counters.
 void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
                        uint32_t* table, hipStream_t s) {
     if (n <= 0) return;
-    uint32_t* tbl1 = table + (size_t)256 * sort_blocks(n);
-    if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, total_bits, bits_per_pass, table, tbl1, s);
-    else radix_sort_impl<16>(key, val, n, total_bits, bits_per_pass, table, tbl1, s);
+    uint32_t* totals = table + (size_t)256 * sort_blocks(n);  // 4 x 256 per-pass digit totals
+    if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, total_bits, bits_per_pass, table, totals, s);
+    else radix_sort_impl<16>(key, val, n, total_bits, bits_per_pass, table, totals, s);
 }
 
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,

@@ -67,7 +67,7 @@ inline GeomLayout geom_layout(char* base, int P) {
     g.idx[1] = (uint32_t*)take(p * 4);
     g.offsets = (uint32_t*)take(p * 4);
     g.scan_tmp = (uint32_t*)take(((size_t)scan_blocks(P) + 1) * 4);
-    g.radix_tbl = (uint32_t*)take((size_t)2 * 256 * sort_blocks(P) * 4);
+    g.radix_tbl = (uint32_t*)take(((size_t)256 * sort_blocks(P) + 1024) * 4);
     g.counters = (uint32_t*)take(16);
     g.bytes = off;
     return g;
@@ -117,7 +117,7 @@ inline BinLayout bin_layout(char* base, int R) {
     b.key[1] = (uint32_t*)take(r * 4);
     b.val[0] = (uint32_t*)take(r * 4);
     b.val[1] = (uint32_t*)take(r * 4);
-    b.radix_tbl = (uint32_t*)take((size_t)2 * 256 * sort_blocks(R) * 4);
+    b.radix_tbl = (uint32_t*)take(((size_t)256 * sort_blocks(R) + 1024) * 4);
     b.sub_list = (uint2*)take(r * 4 * 8);
     b.bytes = off;
     return b;
@@ -194,7 +194,7 @@ struct GeomBwdArgs {
 void launch_preprocess(const PreArgs& a, bool svgss, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 // stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
-// input in slot 0 of the ping/pong buffers, result in slot (passes & 1); table: 2 x 256 x sort_blocks(n) counters
+// input in slot 0 of the ping/pong buffers, result in slot (passes & 1); table: 256 x sort_blocks(n) + 1024 counters
 void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
                        uint32_t* table, hipStream_t s);
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
