@@ -114,7 +114,77 @@ def main():
             "GaussianRasterizationSettings", "GaussianRasterizer", "_RasterizeGaussians", "rasterize_gaussians", "_C",
             "cpu_deep_copy_tuple")))
     np.savez(os.path.join(OUT, "binding_api.npz"), **api)
+    shading_fixtures()
     print("wrote", sorted(os.listdir(OUT)))
+
+
+
+def shading_fixtures():
+    """Fixtures for the per-splat SV-BRDF shading (gaussian_renderer/svgss.py:537-631, the REFERENCE's own
+    rendering_equation4 / GGX_specular4 imported and run on CPU, forward values and autograd gradients)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from gaussian_renderer.svgss import rendering_equation4
+
+    class EnvStandIn:
+        """scene/direct_light_map.py:70-83,103-106 needs .cuda() in __init__; its direct_light() is 14 lines of
+        torch ops (softplus + F.grid_sample, x2) which are reproduced here only to FEED the reference function;
+        the lookup itself is pinned against F.grid_sample."""
+
+        def __init__(self, env):
+            self.env = env
+
+        def direct_light(self, dirs):
+            shape = dirs.shape
+            dirs = dirs.reshape(-1, 3)
+            envir_map = F.softplus(self.env).permute(0, 3, 1, 2)
+            phi = torch.arccos(dirs[:, 2]).reshape(-1) - 1e-6
+            theta = torch.atan2(dirs[:, 1], dirs[:, 0]).reshape(-1)
+            query_y = (phi / np.pi) * 2 - 1
+            query_x = -theta / np.pi
+            grid = torch.stack((query_x, query_y)).permute(1, 0).unsqueeze(0).unsqueeze(0)
+            light_rgbs = F.grid_sample(envir_map, grid, align_corners=True).squeeze().permute(1, 0).reshape(-1, 3)
+            return light_rgbs.reshape(*shape) * 2.0
+
+    out = {}
+    for tag, n, Ns, seed in (("a", 48, 8, 0), ("b", 33, 64, 1)):
+        g = torch.Generator().manual_seed(seed)
+        rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+        base = (torch.sigmoid(rnd(n, 12)) * 0.77 + 0.03).requires_grad_(True)
+        rough = (torch.sigmoid(rnd(n, 4)) * 0.9 + 0.09).requires_grad_(True)
+        nrm0 = F.normalize(rnd(n, 1, 3), dim=-1)
+        normals = (nrm0 + 0.1 * rnd(n, 4, 3)).requires_grad_(True)
+        viewdirs = F.normalize(nrm0[:, 0] + 0.6 * rnd(n, 3), dim=-1)
+        dirs = F.normalize(nrm0 + 0.9 * rnd(n, Ns, 3), dim=-1)
+        areas = torch.full((n, Ns, 1), 2 * np.pi, dtype=torch.float64)
+        vis = (torch.rand(n, Ns, 1, generator=g, dtype=torch.float64) > 0.3).to(torch.float64)
+        radiance = (0.2 * rnd(n, Ns, 3)).abs().requires_grad_(True)
+        env = (3.0 * torch.rand(1, 16, 32, 3, generator=g, dtype=torch.float64)).requires_grad_(True)
+        light = EnvStandIn(env)
+        pbr, ex = rendering_equation4(base, rough, normals, viewdirs, radiance, light, visibility_precompute=vis,
+                                      incident_dirs_precompute=dirs, incident_areas_precompute=areas)
+        wts = {k: rnd(*ex[k].shape) for k in ("diffuse_light", "specular", "direct", "indirect")}
+        w_pbr, w_inc, w_glob = rnd(*pbr.shape), rnd(n, 3), rnd(n, 3)
+        loss = (pbr * w_pbr).sum() + sum((ex[k] * wts[k]).sum() for k in wts) \
+            + (ex["incident_lights"].mean(-2) * w_inc).sum() + (ex["global_incident_lights"].mean(-2) * w_glob).sum()
+        grads = torch.autograd.grad(loss, [base, rough, normals, radiance, env])
+        pre = "shade_" + tag + "_"
+        for k, v in dict(base=base, rough=rough, normals=normals, viewdirs=viewdirs, dirs=dirs, areas=areas, vis=vis,
+                         radiance=radiance, env=env, pbr=pbr, w_pbr=w_pbr, w_inc=w_inc, w_glob=w_glob,
+                         env_lookup=light.direct_light(dirs)).items():
+            out[pre + k] = v.detach().numpy()
+        for k in ("diffuse_light", "specular", "direct", "indirect"):
+            out[pre + k] = ex[k].detach().numpy()
+            out[pre + "w_" + k] = wts[k].numpy()
+        out[pre + "mean_incident"] = ex["incident_lights"].mean(-2).detach().numpy()
+        out[pre + "mean_global"] = ex["global_incident_lights"].mean(-2).detach().numpy()
+        out[pre + "mean_local"] = ex["local_incident_lights"].mean(-2).detach().numpy()
+        out[pre + "mean_vis"] = ex["incident_visibility"].mean(-2).detach().numpy()
+        for k, gv in zip(("base", "rough", "normals", "radiance", "env"), grads):
+            out[pre + "g_" + k] = gv.numpy()
+    np.savez_compressed(os.path.join(OUT, "shading.npz"), **out)
+    print("wrote shading.npz", len(out), "arrays")
 
 
 if __name__ == "__main__":
