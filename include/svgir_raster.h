@@ -152,6 +152,55 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
 int svgir_mark_visible(int32_t variant, int32_t P, const float* means3D, const float* viewmatrix,
                        const float* projmatrix, uint8_t* present, void* stream);
 
+/* ---- per-splat spatially-varying BRDF shading ---------------------------------------------
+ * Fused replacement of the PyTorch `rendering_equation4` + `GGX_specular4` (gaussian_renderer/svgss.py:537-631) with
+ * the lat-long env lookup of `DirectLightMap.direct_light` / `EnvLight.direct_light`
+ * (scene/direct_light_map.py:70-83, scene/envmap.py:53-72) and the feature packing of svgss.py:143-166.  There is no
+ * reference C/CUDA counterpart (the reference does this with ~40 broadcasting torch ops and [P,Ns,4,3] temporaries).
+ *
+ * Layouts as in the reference: base_color [P,12] (channel*4 + corner), roughness [P,4], normals [P,4,3] (world
+ * space), viewdirs [P,3], radiance / incident_dirs [P,Ns,3], visibility / incident_areas [P,Ns,1],
+ * env [env_h, env_w, 3].  The looked-up light is env_scale * bilinear(f(env)) with f = softplus when
+ * env_softplus != 0 (DirectLightMap: softplus, scale 2) or identity (EnvLight: scale 1), clamped to [0, 64].
+ * `env_work` is a caller-provided scratch of env_h*env_w*3 floats (holds f(env)).
+ *
+ * reduced [P,70]: pbr[12] diffuse_light[12] specular[12] direct[12] indirect[12] mean_incident[3] mean_local[3]
+ *                 mean_global[3] mean_visibility[1]   (means over the Ns samples, like `.mean(-2)` in svgss.py)
+ * features / vfeatures (either may be NULL): the rasterizer inputs of svgss.py:143-166;
+ *   training != 0: features [P,4]  = [mean_vis, mean_local]; vfeatures [P,52] = [pbr, base_color, normal_view,
+ *                  roughness, diffuse_light];   training == 0: features [P,7] = [mean_incident, mean_local, mean_vis],
+ *                  vfeatures [P,64] = [pbr, base_color, normal_view, roughness, direct, indirect];
+ *   normal_view = normals @ viewmatrix[:3,:3], stored channel*4 + corner. */
+typedef struct svgir_shade_params {
+    int32_t P, Ns, env_h, env_w;
+    int32_t env_softplus;
+    int32_t training;
+    float env_scale;
+    const float* base_color;
+    const float* roughness;
+    const float* normals;
+    const float* viewdirs;
+    const float* radiance;
+    const float* visibility;
+    const float* incident_dirs;
+    const float* incident_areas;
+    const float* env;
+    const float* viewmatrix;   /* [16], only for the packed vfeatures; may be NULL when vfeatures is NULL */
+    float* env_work;
+} svgir_shade_params;
+
+#define SVGIR_SHADE_REDUCED 70
+
+int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* features, float* vfeatures, void* stream);
+
+/* Backward of svgir_shade_forward w.r.t. base_color, roughness, normals, radiance and the env texels, given
+ * dL/d(reduced) [P,70] (the gradient of mean_visibility is ignored: visibility is not differentiable in the
+ * reference either).  All outputs are overwritten; dL_denv [env_h,env_w,3] is the gradient w.r.t. the RAW env
+ * (softplus' included).  `env_grad_work`: scratch of env_h*env_w*3 floats. */
+int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, float* dL_dbase_color,
+                         float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
+                         float* env_grad_work, void* stream);
+
 /* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
  * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,
  * the AVERAGE duration in milliseconds and the number of samples since profiling was (re-)enabled.

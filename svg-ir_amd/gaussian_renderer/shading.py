@@ -1,0 +1,172 @@
+"""Fused per-splat spatially-varying BRDF shading -- the MI355X counterpart of the PyTorch code the reference runs
+right before the svgss rasterizer call:
+
+  rendering_equation4 / GGX_specular4            gaussian_renderer/svgss.py:537-631
+  DirectLightMap.direct_light / EnvLight.direct_light   scene/direct_light_map.py:70-83, scene/envmap.py:53-72
+  feature / vfeature packing                      gaussian_renderer/svgss.py:143-166
+
+`rendering_equation4(...)` keeps the reference's name, argument list and return convention `(pbr, extra_results)`;
+`shade_and_pack(...)` additionally fuses the packing and returns the rasterizer's `features` / `vfeatures`.
+The compute is `svgir_shade_forward` / `svgir_shade_backward` of libsvgir_raster.so (csrc/shade.hip); there is no
+PyTorch fallback.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+
+NRED = 70
+
+
+class ShadeParams(C.Structure):
+    _fields_ = [("P", C.c_int32), ("Ns", C.c_int32), ("env_h", C.c_int32), ("env_w", C.c_int32),
+                ("env_softplus", C.c_int32), ("training", C.c_int32), ("env_scale", C.c_float),
+                ("base_color", C.c_void_p), ("roughness", C.c_void_p), ("normals", C.c_void_p),
+                ("viewdirs", C.c_void_p), ("radiance", C.c_void_p), ("visibility", C.c_void_p),
+                ("incident_dirs", C.c_void_p), ("incident_areas", C.c_void_p), ("env", C.c_void_p),
+                ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p)]
+
+
+N.lib.svgir_shade_forward.restype = C.c_int
+N.lib.svgir_shade_forward.argtypes = [C.POINTER(ShadeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+N.lib.svgir_shade_backward.restype = C.c_int
+N.lib.svgir_shade_backward.argtypes = [C.POINTER(ShadeParams)] + [C.c_void_p] * 8
+
+
+def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
+            viewmatrix=None, training=True):
+    dev = base_color.device
+    if dev.type != "cuda":
+        raise RuntimeError("shading: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
+    keep = [N.f32c(t, dev) for t in (base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env,
+                                      viewmatrix)]
+    bc, ro, nr, vd, ra, vi, di, ar, en, vm = keep
+    P, Ns = di.shape[0], di.shape[1]
+    env_h, env_w = en.shape[-3], en.shape[-2]
+    work = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+    p = ShadeParams()
+    p.P, p.Ns, p.env_h, p.env_w = P, Ns, env_h, env_w
+    p.env_softplus, p.training, p.env_scale = int(bool(softplus)), int(bool(training)), float(scale)
+    p.base_color, p.roughness, p.normals, p.viewdirs = N.ptr(bc), N.ptr(ro), N.ptr(nr), N.ptr(vd)
+    p.radiance, p.visibility, p.incident_dirs, p.incident_areas = N.ptr(ra), N.ptr(vi), N.ptr(di), N.ptr(ar)
+    p.env, p.viewmatrix, p.env_work = N.ptr(en), N.ptr(vm), work.data_ptr()
+    keep.append(work)
+    return p, keep, dev, P, Ns, env_h, env_w
+
+
+class _Shade(torch.autograd.Function):
+    """reduced[P,70] = [pbr12, diffuse_light12, specular12, direct12, indirect12, mean_incident3, mean_local3,
+    mean_global3, mean_visibility1]; differentiable w.r.t. base_color, roughness, normals, radiance, env."""
+
+    @staticmethod
+    def forward(ctx, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale):
+        p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
+                                            env, softplus, scale)
+        reduced = torch.empty((P, NRED), dtype=torch.float32, device=dev)
+        if P:
+            N.check(N.lib.svgir_shade_forward(p, reduced.data_ptr(), None, None, N.stream_ptr(dev)), "shade_forward")
+        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env)
+        ctx.cfg = (softplus, scale)
+        return reduced
+
+    @staticmethod
+    def backward(ctx, g_reduced):
+        base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env = ctx.saved_tensors
+        softplus, scale = ctx.cfg
+        p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs,
+                                                    areas, env, softplus, scale)
+        g = N.f32c(g_reduced, dev)
+        d_base = torch.zeros_like(keep[0])
+        d_rough = torch.zeros_like(keep[1])
+        d_norm = torch.zeros_like(keep[2])
+        d_rad = torch.zeros_like(keep[4])
+        d_env = torch.zeros_like(keep[8])
+        gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+        if P:
+            N.check(N.lib.svgir_shade_backward(p, g.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(), d_norm.data_ptr(),
+                                               d_rad.data_ptr(), d_env.data_ptr(), gwork.data_ptr(), N.stream_ptr(dev)),
+                    "shade_backward")
+        return (d_base.reshape(base_color.shape), d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
+                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None)
+
+
+def _env_of(light, dirs):
+    """(env texture [.., He, We, 3], softplus flag, scale, dirs) for the reference's two light classes."""
+    if hasattr(light, "env"):       # scene/direct_light_map.py: learnable map, softplus, x2
+        return light.env, True, 2.0, dirs
+    if hasattr(light, "envmap"):    # scene/envmap.py: HDR map, bilinear down-sample to 32x64, optional rotation
+        envmap = light.envmap.permute(2, 0, 1).unsqueeze(0)
+        envmap = F.interpolate(envmap, size=(32, 64), mode="bilinear", align_corners=False)
+        env = envmap[0].permute(1, 2, 0).contiguous()
+        tr = getattr(light, "transform", None)
+        if tr is not None:
+            dirs = dirs @ tr.T
+        return env, False, 1.0, dirs
+    raise TypeError("direct_light_env_light must expose .env (DirectLightMap) or .envmap (EnvLight)")
+
+
+class MeanOnly:
+    """Stand-in for a per-sample [n, Ns, 3] tensor of the reference's extra_results that its callers only consume
+    through `.mean(-2)` (svgss.py:143-151); the fused kernel never materialises the per-sample values."""
+
+    def __init__(self, mean):
+        self._mean = mean
+
+    def mean(self, dim=-2, *a, **k):
+        assert dim in (-2, 1), "only the mean over the incident samples is available from the fused kernel"
+        return self._mean
+
+
+def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light=None,
+                        visibility_precompute=None, incident_dirs_precompute=None, incident_areas_precompute=None):
+    """Drop-in for gaussian_renderer/svgss.py:537-593.  Returns (pbr [n,12], extra_results)."""
+    dirs, areas = incident_dirs_precompute, incident_areas_precompute
+    env, softplus, scale, ldirs = _env_of(direct_light_env_light, dirs)
+    if ldirs is not dirs:
+        raise NotImplementedError("EnvLight.transform: rotate incident_dirs for the lookup only is not fused yet")
+    red = _Shade.apply(base_color, roughness, normals, viewdirs, radiance, visibility_precompute, dirs, areas, env,
+                       softplus, scale)
+    extra_results = {
+        "incident_dirs": dirs,
+        "incident_lights": MeanOnly(red[:, 60:63]),
+        "local_incident_lights": radiance,
+        "global_incident_lights": MeanOnly(red[:, 66:69]),
+        "incident_visibility": visibility_precompute,
+        "diffuse_light": red[:, 12:24],
+        "specular": red[:, 24:36],
+        "direct": red[:, 36:48],
+        "indirect": red[:, 48:60],
+    }
+    return red[:, 0:12], extra_results
+
+
+def shade_and_pack(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light, visibility, dirs, areas,
+                   viewmatrix, is_training):
+    """Shading + the packing of svgss.py:143-166: returns (features [n,S], vfeatures [n,VS], reduced [n,70]).
+    Without autograd the packing is done inside the kernel; with autograd it is assembled from the differentiable
+    `reduced` tensor."""
+    env, softplus, scale, _ = _env_of(direct_light_env_light, dirs)
+    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (base_color, roughness, normals, radiance, env))
+    if not needs_grad:
+        p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
+                                            env, softplus, scale, viewmatrix=viewmatrix, training=is_training)
+        S, VS = (4, 52) if is_training else (7, 64)
+        red = torch.empty((P, NRED), dtype=torch.float32, device=dev)
+        feats = torch.empty((P, S), dtype=torch.float32, device=dev)
+        vfeats = torch.empty((P, VS), dtype=torch.float32, device=dev)
+        if P:
+            N.check(N.lib.svgir_shade_forward(p, red.data_ptr(), feats.data_ptr(), vfeats.data_ptr(), N.stream_ptr(dev)),
+                    "shade_forward")
+        return feats, vfeats, red
+    red = _Shade.apply(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale)
+    n = base_color.shape[0]
+    nview = (normals @ viewmatrix[:3, :3]).transpose(1, 2).reshape(n, -1)
+    if is_training:
+        feats = torch.cat([red[:, 69:70], red[:, 63:66]], dim=-1)
+        vfeats = torch.cat([red[:, 0:12], base_color, nview, roughness, red[:, 12:24]], dim=-1)
+    else:
+        feats = torch.cat([red[:, 60:63], red[:, 63:66], red[:, 69:70]], dim=-1)
+        vfeats = torch.cat([red[:, 0:12], base_color, nview, roughness, red[:, 36:48], red[:, 48:60]], dim=-1)
+    return feats, vfeats, red
