@@ -82,7 +82,8 @@ lib = _load()
 
 EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_binning_bytes",
            "svgir_image_ncontrib_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
-           "svgir_set_profiling", "svgir_last_timings", "svgir_last_error")
+           "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
+           "svgir_shade_backward")
 
 
 def last_error():

@@ -43,6 +43,8 @@ def test_struct_layouts_match_header_field_order(built):
     assert fields("svgir_params") == [f[0] for f in _native.Params._fields_]
     assert fields("svgir_outputs") == [f[0] for f in _native.Outputs._fields_]
     assert fields("svgir_grads") == [f[0] for f in _native.Grads._fields_]
+    from gaussian_renderer import shading
+    assert fields("svgir_shade_params") == [f[0] for f in shading.ShadeParams._fields_]
 
 
 def test_blob_sizes_and_error_reporting(built):

@@ -1,0 +1,104 @@
+"""GPU parity of the fused shading kernels (csrc/shade.hip) against the shading oracle and the reference-generated
+fixtures (tests/golden/shading.npz).  Tolerance 1e-4 relative to the tensor scale (fp32 kernel vs fp64 oracle)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shading_oracle as so
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shading.npz")
+
+
+class _Light:
+    def __init__(self, env):
+        self.env = env
+
+
+def _close(name, a, b, tol=1e-4):
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    scale = max(float(b.abs().max()), 1e-30)
+    err = float((a - b).abs().max())
+    assert err <= tol * scale + 1e-7, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _fixture(tag):
+    g = np.load(GOLD)
+    pre = "shade_" + tag + "_"
+    return {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+
+
+def _random_case(n, Ns, seed, He=32, We=64):
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    nrm0 = torch.nn.functional.normalize(rnd(n, 1, 3), dim=-1)
+    return dict(
+        base=torch.sigmoid(rnd(n, 12)) * 0.77 + 0.03, rough=torch.sigmoid(rnd(n, 4)) * 0.9 + 0.09,
+        normals=torch.nn.functional.normalize(nrm0 + 0.1 * rnd(n, 4, 3), dim=-1),
+        viewdirs=torch.nn.functional.normalize(nrm0[:, 0] + 0.6 * rnd(n, 3), dim=-1),
+        dirs=torch.nn.functional.normalize(nrm0 + 0.9 * rnd(n, Ns, 3), dim=-1),
+        areas=torch.full((n, Ns, 1), 2 * np.pi, dtype=torch.float64),
+        vis=(torch.rand(n, Ns, 1, generator=g, dtype=torch.float64) > 0.3).double(),
+        radiance=(0.2 * rnd(n, Ns, 3)).abs(), env=3.0 * torch.rand(1, He, We, 3, generator=g, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("case", ["fix_a", "fix_b", "rand64", "rand384"])
+def test_shading_forward_and_packing(built, case):
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _fixture(case[-1]) if case.startswith("fix") else _random_case(500, 64 if case == "rand64" else 384, 7)
+    ref = so.shade(d["base"], d["rough"], d["normals"], d["viewdirs"], d["radiance"], d["vis"], d["dirs"], d["areas"], d["env"])
+    f32 = {k: v.float().to(dev) for k, v in d.items() if k in ("base", "rough", "normals", "viewdirs", "radiance", "vis", "dirs", "areas", "env")}
+    with torch.no_grad():
+        pbr, ex = shading.rendering_equation4(f32["base"], f32["rough"], f32["normals"], f32["viewdirs"], f32["radiance"],
+                                              _Light(f32["env"]), visibility_precompute=f32["vis"],
+                                              incident_dirs_precompute=f32["dirs"], incident_areas_precompute=f32["areas"])
+    _close("pbr", pbr, ref["pbr"])
+    for k in ("diffuse_light", "specular", "direct", "indirect"):
+        _close(k, ex[k], ref[k])
+    _close("mean_incident", ex["incident_lights"].mean(-2), ref["mean_incident"])
+    _close("mean_global", ex["global_incident_lights"].mean(-2), ref["mean_global"])
+    if case.startswith("fix"):   # and directly against the reference's own outputs
+        _close("pbr_vs_reference", pbr, d["pbr"])
+        _close("direct_vs_reference", ex["direct"], d["direct"])
+    view = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))[0]
+    vm = torch.eye(4, dtype=torch.float64)
+    vm[:3, :3] = view
+    for training in (True, False):
+        fr, vr = so.pack(ref, d["base"], d["rough"], d["normals"], view, training)
+        with torch.no_grad():
+            f, vf, _ = shading.shade_and_pack(f32["base"], f32["rough"], f32["normals"], f32["viewdirs"], f32["radiance"],
+                                              _Light(f32["env"]), f32["vis"], f32["dirs"], f32["areas"], vm.float().to(dev), training)
+        assert f.shape == fr.shape and vf.shape == vr.shape
+        _close("features", f, fr)
+        _close("vfeatures", vf, vr)
+
+
+@pytest.mark.parametrize("case", ["fix_a", "fix_b", "rand64"])
+def test_shading_backward(built, case):
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _fixture(case[-1]) if case.startswith("fix") else _random_case(300, 64, 11)
+    names = ("base", "rough", "normals", "radiance", "env")
+    lo = {k: d[k].clone().requires_grad_(True) for k in names}
+    ref = so.shade(lo["base"], lo["rough"], lo["normals"], d["viewdirs"], lo["radiance"], d["vis"], d["dirs"], d["areas"], lo["env"])
+    g = torch.Generator().manual_seed(3)
+    w = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in
+         ("pbr", "diffuse_light", "specular", "direct", "indirect", "mean_incident", "mean_local", "mean_global")}
+    sum(((ref[k] * w[k]).sum() for k in w)).backward()
+    lg = {k: d[k].float().to(dev).requires_grad_(True) for k in names}
+    c = {k: d[k].float().to(dev) for k in ("viewdirs", "vis", "dirs", "areas")}
+    pbr, ex = shading.rendering_equation4(lg["base"], lg["rough"], lg["normals"], c["viewdirs"], lg["radiance"], _Light(lg["env"]),
+                                          visibility_precompute=c["vis"], incident_dirs_precompute=c["dirs"],
+                                          incident_areas_precompute=c["areas"])
+    wd = {k: v.float().to(dev) for k, v in w.items()}
+    loss = (pbr * wd["pbr"]).sum() + sum((ex[k] * wd[k]).sum() for k in ("diffuse_light", "specular", "direct", "indirect"))
+    loss = loss + (ex["incident_lights"].mean(-2) * wd["mean_incident"]).sum() \
+        + (ex["global_incident_lights"].mean(-2) * wd["mean_global"]).sum() \
+        + (ex["local_incident_lights"].mean(-2) * wd["mean_local"]).sum()
+    loss.backward()
+    for k in names:
+        _close("grad_" + k, lg[k].grad, lo[k].grad, tol=3e-4)
