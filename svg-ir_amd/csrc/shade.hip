@@ -97,13 +97,13 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
     for (int ch = 0; ch < 3; ch++) c.fd[ch] = p.base_color[g * 12 + ch * 4 + k] / kPi;
 }
 
-// phase 1 for one Gaussian: fills the wave's sample records, returns the light means in m[10] (valid in lane 63)
+// phase 1 for one chunk of <= 64 samples [s0, s0+cnt) of one Gaussian: fills the wave's sample records (slot =
+// sample - s0) and adds this lane's sample to the per-lane light sums m[10].
 __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_t g, int lane, const float* V,
-                                              float* __restrict__ sS, float* m) {
+                                              float* __restrict__ sS, float* m, int s0, int cnt) {
     const int Ns = p.Ns;
-#pragma unroll
-    for (int i = 0; i < 10; i++) m[i] = 0.f;
-    for (int s = lane; s < Ns; s += 64) {
+    if (lane < cnt) {
+        const int s = s0 + lane;
         const size_t o = g * Ns + s;
         const float d[3] = {p.incident_dirs[o * 3], p.incident_dirs[o * 3 + 1], p.incident_dirs[o * 3 + 2]};
         const float rad[3] = {p.radiance[o * 3], p.radiance[o * 3 + 1], p.radiance[o * 3 + 2]};
@@ -124,7 +124,7 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) E[ch] += t.w[j] * p.env_work[t.idx[j] + ch];
             }
-        float* r = sS + s * SREC;
+        float* r = sS + lane * SREC;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             const float Lg = fminf(64.f, fmaxf(0.f, E[ch] * p.env_scale)) * vis;
@@ -135,8 +135,6 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         r[9] = frac0; r[16] = area;
         m[9] += vis;
     }
-#pragma unroll
-    for (int i = 0; i < 10; i++) m[i] = wave_scan_last(m[i]);
 }
 
 __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
@@ -144,8 +142,8 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
     const svgir_shade_params& p = a.p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Ns = p.Ns;
-    float* sS = smem + (size_t)wave * (Ns * SREC + 80);
-    float* sOut = sS + Ns * SREC;
+    float* sS = smem + (size_t)wave * (64 * SREC + 80);
+    float* sOut = sS + 64 * SREC;
     const size_t g = (size_t)blockIdx.x * 4 + wave;
     const bool valid = g < (size_t)p.P;
     const size_t gg = valid ? g : 0;
@@ -157,18 +155,18 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
         V[0] *= iv; V[1] *= iv; V[2] *= iv;
     }
     float m[10];
-    stage_samples(p, gg, lane, V, sS, m);
-    if (lane == 63) {
 #pragma unroll
-        for (int i = 0; i < 10; i++) sOut[60 + i] = m[i] * inv_ns;
-    }
-    __syncthreads();
-
+    for (int i = 0; i < 10; i++) m[i] = 0.f;
     const int k = lane >> 4, sg = lane & 15;
     GaussConst c;
     load_corner(p, gg, k, V, c);
     float o_pbr[3] = {0, 0, 0}, o_dif[3] = {0, 0, 0}, o_spe[3] = {0, 0, 0}, o_dir[3] = {0, 0, 0}, o_ind[3] = {0, 0, 0};
-    for (int s = sg; s < Ns; s += 16) {
+    for (int s0 = 0; s0 < Ns; s0 += 64) {
+      const int cnt = min(64, Ns - s0);
+      __syncthreads();   // previous chunk consumed
+      stage_samples(p, gg, lane, V, sS, m, s0, cnt);
+      __syncthreads();
+      for (int s = sg; s < cnt; s += 16) {
         const float* r = sS + s * SREC;
         const float ndi = fmaxf(c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2], 0.f);
         const float NoL = fminf(1.f, fmaxf(1e-6f, c.Nh[0] * r[3] + c.Nh[1] * r[4] + c.Nh[2] * r[5]));
@@ -183,6 +181,12 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
             const float f = c.fd[ch] + fs;
             o_pbr[ch] += f * ti; o_dif[ch] += ti; o_spe[ch] += fs * ti; o_dir[ch] += f * td; o_ind[ch] += f * tl;
         }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const float t = wave_scan_last(m[i]);
+        if (lane == 63) sOut[60 + i] = t * inv_ns;
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
@@ -242,9 +246,9 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Ns = p.Ns;
     const int ntex = p.env_h * p.env_w * 3;
-    const int per_wave = Ns * SREC + Ns * 36;
+    const int per_wave = 64 * SREC + 64 * 36;
     float* sS = smem + (size_t)wave * per_wave;
-    float* sX = sS + Ns * SREC;                  // [Ns][4][9] : dLi(3) dLg(3) dLl(3) per (sample, corner)
+    float* sX = sS + 64 * SREC;                  // [64][4][9] : dLi(3) dLg(3) dLl(3) per (sample of the chunk, corner)
     float* sEnv = smem + (size_t)4 * per_wave;   // [ntex] (only when env_in_lds)
     if (env_in_lds) {
         for (int i = threadIdx.x; i < ntex; i += BLOCK) sEnv[i] = 0.f;
@@ -262,10 +266,7 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
             const float iv = 1.f / fmaxf(sqrtf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e-12f);
             V[0] *= iv; V[1] *= iv; V[2] *= iv;
         }
-        float m[10];
-        stage_samples(p, gg, lane, V, sS, m);
-        __syncthreads();
-
+        float m[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // light sums (unused by the adjoint)
         // ---- phase 2 adjoint: lane = (corner k, sample group sg) ----
         GaussConst c;
         load_corner(p, gg, k, V, c);
@@ -277,7 +278,11 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
             gdi[ch] = gr[36 + ch * 4 + k] * inv_ns; gin[ch] = gr[48 + ch * 4 + k] * inv_ns;
         }
         float d_fd[3] = {0, 0, 0}, d_r = 0.f, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
-        for (int s = sg; s < Ns; s += 16) {
+        for (int s0 = 0; s0 < Ns; s0 += 64) {
+          const int cnt = min(64, Ns - s0);
+          stage_samples(p, gg, lane, V, sS, m, s0, cnt);
+          __syncthreads();
+          for (int s = sg; s < cnt; s += 16) {
             const float* r = sS + s * SREC;
             const float ndr = c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2];
             const float ndi = fmaxf(ndr, 0.f);
@@ -327,29 +332,11 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
             const float d_NoV = (c.NoV_raw >= 1e-6f && c.NoV_raw <= 1.f) ? d_nom1 * (1.f - c.kk) : 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) d_Nh[j] += d_NoH * r[6 + j] + d_NoL * r[3 + j] + d_NoV * V[j];
-        }
-        // Nh = sgn * n / |n|  =>  dn += sgn/|n| * (dNh - Nn (Nn . dNh)),  Nn = n/|n|
-        {
-            const float Nn[3] = {c.nraw[0] * c.inv_len, c.nraw[1] * c.inv_len, c.nraw[2] * c.inv_len};
-            const float dot = Nn[0] * d_Nh[0] + Nn[1] * d_Nh[1] + Nn[2] * d_Nh[2];
-#pragma unroll
-            for (int j = 0; j < 3; j++) d_n[j] += c.sgn * c.inv_len * (d_Nh[j] - Nn[j] * dot);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) { d_n[j] = row16_sum(d_n[j]); d_fd[j] = row16_sum(d_fd[j]); }
-        d_r = row16_sum(d_r);
-        if (valid && sg == 0) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                a.d_normals[g * 12 + k * 3 + j] = d_n[j];
-                a.d_base[g * 12 + j * 4 + k] = d_fd[j] / kPi;
-            }
-            a.d_rough[g * 4 + k] = d_r;
-        }
-        __syncthreads();
-
-        // ---- phase 3: lane = sample: radiance gradient, env-texel scatter ----
-        for (int s = lane; s < Ns; s += 64) {
+          }
+          __syncthreads();
+          // ---- phase 3: lane = sample of the chunk: radiance gradient, env-texel scatter ----
+          if (lane < cnt) {
+            const int s = lane;
             float dLi[3] = {0, 0, 0}, dLg[3] = {0, 0, 0}, dLl[3] = {0, 0, 0};
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
@@ -357,7 +344,7 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) { dLi[ch] += x[ch]; dLg[ch] += x[3 + ch]; dLl[ch] += x[6 + ch]; }
             }
-            const size_t o = gg * Ns + s;
+            const size_t o = gg * Ns + s0 + s;
             const float vis = p.visibility[o];
             float dE[3];
             bool any = false;
@@ -394,6 +381,27 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
                     }
                 }
             }
+        
+          }
+          __syncthreads();
+        }
+        // Nh = sgn * n / |n|  =>  dn += sgn/|n| * (dNh - Nn (Nn . dNh)),  Nn = n/|n|
+        {
+            const float Nn[3] = {c.nraw[0] * c.inv_len, c.nraw[1] * c.inv_len, c.nraw[2] * c.inv_len};
+            const float dot = Nn[0] * d_Nh[0] + Nn[1] * d_Nh[1] + Nn[2] * d_Nh[2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) d_n[j] += c.sgn * c.inv_len * (d_Nh[j] - Nn[j] * dot);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) { d_n[j] = row16_sum(d_n[j]); d_fd[j] = row16_sum(d_fd[j]); }
+        d_r = row16_sum(d_r);
+        if (valid && sg == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                a.d_normals[g * 12 + k * 3 + j] = d_n[j];
+                a.d_base[g * 12 + j * 4 + k] = d_fd[j] / kPi;
+            }
+            a.d_rough[g * 4 + k] = d_r;
         }
         __syncthreads();
     }
@@ -434,8 +442,7 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
                        p->env_softplus);
     ShadeArgs a;
     a.p = *p; a.reduced = reduced; a.features = features; a.vfeatures = vfeatures;
-    const size_t lds = (size_t)4 * (p->Ns * SREC + 80) * 4;
-    if (lds > 160 * 1024) return SVGIR_ERR_INVALID;
+    const size_t lds = (size_t)4 * (64 * SREC + 80) * 4;
     hipLaunchKernelGGL(shade_fwd_kernel, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
@@ -456,7 +463,7 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
-    const size_t per_wave = (size_t)(p->Ns * SREC + p->Ns * 36) * 4;
+    const size_t per_wave = (size_t)(64 * SREC + 64 * 36) * 4;
     size_t lds = 4 * per_wave;
     int env_in_lds = 0;
     if (lds + (size_t)ntex * 4 <= 120 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 4; }
