@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-oracle steps (0 = as many as fit ~12 s)")
+    ap.add_argument("--no-shade", action="store_true", help="svgss workloads: skip the SV-BRDF shading stage")
+    ap.add_argument("--samples", type=int, default=0, help="incident samples per surfel (default 64 train / 384 eval)")
     args = ap.parse_args()
 
     from svgir_harness import cameras, runner, scenes, view_parallel as vp
@@ -84,21 +86,47 @@ def main():
     empty = torch.empty(0, dtype=torch.float32, device=dev)
     st = runner.settings(sct, variant)
 
+    # svgss workloads: the per-surfel SV-BRDF shading (rendering_equation4 + feature packing) produces the rasterizer's
+    # features / vfeatures every step, and its backward consumes the rasterizer's dL_dfeatures / dL_dvfeatures.
+    shade = variant == "svgss" and not args.no_shade
+    if shade:
+        from gaussian_renderer import shading
+        from svgir_harness import shade_inputs
+        training = S == 4
+        Ns = args.samples or (64 if training else 384)
+        q = torch.nn.functional.normalize(sct["rotations"], dim=-1)
+        r, x, y, z = q.unbind(-1)   # local z axis of the surfel = geometric normal
+        geo_n = torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y)], dim=-1)
+        sd = shade_inputs.make(P, Ns, seed=5 + rank, device=dev, geo_normals=geo_n)
+        sd["viewdirs"] = torch.nn.functional.normalize(st.campos[None, :] - sct["means3D"], dim=-1)
+        leaves = {k: sd[k].clone().requires_grad_(training) for k in ("base_color", "roughness", "normals", "radiance", "env")}
+        light = shade_inputs.Light(leaves["env"])
+
     def step():
         """One forward + backward through the binding layer; returns (R, checksum tensor)."""
         if variant == "svgss":
-            out = _C.rasterize_gaussians(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], empty,
+            feats_in, vfeats_in = sct["features"], sct["vfeatures"]
+            if shade:
+                for v in leaves.values():
+                    v.grad = None
+                with torch.set_grad_enabled(training):
+                    feats_in, vfeats_in, _ = shading.shade_and_pack(
+                        leaves["base_color"], leaves["roughness"], leaves["normals"], sd["viewdirs"], leaves["radiance"],
+                        light, sd["visibility"], sd["dirs"], sd["areas"], st.viewmatrix, training)
+            out = _C.rasterize_gaussians(st.bg, sct["means3D"], feats_in.detach(), vfeats_in.detach(), empty,
                                          sct["opacities"], sct["scales"], sct["rotations"], st.scale_modifier, empty,
                                          st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
                                          st.tanfovy, st.image_height, st.image_width, sct["shs"], st.sh_degree,
                                          st.campos, False, False, st.config)
             (R, color, normal, depth, opac, feat, vfeat, weights, radii, gb, bb, ib) = out
-            g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], radii, empty,
+            g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], feats_in.detach(), vfeats_in.detach(), radii, empty,
                                                 sct["scales"], sct["rotations"], st.scale_modifier, empty,
                                                 st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
                                                 st.tanfovy, gt["color"], gt["normal"], gt["depth"], gt["opacity"],
                                                 gt["feature"], gt["vfeature"], sct["shs"], st.sh_degree, st.campos,
                                                 gb, R, bb, ib, False, st.config)
+            if shade and training:
+                torch.autograd.backward([feats_in, vfeats_in], [g[4], g[5]])
         else:
             out = _C.rasterize_gaussians(st.bg, sct["means3D"], sct["features"], empty, sct["opacities"],
                                          sct["scales"], sct["rotations"], st.scale_modifier, empty, st.viewmatrix,
@@ -159,21 +187,60 @@ def main():
                                        "algorithmic_bytes_per_launch": ab["fwd"]}},
         "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
     }
+    if shade:
+        # shading kernels: HBM bytes = per-sample inputs (dirs 12 + area 4 + visibility 4 + radiance 12 = 32 B) x Ns
+        # + per-surfel inputs (31 floats) + outputs (reduced 70 floats [+ features/vfeatures in the no-grad path])
+        sf = P * Ns * 32 + P * (31 + 70 + (0 if training else S + VS)) * 4
+        res["config"]["shading"] = f"rendering_equation4 + packing, Ns={Ns} incident samples/surfel, env 32x64, " \
+                                   f"{'forward+backward' if training else 'forward only (eval)'}"
+        res["shading"] = {"fwd": {"avg_launch_ms": stage["shade_fwd"][0], "algorithmic_bytes_per_launch": sf,
+                                  "achieved": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
+                                  "frac": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if training and "shade_bwd" in stage:
+            sb = P * Ns * (32 + 12) + P * (31 + 70 + 28) * 4   # + dL_dradiance per sample, per-surfel gradients
+            res["shading"]["bwd"] = {"avg_launch_ms": stage["shade_bwd"][0], "algorithmic_bytes_per_launch": sb,
+                                     "achieved": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
+                                     "frac": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         var_id = orc.SVGSS if variant == "svgss" else orc.RGSS
         cores = orc.max_threads()
         o = orc.OracleRun(sc, var_id)
-        o.forward()  # warm-up (thread pool, page faults)
-        tc = time.perf_counter()
-        for _ in range(args.cpu_steps):
+
+        def cpu_step():
             o.forward()
             o.backward(grads["color"], grads["normal"], grads["depth"], grads["opacity"], grads["feature"],
                        grads.get("vfeature"))
+
+        tc = time.perf_counter()
+        cpu_step()  # warm-up (thread pool, page faults); also sizes the sample
+        one = time.perf_counter() - tc
+        n_cpu = args.cpu_steps or max(2, min(200, int(12.0 / max(one, 1e-3))))
+        tc = time.perf_counter()
+        for _ in range(n_cpu):
+            cpu_step()
         cpu_el = time.perf_counter() - tc
-        res["cpu_baseline"] = {"value": P * args.cpu_steps / cpu_el, "unit": "surfels/s", "cores": cores, "kind": "port",
-                               "sample": f"{args.cpu_steps} fwd+bwd steps of the same {args.workload} view "
-                                         f"({cpu_el:.1f} s, OpenMP oracle/svgir_oracle.cpp, {cores} threads)"}
+        per_step = cpu_el / n_cpu
+        sample = f"{n_cpu} fwd+bwd rasterizer steps of the same {args.workload} view ({cpu_el:.1f} s, OpenMP " \
+                 f"oracle/svgir_oracle.cpp, {cores} threads)"
+        if shade:
+            # shading oracle (torch fp64 restatement of the reference's PyTorch code) on the first P/10 surfels, x10
+            from oracle import shading_oracle as so
+            n = max(1, P // 10)
+            cd = {k: v[:n].double().cpu() for k, v in sd.items() if k != "env"}
+            cl = {k: leaves[k].detach()[:n].double().cpu().requires_grad_(training) for k in ("base_color", "roughness", "normals", "radiance")}
+            cenv = leaves["env"].detach().double().cpu().requires_grad_(training)
+            ts = time.perf_counter()
+            r = so.shade(cl["base_color"], cl["roughness"], cl["normals"], cd["viewdirs"], cl["radiance"], cd["visibility"],
+                         cd["dirs"], cd["areas"], cenv)
+            if training:
+                (r["pbr"].sum() + r["diffuse_light"].sum() + r["mean_local"].sum()).backward()
+            shade_s = (time.perf_counter() - ts) * (P / n)
+            per_step += shade_s
+            sample += f" + shading oracle (torch fp64, {torch.get_num_threads()} threads) on {n} surfels scaled to P " \
+                      f"({shade_s:.2f} s/step)"
+        res["cpu_baseline"] = {"value": P / per_step, "unit": "surfels/s", "cores": cores, "kind": "port",
+                               "sample": sample}
     print(json.dumps(res))
 
 

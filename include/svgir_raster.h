@@ -193,11 +193,15 @@ typedef struct svgir_shade_params {
 
 int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* features, float* vfeatures, void* stream);
 
-/* Backward of svgir_shade_forward w.r.t. base_color, roughness, normals, radiance and the env texels, given
- * dL/d(reduced) [P,70] (the gradient of mean_visibility is ignored: visibility is not differentiable in the
- * reference either).  All outputs are overwritten; dL_denv [env_h,env_w,3] is the gradient w.r.t. the RAW env
- * (softplus' included).  `env_grad_work`: scratch of env_h*env_w*3 floats. */
-int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, float* dL_dbase_color,
+/* Backward of svgir_shade_forward w.r.t. base_color, roughness, normals, radiance and the env texels, given any of
+ * dL/d(reduced) [P,70], dL/d(features) [P,S] and dL/d(vfeatures) [P,VS] (each may be NULL, not all three; the
+ * packed rows follow p->training as in the forward and need p->viewmatrix; the gradient of mean_visibility is
+ * ignored: visibility is not differentiable in the reference either).  The packing's direct terms (vfeatures
+ * carries base_color, view-space normals and roughness, svgss.py:152-166) are included.  All outputs are
+ * overwritten; dL_denv [env_h,env_w,3] is the gradient w.r.t. the RAW env (softplus' included).
+ * `env_grad_work`: scratch of env_h*env_w*3 floats. */
+int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
+                         const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
                          float* env_grad_work, void* stream);
 

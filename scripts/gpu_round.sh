@@ -1,0 +1,20 @@
+#!/bin/bash
+# One GPU session: tests, bench lines and rocprofv3 kernel-trace summaries.  usage: scripts/gpu_round.sh <tag> [quick]
+set -u
+export TMPDIR=/tmp
+R=$PWD
+TAG=${1:-x}
+mkdir -p gpurun_out
+if [ "${2:-}" != "quick" ]; then
+  python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/${TAG}_tests.log
+  cat gpurun_out/${TAG}_tests.log
+fi
+for W in cfg2 cfg3_train cfg3_eval; do
+  python bench.py --workload $W > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err
+  tail -c 2500 gpurun_out/${TAG}_bench_$W.json; tail -3 gpurun_out/${TAG}_bench_$W.err
+done
+for W in cfg2 cfg3_train; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$W -o p -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $W > $R/gpurun_out/${TAG}_prof_$W.log 2>&1)
+  DB=$(find gpurun_out/${TAG}_prof_$W -name "*.db" | head -1)
+  python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_${W}_kernel_stats.txt "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $W" | head -30
+done

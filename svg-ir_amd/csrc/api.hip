@@ -97,6 +97,32 @@ void resolve_pending() {
     for (auto e : seen) (void)hipEventDestroy(e);
 }
 
+}  // namespace
+
+namespace svgir {
+StageMarks stage_begin(hipStream_t s) {
+    StageMarks t{s, g_prof.load(), nullptr};
+    if (t.on) {
+        if (hipEventCreate(&t.prev) != hipSuccess) t.on = false;
+        else (void)hipEventRecord(t.prev, s);
+    }
+    return t;
+}
+void stage_mark(StageMarks& t, const char* name) {
+    if (!t.on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { t.on = false; return; }
+    (void)hipEventRecord(e, t.s);
+    {
+        std::lock_guard<std::mutex> lk(g_times_mu);
+        g_pending.push_back({t.prev, e, name});
+    }
+    t.prev = e;
+}
+}  // namespace svgir
+
+namespace {
+
 CfgRef cfg_ref(const svgir_params* p) {
     CfgRef c;
     if (p->variant == SVGIR_SVGSS) { c.ptr = p->config; c.len = p->config ? p->config_len : 0; }

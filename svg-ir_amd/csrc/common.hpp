@@ -190,6 +190,11 @@ struct GeomBwdArgs {
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot, *dL_dviewmat, *dL_dprojmat, *dL_dcampos;
 };
 
+// ---- stage timing shared by the entry points (api.hip owns the state; no-ops unless svgir_set_profiling(1)) ----
+struct StageMarks { hipStream_t s; bool on; hipEvent_t prev; };
+StageMarks stage_begin(hipStream_t s);
+void stage_mark(StageMarks& t, const char* name);   // `name` = the stage that ENDS here (static string)
+
 // ---- host-side launchers (one per .hip file) ---------------------------------------------------------------
 void launch_preprocess(const PreArgs& a, bool svgss, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);

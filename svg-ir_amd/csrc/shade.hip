@@ -234,9 +234,31 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
 // ----------------------------------------------------------------------------------------------------------------
 struct ShadeBwdArgs {
     svgir_shade_params p;
-    const float* g_red;
+    const float* g_red;          // may be null when g_feat / g_vfeat carry the upstream gradient
+    const float *g_feat, *g_vfeat;  // optional: gradients w.r.t. the packed features [P,S] / vfeatures [P,VS]
     float *d_base, *d_rough, *d_normals, *d_radiance, *d_envtab;  // d_envtab: gradient w.r.t. the f(env) table
 };
+
+// Upstream gradient of reduced[g][i]: dL_dreduced plus the entries of the packed features / vfeatures rows that alias
+// it (adjoint of the forward epilogue's packing, gaussian_renderer/svgss.py:143-166).
+__device__ __forceinline__ float upstream(const ShadeBwdArgs& a, size_t g, int i) {
+    float v = a.g_red ? a.g_red[g * NRED + i] : 0.f;
+    const bool tr = a.p.training != 0;
+    if (a.g_vfeat) {
+        const float* vf = a.g_vfeat + g * (tr ? 52 : 64);
+        if (i < 12) v += vf[i];
+        else if (i < 24) { if (tr) v += vf[40 + (i - 12)]; }
+        else if (i >= 36 && i < 48) { if (!tr) v += vf[40 + (i - 36)]; }
+        else if (i >= 48 && i < 60) { if (!tr) v += vf[52 + (i - 48)]; }
+    }
+    if (a.g_feat) {
+        const float* f = a.g_feat + g * (tr ? 4 : 7);
+        if (i >= 60 && i < 63) { if (!tr) v += f[i - 60]; }
+        else if (i >= 63 && i < 66) v += tr ? f[1 + (i - 63)] : f[3 + (i - 63)];
+        else if (i == 69) v += tr ? f[0] : f[6];
+    }
+    return v;
+}
 
 // Persistent workgroups (4 waves, one Gaussian per wave per iteration).  LDS: 4 x sample records, 4 x per-sample
 // light-gradient exchange [Ns][4 corners][9], and one workgroup-private env-gradient image.
@@ -270,12 +292,12 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
         // ---- phase 2 adjoint: lane = (corner k, sample group sg) ----
         GaussConst c;
         load_corner(p, gg, k, V, c);
-        const float* gr = a.g_red + gg * NRED;
         float gp[3], gd[3], gs[3], gdi[3], gin[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            gp[ch] = gr[ch * 4 + k] * inv_ns; gd[ch] = gr[12 + ch * 4 + k] * inv_ns; gs[ch] = gr[24 + ch * 4 + k] * inv_ns;
-            gdi[ch] = gr[36 + ch * 4 + k] * inv_ns; gin[ch] = gr[48 + ch * 4 + k] * inv_ns;
+            gp[ch] = upstream(a, gg, ch * 4 + k) * inv_ns; gd[ch] = upstream(a, gg, 12 + ch * 4 + k) * inv_ns;
+            gs[ch] = upstream(a, gg, 24 + ch * 4 + k) * inv_ns; gdi[ch] = upstream(a, gg, 36 + ch * 4 + k) * inv_ns;
+            gin[ch] = upstream(a, gg, 48 + ch * 4 + k) * inv_ns;
         }
         float d_fd[3] = {0, 0, 0}, d_r = 0.f, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
         for (int s0 = 0; s0 < Ns; s0 += 64) {
@@ -350,7 +372,8 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
             bool any = false;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const float gi = gr[60 + ch] * inv_ns, gl = gr[63 + ch] * inv_ns, gg_ = gr[66 + ch] * inv_ns;
+                const float gi = upstream(a, gg, 60 + ch) * inv_ns, gl = upstream(a, gg, 63 + ch) * inv_ns,
+                            gg_ = upstream(a, gg, 66 + ch) * inv_ns;
                 if (valid) a.d_radiance[o * 3 + ch] = dLi[ch] + dLl[ch] + gi + gl;
                 dE[ch] = (dLi[ch] + dLg[ch] + gi + gg_) * vis;
                 any = any || dE[ch] != 0.f;
@@ -396,12 +419,21 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
         for (int j = 0; j < 3; j++) { d_n[j] = row16_sum(d_n[j]); d_fd[j] = row16_sum(d_fd[j]); }
         d_r = row16_sum(d_r);
         if (valid && sg == 0) {
+            // direct terms of the packing: vfeatures[12:24] = base_color, [24:36] = (normals @ view[:3,:3])^T,
+            // [36:40] = roughness
+            const float* vf = a.g_vfeat ? a.g_vfeat + g * (p.training ? 52 : 64) : nullptr;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                a.d_normals[g * 12 + k * 3 + j] = d_n[j];
-                a.d_base[g * 12 + j * 4 + k] = d_fd[j] / kPi;
+                float dn = d_n[j], db = d_fd[j] / kPi;
+                if (vf) {
+                    db += vf[12 + j * 4 + k];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) dn += vf[24 + ch * 4 + k] * p.viewmatrix[j * 4 + ch];
+                }
+                a.d_normals[g * 12 + k * 3 + j] = dn;
+                a.d_base[g * 12 + j * 4 + k] = db;
             }
-            a.d_rough[g * 4 + k] = d_r;
+            a.d_rough[g * 4 + k] = d_r + (vf ? vf[36 + k] : 0.f);
         }
         __syncthreads();
     }
@@ -438,30 +470,35 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
         return SVGIR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
+    StageMarks tm = stage_begin(s);
     hipLaunchKernelGGL(env_table_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, p->env_work, ntex,
                        p->env_softplus);
+    stage_mark(tm, "shade_env_table");
     ShadeArgs a;
     a.p = *p; a.reduced = reduced; a.features = features; a.vfeatures = vfeatures;
     const size_t lds = (size_t)4 * (64 * SREC + 80) * 4;
     hipLaunchKernelGGL(shade_fwd_kernel, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
+    stage_mark(tm, "shade_fwd");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 
-int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, float* dL_dbase_color,
+int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
+                         const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
                          float* env_grad_work, void* stream) {
     if (!p || p->P < 0 || p->Ns <= 0 || p->env_h <= 0 || p->env_w <= 0) return SVGIR_ERR_INVALID;
     if (p->P == 0) return 0;
-    if (!dL_dreduced || !dL_dbase_color || !dL_droughness || !dL_dnormals || !dL_dradiance || !dL_denv ||
+    if ((!dL_dreduced && !dL_dfeatures && !dL_dvfeatures) || (dL_dvfeatures && !p->viewmatrix) || !dL_dbase_color || !dL_droughness || !dL_dnormals || !dL_dradiance || !dL_denv ||
         !env_grad_work || !p->env_work)
         return SVGIR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
+    StageMarks tm = stage_begin(s);
     hipLaunchKernelGGL(env_table_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, p->env_work, ntex,
                        p->env_softplus);
     if (hipMemsetAsync(env_grad_work, 0, (size_t)ntex * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
     ShadeBwdArgs a;
-    a.p = *p; a.g_red = dL_dreduced; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
+    a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
     const size_t per_wave = (size_t)(64 * SREC + 64 * 36) * 4;
     size_t lds = 4 * per_wave;
@@ -469,9 +506,12 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     if (lds + (size_t)ntex * 4 <= 120 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 4; }
     if (lds > 160 * 1024) return SVGIR_ERR_INVALID;
     const int blocks = std::min((p->P + 3) / 4, 256 * 2);
+    stage_mark(tm, "shade_bwd_prologue");
     hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(BLOCK), lds, s, a, env_in_lds);
+    stage_mark(tm, "shade_bwd");
     hipLaunchKernelGGL(env_grad_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, env_grad_work,
                        dL_denv, ntex, p->env_softplus);
+    stage_mark(tm, "shade_env_grad");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 

@@ -140,6 +140,21 @@ class BlobAllocator:
         return t
 
 
+def zeros_like_blob(device, shapes):
+    """Zero-initialised fp32 tensors of `shapes` carved out of ONE allocation (a single fill kernel instead of one
+    per gradient tensor); every view starts on a 256-byte boundary."""
+    sizes = [1] * len(shapes)
+    for i, sh in enumerate(shapes):
+        for d in sh:
+            sizes[i] *= int(d)
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 63) // 64 * 64
+    blob = torch.zeros(tot, dtype=torch.float32, device=device)
+    return [blob[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
 def stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -150,10 +165,10 @@ def set_profiling(on):
 
 def last_timings(with_counts=False):
     """Average milliseconds per stage since profiling was enabled (resolves the recorded HIP events)."""
-    names = (C.c_char_p * 16)()
-    ms = (C.c_float * 16)()
-    cnt = (C.c_int * 16)()
-    n = lib.svgir_last_timings(names, ms, cnt, 16)
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    cnt = (C.c_int * 32)()
+    n = lib.svgir_last_timings(names, ms, cnt, 32)
     if with_counts:
         return [(names[i].decode(), float(ms[i]), int(cnt[i])) for i in range(n)]
     return [(names[i].decode(), float(ms[i])) for i in range(n)]

@@ -32,7 +32,7 @@ class ShadeParams(C.Structure):
 N.lib.svgir_shade_forward.restype = C.c_int
 N.lib.svgir_shade_forward.argtypes = [C.POINTER(ShadeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 N.lib.svgir_shade_backward.restype = C.c_int
-N.lib.svgir_shade_backward.argtypes = [C.POINTER(ShadeParams)] + [C.c_void_p] * 8
+N.lib.svgir_shade_backward.argtypes = [C.POINTER(ShadeParams)] + [C.c_void_p] * 10
 
 
 def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
@@ -78,18 +78,58 @@ class _Shade(torch.autograd.Function):
         p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs,
                                                     areas, env, softplus, scale)
         g = N.f32c(g_reduced, dev)
-        d_base = torch.zeros_like(keep[0])
-        d_rough = torch.zeros_like(keep[1])
-        d_norm = torch.zeros_like(keep[2])
-        d_rad = torch.zeros_like(keep[4])
-        d_env = torch.zeros_like(keep[8])
+        d_base, d_rough, d_norm, d_rad, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 4, 8))  # all overwritten
         gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
         if P:
-            N.check(N.lib.svgir_shade_backward(p, g.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(), d_norm.data_ptr(),
+            N.check(N.lib.svgir_shade_backward(p, g.data_ptr(), None, None, d_base.data_ptr(), d_rough.data_ptr(), d_norm.data_ptr(),
                                                d_rad.data_ptr(), d_env.data_ptr(), gwork.data_ptr(), N.stream_ptr(dev)),
                     "shade_backward")
+        else:
+            d_env.zero_()
         return (d_base.reshape(base_color.shape), d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
                 d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None)
+
+
+class _ShadePack(torch.autograd.Function):
+    """Shading + packing in one kernel: (features [P,S], vfeatures [P,VS], reduced [P,70]); the backward feeds the
+    rasterizer's dL_dfeatures / dL_dvfeatures (and dL_dreduced, if used) straight into svgir_shade_backward."""
+
+    @staticmethod
+    def forward(ctx, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix,
+                softplus, scale, training):
+        p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
+                                            env, softplus, scale, viewmatrix=viewmatrix, training=training)
+        S, VS = (4, 52) if training else (7, 64)
+        red = torch.empty((P, NRED), dtype=torch.float32, device=dev)
+        feats = torch.empty((P, S), dtype=torch.float32, device=dev)
+        vfeats = torch.empty((P, VS), dtype=torch.float32, device=dev)
+        if P:
+            N.check(N.lib.svgir_shade_forward(p, red.data_ptr(), feats.data_ptr(), vfeats.data_ptr(), N.stream_ptr(dev)),
+                    "shade_forward")
+        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix)
+        ctx.cfg = (softplus, scale, training)
+        ctx.set_materialize_grads(False)
+        return feats, vfeats, red
+
+    @staticmethod
+    def backward(ctx, g_feat, g_vfeat, g_red):
+        base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix = ctx.saved_tensors
+        softplus, scale, training = ctx.cfg
+        p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs,
+                                                    areas, env, softplus, scale, viewmatrix=viewmatrix, training=training)
+        if g_feat is None and g_vfeat is None and g_red is None:
+            return (None,) * 13
+        gf, gv, gr = (N.f32c(t, dev) for t in (g_feat, g_vfeat, g_red))
+        d_base, d_rough, d_norm, d_rad, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 4, 8))
+        gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+        if P:
+            N.check(N.lib.svgir_shade_backward(p, N.ptr(gr), N.ptr(gf), N.ptr(gv), d_base.data_ptr(), d_rough.data_ptr(),
+                                               d_norm.data_ptr(), d_rad.data_ptr(), d_env.data_ptr(), gwork.data_ptr(),
+                                               N.stream_ptr(dev)), "shade_backward")
+        else:
+            d_env.zero_()
+        return (d_base.reshape(base_color.shape), d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
+                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None, None)
 
 
 def _env_of(light, dirs):
@@ -145,28 +185,7 @@ def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, dire
 def shade_and_pack(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light, visibility, dirs, areas,
                    viewmatrix, is_training):
     """Shading + the packing of svgss.py:143-166: returns (features [n,S], vfeatures [n,VS], reduced [n,70]).
-    Without autograd the packing is done inside the kernel; with autograd it is assembled from the differentiable
-    `reduced` tensor."""
+    The packing and its adjoint are done inside the kernels in both the no-grad and the autograd path."""
     env, softplus, scale, _ = _env_of(direct_light_env_light, dirs)
-    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (base_color, roughness, normals, radiance, env))
-    if not needs_grad:
-        p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
-                                            env, softplus, scale, viewmatrix=viewmatrix, training=is_training)
-        S, VS = (4, 52) if is_training else (7, 64)
-        red = torch.empty((P, NRED), dtype=torch.float32, device=dev)
-        feats = torch.empty((P, S), dtype=torch.float32, device=dev)
-        vfeats = torch.empty((P, VS), dtype=torch.float32, device=dev)
-        if P:
-            N.check(N.lib.svgir_shade_forward(p, red.data_ptr(), feats.data_ptr(), vfeats.data_ptr(), N.stream_ptr(dev)),
-                    "shade_forward")
-        return feats, vfeats, red
-    red = _Shade.apply(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale)
-    n = base_color.shape[0]
-    nview = (normals @ viewmatrix[:3, :3]).transpose(1, 2).reshape(n, -1)
-    if is_training:
-        feats = torch.cat([red[:, 69:70], red[:, 63:66]], dim=-1)
-        vfeats = torch.cat([red[:, 0:12], base_color, nview, roughness, red[:, 12:24]], dim=-1)
-    else:
-        feats = torch.cat([red[:, 60:63], red[:, 63:66], red[:, 69:70]], dim=-1)
-        vfeats = torch.cat([red[:, 0:12], base_color, nview, roughness, red[:, 36:48], red[:, 48:60]], dim=-1)
-    return feats, vfeats, red
+    return _ShadePack.apply(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix,
+                            softplus, scale, bool(is_training))

@@ -94,13 +94,10 @@ class _CBinding:
         VS = vfeatures.size(1) if vfeatures.dim() == 2 else 0
         H, W = dL_dout_color.size(1), dL_dout_color.size(2)
         M = sh.size(1) if sh.numel() != 0 else 0
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
-        dL_dmeans3D, dL_dmeans2D = z(P, 3), z(P, 3)
-        dL_dfeatures, dL_dvfeatures = z(P, S), z(P, VS)
-        dL_dcolors, dL_dnormal, dL_ddepth = z(P, 3), z(P, 3), z(P, 1)
-        dL_dconic, dL_dopacity = z(P, 2, 2), z(P, 1)
-        dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
-        dL_dviewmat, dL_dprojmat, dL_dcampos = z(4, 4), z(4, 4), z(3)
+        (dL_dmeans3D, dL_dmeans2D, dL_dfeatures, dL_dvfeatures, dL_dcolors, dL_dnormal, dL_ddepth, dL_dconic,
+         dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos) = \
+            N.zeros_like_blob(dev, [(P, 3), (P, 3), (P, S), (P, VS), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6),
+                                    (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)])
         if P != 0:
             keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, vfeatures, scales, rotations,
                                               cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint, patchbbox,

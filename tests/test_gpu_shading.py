@@ -112,3 +112,46 @@ def test_shading_backward(built, case):
     loss.backward()
     for k in names:
         _close("grad_" + k, lg[k].grad, lo[k].grad, tol=gtol)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_shade_and_pack_backward(built, training):
+    """Gradients through the fused packing (features / vfeatures / reduced all used) vs autograd of the oracle."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _random_case(200, 96, 23, rough_lo=0.3)   # 96 samples: one full + one partial 64-sample chunk
+    names = ("base", "rough", "normals", "radiance", "env")
+    view = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))[0]
+    vm = torch.eye(4, dtype=torch.float64)
+    vm[:3, :3] = view
+    lo = {k: d[k].clone().requires_grad_(True) for k in names}
+    ref = so.shade(lo["base"], lo["rough"], lo["normals"], d["viewdirs"], lo["radiance"], d["vis"], d["dirs"], d["areas"], lo["env"])
+    fr, vr = so.pack(ref, lo["base"], lo["rough"], lo["normals"], view, training)
+    g = torch.Generator().manual_seed(5)
+    wf = torch.randn(fr.shape, generator=g, dtype=torch.float64)
+    wv = torch.randn(vr.shape, generator=g, dtype=torch.float64)
+    wp = torch.randn(ref["pbr"].shape, generator=g, dtype=torch.float64)
+    ((fr * wf).sum() + (vr * wv).sum() + (ref["pbr"] * wp).sum()).backward()
+    lg = {k: d[k].float().to(dev).requires_grad_(True) for k in names}
+    c = {k: d[k].float().to(dev) for k in ("viewdirs", "vis", "dirs", "areas")}
+    f, vf, red = shading.shade_and_pack(lg["base"], lg["rough"], lg["normals"], c["viewdirs"], lg["radiance"], _Light(lg["env"]),
+                                        c["vis"], c["dirs"], c["areas"], vm.float().to(dev), training)
+    _close("features", f, fr, tol=1e-4)
+    _close("vfeatures", vf, vr, tol=1e-4)
+    ((f * wf.float().to(dev)).sum() + (vf * wv.float().to(dev)).sum() + (red[:, 0:12] * wp.float().to(dev)).sum()).backward()
+    for k in names:
+        _close("grad_" + k, lg[k].grad, lo[k].grad, tol=3e-4)
+    # only one of the outputs used: the other upstream gradients arrive as None
+    for v in lg.values():
+        v.grad = None
+    f2, vf2, _ = shading.shade_and_pack(lg["base"], lg["rough"], lg["normals"], c["viewdirs"], lg["radiance"], _Light(lg["env"]),
+                                        c["vis"], c["dirs"], c["areas"], vm.float().to(dev), training)
+    for v in lo.values():
+        v.grad = None
+    ref = so.shade(lo["base"], lo["rough"], lo["normals"], d["viewdirs"], lo["radiance"], d["vis"], d["dirs"], d["areas"], lo["env"])
+    fr, vr = so.pack(ref, lo["base"], lo["rough"], lo["normals"], view, training)
+    (fr * wf).sum().backward()
+    (f2 * wf.float().to(dev)).sum().backward()
+    for k in ("radiance", "env"):
+        ref_g = lo[k].grad if lo[k].grad is not None else torch.zeros_like(lo[k])
+        _close("featonly_grad_" + k, lg[k].grad, ref_g, tol=3e-4)
