@@ -130,7 +130,7 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
             const float Lg = fminf(64.f, fmaxf(0.f, E[ch] * p.env_scale)) * vis;
             r[ch] = d[ch]; r[3 + ch] = L[ch]; r[6 + ch] = H[ch];
             r[10 + ch] = Lg; r[13 + ch] = rad[ch];
-            m[ch] += rad[ch] + Lg; m[3 + ch] += rad[ch]; m[6 + ch] += Lg;
+            m[3 + ch] += rad[ch]; m[6 + ch] += Lg;
         }
         r[9] = frac0; r[16] = area;
         m[9] += vis;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
         const float NoH = fminf(1.f, fmaxf(1e-6f, c.Nh[0] * r[6] + c.Nh[1] * r[7] + c.Nh[2] * r[8]));
         const float nom0 = NoH * NoH * (c.a2 - 1.f) + 1.f;
         const float nom = fminf(4.f * kPi, fmaxf(1e-6f, 4.f * kPi * nom0 * nom0 * c.nom1 * (NoL * (1.f - c.kk) + c.kk)));
-        const float fs = r[9] * c.a2 / nom;
+        const float fs = r[9] * c.a2 * __builtin_amdgcn_rcpf(nom);
         const float ge = r[16] * ndi;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -184,9 +184,13 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 10; i++) {
+    for (int i = 3; i < 10; i++) {   // local(3), global(3), visibility; incident = local + global
         const float t = wave_scan_last(m[i]);
         if (lane == 63) sOut[60 + i] = t * inv_ns;
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) sOut[60 + i] = sOut[63 + i] + sOut[66 + i];
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
@@ -239,175 +243,293 @@ struct ShadeBwdArgs {
     float *d_base, *d_rough, *d_normals, *d_radiance, *d_envtab;  // d_envtab: gradient w.r.t. the f(env) table
 };
 
-// Upstream gradient of reduced[g][i]: dL_dreduced plus the entries of the packed features / vfeatures rows that alias
-// it (adjoint of the forward epilogue's packing, gaussian_renderer/svgss.py:143-166).
-__device__ __forceinline__ float upstream(const ShadeBwdArgs& a, size_t g, int i) {
-    float v = a.g_red ? a.g_red[g * NRED + i] : 0.f;
-    const bool tr = a.p.training != 0;
-    if (a.g_vfeat) {
-        const float* vf = a.g_vfeat + g * (tr ? 52 : 64);
-        if (i < 12) v += vf[i];
-        else if (i < 24) { if (tr) v += vf[40 + (i - 12)]; }
-        else if (i >= 36 && i < 48) { if (!tr) v += vf[40 + (i - 36)]; }
-        else if (i >= 48 && i < 60) { if (!tr) v += vf[52 + (i - 48)]; }
-    }
-    if (a.g_feat) {
-        const float* f = a.g_feat + g * (tr ? 4 : 7);
-        if (i >= 60 && i < 63) { if (!tr) v += f[i - 60]; }
-        else if (i >= 63 && i < 66) v += tr ? f[1 + (i - 63)] : f[3 + (i - 63)];
-        else if (i == 69) v += tr ? f[0] : f[6];
-    }
-    return v;
+// ---- backward sample record (BREC floats): the forward's 17 + dmul(3) = d(global light)/d(env lookup) incl. the
+// clamp and visibility, + the bilinear footprint {x0 | y0 << 16, fx, fy} so the adjoint never re-evaluates acos/atan2.
+constexpr int BREC = 23;
+#ifndef SHADE_BWAVES
+#define SHADE_BWAVES 4   // measured on MI355X (P=200k, Ns=64): 4 waves x 3/SIMD 0.71 ms, 8x4 0.79, 8x2 0.83, 4x4 1.05
+#define SHADE_BWPE 3
+#endif
+constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
+
+struct RawSample { float d[3], rad[3], vis, area; };
+
+__device__ __forceinline__ RawSample load_raw(const svgir_shade_params& p, size_t g, int s, int lane, int cnt) {
+    const size_t o = g * (size_t)p.Ns + (size_t)(s + (lane < cnt ? lane : 0));
+    RawSample r;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { r.d[j] = p.incident_dirs[o * 3 + j]; r.rad[j] = p.radiance[o * 3 + j]; }
+    r.vis = p.visibility[o]; r.area = p.incident_areas[o];
+    return r;
 }
 
-// Persistent workgroups (4 waves, one Gaussian per wave per iteration).  LDS: 4 x sample records, 4 x per-sample
-// light-gradient exchange [Ns][4 corners][9], and one workgroup-private env-gradient image.
-__global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, int env_in_lds) {
+__device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const RawSample& x, int lane, const float* V,
+                                              float* __restrict__ sS) {
+    const float* d = x.d;
+    const float il = 1.f / fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+    const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
+    float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
+    const float ih = 1.f / fmaxf(sqrtf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e-12f);
+    H[0] *= ih; H[1] *= ih; H[2] *= ih;
+    const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
+    const float frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+    // bilinear footprint (same arithmetic as env_taps)
+    const int He = p.env_h, We = p.env_w;
+    const float phi = acosf(d[2]) - 1e-6f;
+    const float theta = atan2f(d[1], d[0]);
+    const float gy = phi / kPi * 2.f - 1.f;
+    const float gx = -theta / kPi;
+    const float xx = (gx + 1.f) * 0.5f * (float)(We - 1);
+    const float yy = (gy + 1.f) * 0.5f * (float)(He - 1);
+    const float x0f = floorf(xx), y0f = floorf(yy);
+    const float fx = xx - x0f, fy = yy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    float E[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int xi = x0 + (j & 1), yi = y0 + (j >> 1);
+        if (xi >= 0 && xi < We && yi >= 0 && yi < He) {
+            const float w = ((j & 1) ? fx : 1.f - fx) * ((j >> 1) ? fy : 1.f - fy);
+            const float* t = p.env_work + (yi * We + xi) * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) E[ch] += w * t[ch];
+        }
+    }
+    float* r = sS + lane * BREC;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float Es = E[ch] * p.env_scale;
+        r[ch] = d[ch]; r[3 + ch] = L[ch]; r[6 + ch] = H[ch];
+        r[10 + ch] = fminf(64.f, fmaxf(0.f, Es)) * x.vis; r[13 + ch] = x.rad[ch];
+        r[17 + ch] = (Es >= 0.f && Es <= 64.f) ? x.vis * p.env_scale : 0.f;
+    }
+    r[9] = frac0; r[16] = x.area;
+    // footprint origin, biased by +1 (x0, y0 >= -1 by construction), 16 bits each
+    const int xb = min(max(x0 + 1, 0), 65535), yb = min(max(y0 + 1, 0), 65535);
+    r[20] = __builtin_bit_cast(float, (uint32_t)xb | ((uint32_t)yb << 16));
+    r[21] = fx; r[22] = fy;
+}
+
+__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of a quad, result in all 4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    return v;
+}
+// sum over the 16 lanes of the wave that share (lane & 3); result in all of them
+__device__ __forceinline__ float stride4_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+// LDS traffic private to one wave: DS operations of a wave complete in order, only the compiler has to be fenced
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifdef SHADE_TIMING
+__device__ unsigned long long g_shade_tm[8];
+#define TM_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_acc[i] += t_ - tm_prev; tm_prev = t_; } while (0)
+#else
+#define TM_MARK(i)
+#endif
+
+// Persistent workgroups of BWAVES waves; every wave owns one Gaussian at a time and never synchronises with the other
+// waves (its sample records are wave-private LDS).  Lane = (sample group sg = lane / 4, corner k = lane % 4): the
+// four corners of one incident sample sit in one DPP quad, so the per-sample light gradients are summed with two
+// quad_perm adds and the quad then shares the adjoint of the sample: lane k stores channel k of dL/dradiance and
+// scatters bilinear tap k of the env-lookup gradient into the workgroup-private LDS image (flushed with one global
+// atomic per texel per workgroup).  The next chunk of samples is prefetched into registers while the current one is
+// processed.
+__global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_eu(SHADE_BWPE, SHADE_BWPE))) shade_bwd_kernel(const ShadeBwdArgs a, int env_in_lds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int Ns = p.Ns;
-    const int ntex = p.env_h * p.env_w * 3;
-    const int per_wave = 64 * SREC + 64 * 36;
-    float* sS = smem + (size_t)wave * per_wave;
-    float* sX = sS + 64 * SREC;                  // [64][4][9] : dLi(3) dLg(3) dLl(3) per (sample of the chunk, corner)
-    float* sEnv = smem + (size_t)4 * per_wave;   // [ntex] (only when env_in_lds)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int Ns = p.Ns, We = p.env_w, He = p.env_h;
+    const int ntex = He * We * 3;
+    float* sS = smem + (size_t)wave * (64 * BREC);
+    float* sEnv = smem + (size_t)BWAVES * (64 * BREC);   // [ntex] (only when env_in_lds)
     if (env_in_lds) {
-        for (int i = threadIdx.x; i < ntex; i += BLOCK) sEnv[i] = 0.f;
+        for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) sEnv[i] = 0.f;
     }
     __syncthreads();
     const float inv_ns = 1.f / (float)Ns;
-    const int k = lane >> 4, sg = lane & 15;
+    const int k = lane & 3, sg = lane >> 2;
+    const int P = p.P;
+    const int gstep = (int)gridDim.x * BWAVES;
+    int g = (int)blockIdx.x * BWAVES + wave;   // wave-uniform
 
-    for (size_t g0 = (size_t)blockIdx.x * 4; g0 < (size_t)p.P; g0 += (size_t)gridDim.x * 4) {
-        const size_t g = g0 + wave;
-        const bool valid = g < (size_t)p.P;
-        const size_t gg = valid ? g : 0;
+    RawSample raw;
+    if (g < P) raw = load_raw(p, (size_t)g, 0, lane, min(64, Ns));
+#ifdef SHADE_TIMING
+    unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tm_prev = __builtin_amdgcn_s_memtime();
+#endif
+    for (; g < P; g += gstep) {
+        TM_MARK(0);
+        const size_t gg = (size_t)g;
         float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
         {
             const float iv = 1.f / fmaxf(sqrtf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e-12f);
             V[0] *= iv; V[1] *= iv; V[2] *= iv;
         }
-        float m[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // light sums (unused by the adjoint)
-        // ---- phase 2 adjoint: lane = (corner k, sample group sg) ----
         GaussConst c;
         load_corner(p, gg, k, V, c);
-        float gp[3], gd[3], gs[3], gdi[3], gin[3];
+        // Upstream gradients of this (Gaussian, corner): dL_dreduced plus the rows of the packed features / vfeatures
+        // that alias it (see upstream()); all loads of a source are issued together under one uniform branch.
+        float gp[3] = {0, 0, 0}, gd[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gdi[3] = {0, 0, 0}, gin[3] = {0, 0, 0};
+        float gmi[3] = {0, 0, 0}, gml[3] = {0, 0, 0}, gmg[3] = {0, 0, 0};
+        float dir_b[3] = {0, 0, 0}, dir_n[3] = {0, 0, 0}, dir_r = 0.f;   // direct terms of the packing
+        const bool tr = p.training != 0;
+        if (a.g_red) {
+            const float* gr = a.g_red + gg * NRED;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                gp[ch] = gr[ch * 4 + k]; gd[ch] = gr[12 + ch * 4 + k]; gs[ch] = gr[24 + ch * 4 + k];
+                gdi[ch] = gr[36 + ch * 4 + k]; gin[ch] = gr[48 + ch * 4 + k];
+                gmi[ch] = gr[60 + ch]; gml[ch] = gr[63 + ch]; gmg[ch] = gr[66 + ch];
+            }
+        }
+        if (a.g_vfeat) {
+            const float* vf = a.g_vfeat + gg * (tr ? 52 : 64);
+            float t0[3], t1[3], t2[3], nv[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                t0[ch] = vf[ch * 4 + k]; t1[ch] = vf[40 + ch * 4 + k]; t2[ch] = tr ? 0.f : vf[52 + ch * 4 + k];
+                dir_b[ch] = vf[12 + ch * 4 + k]; nv[ch] = vf[24 + ch * 4 + k];
+            }
+            dir_r = vf[36 + k];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                gp[ch] += t0[ch];
+                if (tr) gd[ch] += t1[ch]; else { gdi[ch] += t1[ch]; gin[ch] += t2[ch]; }
+            }
+            // vfeatures[24:36] = (normals @ view[:3,:3])^T  =>  dn[j] += sum_ch g[ch] * view[j][ch]
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                dir_n[j] = nv[0] * p.viewmatrix[j * 4 + 0] + nv[1] * p.viewmatrix[j * 4 + 1] + nv[2] * p.viewmatrix[j * 4 + 2];
+        }
+        if (a.g_feat) {
+            const float* f = a.g_feat + gg * (tr ? 4 : 7);
+            if (tr) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) gml[ch] += f[1 + ch];
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) { gmi[ch] += f[ch]; gml[ch] += f[3 + ch]; }
+            }
+        }
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            gp[ch] = upstream(a, gg, ch * 4 + k) * inv_ns; gd[ch] = upstream(a, gg, 12 + ch * 4 + k) * inv_ns;
-            gs[ch] = upstream(a, gg, 24 + ch * 4 + k) * inv_ns; gdi[ch] = upstream(a, gg, 36 + ch * 4 + k) * inv_ns;
-            gin[ch] = upstream(a, gg, 48 + ch * 4 + k) * inv_ns;
+            gp[ch] *= inv_ns; gd[ch] *= inv_ns; gs[ch] *= inv_ns; gdi[ch] *= inv_ns; gin[ch] *= inv_ns;
+            gmi[ch] *= inv_ns; gml[ch] *= inv_ns; gmg[ch] *= inv_ns;
         }
+        // lane k owns channel k (< 3) of dL/dradiance: constant part
+        const float grad_const = k == 0 ? gmi[0] + gml[0] : (k == 1 ? gmi[1] + gml[1] : gmi[2] + gml[2]);
         float d_fd[3] = {0, 0, 0}, d_r = 0.f, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
+        const float NoV = fminf(1.f, fmaxf(1e-6f, c.NoV_raw));
+        const bool nov_in = c.NoV_raw >= 1e-6f && c.NoV_raw <= 1.f;
         for (int s0 = 0; s0 < Ns; s0 += 64) {
-          const int cnt = min(64, Ns - s0);
-          stage_samples(p, gg, lane, V, sS, m, s0, cnt);
-          __syncthreads();
-          for (int s = sg; s < cnt; s += 16) {
-            const float* r = sS + s * SREC;
-            const float ndr = c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2];
-            const float ndi = fmaxf(ndr, 0.f);
-            const float NoLr = c.Nh[0] * r[3] + c.Nh[1] * r[4] + c.Nh[2] * r[5];
-            const float NoHr = c.Nh[0] * r[6] + c.Nh[1] * r[7] + c.Nh[2] * r[8];
-            const float NoL = fminf(1.f, fmaxf(1e-6f, NoLr)), NoH = fminf(1.f, fmaxf(1e-6f, NoHr));
-            const float nom0 = NoH * NoH * (c.a2 - 1.f) + 1.f;
-            const float nom2 = NoL * (1.f - c.kk) + c.kk;
-            const float nomr = 4.f * kPi * nom0 * nom0 * c.nom1 * nom2;
-            const float nom = fminf(4.f * kPi, fmaxf(1e-6f, nomr));
-            const float inv_nom = 1.f / nom;
-            const float fs = r[9] * c.a2 * inv_nom;
-            const float area = r[16], ge = area * ndi;
-            float d_fs = 0.f, d_ndi = 0.f;
-            float* x = sX + (s * 4 + k) * 9;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float Lg = r[10 + ch], Ll = r[13 + ch], Li = Lg + Ll;
-                const float f = c.fd[ch] + fs;
-                // outputs: pbr = f*Li*ge, dif = Li*ge, spe = fs*Li*ge, dir = f*Lg*ge, ind = f*Ll*ge
-                const float cLi = gp[ch] * f + gd[ch] + gs[ch] * fs;   // d/d(Li*ge)
-                const float cLg = gdi[ch] * f, cLl = gin[ch] * f;
-                x[ch] = cLi * ge; x[3 + ch] = cLg * ge; x[6 + ch] = cLl * ge;
-                const float df = (gp[ch] * Li + gdi[ch] * Lg + gin[ch] * Ll) * ge;   // d/df
-                d_fd[ch] += df;
-                d_fs += df + gs[ch] * Li * ge;
-                d_ndi += (cLi * Li + cLg * Lg + cLl * Ll) * area;
+            const int cnt = min(64, Ns - s0);
+            wave_lds_sync();   // previous chunk consumed
+            TM_MARK(1);
+            if (lane < cnt) stage_raw_bwd(p, raw, lane, V, sS);
+            TM_MARK(2);
+            {   // prefetch the next chunk (of this Gaussian or of the wave's next one)
+                const bool more = s0 + 64 < Ns;
+                const int gn = more ? g : g + gstep;
+                const int sn = more ? s0 + 64 : 0;
+                if (gn < P) raw = load_raw(p, (size_t)gn, sn, lane, min(64, Ns - sn));
             }
-            if (ndr > 0.f) {
-#pragma unroll
-                for (int j = 0; j < 3; j++) d_n[j] += d_ndi * r[j];
-            }
-            // fs = frac0 * a2 / nom
-            const float d_nom = (nomr >= 1e-6f && nomr <= 4.f * kPi) ? -d_fs * fs * inv_nom : 0.f;
-            const float t4 = 4.f * kPi;
-            const float d_nom0 = d_nom * t4 * 2.f * nom0 * c.nom1 * nom2;
-            const float d_nom1 = d_nom * t4 * nom0 * nom0 * nom2;
-            const float d_nom2 = d_nom * t4 * nom0 * nom0 * c.nom1;
-            // a2 enters frac (fs/a2) and nom0; kk enters nom1, nom2
-            const float NoV = fminf(1.f, fmaxf(1e-6f, c.NoV_raw));
-            const float d_a2 = d_fs * r[9] * inv_nom + d_nom0 * NoH * NoH;
-            const float d_kk = d_nom1 * (1.f - NoV) + d_nom2 * (1.f - NoL);
-            // a2 = r^4, kk = (r^2 + 2r + 1)/8
-            d_r += d_a2 * 4.f * c.r * c.r * c.r + d_kk * (2.f * c.r + 2.f) / 8.f;
-            const float d_NoH = (NoHr >= 1e-6f && NoHr <= 1.f) ? d_nom0 * 2.f * NoH * (c.a2 - 1.f) : 0.f;
-            const float d_NoL = (NoLr >= 1e-6f && NoLr <= 1.f) ? d_nom2 * (1.f - c.kk) : 0.f;
-            const float d_NoV = (c.NoV_raw >= 1e-6f && c.NoV_raw <= 1.f) ? d_nom1 * (1.f - c.kk) : 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; j++) d_Nh[j] += d_NoH * r[6 + j] + d_NoL * r[3 + j] + d_NoV * V[j];
-          }
-          __syncthreads();
-          // ---- phase 3: lane = sample of the chunk: radiance gradient, env-texel scatter ----
-          if (lane < cnt) {
-            const int s = lane;
-            float dLi[3] = {0, 0, 0}, dLg[3] = {0, 0, 0}, dLl[3] = {0, 0, 0};
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++) {
-                const float* x = sX + (s * 4 + kc) * 9;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) { dLi[ch] += x[ch]; dLg[ch] += x[3 + ch]; dLl[ch] += x[6 + ch]; }
-            }
-            const size_t o = gg * Ns + s0 + s;
-            const float vis = p.visibility[o];
-            float dE[3];
-            bool any = false;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float gi = upstream(a, gg, 60 + ch) * inv_ns, gl = upstream(a, gg, 63 + ch) * inv_ns,
-                            gg_ = upstream(a, gg, 66 + ch) * inv_ns;
-                if (valid) a.d_radiance[o * 3 + ch] = dLi[ch] + dLl[ch] + gi + gl;
-                dE[ch] = (dLi[ch] + dLg[ch] + gi + gg_) * vis;
-                any = any || dE[ch] != 0.f;
-            }
-            if (valid && any) {
-                const float* r = sS + s * SREC;
-                const float d[3] = {r[0], r[1], r[2]};
-                EnvTap t;
-                env_taps(d, p.env_h, p.env_w, t);
-                float E[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (t.idx[j] >= 0) {
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) E[ch] += t.w[j] * p.env_work[t.idx[j] + ch];
-                    }
+            wave_lds_sync();
+            TM_MARK(3);
+#pragma unroll 1
+            for (int it = 0; it < 4; it++) {
+                const int s = sg + 16 * it;
+                if (16 * it >= cnt) break;   // wave-uniform
+                const bool act = s < cnt;
+                const float* r = sS + (act ? s : 0) * BREC;
+                const float ndr = c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2];
+                const float ndi = fmaxf(ndr, 0.f);
+                const float NoLr = c.Nh[0] * r[3] + c.Nh[1] * r[4] + c.Nh[2] * r[5];
+                const float NoHr = c.Nh[0] * r[6] + c.Nh[1] * r[7] + c.Nh[2] * r[8];
+                const float NoL = fminf(1.f, fmaxf(1e-6f, NoLr)), NoH = fminf(1.f, fmaxf(1e-6f, NoHr));
+                const float nom0 = NoH * NoH * (c.a2 - 1.f) + 1.f;
+                const float nom2 = NoL * (1.f - c.kk) + c.kk;
+                const float nomr = 4.f * kPi * nom0 * nom0 * c.nom1 * nom2;
+                const float nom = fminf(4.f * kPi, fmaxf(1e-6f, nomr));
+                const float inv_nom = __builtin_amdgcn_rcpf(nom);
+                const float fs = r[9] * c.a2 * inv_nom;
+                const float area = act ? r[16] : 0.f, ge = area * ndi;
+                float d_fs = 0.f, d_ndi = 0.f;
+                float xi[3], xg[3], xl[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const float Es = E[ch] * p.env_scale;
-                    const float dt = (Es >= 0.f && Es <= 64.f) ? dE[ch] * p.env_scale : 0.f;
-                    if (dt != 0.f) {
+                    const float Lg = r[10 + ch], Ll = r[13 + ch], Li = Lg + Ll;
+                    const float f = c.fd[ch] + fs;
+                    // outputs: pbr = f*Li*ge, dif = Li*ge, spe = fs*Li*ge, dir = f*Lg*ge, ind = f*Ll*ge
+                    const float cLi = gp[ch] * f + gd[ch] + gs[ch] * fs;   // d/d(Li*ge)
+                    const float cLg = gdi[ch] * f, cLl = gin[ch] * f;
+                    xi[ch] = cLi * ge; xg[ch] = cLg * ge; xl[ch] = cLl * ge;
+                    const float df = (gp[ch] * Li + gdi[ch] * Lg + gin[ch] * Ll) * ge;   // d/df
+                    d_fd[ch] += df;
+                    d_fs += df + gs[ch] * Li * ge;
+                    d_ndi += (cLi * Li + cLg * Lg + cLl * Ll) * area;
+                }
+                if (ndr > 0.f) {
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (t.idx[j] >= 0) {
-                                if (env_in_lds) atomicAdd(&sEnv[t.idx[j] + ch], dt * t.w[j]);
-                                else atomic_add_f32(&a.d_envtab[t.idx[j] + ch], dt * t.w[j]);
+                    for (int j = 0; j < 3; j++) d_n[j] += d_ndi * r[j];
+                }
+                // fs = frac0 * a2 / nom
+                const float d_nom = (nomr >= 1e-6f && nomr <= 4.f * kPi) ? -d_fs * fs * inv_nom : 0.f;
+                const float t4 = 4.f * kPi;
+                const float d_nom0 = d_nom * t4 * 2.f * nom0 * c.nom1 * nom2;
+                const float d_nom1 = d_nom * t4 * nom0 * nom0 * nom2;
+                const float d_nom2 = d_nom * t4 * nom0 * nom0 * c.nom1;
+                // a2 enters frac (fs/a2) and nom0; kk enters nom1, nom2
+                const float d_a2 = d_fs * r[9] * inv_nom + d_nom0 * NoH * NoH;
+                const float d_kk = d_nom1 * (1.f - NoV) + d_nom2 * (1.f - NoL);
+                // a2 = r^4, kk = (r^2 + 2r + 1)/8
+                d_r += d_a2 * 4.f * c.r * c.r * c.r + d_kk * (2.f * c.r + 2.f) / 8.f;
+                const float d_NoH = (NoHr >= 1e-6f && NoHr <= 1.f) ? d_nom0 * 2.f * NoH * (c.a2 - 1.f) : 0.f;
+                const float d_NoL = (NoLr >= 1e-6f && NoLr <= 1.f) ? d_nom2 * (1.f - c.kk) : 0.f;
+                const float d_NoV = nov_in ? d_nom1 * (1.f - c.kk) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; j++) d_Nh[j] += d_NoH * r[6 + j] + d_NoL * r[3 + j] + d_NoV * V[j];
+
+                // ---- adjoint of the sample: sum the four corners (one quad), then lane k takes channel / tap k ----
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) { xi[ch] = quad_sum(xi[ch]); xg[ch] = quad_sum(xg[ch]); xl[ch] = quad_sum(xl[ch]); }
+                if (act) {
+                    const size_t o = gg * Ns + s0 + s;
+                    if (k < 3) {
+                        const float v = k == 0 ? xi[0] + xl[0] : (k == 1 ? xi[1] + xl[1] : xi[2] + xl[2]);
+                        a.d_radiance[o * 3 + k] = v + grad_const;
+                    }
+                    const uint32_t xy = __builtin_bit_cast(uint32_t, r[20]);
+                    const int tx = (int)(xy & 0xffffu) - 1 + (k & 1), ty = (int)(xy >> 16) - 1 + (k >> 1);
+                    if (tx >= 0 && tx < We && ty >= 0 && ty < He) {
+                        const float fx = r[21], fy = r[22];
+                        const float w = ((k & 1) ? fx : 1.f - fx) * ((k >> 1) ? fy : 1.f - fy);
+                        const int idx = (ty * We + tx) * 3;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            const float dt = (xi[ch] + xg[ch] + gmi[ch] + gmg[ch]) * r[17 + ch] * w;
+                            if (dt != 0.f) {
+                                // (ds_add_f32 is ~10x slower than the integer LDS atomics on gfx950 -- measured
+                                // ~500 cycles per wave instruction; still far cheaper than L2 atomics on 6144 texels)
+                                if (env_in_lds) atomicAdd(&sEnv[idx + ch], dt);
+                                else atomic_add_f32(&a.d_envtab[idx + ch], dt);
                             }
+                        }
                     }
                 }
             }
-        
-          }
-          __syncthreads();
         }
+        TM_MARK(4);
         // Nh = sgn * n / |n|  =>  dn += sgn/|n| * (dNh - Nn (Nn . dNh)),  Nn = n/|n|
         {
             const float Nn[3] = {c.nraw[0] * c.inv_len, c.nraw[1] * c.inv_len, c.nraw[2] * c.inv_len};
@@ -416,33 +538,30 @@ __global__ void __launch_bounds__(BLOCK) shade_bwd_kernel(const ShadeBwdArgs a, 
             for (int j = 0; j < 3; j++) d_n[j] += c.sgn * c.inv_len * (d_Nh[j] - Nn[j] * dot);
         }
 #pragma unroll
-        for (int j = 0; j < 3; j++) { d_n[j] = row16_sum(d_n[j]); d_fd[j] = row16_sum(d_fd[j]); }
-        d_r = row16_sum(d_r);
-        if (valid && sg == 0) {
-            // direct terms of the packing: vfeatures[12:24] = base_color, [24:36] = (normals @ view[:3,:3])^T,
-            // [36:40] = roughness
-            const float* vf = a.g_vfeat ? a.g_vfeat + g * (p.training ? 52 : 64) : nullptr;
+        for (int j = 0; j < 3; j++) { d_n[j] = stride4_sum(d_n[j]); d_fd[j] = stride4_sum(d_fd[j]); }
+        d_r = stride4_sum(d_r);
+        if (sg == 0) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                float dn = d_n[j], db = d_fd[j] / kPi;
-                if (vf) {
-                    db += vf[12 + j * 4 + k];
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) dn += vf[24 + ch * 4 + k] * p.viewmatrix[j * 4 + ch];
-                }
-                a.d_normals[g * 12 + k * 3 + j] = dn;
-                a.d_base[g * 12 + j * 4 + k] = db;
+                a.d_normals[gg * 12 + k * 3 + j] = d_n[j] + dir_n[j];
+                a.d_base[gg * 12 + j * 4 + k] = d_fd[j] / kPi + dir_b[j];
             }
-            a.d_rough[g * 4 + k] = d_r + (vf ? vf[36 + k] : 0.f);
+            a.d_rough[gg * 4 + k] = d_r + dir_r;
         }
-        __syncthreads();
+        TM_MARK(5);
     }
+    __syncthreads();
+    TM_MARK(6);
     if (env_in_lds) {
-        for (int i = threadIdx.x; i < ntex; i += BLOCK) {
+        for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) {
             const float v = sEnv[i];
             if (v != 0.f) atomic_add_f32(&a.d_envtab[i], v);
         }
     }
+    TM_MARK(7);
+#ifdef SHADE_TIMING
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_shade_tm[i], tm_acc[i]);
+#endif
 }
 
 // dL/d env_raw = dL/d f(env) * f'(env);  softplus' = sigmoid
@@ -500,19 +619,27 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
-    const size_t per_wave = (size_t)(64 * SREC + 64 * 36) * 4;
-    size_t lds = 4 * per_wave;
+    const size_t per_wave = (size_t)(64 * BREC) * 4;
+    size_t lds = BWAVES * per_wave;
     int env_in_lds = 0;
-    if (lds + (size_t)ntex * 4 <= 120 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 4; }
-    if (lds > 160 * 1024) return SVGIR_ERR_INVALID;
-    const int blocks = std::min((p->P + 3) / 4, 256 * 2);
+    if (p->env_w > 65000 || p->env_h > 65000) return SVGIR_ERR_INVALID;
+    if (lds + (size_t)ntex * 4 <= 76 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 4; }   // >= two workgroups per CU
+    const int blocks = std::min((p->P + BWAVES - 1) / BWAVES, 256 * (SHADE_BWPE * 4 / BWAVES));
     stage_mark(tm, "shade_bwd_prologue");
-    hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(BLOCK), lds, s, a, env_in_lds);
+    hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(BWAVES * 64), lds, s, a, env_in_lds);
     stage_mark(tm, "shade_bwd");
     hipLaunchKernelGGL(env_grad_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, env_grad_work,
                        dL_denv, ntex, p->env_softplus);
     stage_mark(tm, "shade_env_grad");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
+
+#ifdef SHADE_TIMING
+int svgir_debug_shade_timing(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_shade_tm), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_tm), z, 64); }
+    return 0;
+}
+#endif
 
 }  // extern "C"
