@@ -127,7 +127,9 @@ int svgir_abi_version(void);
  * rasterizer_impl.h:73-84). */
 size_t svgir_geom_bytes(int32_t P);
 size_t svgir_image_bytes(int32_t W, int32_t H);
-size_t svgir_binning_bytes(int32_t num_rendered);
+/* The binning blob also holds the per-segment forward states that parallelise the backward over depth, hence the
+ * dependence on the image size and channel counts (S features, VS vfeature floats; VS = 0 for rgss). */
+size_t svgir_binning_bytes(int32_t num_rendered, int32_t W, int32_t H, int32_t S, int32_t VS);
 /* Byte offset of the int32 n_contrib[H*W] plane inside the image blob (rgss returns a view of it, Q10). */
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H);
 

@@ -165,7 +165,10 @@ extern "C" {
 int svgir_abi_version(void) { return SVGIR_ABI_VERSION; }
 size_t svgir_geom_bytes(int32_t P) { return geom_layout(nullptr, P).bytes; }
 size_t svgir_image_bytes(int32_t W, int32_t H) { return image_layout(nullptr, W, H).bytes; }
-size_t svgir_binning_bytes(int32_t R) { return bin_layout(nullptr, R).bytes; }
+size_t svgir_binning_bytes(int32_t R, int32_t W, int32_t H, int32_t S, int32_t VS) {
+    const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    return bin_layout(nullptr, R, T, seg_nstate(S, VS)).bytes;
+}
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H) { return image_layout(nullptr, W, H).ncontrib_off; }
 const char* svgir_last_error(void) { return g_err.c_str(); }
 void svgir_set_profiling(int enabled) {
@@ -257,9 +260,11 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     if (R_host > 0x7fffffffu) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
     const int R = (int)R_host;
 
-    char* bblob = binning(bin_layout(nullptr, R).bytes, binning_ctx);
+    const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
+    char* bblob = binning(bin_layout(nullptr, R, T, nstate).bytes, binning_ctx);
     if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
-    const BinLayout B = bin_layout(bblob, R);
+    const BinLayout B = bin_layout(bblob, R, T, nstate);
+    HIP_OK(hipMemsetAsync(B.seg_map, 0xFF, B.seg_cap * 4, s));
     const TileSortPlan plan = tile_sort_plan(T);
 
     if (R > 0) {
@@ -281,6 +286,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
     ra.bg = p->background;
     ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_count = I.sub_count; ra.tile_order = I.tile_order;
+    ra.sub_ndump = I.sub_ndump; ra.seg_map = B.seg_map; ra.seg_state = B.seg_state;
     ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
     ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
     ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
@@ -313,7 +319,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
     const GeomLayout G = geom_layout(geom_blob, P);
     const ImageLayout I = image_layout(image_blob, W, H);
-    const BinLayout B = bin_layout(binning_blob, R);
+    const BinLayout B = bin_layout(binning_blob, R, T, seg_nstate(p->S, svgss ? p->VS : 0));
     const int fin = tile_sort_plan(T).passes & 1;
     StageTimer tm(s, g_prof.load());
 
@@ -322,6 +328,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.ranges = I.ranges; ba.point_list = B.val[fin]; ba.rec = G.rec; ba.features = p->features; ba.vfeatures = p->vfeatures;
     ba.bg = p->background;
     ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count; ba.tile_order = I.tile_order;
+    ba.sub_ndump = I.sub_ndump; ba.seg_map = B.seg_map; ba.seg_state = B.seg_state; ba.seg_cap = (int)B.seg_cap;
     ba.backward_geometry = p->backward_geometry;
     ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;
     ba.g_color = g->dL_dout_color; ba.g_normal = g->dL_dout_normal; ba.g_depth = g->dL_dout_depth;

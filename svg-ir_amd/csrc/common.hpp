@@ -80,6 +80,7 @@ struct ImageLayout {
     uint32_t* ranges;    // [2*T]
     uint32_t* tile_order; // [T] tiles sorted by descending list length (heaviest work is dispatched first)
     uint32_t* sub_count; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the forward)
+    uint32_t* sub_ndump; // [4*T] #segment-boundary states the forward dumped for the sub-tile (see SEG)
     size_t ncontrib_off;
     size_t bytes;
 };
@@ -96,9 +97,19 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.ranges = (uint32_t*)take(T * 8);
     im.tile_order = (uint32_t*)take(T * 4);
     im.sub_count = (uint32_t*)take(T * 4 * 4);
+    im.sub_ndump = (uint32_t*)take(T * 4 * 4);
     im.bytes = off;
     return im;
 }
+
+// Backward segments.  The backward composite is parallelised over depth: one wave per SEG consecutive candidates of a
+// sub-tile's compact list.  The forward dumps its per-pixel blend state (T and every accumulator) after each SEG-th
+// candidate and once at the end; a backward segment starts its back-to-front replay from the state at its far end
+// (transmittance there, and "everything behind" = (final - prefix) / T) instead of from the end of the list.
+// Segment / state slot of sub-tile i = 4*tile+w, segment k:  (4*r0 + w*len) / SEG + i + k   (disjoint by construction).
+constexpr int SEG = 128;
+inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
+constexpr int SEG_K_BITS = 14;   // seg_map entry = (sub-tile id << SEG_K_BITS) | k ; 0xFFFFFFFF = no segment
 
 struct BinLayout {
     uint32_t* key[2];  // [R] tile ids ping/pong
@@ -106,9 +117,13 @@ struct BinLayout {
     uint32_t* radix_tbl;
     uint2* sub_list;   // [4*R] compact per-sub-tile candidate lists {Gaussian id, slot in the tile list}; sub-tile w
                        // of a tile with range [r0,r1) owns entries [4*r0 + w*(r1-r0), 4*r0 + (w+1)*(r1-r0))
+    uint32_t* seg_map; // [seg_capacity] live backward segments (written by the forward)
+    float* seg_state;  // [seg_capacity][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
+    size_t seg_cap;
     size_t bytes;
 };
-inline BinLayout bin_layout(char* base, int R) {
+inline int seg_nstate(int S, int VS) { return 8 + S + VS / 4; }
+inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     BinLayout b;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
@@ -119,6 +134,9 @@ inline BinLayout bin_layout(char* base, int R) {
     b.val[1] = (uint32_t*)take(r * 4);
     b.radix_tbl = (uint32_t*)take(((size_t)256 * sort_blocks(R) + 1024) * 4);
     b.sub_list = (uint2*)take(r * 4 * 8);
+    b.seg_cap = seg_capacity(R, T);
+    b.seg_map = (uint32_t*)take(b.seg_cap * 4);
+    b.seg_state = (float*)take(b.seg_cap * (size_t)nstate * 64 * 4);
     b.bytes = off;
     return b;
 }
@@ -164,6 +182,7 @@ struct RenderArgs {
     const float* bg;
     CfgRef cfg;
     uint2* sub_list; uint32_t* sub_count; const uint32_t* tile_order;
+    uint32_t* sub_ndump; uint32_t* seg_map; float* seg_state;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
 };
@@ -175,6 +194,7 @@ struct RenderBwdArgs {
     const float* bg;
     CfgRef cfg; int backward_geometry;
     const uint2* sub_list; const uint32_t* sub_count; const uint32_t* tile_order;
+    const uint32_t* sub_ndump; const uint32_t* seg_map; const float* seg_state; int seg_cap;
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;

@@ -6,9 +6,12 @@
 // alpha to conic, mean2D (incl. the un-weighted depth-differencing term, Q5) and opacity.
 //
 // CDNA4 mapping
-//   * one wave64 per 8x8-pixel sub-tile (one wave per workgroup, no barriers across waves), walking -- in reverse --
-//     the compact candidate list {Gaussian id, slot} that the forward kernel wrote for this sub-tile, so nothing is
-//     culled twice; the replay starts at the wave's deepest contributor (max n_contrib over its 64 pixels);
+//   * one wave64 per depth segment of an 8x8-pixel sub-tile (one wave per workgroup, no barriers across waves): SEG
+//     consecutive entries of the compact candidate list {Gaussian id, slot} that the forward kernel wrote for the
+//     sub-tile (nothing is culled twice), walked in reverse.  The deepest live segment starts from final_T like the
+//     reference; every other one starts from the forward state dumped at its far end (T there, and the blend of
+//     everything behind = (final accumulators - prefix accumulators) / T), which turns the reference's strictly
+//     sequential per-pixel replay into ~2x more, much shorter and evenly sized work items;
 //   * candidates are staged CHB at a time into LDS like in the forward (stage.hpp); LDS per wave is kept small
 //     (9 KB rgss / 18 KB svgss-train) because the kernel is latency-bound and lives off waves per SIMD;
 //   * per-pixel replay state (running accumulators, last values, upstream gradients) lives in VGPRs thanks to
@@ -40,6 +43,15 @@ __device__ __forceinline__ float octant_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
     return v;
 }
+
+#ifdef RENDER_TIMING
+__device__ unsigned long long g_bwd_tm[8];
+#define TM_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_acc[i] += t_ - tm_prev; tm_prev = t_; } while (0)
+#define TM_COUNT(i, n) tm_acc[i] += (unsigned long long)(n)
+#else
+#define TM_MARK(i)
+#define TM_COUNT(i, n)
+#endif
 
 template <int S, int VC>
 struct BwdGeom {
@@ -75,11 +87,19 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [SB][NVW][PROW] blend-weight panel
     float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [SB][6][8] octant-reduced geometric gradients
 
-    int tile, sub;
-    sub_tile_of_block(blockIdx.x, a.gx * a.gy, a.tile_order, tile, sub);
-    if (tile < 0) return;
-    const int count = (int)a.sub_count[4 * tile + sub];
-    if (count == 0) return;
+    // one wave per live depth segment (common.hpp SEG): seg_map[b] = (sub-tile id << SEG_K_BITS) | k
+    const uint32_t sm = a.seg_map[blockIdx.x];
+    if (sm == 0xFFFFFFFFu) return;
+#ifdef RENDER_TIMING
+    unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tm_prev = __builtin_amdgcn_s_memtime();
+#endif
+    const int sid = (int)(sm >> SEG_K_BITS), kseg = (int)(sm & ((1u << SEG_K_BITS) - 1u));
+    const int tile = sid >> 2, sub = sid & 3;
+    const int count = (int)a.sub_count[sid];
+    const int ndump = (int)a.sub_ndump[sid];
+    const int seg_lo = kseg * SEG, seg_hi = min(count, seg_lo + SEG);
+    if (seg_hi <= seg_lo) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int lane = threadIdx.x;
     const int px = tx * TILE + (sub & 1) * 8 + (lane & 7);
@@ -165,9 +185,27 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
     for (int i = 0; i < SS; i++) { acc_f[i] = 0.f; last_f[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < VV; i++) { acc_vf[i] = 0.f; last_vf[i] = 0.f; }
+    if (kseg < ndump) {
+        // Not the deepest live segment: start from the forward state dumped at this segment's far end.  With
+        // last_alpha = 0 the replay recurrence takes acc = blend of everything behind = (final - prefix) / T_end.
+        constexpr int NST = 8 + S + VC;
+        const uint32_t base = blockIdx.x - (uint32_t)kseg;   // state slot of (sub-tile, 0)
+        const float* e = a.seg_state + ((size_t)(base + kseg) * NST) * 64 + lane;
+        const float* f = a.seg_state + ((size_t)(base + ndump) * NST) * 64 + lane;   // final state
+        T = e[0];
+        const float iT = __builtin_amdgcn_rcpf(T);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { acc_c[i] = (f[(1 + i) * 64] - e[(1 + i) * 64]) * iT; acc_n[i] = (f[(4 + i) * 64] - e[(4 + i) * 64]) * iT; }
+        acc_d = (f[7 * 64] - e[7 * 64]) * iT;
+#pragma unroll
+        for (int i = 0; i < S; i++) acc_f[i] = (f[(8 + i) * 64] - e[(8 + i) * 64]) * iT;
+#pragma unroll
+        for (int i = 0; i < VC; i++) acc_vf[i] = (f[(8 + S + i) * 64] - e[(8 + S + i) * 64]) * iT;
+    }
 
-    for (int top = count; top > 0; top -= CHB) {  // this batch covers list entries [top - m, top), in reverse
-        const int m = min((int)CHB, top);
+    TM_MARK(0);   // setup: upstream gradients, G matrix, start state
+    for (int top = seg_hi; top > seg_lo; top -= CHB) {  // this batch covers list entries [top - m, top), in reverse
+        const int m = min((int)CHB, top - seg_lo);
         uint2 e = make_uint2(0u, 0xFFFFFFFFu);
         if (lane < m) e = sub_in[top - 1 - lane];
         // entries are ordered by slot: if even the shallowest entry of the batch is behind every pixel, skip it
@@ -177,6 +215,8 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
         __syncthreads();
         stage_candidates<S, VC, CHB>(sD, m, [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
         __syncthreads();
+        TM_MARK(1);   // staging (list entries, gathers, LDS stores)
+        TM_COUNT(5, m);
 
         for (int c0 = 0; c0 < m; c0 += SB) {
             const int nsub = min(SB, m - c0);
@@ -294,6 +334,8 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                     if ((lane & 7) == 0) sPg[(cs * 6 + k) * 8 + (lane >> 3)] = s8;
                 }
             }
+            TM_MARK(2);   // phase A
+            TM_COUNT(6, __popc(live));
             if (live == 0) continue;  // uniform
             __syncthreads();          // panel (and, the first time, G) visible to the phase-B lanes
 
@@ -381,14 +423,19 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                 }
             }
             __syncthreads();  // panel consumed before the next phase A overwrites it
+            TM_MARK(3);   // phase B
         }
     }
+#ifdef RENDER_TIMING
+    tm_acc[7] += 1;
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_bwd_tm[i], tm_acc[i]);
+#endif
 }
 
 template <int S, int VC, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
     using BG = BwdGeom<S, VC>;
-    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), BG::lds_bytes, s, a);
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(a.seg_cap), dim3(64), BG::lds_bytes, s, a);
 }
 
 }  // namespace
@@ -401,5 +448,13 @@ int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s) {
 #undef CASE
     return -1;
 }
+
+#ifdef RENDER_TIMING
+extern "C" int svgir_debug_bwd_timing(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(svgir::g_bwd_tm), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_bwd_tm), z, 64); }
+    return 0;
+}
+#endif
 
 }  // namespace svgir

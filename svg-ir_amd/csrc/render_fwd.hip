@@ -16,7 +16,10 @@
 //     together) and consumed with wave-uniform broadcast reads; channel counts are template parameters so every
 //     accumulator lives in a VGPR (the reference keeps >640 floats per thread in scratch, forward.cu:483-493);
 //   * the per-(pixel,splat) out_weights atomic of the reference (forward.cu:653) becomes one DPP wave reduction
-//     + one atomic per (wave, splat).
+//     + one atomic per (wave, splat);
+//   * after every SEG-th candidate (and once at the end) the wave dumps its blend state -- T and every accumulator,
+//     [state][channel][64 pixels] -- and registers the live backward segments of its sub-tile (common.hpp SEG): the
+//     backward is parallel over depth segments and starts each one from these states.
 #include "common.hpp"
 #include "stage.hpp"
 
@@ -59,6 +62,20 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
 #pragma unroll
     for (int i = 0; i < (VC > 0 ? VC : 1); i++) VF[i] = 0.f;
     uint32_t last_contributor = 0;
+
+    // segment-boundary state dumps (see common.hpp SEG)
+    constexpr int NST = 8 + S + VC;
+    const uint32_t dump_base = (uint32_t)(((size_t)4 * r0 + (size_t)sub * len) / SEG) + (uint32_t)(4 * tile + sub);
+    uint32_t ndump = 0;
+    auto dump_state = [&](uint32_t j) {
+        float* d = a.seg_state + ((size_t)(dump_base + j) * NST) * 64 + lane;
+        d[0] = T; d[64] = C[0]; d[128] = C[1]; d[192] = C[2];
+        d[256] = N[0]; d[320] = N[1]; d[384] = N[2]; d[448] = D;
+#pragma unroll
+        for (int ch = 0; ch < S; ch++) d[(8 + ch) * 64] = F[ch];
+#pragma unroll
+        for (int ch = 0; ch < VC; ch++) d[(8 + S + ch) * 64] = VF[ch];
+    };
 
     uint32_t head = 0, tail = 0;  // candidate ring indices (wave-uniform)
     bool wave_done = __all(done);
@@ -147,12 +164,20 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
                     const float wsum = wave_scan_last(w);
                     if (lane == 63) atomic_add_f32(&a.out_weights[e.x], wsum);
                 }
+                if (((head + (uint32_t)c + 1u) & (uint32_t)(SEG - 1)) == 0u) dump_state(ndump++);
                 if (__any(newly_done) && __all(done)) { wave_done = true; break; }
             }
             head += (uint32_t)m;
         }
     }
-    if (lane == 0) a.sub_count[4 * tile + sub] = tail;
+    if (lane == 0) { a.sub_count[4 * tile + sub] = tail; a.sub_ndump[4 * tile + sub] = ndump; }
+    if (tail != 0) {
+        dump_state(ndump);   // final state
+        // live segments: those that hold at least one processed candidate
+        const uint32_t nseg = min((tail + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u);
+        for (uint32_t k = lane; k < nseg; k += 64)
+            a.seg_map[dump_base + k] = ((uint32_t)(4 * tile + sub) << SEG_K_BITS) | k;
+    }
 
     if (inside) {
         const size_t N_ = (size_t)a.W * a.H;

@@ -58,7 +58,7 @@ def _load():
     lib.svgir_image_bytes.restype = C.c_size_t
     lib.svgir_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.svgir_binning_bytes.restype = C.c_size_t
-    lib.svgir_binning_bytes.argtypes = [C.c_int32]
+    lib.svgir_binning_bytes.argtypes = [C.c_int32] * 5
     lib.svgir_image_ncontrib_offset.restype = C.c_size_t
     lib.svgir_image_ncontrib_offset.argtypes = [C.c_int32, C.c_int32]
     lib.svgir_forward.restype = C.c_int

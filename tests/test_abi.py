@@ -55,7 +55,7 @@ def test_blob_sizes_and_error_reporting(built):
     assert lib.svgir_image_bytes(800, 800) >= 800 * 800 * 12
     off = lib.svgir_image_ncontrib_offset(800, 800)
     assert off % 256 == 0 and off + 800 * 800 * 4 <= lib.svgir_image_bytes(800, 800)
-    assert lib.svgir_binning_bytes(0) > 0 and lib.svgir_binning_bytes(10 ** 6) >= 16 * 10 ** 6
+    assert lib.svgir_binning_bytes(0, 64, 64, 0, 0) > 0 and lib.svgir_binning_bytes(10 ** 6, 800, 800, 5, 0) >= 16 * 10 ** 6
     # invalid parameter blocks are rejected before any HIP call, with a message
     p = N.Params()
     p.variant, p.P, p.W, p.H = 7, 10, 16, 16
