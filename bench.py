@@ -158,6 +158,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     stage = {n: (ms, cnt) for n, ms, cnt in _native.last_timings(with_counts=True)}
+    if os.environ.get("SVGIR_BENCH_MEMSTATS"):
+        ms_ = torch.cuda.memory_stats(dev)
+        print("memstats:", {k: ms_[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries",
+                                                "reserved_bytes.all.peak", "allocated_bytes.all.peak")},
+              "blob callbacks:", _native.ALLOC_STATS, file=sys.stderr)
     _native.set_profiling(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

@@ -134,8 +134,10 @@ size_t svgir_binning_bytes(int32_t num_rendered, int32_t W, int32_t H, int32_t S
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H);
 
 /* Forward pass.  Replaces CudaRasterizer::Rasterizer::forward (svgss rasterizer_impl.cu:209-382,
- * rgss :209-407).  Calls geom(), image() and -- after one 4-byte device->host read of the instance count --
- * binning().  Returns num_rendered (R >= 0) or a negative svgir_status. */
+ * rgss :209-407).  Calls geom(), image() and binning().  binning() is called speculatively -- sized for the
+ * previous call's instance count -- while the GPU still computes the count, and once more after the one 4-byte
+ * device->host read of the instance count if that guess was too small (only the LAST pointer it returned is used).
+ * Returns num_rendered (R >= 0) or a negative svgir_status. */
 int svgir_forward(const svgir_params* p, const svgir_outputs* o,
                   svgir_alloc_fn geom, void* geom_ctx,
                   svgir_alloc_fn binning, void* binning_ctx,

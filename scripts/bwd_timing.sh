@@ -15,7 +15,7 @@ buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     runpy.run_path("bench.py", run_name="__main__")
 r = json.loads(buf.getvalue())
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 N.lib.svgir_debug_bwd_timing(out, 1)
 names = ["setup", "staging", "phase A", "phase B"]
 tot = sum(out[:4]); waves = out[7]; cand = out[5]; live = out[6]
@@ -23,4 +23,7 @@ print(f"render_bwd {r['stage_ms']['render_bwd']:.3f} ms; waves {waves/12:.0f}/la
 for nm, v in zip(names, out[:4]):
     print(f"  {nm:10s} {v / max(waves,1):10.0f} cyc/wave  {v / max(cand,1):8.0f} cyc/staged-candidate  {100.0 * v / tot:5.1f}%")
 print(f"  total      {tot / max(waves,1):10.0f} cyc/wave  {tot / max(cand,1):8.0f} cyc/staged-candidate")
+if sum(out[8:12]):
+    for nm, v in zip(["A: loop+slot", "A: alpha", "A: replay math", "A: panel/octant"], out[8:12]):
+        print(f"  {nm:16s} {v / max(cand,1):8.0f} cyc/staged-candidate  {v / max(live,1):8.0f} cyc/live-candidate")
 PY

@@ -6,6 +6,7 @@
 // host synchronisation is the 4-byte read of the instance count R that sizes the binning blob -- the same one
 // the reference has at rasterizer_impl.cu:311 -- plus, when svgir_set_profiling(1), one sync per call to read
 // the HIP event timings.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <atomic>
@@ -25,6 +26,7 @@ thread_local std::string g_err;
 // HIP events recorded on the launch stream; they are resolved lazily (svgir_last_timings), so enabling profiling
 // adds no synchronisation to forward/backward.
 std::atomic<bool> g_prof{false};
+std::atomic<int> g_last_R{0};   // instance count of the previous forward: sizes the speculative binning blob
 std::mutex g_times_mu;
 struct Pending { hipEvent_t a, b; const char* name; };
 std::vector<Pending> g_pending;
@@ -255,21 +257,37 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     if (int rc = check("offsets scan")) return rc;
     uint32_t R_host = 0;
     HIP_OK(hipMemcpyAsync(&R_host, G.counters, 4, hipMemcpyDeviceToHost, s));
+    // While the GPU is still busy with the stages above, speculatively allocate the binning blob for the previous
+    // call's instance count (+12 %): the host work left after the synchronisation is then just the kernel launches.
+    const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
+    char* bblob = nullptr;
+    size_t bbytes = 0;
+    if (const int guess = g_last_R.load()) {
+        bbytes = bin_layout(nullptr, (int)std::min<long long>(0x7fffffffLL, (long long)guess + guess / 8 + 1024), T, nstate).bytes;
+        bblob = binning(bbytes, binning_ctx);
+        if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
+    }
     HIP_OK(hipStreamSynchronize(s));
     tm.mark("scan");
     if (R_host > 0x7fffffffu) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
     const int R = (int)R_host;
+    g_last_R.store(R);
 
-    const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
-    char* bblob = binning(bin_layout(nullptr, R, T, nstate).bytes, binning_ctx);
-    if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
+    const size_t need = bin_layout(nullptr, R, T, nstate).bytes;
+    if (!bblob || need > bbytes) {   // first call, or the scene grew: allocate the exact size now
+        bblob = binning(need, binning_ctx);
+        if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
+    }
     const BinLayout B = bin_layout(bblob, R, T, nstate);
-    HIP_OK(hipMemsetAsync(B.seg_map, 0xFF, B.seg_cap * 4, s));
     const TileSortPlan plan = tile_sort_plan(T);
 
     if (R > 0) {
-        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], s);
+        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], I.ranges, B.seg_map,
+                    B.seg_cap, s);
         if (int rc = check("emit")) return rc;
+    } else {
+        HIP_OK(hipMemsetAsync(I.ranges, 0, (size_t)T * 8, s));
+        HIP_OK(hipMemsetAsync(B.seg_map, 0xFF, B.seg_cap * 4, s));
     }
     tm.mark("emit");
     launch_radix_sort(B.key, B.val, R, plan.bits, plan.bits_per_pass, B.radix_tbl, s);

@@ -214,8 +214,13 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
                                                      const uint32_t* __restrict__ tiles,
                                                      const uint32_t* __restrict__ offsets, const float* __restrict__ rec,
                                                      const int32_t* __restrict__ radii, int gx, int gy,
-                                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals) {
+                                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
+                                                     uint32_t* __restrict__ ranges, int n_ranges,
+                                                     uint32_t* __restrict__ seg_map, int n_seg) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
+    // piggy-backed initialisation of two small tables used by later stages (saves two memset launches)
+    for (int j = i; j < n_ranges; j += gridDim.x * BLOCK) ranges[j] = 0u;
+    for (int j = i; j < n_seg; j += gridDim.x * BLOCK) seg_map[j] = 0xFFFFFFFFu;
     if (i >= P) return;
     const uint32_t g = order[i];
     if (tiles[g] == 0) return;
@@ -332,13 +337,14 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
 }
 
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
-                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, hipStream_t s) {
+                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, uint32_t* ranges,
+                 uint32_t* seg_map, size_t seg_cap, hipStream_t s) {
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,
-                       radii, gx, gy, tile_keys, vals);
+                       radii, gx, gy, tile_keys, vals, ranges, 2 * gx * gy, seg_map, (int)seg_cap);
 }
 
+// `ranges` must already be zero (launch_emit clears it)
 void launch_ranges(int R, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s) {
-    hipMemsetAsync(ranges, 0, (size_t)T * 8, s);
     if (R > 0) hipLaunchKernelGGL(ranges_kernel, dim3((R + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, R, tile_keys, ranges);
 }
 

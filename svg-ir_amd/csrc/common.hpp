@@ -225,8 +225,10 @@ void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, in
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
                          uint32_t* total_out, hipStream_t s);
+// also clears ranges[2*gx*gy] and marks every seg_map[seg_cap] entry empty
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
-                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, hipStream_t s);
+                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, uint32_t* ranges,
+                 uint32_t* seg_map, size_t seg_cap, hipStream_t s);
 void launch_ranges(int R, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
 // order[] = tile ids sorted by descending list length (longest-processing-time-first dispatch of the composite waves)
 void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream_t s);
@@ -254,6 +256,14 @@ __device__ __forceinline__ float wave_sum(float v) {  // uniform result
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_last(v)), 63));
 }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+// Ordering point for LDS traffic that is private to ONE wave (single-wave workgroups, or per-wave LDS regions): the DS
+// operations of a wave execute in issue order, so only the compiler has to be kept from moving LDS accesses across it.
+// Unlike __syncthreads() it does not drain vmcnt, i.e. it never waits for outstanding global atomics / stores.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #endif
 
 }  // namespace svgir

@@ -24,9 +24,11 @@
 //       phase A (lane = pixel): replay, alpha gradient; the 1+4 per-pair scalars go to an LDS panel
 //                [candidate][vector][pixel]; the 6 geometric gradients are pre-reduced over 8-lane octants with 3
 //                DPP steps and stored as [candidate][6][8];
-//       phase B (lane = candidate x pixel-octant): every lane contracts 8 pixels of its candidate's panel rows with
-//                the matching rows of G (LDS), a 3-step DPP butterfly over the 8 octant lanes finishes the sums, and
-//                each lane then issues the atomics of the channels it owns (channel mod 8 == octant).
+//       phase B: the contraction panel[rows][64 pixels] x G[64 pixels][channels] runs on the matrix pipe as
+//                16 (+16 for the vfeature channels) v_mfma_f32_16x16x4_f32 per sub-batch -- exact fp32, G held in
+//                registers in the B-operand layout -- and each lane issues the atomics of the (row, channel)
+//                results it ends up holding.  (This is the one genuinely dense contraction of the path; the
+//                blending itself stays scalar.)
 #include "common.hpp"
 #include "stage.hpp"
 
@@ -34,7 +36,6 @@ namespace svgir {
 
 namespace {
 
-constexpr int PROW = 65;   // panel row stride (floats): 64 pixels + 1 pad => conflict-free rows
 
 // sum over the 8 lanes of an aligned octant (lanes differing in their low 3 bits); result in all 8 lanes
 __device__ __forceinline__ float octant_sum(float v) {
@@ -45,53 +46,71 @@ __device__ __forceinline__ float octant_sum(float v) {
 }
 
 #ifdef RENDER_TIMING
-__device__ unsigned long long g_bwd_tm[8];
+__device__ unsigned long long g_bwd_tm[16];
 #define TM_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_acc[i] += t_ - tm_prev; tm_prev = t_; } while (0)
 #define TM_COUNT(i, n) tm_acc[i] += (unsigned long long)(n)
+#ifdef RENDER_TIMING_FINE
+#define TM_FINE(i) TM_MARK(i)
 #else
+#define TM_FINE(i)
+#endif
+#else
+#define TM_FINE(i)
 #define TM_MARK(i)
 #define TM_COUNT(i, n)
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef EXP_NO_ATOMICS   // timing experiment: keep the arithmetic alive, drop (almost) every atomic
+#define BWD_ATOMIC(p, v) do { if ((v) == 123.456f) atomic_add_f32((p), (v)); } while (0)
+#else
+#define BWD_ATOMIC(p, v) atomic_add_f32((p), (v))
 #endif
 
 template <int S, int VC>
 struct BwdGeom {
     using SG = StageGeom<S, VC>;
     static constexpr int CHB = 16;                       // candidates staged per batch
-    static constexpr int SB = (VC > 8) ? 4 : 8;          // candidates per phase-A/phase-B sub-batch
-    static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S
+    static constexpr int SB = (VC > 0) ? 4 : 8;          // candidates per phase-A/phase-B sub-batch
+    static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S  (<= 16)
     static constexpr int NG = NC0 + VC;                  // columns of G
     static constexpr int GROW = NG + 1;
-    static constexpr int NVW = 1 + (VC > 0 ? 4 : 0);     // panel vectors: w, w*corner[4]
+    static constexpr int PROWS = (VC > 0) ? 16 : SB;     // panel rows: (candidate, corner) or candidate
+    static constexpr int PS = 68;                        // panel row stride (floats): 16-byte aligned rows
+#ifndef BWD_WPE_V
+#define BWD_WPE_V 2
+#define BWD_WPE_P 4
+#endif
+    static constexpr int WPE = (VC > 0) ? BWD_WPE_V : BWD_WPE_P;   // waves per SIMD the register budget is held to
     static constexpr size_t off_q = (size_t)CHB * SG::NF * 4;
-    static constexpr size_t off_g = off_q + (size_t)CHB * 8;
-    static constexpr size_t off_p = off_g + (size_t)64 * GROW * 4;
-    static constexpr size_t off_pg = off_p + (size_t)SB * NVW * PROW * 4;
-    static constexpr size_t lds_bytes = off_pg + (size_t)SB * 6 * 8 * 4;
+    static constexpr size_t off_p = off_q + (size_t)SEG * 8;   // the whole segment's {gid, slot} entries
+    static constexpr size_t off_pg = off_p + (size_t)PROWS * PS * 4;
+    static constexpr size_t run_bytes = off_pg + (size_t)SB * 6 * 8 * 4;
+    static constexpr size_t g_bytes = (size_t)64 * GROW * 4;   // G is only staged through LDS once, at setup
+    static constexpr size_t lds_bytes = run_bytes > g_bytes ? run_bytes : g_bytes;
+    static_assert(NC0 <= 16 && VC <= 16, "one 16-wide MFMA column tile per channel group");
 };
 
 template <int S, int VC, bool SVGSS>
-__global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BwdGeom<S, VC>::WPE, BwdGeom<S, VC>::WPE)))
+render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int VS = VC * 4;
     using SG = StageGeom<S, VC>;
     using BG = BwdGeom<S, VC>;
-    constexpr int SB = BG::SB, NC0 = BG::NC0, GROW = BG::GROW, NVW = BG::NVW, CHB = BG::CHB;
-    constexpr int LPC = 64 / SB;            // phase-B lanes per candidate (8 or 16)
-    constexpr int PPL = 64 / LPC;           // pixels contracted per phase-B lane (8 or 4)
-    constexpr int NKP = (NC0 + LPC - 1) / LPC;   // ownership rounds for the plain channels
-    constexpr int NVG = (VC + 3) / 4;       // vfeature groups of 4 channels (16 outputs)
+    constexpr int SB = BG::SB, NC0 = BG::NC0, GROW = BG::GROW, CHB = BG::CHB, PS = BG::PS;
     constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sD = reinterpret_cast<float*>(smem);                    // [CHB][NF] staged candidates
-    uint2* sQ = reinterpret_cast<uint2*>(smem + BG::off_q);        // [CHB] {gid, slot} of the batch
-    float* sG = reinterpret_cast<float*>(smem + BG::off_g);        // [64][GROW] upstream gradients
-    float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [SB][NVW][PROW] blend-weight panel
+    uint2* sQ = reinterpret_cast<uint2*>(smem + BG::off_q);        // [SEG] {gid, slot} of the segment, deepest first
+    float* sG = reinterpret_cast<float*>(smem);                    // [64][GROW] upstream gradients (setup only; aliases sD..)
+    float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [PROWS][PS] blend-weight panel (MFMA A operand)
     float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [SB][6][8] octant-reduced geometric gradients
 
     // one wave per live depth segment (common.hpp SEG): seg_map[b] = (sub-tile id << SEG_K_BITS) | k
     const uint32_t sm = a.seg_map[blockIdx.x];
     if (sm == 0xFFFFFFFFu) return;
 #ifdef RENDER_TIMING
-    unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tm_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tm_prev = __builtin_amdgcn_s_memtime();
 #endif
     const int sid = (int)(sm >> SEG_K_BITS), kseg = (int)(sm & ((1u << SEG_K_BITS) - 1u));
@@ -152,24 +171,30 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
         for (int i = 0; i < VC; i++) g[NC0 + i] = gVF[i];
     }
 
-    // phase-B role of this lane: candidate cB of the sub-batch, pixel group oB
-    const int cB = lane / LPC, oB = lane % LPC;
-    float* pbase[NKP];   // destination of plain channel (LPC*k + oB)
-    int pstride[NKP];
+    // Phase B is the contraction  out[row][ch] = sum_pixel panel[row][pixel] * G[pixel][ch]  on the matrix pipe
+    // (v_mfma_f32_16x16x4_f32, exact fp32).  G is transposed once through LDS into the B-operand layout and then
+    // lives in registers: lane l holds G[pixel = 16*(l>>4) + kk][channel = l&15] for kk = 0..15, one set for the
+    // plain channels and one for the vfeature channels.
+    wave_lds_sync();
+    const int colB = lane & 15, grpB = lane >> 4;
+    float Bp[16], Bv[16];
 #pragma unroll
-    for (int k = 0; k < NKP; k++) {
-        const int ci = LPC * k + oB;
-        float* b = nullptr; int st = 0;
-        if (ci < 3) { b = a.dL_dcolor + ci; st = 3; }
-        else if (ci < 6) { b = a.dL_dnormal + (ci - 3); st = 3; }
-        else if (ci < 7) { b = a.dL_ddepth; st = 1; }
-        else if (ci < NC0) { b = a.dL_dfeature + (ci - 7); st = S; }
-        pbase[k] = b; pstride[k] = st;
+    for (int kk = 0; kk < 16; kk++) {
+        const float* g = sG + (16 * grpB + kk) * GROW;
+        Bp[kk] = colB < NC0 ? g[colB] : 0.f;
+        Bv[kk] = (VC > 0 && colB < VC) ? g[NC0 + (VC > 0 ? colB : 0)] : 0.f;
     }
-    // geometric channel owned by this lane in phase B (octant-partial index oB & 7 < 6 on the first 8 lanes per candidate)
+    wave_lds_sync();   // sG is dead from here on (its LDS is reused by the staging buffers and the panel)
+    // destination of the plain channel colB
+    float* pbase = nullptr; int pstride = 0;
+    if (colB < 3) { pbase = a.dL_dcolor + colB; pstride = 3; }
+    else if (colB < 6) { pbase = a.dL_dnormal + (colB - 3); pstride = 3; }
+    else if (colB < 7) { pbase = a.dL_ddepth; pstride = 1; }
+    else if (colB < NC0) { pbase = a.dL_dfeature + (colB - 7); pstride = S; }
+    // geometric channel owned by this lane in phase B: lane = (candidate lane>>3, value lane&7 < 6)
     float* gbase = nullptr; int gstride = 0;
     {
-        const int j = oB;
+        const int j = lane & 7;
         if (j < 2) { gbase = a.dL_dmean2D + j; gstride = 3; }
         else if (j < 5) { gbase = a.dL_dconic + (j == 4 ? 3 : j - 2); gstride = 4; }
         else if (j < 6) { gbase = a.dL_dopacity; gstride = 1; }
@@ -203,19 +228,35 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
         for (int i = 0; i < VC; i++) acc_vf[i] = (f[(8 + S + i) * 64] - e[(8 + S + i) * 64]) * iT;
     }
 
+    // The segment's list entries go to LDS once, deepest first (the replay walks back to front).
+    const int nent = seg_hi - seg_lo;
+    int nskip = 0;   // entries that lie behind every pixel of this wave (a prefix: slots descend)
+    for (int i = lane; i < SEG; i += 64) {
+        uint2 e = make_uint2(0u, 0u);
+        if (i < nent) { e = sub_in[seg_hi - 1 - i]; sQ[i] = e; }
+        nskip += __popcll(__ballot(i < nent && e.y >= wmax));
+    }
+    wave_lds_sync();
     TM_MARK(0);   // setup: upstream gradients, G matrix, start state
-    for (int top = seg_hi; top > seg_lo; top -= CHB) {  // this batch covers list entries [top - m, top), in reverse
-        const int m = min((int)CHB, top - seg_lo);
-        uint2 e = make_uint2(0u, 0xFFFFFFFFu);
-        if (lane < m) e = sub_in[top - 1 - lane];
-        // entries are ordered by slot: if even the shallowest entry of the batch is behind every pixel, skip it
-        if (__ballot(e.y < wmax) == 0ull) continue;
-        __syncthreads();  // previous batch fully consumed
-        if (lane < m) sQ[lane] = e;
-        __syncthreads();
-        stage_candidates<S, VC, CHB>(sD, m, [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
-        __syncthreads();
-        TM_MARK(1);   // staging (list entries, gathers, LDS stores)
+    // Batches of CHB candidates; the gathers of batch b+1 are in flight (registers) while batch b is replayed, so
+    // neither their latency nor the completion of this batch's gradient atomics is waited for.
+    StageRegs<S, VC, CHB> sr;
+    int base = (nskip / CHB) * CHB;
+    if (base < nent)
+        stage_load<S, VC, CHB>(sr, min((int)CHB, nent - base), [&](int s) { return sQ[base + s].x; }, lane, a.rec,
+                               a.features, a.vfeatures);
+    for (; base < nent; base += CHB) {
+        const int m = min((int)CHB, nent - base);
+        wave_lds_sync();  // previous batch fully consumed
+        stage_store<S, VC, CHB>(sr, sD, m, lane);
+        {
+            const int nb = base + CHB;
+            if (nb < nent)
+                stage_load<S, VC, CHB>(sr, min((int)CHB, nent - nb), [&](int s) { return sQ[nb + s].x; }, lane, a.rec,
+                                       a.features, a.vfeatures);
+        }
+        wave_lds_sync();
+        TM_MARK(1);   // staging (LDS stores, prefetch issue)
         TM_COUNT(5, m);
 
         for (int c0 = 0; c0 < m; c0 += SB) {
@@ -227,7 +268,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                 const float* r = sD + c * SG::NF;
                 const float4* q = reinterpret_cast<const float4*>(r);
                 // all LDS reads of the candidate are issued up front (one latency exposure)
-                const uint32_t slot = sQ[c].y;
+                const uint32_t slot = sQ[base + c].y;
                 const float4 A = q[0];   // x, y, conic.x, conic.y
                 const float4 B = q[1];   // conic.z, opacity, depth, J6
                 const float4 Jv = q[2];  // J0..J3
@@ -238,6 +279,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
 #pragma unroll
                 for (int ch = 0; ch < S; ch++) fl[ch] = r[SG::F_OFF + ch];
                 if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
+                TM_FINE(8);    // loop overhead + slot read
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 float power;
                 if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
@@ -245,8 +287,12 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                 const float G = __expf(power);
                 const float alpha = fminf(0.99f, B.y * G);
                 const bool pass = slot < last_contributor && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                TM_FINE(9);    // alpha
                 if (__ballot(pass) == 0ull) continue;
                 live |= 1u << cs;
+#ifdef EXP_NO_REPLAY
+                if (live != 0xdeadbeefu) { T *= 0.999f; continue; }
+#endif
 
                 float vw = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
                 float ge[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -325,110 +371,83 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(const RenderBwdArgs a) {
                     ge[4] = dL_ddist * (dy * dy);
                     ge[5] = G * dL_dalpha;
                 }
-                float* pr = sP + cs * (NVW * PROW) + lane;
-                pr[0] = vw;
-                if (VC > 0) { pr[1 * PROW] = vc0; pr[2 * PROW] = vc1; pr[3 * PROW] = vc2; pr[4 * PROW] = vc3; }
+                TM_FINE(10);   // replay math
+                if (VC > 0) {   // rows (candidate, corner); the four corner weights sum to the blend weight
+                    float* pr = sP + (cs * 4) * PS + lane;
+                    pr[0] = sp ? vc0 : vw; pr[PS] = vc1; pr[2 * PS] = vc2; pr[3 * PS] = vc3;
+                } else {
+                    sP[cs * PS + lane] = vw;
+                }
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     const float s8 = octant_sum(ge[k]);
                     if ((lane & 7) == 0) sPg[(cs * 6 + k) * 8 + (lane >> 3)] = s8;
                 }
+                TM_FINE(11);   // panel + octant writes
             }
             TM_MARK(2);   // phase A
             TM_COUNT(6, __popc(live));
+#ifdef EXP_NO_PHASEB
+            if (live != 0xdeadbeefu) continue;
+#endif
             if (live == 0) continue;  // uniform
-            __syncthreads();          // panel (and, the first time, G) visible to the phase-B lanes
+            wave_lds_sync();          // panel (and, the first time, G) visible to the phase-B lanes
 
-            // ---------------- phase B: lane = (candidate cB, pixel group oB) ----------------
+            // ---------------- phase B: panel x G on the matrix pipe ----------------
             {
-                const bool mine = cB < nsub && ((live >> cB) & 1u);
-                const int gidB = mine ? (int)sQ[c0 + cB].x : 0;
-                const float* prow = sP + cB * (NVW * PROW) + oB * PPL;
-                const float* grow = sG + (oB * PPL) * GROW;
-                // --- plain channels: colour, normal, depth, features (vector w) ---
-                {
-                    float out[NC0];
+                const int rowA = VC > 0 ? colB : min(colB, SB - 1);
+                const float4* ap = reinterpret_cast<const float4*>(sP + rowA * PS + 16 * grpB);
+                const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+                const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w,
+                                      a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < NC0; i++) out[i] = 0.f;
-#pragma unroll
-                    for (int i = 0; i < PPL; i++) {
-                        const float w = prow[i];
-                        const float* g = grow + i * GROW;
-#pragma unroll
-                        for (int ch = 0; ch < NC0; ch++) out[ch] += w * g[ch];
-                    }
-#pragma unroll
-                    for (int i = 0; i < NC0; i++) {
-                        out[i] = octant_sum(out[i]);
-                        if (LPC == 16)  // 16 lanes per candidate: fold the two octants (row_ror:8 within the 16-lane row)
-                            out[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, out[i]), 0x128, 0xf, 0xf, false));
-                    }
-#pragma unroll
-                    for (int k = 0; k < NKP; k++) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int j = 0; j < LPC; j++)
-                            if (LPC * k + j < NC0) v = (oB == j) ? out[LPC * k + j] : v;
-                        if (mine && LPC * k + oB < NC0 && v != 0.f) atomic_add_f32(pbase[k] + (size_t)gidB * pstride[k], v);
-                    }
+                for (int kk = 0; kk < 16; kk++) {
+                    accP = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Bp[kk], accP, 0, 0, 0);
+                    if (VC > 0) accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Bv[kk], accV, 0, 0, 0);
                 }
-                // --- vfeature channels, 4 channels (16 outputs) at a time (vectors w*corner[k]) ---
+                // D layout: lane l, register r -> row 4*(l>>4) + r, column l&15
                 if (VC > 0) {
+                    // rows = (candidate grpB, corner r)
+                    const bool mine = grpB < nsub && ((live >> grpB) & 1u);
+                    const int gidB = mine ? (int)sQ[base + c0 + grpB].x : 0;
+                    const float v = (accP[0] + accP[1]) + (accP[2] + accP[3]);
+                    if (mine && colB < NC0 && v != 0.f) BWD_ATOMIC(pbase + (size_t)gidB * pstride, v);
+                    if (mine && sp && colB < VC) {
+                        float* dst = a.dL_dvfeature + (size_t)gidB * VS + colB * 4;
 #pragma unroll
-                    for (int gq = 0; gq < NVG; gq++) {
-                        float out[16];
+                        for (int r = 0; r < 4; r++)
+                            if (accV[r] != 0.f) BWD_ATOMIC(dst + r, accV[r]);
+                    }
+                } else {
+                    // rows = candidates 4*grpB + r (only rows < SB exist)
 #pragma unroll
-                        for (int i = 0; i < 16; i++) out[i] = 0.f;
-#pragma unroll
-                        for (int i = 0; i < PPL; i++) {
-                            const float w0 = prow[1 * PROW + i], w1 = prow[2 * PROW + i], w2 = prow[3 * PROW + i], w3 = prow[4 * PROW + i];
-                            const float* g = grow + i * GROW + NC0 + 4 * gq;
-#pragma unroll
-                            for (int ch = 0; ch < 4; ch++) {
-                                if (4 * gq + ch < VC) {
-                                    const float gv = g[ch];
-                                    out[4 * ch + 0] += w0 * gv; out[4 * ch + 1] += w1 * gv;
-                                    out[4 * ch + 2] += w2 * gv; out[4 * ch + 3] += w3 * gv;
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            out[i] = octant_sum(out[i]);
-                            if (LPC == 16)
-                                out[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, out[i]), 0x128, 0xf, 0xf, false));
-                        }
-                        // lane oB owns outputs j with j % LPC == oB
-#pragma unroll
-                        for (int k = 0; k < 16 / LPC; k++) {
-                            float v = 0.f;
-#pragma unroll
-                            for (int j = 0; j < LPC; j++) v = (oB == j) ? out[LPC * k + j] : v;
-                            const int jj = LPC * k + oB;
-                            if (mine && 16 * gq + jj < VS && v != 0.f)
-                                atomic_add_f32(a.dL_dvfeature + (size_t)gidB * VS + 16 * gq + jj, v);
-                        }
+                    for (int r = 0; r < 4; r++) {
+                        const int cB = 4 * grpB + r;
+                        const bool mine = cB < nsub && ((live >> cB) & 1u);
+                        if (mine && colB < NC0 && accP[r] != 0.f)
+                            BWD_ATOMIC(pbase + (size_t)sQ[base + c0 + cB].x * pstride, accP[r]);
                     }
                 }
                 // --- geometric channels: finish the octant partials ---
                 {
-                    // lane (cB, oB): value index j = oB % 8 (< 6), partial p handled by ... all 8 partials summed here
-                    float v = 0.f;
-                    const int j = oB & 7;
-                    if (j < 6) {
+                    const int cB = lane >> 3, j = lane & 7;
+                    const bool mine = cB < nsub && ((live >> cB) & 1u) && j < 6;
+                    if (mine) {
+                        float v = 0.f;
 #pragma unroll
-                        for (int p = 0; p < 8; p++) v += sPg[(cB * 6 + j) * 8 + p];
+                        for (int p8 = 0; p8 < 8; p8++) v += sPg[(cB * 6 + j) * 8 + p8];
+                        if (v != 0.f) BWD_ATOMIC(gbase + (size_t)sQ[base + c0 + cB].x * gstride, v);
                     }
-                    if (mine && oB < 6 && v != 0.f) atomic_add_f32(gbase + (size_t)gidB * gstride, v);
                 }
             }
-            __syncthreads();  // panel consumed before the next phase A overwrites it
+            wave_lds_sync();  // panel consumed before the next phase A overwrites it
             TM_MARK(3);   // phase B
         }
     }
 #ifdef RENDER_TIMING
     tm_acc[7] += 1;
-    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_bwd_tm[i], tm_acc[i]);
+    if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_bwd_tm[i], tm_acc[i]);
 #endif
 }
 
@@ -450,9 +469,9 @@ int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s) {
 }
 
 #ifdef RENDER_TIMING
-extern "C" int svgir_debug_bwd_timing(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(svgir::g_bwd_tm), 64) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_bwd_tm), z, 64); }
+extern "C" int svgir_debug_bwd_timing(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(svgir::g_bwd_tm), 128) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_bwd_tm), z, 128); }
     return 0;
 }
 #endif

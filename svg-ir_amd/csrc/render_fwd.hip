@@ -27,6 +27,12 @@ namespace svgir {
 
 namespace {
 
+#ifdef FWD_USE_BARRIER
+#define FWD_SYNC() __syncthreads()
+#else
+#define FWD_SYNC() wave_lds_sync()
+#endif
+
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
     using SG = StageGeom<S, VC>;
@@ -103,10 +109,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
         // ---- stage + blend queued candidates, CH at a time ----
         while (!wave_done && (tail - head >= (uint32_t)SG::CH || (last_scan && tail != head))) {
             const int m = min((int)SG::CH, (int)(tail - head));
-            __syncthreads();  // ring writes visible; previous batch fully consumed
+            FWD_SYNC();  // ring writes visible; previous batch fully consumed
             stage_candidates<S, VC, SG::CH>(sD, m, [&](int s) { return sQ[(head + s) & (SG::QN - 1)].x; }, lane, a.rec,
                                     a.features, a.vfeatures);
-            __syncthreads();
+            FWD_SYNC();
             for (int c = 0; c < m; c++) {
                 const float4* q = reinterpret_cast<const float4*>(sD + c * SG::NF);
                 const float4 A = q[0];   // x, y, conic.x, conic.y
@@ -164,15 +170,16 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
                     const float wsum = wave_scan_last(w);
                     if (lane == 63) atomic_add_f32(&a.out_weights[e.x], wsum);
                 }
-                if (((head + (uint32_t)c + 1u) & (uint32_t)(SEG - 1)) == 0u) dump_state(ndump++);
                 if (__any(newly_done) && __all(done)) { wave_done = true; break; }
             }
             head += (uint32_t)m;
+            // batches are CH-aligned and CH divides SEG: segment boundaries are batch ends
+            if (!wave_done && (head & (uint32_t)(SEG - 1)) == 0u) dump_state(ndump++);
         }
     }
     if (lane == 0) { a.sub_count[4 * tile + sub] = tail; a.sub_ndump[4 * tile + sub] = ndump; }
     if (tail != 0) {
-        dump_state(ndump);   // final state
+        if (ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
         // live segments: those that hold at least one processed candidate
         const uint32_t nseg = min((tail + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u);
         for (uint32_t k = lane; k < nseg; k += 64)

@@ -323,13 +323,6 @@ __device__ __forceinline__ float stride4_sum(float v) {
     v += __shfl_xor(v, 32);
     return v;
 }
-// LDS traffic private to one wave: DS operations of a wave complete in order, only the compiler has to be fenced
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 #ifdef SHADE_TIMING
 __device__ unsigned long long g_shade_tm[8];
 #define TM_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_acc[i] += t_ - tm_prev; tm_prev = t_; } while (0)

@@ -27,6 +27,7 @@ struct StageGeom {
     static constexpr int F_OFF = REC;
     static constexpr int V_OFF = REC + S4;
     static constexpr size_t lds_bytes() { return (size_t)CH * NF * 4 + (size_t)QN * 8; }
+    static_assert(SEG % CH == 0, "segment boundaries must fall on staging-batch boundaries");
 };
 
 #if defined(__HIPCC__)
@@ -55,60 +56,84 @@ __device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, flo
     return qmin <= tau2 + slack;
 }
 
-// Wave-level gather of m (<= CH) candidates into LDS slots [0, m).  `gid_of(s)` returns the Gaussian id of the
-// candidate that goes to slot s (a wave-uniform-free LDS read).  All global loads of the batch are issued before
-// the first LDS store.  The caller separates the stores from the subsequent LDS reads with a workgroup barrier
-// (one wave per workgroup => s_barrier is only an ordering point).
-template <int S, int VC, int CHN, typename GidOf>
-__device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, GidOf gid_of, int lane,
-                                                 const float* __restrict__ rec, const float* __restrict__ feat,
-                                                 const float* __restrict__ vfeat) {
+// Wave-level gather of m (<= CHN) candidates into LDS slots [0, m), split in two halves so that the global loads of
+// the NEXT batch can be in flight while the current one is consumed:
+//   stage_load : all 16-byte record / vfeature loads and the feature loads of the batch into registers
+//                (`gid_of(s)` returns the Gaussian id of the candidate that goes to slot s; loads are unconditional
+//                with clamped indices, which keeps everything in registers);
+//   stage_store: registers -> LDS (predicated).
+// The caller separates the stores from the subsequent LDS reads with wave_lds_sync().
+template <int S, int VC, int CHN>
+struct StageRegs {
     using SG = StageGeom<S, VC>;
-    constexpr int KV = (CHN * SG::C4 + 63) / 64;  // 16-byte loads per lane per batch
-    constexpr int KF = (CHN * S + 63) / 64;       // feature floats per lane per batch
-    float4* sD4 = reinterpret_cast<float4*>(sD);
+    static constexpr int KV = (CHN * SG::C4 + 63) / 64;  // 16-byte loads per lane per batch
+    static constexpr int KF = (CHN * S + 63) / 64;       // feature floats per lane per batch
+    float4 v[KV];
+    float fv[KF > 0 ? KF : 1];
+};
+
+template <int S, int VC, int CHN, typename GidOf>
+__device__ __forceinline__ void stage_load(StageRegs<S, VC, CHN>& r, int m, GidOf gid_of, int lane,
+                                           const float* __restrict__ rec, const float* __restrict__ feat,
+                                           const float* __restrict__ vfeat) {
+    using SG = StageGeom<S, VC>;
+    using SR = StageRegs<S, VC, CHN>;
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
     const float4* vf4 = reinterpret_cast<const float4*>(vfeat);
     const int total = m * SG::C4;  // >= C4 (m >= 1)
-    // Loads are unconditional (index clamped), only the LDS stores are predicated: keeps everything in registers.
-    float4 v[KV];
 #pragma unroll
-    for (int u = 0; u < KV; u++) {
+    for (int u = 0; u < SR::KV; u++) {
         const int k = min(u * 64 + lane, total - 1);
         const int s = k / SG::C4, part = k - s * SG::C4;
         const size_t id = (size_t)gid_of(s);
         const float4* src = part < 6 ? rec4 + id * 6 + part : vf4 + id * VC + (part - 6);
-        v[u] = *src;
+        r.v[u] = *src;
     }
-    float fv[KF > 0 ? KF : 1];
     if (S > 0) {
         const int totf = m * S;
 #pragma unroll
-        for (int u = 0; u < KF; u++) {
+        for (int u = 0; u < SR::KF; u++) {
             const int k = min(u * 64 + lane, totf - 1);
             const int s = k / S, c = k - s * S;
-            fv[u] = feat[(size_t)gid_of(s) * S + c];
+            r.fv[u] = feat[(size_t)gid_of(s) * S + c];
         }
     }
+}
+
+template <int S, int VC, int CHN>
+__device__ __forceinline__ void stage_store(const StageRegs<S, VC, CHN>& r, float* __restrict__ sD, int m, int lane) {
+    using SG = StageGeom<S, VC>;
+    using SR = StageRegs<S, VC, CHN>;
+    float4* sD4 = reinterpret_cast<float4*>(sD);
+    const int total = m * SG::C4;
 #pragma unroll
-    for (int u = 0; u < KV; u++) {
+    for (int u = 0; u < SR::KV; u++) {
         const int k = u * 64 + lane;
         if (k < total) {
             const int s = k / SG::C4, part = k - s * SG::C4;
-            sD4[s * SG::NF4 + (part < 6 ? part : SG::V_OFF / 4 + (part - 6))] = v[u];
+            sD4[s * SG::NF4 + (part < 6 ? part : SG::V_OFF / 4 + (part - 6))] = r.v[u];
         }
     }
     if (S > 0) {
         const int totf = m * S;
 #pragma unroll
-        for (int u = 0; u < KF; u++) {
+        for (int u = 0; u < SR::KF; u++) {
             const int k = u * 64 + lane;
             if (k < totf) {
                 const int s = k / S, c = k - s * S;
-                sD[s * SG::NF + SG::F_OFF + c] = fv[u];
+                sD[s * SG::NF + SG::F_OFF + c] = r.fv[u];
             }
         }
     }
+}
+
+template <int S, int VC, int CHN, typename GidOf>
+__device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, GidOf gid_of, int lane,
+                                                 const float* __restrict__ rec, const float* __restrict__ feat,
+                                                 const float* __restrict__ vfeat) {
+    StageRegs<S, VC, CHN> r;
+    stage_load<S, VC, CHN>(r, m, gid_of, lane, rec, feat, vfeat);
+    stage_store<S, VC, CHN>(r, sD, m, lane);
 }
 
 // Block -> (tile, sub-tile) mapping: the four waves of a tile get block ids congruent mod 8, i.e. they run on the

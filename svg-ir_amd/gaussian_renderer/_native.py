@@ -5,6 +5,7 @@ There is NO fallback: if the shared library is missing or fails to load, importi
 """
 import ctypes as C
 import os
+import time
 
 import torch
 
@@ -115,6 +116,9 @@ def f32c(t, device):
     return t.contiguous()
 
 
+ALLOC_STATS = {"calls": 0, "seconds": 0.0, "max_seconds": 0.0}   # wall time spent inside the allocation callbacks
+
+
 class BlobAllocator:
     """The three resizable byte blobs of the reference glue (rasterize_points.cu:27-33) as torch uint8 tensors."""
 
@@ -125,8 +129,13 @@ class BlobAllocator:
 
     def fn(self, name):
         def alloc(nbytes, _ctx):
+            t0 = time.perf_counter()
             t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
             self.tensors[name] = t
+            dt = time.perf_counter() - t0
+            ALLOC_STATS["calls"] += 1
+            ALLOC_STATS["seconds"] += dt
+            ALLOC_STATS["max_seconds"] = max(ALLOC_STATS["max_seconds"], dt)
             return t.data_ptr()
 
         f = ALLOC_FN(alloc)

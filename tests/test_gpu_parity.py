@@ -116,6 +116,21 @@ def test_baseline_configs_full_size(built, cfg, variant):
         _check_backward(leaves, o, variant)
 
 
+@pytest.mark.parametrize("variant,S,VS", [("rgss", 5, 0), ("svgss", 3, 8)])
+def test_deep_translucent_stack_many_backward_segments(built, variant, S, VS):
+    """Hundreds of faint surfels over every pixel: no early termination, sub-tile candidate lists several times longer
+    than one backward segment (common.hpp SEG = 128), so most backward waves start from a dumped forward state."""
+    sc = scenes.surface_scene(P=5000, W=72, H=56, seed=41, sh_degree=1, variant=variant, S=S, VS=VS, scale_lo=0.08,
+                              scale_hi=0.25)
+    sc["opacities"] = (sc["opacities"] * 0.04).astype(np.float32)
+    grads = scenes.upstream_grads(sc, variant, seed=9)
+    out, leaves, o, R = _run_both(sc, variant, grads)
+    T = ((72 + 15) // 16) * ((56 + 15) // 16)
+    assert R / T > 500, "scene not deep enough to exercise the segmented backward"
+    _check_forward(out, o, R, variant)
+    _check_backward(leaves, o, variant)
+
+
 def test_config_flags_and_quirks(built):
     """normalize_depth off, per-pixel depth off, surface off (svgss config tensor), scale modifier, Q1."""
     base = scenes.surface_scene(P=3000, W=112, H=80, seed=31, sh_degree=2, variant="svgss", S=3, VS=8, scale_lo=0.02, scale_hi=0.08)
