@@ -10,8 +10,10 @@
 //   6-7 bits at 800x800 / 1600x1600).  A stable sort by tile of a depth-ordered list is exactly the
 //   (tile, depth, id) order the reference's stable 64-bit sort produces (quirk Q12).
 //
-// The radix pass is a hand-written stable LSD pass: per-block digit histogram -> one-block exclusive scan of the
-// [digit][block] table -> stable scatter using wave-level digit matching (ballots) for the in-wave rank.
+// The radix pass is a hand-written stable LSD pass of TWO kernels: per-block digit histogram (+ per-group-of-32-blocks
+// digit totals) -> stable scatter.  The scatter block derives its own output cursors from the group totals and the
+// <= 31 histogram rows of the preceding blocks of its group (a two-level prefix, ~50 coalesced 1 KB row reads per
+// block), so no separate scan kernel sits between the two; the in-wave rank uses wave-level digit matching (ballots).
 #include <algorithm>
 
 #include "common.hpp"
@@ -21,13 +23,13 @@ namespace svgir {
 namespace {
 
 // ---- radix pass --------------------------------------------------------------------------------------------
-// Digit table layout: [block][256] counts.  A pass is: (hist ->) column scan -> scatter.  The scatter of pass k also
-// accumulates the digit table of pass k+1 (it knows where every key lands), so only the first pass needs a histogram
-// kernel -- and the producers of the keys (preprocess / emit) could provide even that.
+// Digit table layout: table[block][256] counts; gtot[group][256] = counts summed over the GS blocks of a group.
+constexpr int GS = 32;
+
 template <int ITEMS>
 __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int bit_lo,
                                                            uint32_t mask, uint32_t* __restrict__ table,
-                                                           uint32_t* __restrict__ totals) {
+                                                           uint32_t* __restrict__ gtot) {
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -40,39 +42,7 @@ __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __res
     __syncthreads();
     const uint32_t c = hist[threadIdx.x];
     table[(size_t)blockIdx.x * 256 + threadIdx.x] = c;
-    if (c) atomicAdd(&totals[threadIdx.x], c);
-}
-
-// 8 blocks x 1024 threads: turns table[nb][256] (counts) into output cursors in place:
-//   cursor[b][d] = sum_{d' < d} total[d'] + sum_{b' < b} count[b'][d].
-// Block g owns digits [32g, 32g+32): thread (digit j, segment sg) walks nb/32 consecutive table rows.  The per-digit
-// totals were accumulated by the histogram kernel (`totals`, 256 counters), so no block depends on another.
-__global__ void __launch_bounds__(1024) column_scan_kernel(uint32_t* __restrict__ table, int nb,
-                                                           const uint32_t* __restrict__ totals) {
-    __shared__ uint32_t partial[32][33];
-    __shared__ uint32_t dbase_s[32];
-    const int t = threadIdx.x, j = t & 31, sg = t >> 5;
-    const int d = blockIdx.x * 32 + j;
-    const int per = (nb + 31) / 32;
-    const int b0 = min(nb, sg * per), b1 = min(nb, b0 + per);
-    uint32_t s = 0;
-    for (int b = b0; b < b1; b++) s += table[(size_t)b * 256 + d];
-    partial[sg][j] = s;
-    if (t < 32) {
-        // exclusive prefix of the digit totals up to digit d (256 values: plain loop, 8 blocks do it redundantly)
-        uint32_t acc = 0;
-        for (int dd = 0; dd < d; dd++) acc += totals[dd];
-        dbase_s[t] = acc;
-    }
-    __syncthreads();
-    uint32_t run = dbase_s[j];
-    for (int p = 0; p < sg; p++) run += partial[p][j];
-    for (int b = b0; b < b1; b++) {
-        const size_t i = (size_t)b * 256 + d;
-        const uint32_t c = table[i];
-        table[i] = run;
-        run += c;
-    }
+    if (c) atomicAdd(&gtot[(size_t)(blockIdx.x / GS) * 256 + threadIdx.x], c);
 }
 
 template <int ITEMS>
@@ -80,12 +50,13 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ vin,
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                               int n, int bit_lo, int nbits,
-                                                              const uint32_t* __restrict__ table) {
+                                                              const uint32_t* __restrict__ table,
+                                                              const uint32_t* __restrict__ gtot, int ngroups) {
     __shared__ uint32_t running[256];     // global output cursor per digit for this block
     __shared__ uint32_t wave_cnt[4][256];  // per-wave digit counts of the current chunk
+    __shared__ uint32_t wtot[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t mask = (1u << nbits) - 1;
-    running[t] = table[(size_t)blockIdx.x * 256 + t];
     const int base = blockIdx.x * (BLOCK * ITEMS);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // all loads of the block up front
@@ -95,6 +66,32 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
         const int e = base + c * BLOCK + t;
         ks[c] = e < n ? kin[e] : 0u;
         vs[c] = e < n ? vin[e] : 0u;
+    }
+    // Output cursor of digit t for this block:
+    //   sum_{d < t} total[d]  +  sum_{groups before mine} gtot[g][t]  +  sum_{blocks before me in my group} table[b][t]
+    {
+        const int g = blockIdx.x / GS;
+        uint32_t tot = 0, pre = 0;
+#pragma unroll 8
+        for (int gg = 0; gg < ngroups; gg++) {
+            const uint32_t v = gtot[(size_t)gg * 256 + t];
+            tot += v;
+            pre += gg < g ? v : 0u;
+        }
+#pragma unroll 8
+        for (int b = g * GS; b < (int)blockIdx.x; b++) pre += table[(size_t)b * 256 + t];
+        uint32_t incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) woff += w < wave ? wtot[w] : 0u;
+        running[t] = woff + incl - tot + pre;
     }
 #pragma unroll
     for (int c = 0; c < ITEMS; c++) {
@@ -302,29 +299,30 @@ void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream
 
 template <int ITEMS>
 static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
-                            uint32_t* tbl, uint32_t* totals, hipStream_t s) {
+                            uint32_t* tbl, uint32_t* gtot, hipStream_t s) {
     const int per = BLOCK * ITEMS;
     const int nb = (n + per - 1) / per;
+    const int ng = (nb + GS - 1) / GS;
     const int passes = (total_bits + bits_per_pass - 1) / bits_per_pass;
-    (void)hipMemsetAsync(totals, 0, (size_t)passes * 256 * 4, s);
+    (void)hipMemsetAsync(gtot, 0, (size_t)passes * ng * 256 * 4, s);
     for (int p = 0; p < passes; p++) {
         const int lo = p * bits_per_pass, nbits = std::min(bits_per_pass, total_bits - lo);
+        uint32_t* gt = gtot + (size_t)p * ng * 256;
         hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], n, lo, (1u << nbits) - 1,
-                           tbl, totals + 256 * p);
-        hipLaunchKernelGGL(column_scan_kernel, dim3(8), dim3(1024), 0, s, tbl, nb, totals + 256 * p);
+                           tbl, gt);
         hipLaunchKernelGGL((radix_scatter_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], val[p & 1],
-                           key[(p + 1) & 1], val[(p + 1) & 1], n, lo, nbits, tbl);
+                           key[(p + 1) & 1], val[(p + 1) & 1], n, lo, nbits, tbl, gt, ng);
     }
 }
 
 // Stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
-// the result lands in slot (passes & 1) of the ping/pong buffers.  `table` holds 256 x sort_blocks(n) + 1024 counters.
+// the result lands in slot (passes & 1) of the ping/pong buffers.  `table` holds radix_table_words(n) counters.
 void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
                        uint32_t* table, hipStream_t s) {
     if (n <= 0) return;
-    uint32_t* totals = table + (size_t)256 * sort_blocks(n);  // 4 x 256 per-pass digit totals
-    if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, total_bits, bits_per_pass, table, totals, s);
-    else radix_sort_impl<16>(key, val, n, total_bits, bits_per_pass, table, totals, s);
+    uint32_t* gtot = table + (size_t)256 * sort_blocks(n);  // [passes <= 4][groups][256] group digit totals
+    if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, total_bits, bits_per_pass, table, gtot, s);
+    else radix_sort_impl<16>(key, val, n, total_bits, bits_per_pass, table, gtot, s);
 }
 
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,

@@ -36,6 +36,8 @@ constexpr int SORT_ITEMS = 16;                      // elements per thread per b
 constexpr int SORT_BLOCK_ELEMS = BLOCK * SORT_ITEMS;  // 4096
 // upper bound of the number of radix blocks for n keys (1024 keys per block for small inputs)
 inline int sort_blocks(int n) { return n <= 0 ? 1 : (n + 1023) / 1024; }
+// radix scratch: [sort_blocks][256] block histograms + [4 passes][sort_blocks/32 + 1][256] group totals
+inline size_t radix_table_words(int n) { return (size_t)256 * sort_blocks(n) + (size_t)4 * 256 * (sort_blocks(n) / 32 + 1); }
 constexpr int SCAN_BLOCK_ELEMS = 2048;
 inline int scan_blocks(int n) { return n <= 0 ? 1 : (n + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS; }
 
@@ -67,7 +69,7 @@ inline GeomLayout geom_layout(char* base, int P) {
     g.idx[1] = (uint32_t*)take(p * 4);
     g.offsets = (uint32_t*)take(p * 4);
     g.scan_tmp = (uint32_t*)take(((size_t)scan_blocks(P) + 1) * 4);
-    g.radix_tbl = (uint32_t*)take(((size_t)256 * sort_blocks(P) + 1024) * 4);
+    g.radix_tbl = (uint32_t*)take(radix_table_words(P) * 4);
     g.counters = (uint32_t*)take(16);
     g.bytes = off;
     return g;
@@ -132,7 +134,7 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     b.key[1] = (uint32_t*)take(r * 4);
     b.val[0] = (uint32_t*)take(r * 4);
     b.val[1] = (uint32_t*)take(r * 4);
-    b.radix_tbl = (uint32_t*)take(((size_t)256 * sort_blocks(R) + 1024) * 4);
+    b.radix_tbl = (uint32_t*)take(radix_table_words(R) * 4);
     b.sub_list = (uint2*)take(r * 4 * 8);
     b.seg_cap = seg_capacity(R, T);
     b.seg_map = (uint32_t*)take(b.seg_cap * 4);
@@ -219,7 +221,7 @@ void stage_mark(StageMarks& t, const char* name);   // `name` = the stage that E
 void launch_preprocess(const PreArgs& a, bool svgss, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 // stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
-// input in slot 0 of the ping/pong buffers, result in slot (passes & 1); table: 256 x sort_blocks(n) + 1024 counters
+// input in slot 0 of the ping/pong buffers, result in slot (passes & 1); table: radix_table_words(n) counters
 void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
                        uint32_t* table, hipStream_t s);
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
