@@ -177,6 +177,15 @@ def main():
     dom_ms = stage[dom][0]
     achieved = ab["bwd"] / (dom_ms * 1e-3) / 1e9
     fwd_ms = stage["render"][0]
+    # HBM bytes per launch of the dominant kernel from the PMC counters: a committed measurement of this workload
+    # (scripts/pmc_traffic.sh -> profiles/traffic_<workload>.json: separate rocprofv3 --pmc passes, gfx950 correction)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            for kname, kv in json.load(f).get("kernels", {}).items():
+                if kname.startswith("render_bwd_kernel"):
+                    traffic = kv["read_bytes"] + kv["write_bytes"]
     res = {
         "metric": "Gaussian-surfels/sec fwd+bwd @800x800 (1 view)",
         "value": value, "unit": "surfels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,7 +195,7 @@ def main():
                                f"S={S}, VS={VS}, fwd+bwd, one view per step per GPU (BASELINE.json configs[1] for cfg2)",
                    "num_rendered": int(R), "views_per_step": world, "parallelism": f"view-parallel x{world}"},
         "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel (backward composite)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": ab["bwd"], "avg_launch_ms": dom_ms, "launches": stage[dom][1],
                      "fwd_composite": {"achieved": ab["fwd"] / (fwd_ms * 1e-3) / 1e9, "avg_launch_ms": fwd_ms,
                                        "algorithmic_bytes_per_launch": ab["fwd"]}},

@@ -9,6 +9,9 @@ if [ "${2:-}" != "quick" ]; then
   python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/${TAG}_tests.log
   cat gpurun_out/${TAG}_tests.log
 fi
+for W in cfg2 cfg3_train; do   # PMC traffic first: bench.py reports it as roofline.traffic
+  scripts/pmc_traffic.sh $W ${TAG}_$W > /dev/null 2>&1 && cp gpurun_out/${TAG}_${W}_traffic.json profiles/traffic_$W.json
+done
 for W in cfg2 cfg3_train cfg3_eval; do
   python bench.py --workload $W > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err
   tail -c 2500 gpurun_out/${TAG}_bench_$W.json; tail -3 gpurun_out/${TAG}_bench_$W.err

@@ -126,31 +126,6 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
     }
 }
 
-// One-block exclusive scan of `count` uint32 values, in place.
-__global__ void __launch_bounds__(1024) table_scan_kernel(uint32_t* __restrict__ table, int count) {
-    __shared__ uint32_t wsum[16];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (count + 1023) / 1024;
-    const int lo = min(count, t * per), hi = min(count, lo + per);
-    uint32_t s = 0;
-    for (int i = lo; i < hi; i++) s += table[i];
-    uint32_t incl = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t acc = 0;
-        for (int w = 0; w < 16; w++) { const uint32_t v = wsum[w]; wsum[w] = acc; acc += v; }
-    }
-    __syncthreads();
-    uint32_t run = wsum[wave] + incl - s;
-    for (int i = lo; i < hi; i++) { const uint32_t v = table[i]; table[i] = run; run += v; }
-}
-
 // ---- instance offsets: exclusive scan of tiles[order[i]] ---------------------------------------------------
 __device__ __forceinline__ uint32_t block_exclusive_scan_2048(uint32_t (&v)[8], uint32_t* wsum, uint32_t& total) {
     // each thread owns 8 consecutive values; returns the exclusive prefix of the thread's first value
@@ -192,18 +167,27 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
                                                               uint32_t* __restrict__ offsets, int nblocks,
                                                               uint32_t* __restrict__ total_out) {
     __shared__ uint32_t wsum[4];
+    __shared__ uint32_t psum[4];
     uint32_t v[8];
     const int base = blockIdx.x * SCAN_BLOCK_ELEMS + threadIdx.x * 8;
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? tiles[order[base + i]] : 0;
+    // sum of the preceding blocks' totals (the block sums are few: every block adds them up itself, no scan kernel)
+    uint32_t pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) pre += block_sums[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+    if ((threadIdx.x & 63) == 0) psum[threadIdx.x >> 6] = pre;
     uint32_t total;
-    uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan_2048(v, wsum, total);
+    uint32_t run = block_exclusive_scan_2048(v, wsum, total);   // contains a __syncthreads()
+    const uint32_t before = psum[0] + psum[1] + psum[2] + psum[3];
+    run += before;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (base + i < n) offsets[base + i] = run;
         run += v[i];
     }
-    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) total_out[0] = block_sums[blockIdx.x] + total;
+    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) total_out[0] = before + total;
 }
 
 // ---- emit --------------------------------------------------------------------------------------------------
@@ -329,7 +313,6 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
                          uint32_t* total_out, hipStream_t s) {
     const int nb = scan_blocks(n);
     hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp);
-    hipLaunchKernelGGL(table_scan_kernel, dim3(1), dim3(1024), 0, s, scan_tmp, nb);
     hipLaunchKernelGGL(offsets_write_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp, offsets, nb,
                        total_out);
 }
