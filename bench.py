@@ -140,9 +140,15 @@ def main():
                                                 st.campos, gb, R, bb, ib, True, False)
         return R, color, g[3]
 
+    mvec = torch.zeros(3, dtype=torch.float32, device=dev)
+
     def metrics(R, color, gmean):
-        # "loss"-like scalars gathered across ranks with ONE collective per step
-        return torch.stack([color.sum(), gmean.abs().sum(), torch.tensor(float(R), device=dev)])
+        # "loss"-like scalars gathered across ranks with ONE collective per step (device-side reductions only: an
+        # H2D scalar copy per step would stall the launch queue)
+        torch.sum(color.reshape(-1), dim=0, out=mvec[0])
+        torch.sum(gmean.reshape(-1), dim=0, out=mvec[1])
+        mvec[2].fill_(float(R))
+        return mvec
 
     for _ in range(args.warmup):
         R, color, gm = step()
