@@ -133,6 +133,15 @@ __device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, 
                                                  const float* __restrict__ vfeat) {
     StageRegs<S, VC, CHN> r;
     stage_load<S, VC, CHN>(r, m, gid_of, lane, rec, feat, vfeat);
+    // Keep the compiler from sinking each load into its predicated LDS store (which serialises load -> wait -> store
+    // per 16-byte chunk): every loaded value has to be live here, so all loads of the batch are in flight together.
+#pragma unroll
+    for (int u = 0; u < StageRegs<S, VC, CHN>::KV; u++)
+        asm volatile("" : "+v"(r.v[u].x), "+v"(r.v[u].y), "+v"(r.v[u].z), "+v"(r.v[u].w));
+    if (S > 0) {
+#pragma unroll
+        for (int u = 0; u < StageRegs<S, VC, CHN>::KF; u++) asm volatile("" : "+v"(r.fv[u]));
+    }
     stage_store<S, VC, CHN>(r, sD, m, lane);
 }
 
