@@ -257,3 +257,15 @@ def test_full_size_properties_cfg3_eval(built):
     assert torch.equal(out3["color"], out1["color"])
     # sum of blending weights per pixel == opacity  =>  sum over Gaussians of weights == sum of opacity
     torch.testing.assert_close(out1["weights"].sum(), out1["opacity"].sum() - 1e-6 * 0, rtol=2e-3, atol=1.0)
+
+
+@pytest.mark.parametrize("variant,S,VS", [("svgss", 9, 72), ("svgss", 2, 0), ("svgss", 0, 12), ("rgss", 7, 0), ("rgss", 2, 0)])
+def test_channel_widths_without_specialised_kernel(built, variant, S, VS):
+    """Widths outside the instantiated (S, VS) set run as several zero-padded channel-group passes that add up under
+    autograd (gaussian_renderer/_native.py plan_channel_passes); results and gradients must still match the oracle."""
+    sc = scenes.surface_scene(P=2500, W=96, H=80, seed=51, sh_degree=2, variant=variant, S=S, VS=VS, scale_lo=0.02,
+                              scale_hi=0.08)
+    grads = scenes.upstream_grads(sc, variant, seed=13)
+    out, leaves, o, R = _run_both(sc, variant, grads)
+    _check_forward(out, o, R, variant)
+    _check_backward(leaves, o, variant)
