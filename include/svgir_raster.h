@@ -191,6 +191,8 @@ typedef struct svgir_shade_params {
     const float* env;
     const float* viewmatrix;   /* [16], only for the packed vfeatures; may be NULL when vfeatures is NULL */
     float* env_work;
+    const float* env_transform; /* [9] row-major 3x3 or NULL: the env lookup uses transform * dir (EnvLight.transform,
+                                 * scene/envmap.py:57-60); every other term keeps the untransformed direction */
 } svgir_shade_params;
 
 #define SVGIR_SHADE_REDUCED 70

@@ -19,9 +19,11 @@ import torch
 import torch.nn.functional as F
 
 
-def env_lookup(env, dirs):
-    """2*bilinear(softplus(env)) at lat-long coordinates of `dirs` [..,3] (grid_sample, align_corners=True, zero pad)."""
-    sp = F.softplus(env)[0]  # [He,We,3]
+def env_lookup(env, dirs, softplus=True, scale=2.0):
+    """scale*bilinear(f(env)) at lat-long coordinates of `dirs` [..,3] (grid_sample, align_corners=True, zero pad);
+    f = softplus, scale 2 for DirectLightMap (scene/direct_light_map.py:70-83); identity, scale 1 for EnvLight
+    (scene/envmap.py:53-72)."""
+    sp = (F.softplus(env) if softplus else env).reshape((-1,) + tuple(env.shape[-3:]))[0]  # [He,We,3]
     He, We = sp.shape[0], sp.shape[1]
     d = dirs.reshape(-1, 3)
     phi = torch.arccos(d[:, 2]) - 1e-6
@@ -41,7 +43,7 @@ def env_lookup(env, dirs):
             ok = (xi >= 0) & (xi < We) & (yi >= 0) & (yi < He)
             tex = sp[yi.clamp(0, He - 1), xi.clamp(0, We - 1)]
             out = out + torch.where(ok[:, None], tex * (wx * wy)[:, None], torch.zeros_like(tex))
-    return (out * 2.0).reshape(dirs.shape)
+    return (out * scale).reshape(dirs.shape)
 
 
 def _normalize(v):
@@ -70,11 +72,14 @@ def ggx(normals, viewdirs, dirs, rough, fresnel=0.04):
     return frac / nom
 
 
-def shade(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env):
+def shade(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus=True, scale=2.0,
+          transform=None):
     """Returns dict of reduced outputs: pbr, diffuse_light, specular, direct, indirect [n,12];
-    mean_incident, mean_local, mean_global [n,3]; mean_vis [n,1]."""
+    mean_incident, mean_local, mean_global [n,3]; mean_vis [n,1].  `transform` [3,3]: the env lookup uses
+    dirs @ transform.T (EnvLight.transform, scene/envmap.py:57-60), everything else the untransformed dirs."""
     n, Ns = dirs.shape[0], dirs.shape[1]
-    glob = env_lookup(env, dirs).clamp(0, 64) * visibility          # [n,Ns,3]
+    ldirs = dirs if transform is None else dirs @ transform.T
+    glob = env_lookup(env, ldirs, softplus, scale).clamp(0, 64) * visibility          # [n,Ns,3]
     loc = radiance
     inc = loc + glob
     ndi = (normals[:, None] * dirs[:, :, None]).sum(-1).clamp(min=0)  # [n,Ns,4]

@@ -116,7 +116,13 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
         const float frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
         EnvTap t;
-        env_taps(d, p.env_h, p.env_w, t);
+        float dl[3] = {d[0], d[1], d[2]};
+        if (p.env_transform) {
+            const float* m = p.env_transform;
+#pragma unroll
+            for (int j = 0; j < 3; j++) dl[j] = m[3 * j] * d[0] + m[3 * j + 1] * d[1] + m[3 * j + 2] * d[2];
+        }
+        env_taps(dl, p.env_h, p.env_w, t);
         float E[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -275,8 +281,14 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     const float frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
     // bilinear footprint (same arithmetic as env_taps)
     const int He = p.env_h, We = p.env_w;
-    const float phi = acosf(d[2]) - 1e-6f;
-    const float theta = atan2f(d[1], d[0]);
+    float dl[3] = {d[0], d[1], d[2]};
+    if (p.env_transform) {
+        const float* m = p.env_transform;
+#pragma unroll
+        for (int j = 0; j < 3; j++) dl[j] = m[3 * j] * d[0] + m[3 * j + 1] * d[1] + m[3 * j + 2] * d[2];
+    }
+    const float phi = acosf(dl[2]) - 1e-6f;
+    const float theta = atan2f(dl[1], dl[0]);
     const float gy = phi / kPi * 2.f - 1.f;
     const float gx = -theta / kPi;
     const float xx = (gx + 1.f) * 0.5f * (float)(We - 1);

@@ -26,7 +26,7 @@ class ShadeParams(C.Structure):
                 ("base_color", C.c_void_p), ("roughness", C.c_void_p), ("normals", C.c_void_p),
                 ("viewdirs", C.c_void_p), ("radiance", C.c_void_p), ("visibility", C.c_void_p),
                 ("incident_dirs", C.c_void_p), ("incident_areas", C.c_void_p), ("env", C.c_void_p),
-                ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p)]
+                ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p), ("env_transform", C.c_void_p)]
 
 
 N.lib.svgir_shade_forward.restype = C.c_int
@@ -36,13 +36,13 @@ N.lib.svgir_shade_backward.argtypes = [C.POINTER(ShadeParams)] + [C.c_void_p] * 
 
 
 def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
-            viewmatrix=None, training=True):
+            viewmatrix=None, training=True, env_transform=None):
     dev = base_color.device
     if dev.type != "cuda":
         raise RuntimeError("shading: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
     keep = [N.f32c(t, dev) for t in (base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env,
-                                      viewmatrix)]
-    bc, ro, nr, vd, ra, vi, di, ar, en, vm = keep
+                                      viewmatrix, env_transform)]
+    bc, ro, nr, vd, ra, vi, di, ar, en, vm, et = keep
     P, Ns = di.shape[0], di.shape[1]
     env_h, env_w = en.shape[-3], en.shape[-2]
     work = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
@@ -51,7 +51,7 @@ def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs
     p.env_softplus, p.training, p.env_scale = int(bool(softplus)), int(bool(training)), float(scale)
     p.base_color, p.roughness, p.normals, p.viewdirs = N.ptr(bc), N.ptr(ro), N.ptr(nr), N.ptr(vd)
     p.radiance, p.visibility, p.incident_dirs, p.incident_areas = N.ptr(ra), N.ptr(vi), N.ptr(di), N.ptr(ar)
-    p.env, p.viewmatrix, p.env_work = N.ptr(en), N.ptr(vm), work.data_ptr()
+    p.env, p.viewmatrix, p.env_work, p.env_transform = N.ptr(en), N.ptr(vm), work.data_ptr(), N.ptr(et)
     keep.append(work)
     return p, keep, dev, P, Ns, env_h, env_w
 
@@ -61,22 +61,23 @@ class _Shade(torch.autograd.Function):
     mean_global3, mean_visibility1]; differentiable w.r.t. base_color, roughness, normals, radiance, env."""
 
     @staticmethod
-    def forward(ctx, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale):
+    def forward(ctx, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
+                env_transform=None):
         p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
-                                            env, softplus, scale)
+                                            env, softplus, scale, env_transform=env_transform)
         reduced = torch.empty((P, NRED), dtype=torch.float32, device=dev)
         if P:
             N.check(N.lib.svgir_shade_forward(p, reduced.data_ptr(), None, None, N.stream_ptr(dev)), "shade_forward")
         ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env)
-        ctx.cfg = (softplus, scale)
+        ctx.cfg = (softplus, scale, env_transform)
         return reduced
 
     @staticmethod
     def backward(ctx, g_reduced):
         base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env = ctx.saved_tensors
-        softplus, scale = ctx.cfg
+        softplus, scale, env_transform = ctx.cfg
         p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs,
-                                                    areas, env, softplus, scale)
+                                                    areas, env, softplus, scale, env_transform=env_transform)
         g = N.f32c(g_reduced, dev)
         d_base, d_rough, d_norm, d_rad, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 4, 8))  # all overwritten
         gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
@@ -87,7 +88,7 @@ class _Shade(torch.autograd.Function):
         else:
             d_env.zero_()
         return (d_base.reshape(base_color.shape), d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
-                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None)
+                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None)
 
 
 class _ShadePack(torch.autograd.Function):
@@ -96,9 +97,10 @@ class _ShadePack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix,
-                softplus, scale, training):
+                softplus, scale, training, env_transform=None):
         p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
-                                            env, softplus, scale, viewmatrix=viewmatrix, training=training)
+                                            env, softplus, scale, viewmatrix=viewmatrix, training=training,
+                                            env_transform=env_transform)
         S, VS = (4, 52) if training else (7, 64)
         red = torch.empty((P, NRED), dtype=torch.float32, device=dev)
         feats = torch.empty((P, S), dtype=torch.float32, device=dev)
@@ -107,18 +109,19 @@ class _ShadePack(torch.autograd.Function):
             N.check(N.lib.svgir_shade_forward(p, red.data_ptr(), feats.data_ptr(), vfeats.data_ptr(), N.stream_ptr(dev)),
                     "shade_forward")
         ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix)
-        ctx.cfg = (softplus, scale, training)
+        ctx.cfg = (softplus, scale, training, env_transform)
         ctx.set_materialize_grads(False)
         return feats, vfeats, red
 
     @staticmethod
     def backward(ctx, g_feat, g_vfeat, g_red):
         base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix = ctx.saved_tensors
-        softplus, scale, training = ctx.cfg
+        softplus, scale, training, env_transform = ctx.cfg
         p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs,
-                                                    areas, env, softplus, scale, viewmatrix=viewmatrix, training=training)
+                                                    areas, env, softplus, scale, viewmatrix=viewmatrix, training=training,
+                                                    env_transform=env_transform)
         if g_feat is None and g_vfeat is None and g_red is None:
-            return (None,) * 13
+            return (None,) * 14
         gf, gv, gr = (N.f32c(t, dev) for t in (g_feat, g_vfeat, g_red))
         d_base, d_rough, d_norm, d_rad, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 4, 8))
         gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
@@ -129,21 +132,19 @@ class _ShadePack(torch.autograd.Function):
         else:
             d_env.zero_()
         return (d_base.reshape(base_color.shape), d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
-                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None, None)
+                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None, None, None)
 
 
-def _env_of(light, dirs):
-    """(env texture [.., He, We, 3], softplus flag, scale, dirs) for the reference's two light classes."""
+def _env_of(light):
+    """(env texture [.., He, We, 3], softplus flag, scale, lookup transform [3,3] or None) for the reference's two
+    light classes."""
     if hasattr(light, "env"):       # scene/direct_light_map.py: learnable map, softplus, x2
-        return light.env, True, 2.0, dirs
+        return light.env, True, 2.0, None
     if hasattr(light, "envmap"):    # scene/envmap.py: HDR map, bilinear down-sample to 32x64, optional rotation
         envmap = light.envmap.permute(2, 0, 1).unsqueeze(0)
         envmap = F.interpolate(envmap, size=(32, 64), mode="bilinear", align_corners=False)
         env = envmap[0].permute(1, 2, 0).contiguous()
-        tr = getattr(light, "transform", None)
-        if tr is not None:
-            dirs = dirs @ tr.T
-        return env, False, 1.0, dirs
+        return env, False, 1.0, getattr(light, "transform", None)   # lookup direction = dirs @ transform.T
     raise TypeError("direct_light_env_light must expose .env (DirectLightMap) or .envmap (EnvLight)")
 
 
@@ -163,11 +164,9 @@ def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, dire
                         visibility_precompute=None, incident_dirs_precompute=None, incident_areas_precompute=None):
     """Drop-in for gaussian_renderer/svgss.py:537-593.  Returns (pbr [n,12], extra_results)."""
     dirs, areas = incident_dirs_precompute, incident_areas_precompute
-    env, softplus, scale, ldirs = _env_of(direct_light_env_light, dirs)
-    if ldirs is not dirs:
-        raise NotImplementedError("EnvLight.transform: rotate incident_dirs for the lookup only is not fused yet")
+    env, softplus, scale, transform = _env_of(direct_light_env_light)
     red = _Shade.apply(base_color, roughness, normals, viewdirs, radiance, visibility_precompute, dirs, areas, env,
-                       softplus, scale)
+                       softplus, scale, transform)
     extra_results = {
         "incident_dirs": dirs,
         "incident_lights": MeanOnly(red[:, 60:63]),
@@ -186,6 +185,6 @@ def shade_and_pack(base_color, roughness, normals, viewdirs, radiance, direct_li
                    viewmatrix, is_training):
     """Shading + the packing of svgss.py:143-166: returns (features [n,S], vfeatures [n,VS], reduced [n,70]).
     The packing and its adjoint are done inside the kernels in both the no-grad and the autograd path."""
-    env, softplus, scale, _ = _env_of(direct_light_env_light, dirs)
+    env, softplus, scale, transform = _env_of(direct_light_env_light)
     return _ShadePack.apply(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix,
-                            softplus, scale, bool(is_training))
+                            softplus, scale, bool(is_training), transform)
