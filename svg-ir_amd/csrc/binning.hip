@@ -34,10 +34,13 @@ __global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __res
     hist[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * (BLOCK * ITEMS);
+    uint32_t k[ITEMS];   // all loads first (clamped index), then the LDS atomics: one memory latency, not ITEMS
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) k[i] = keys[min(base + i * BLOCK + (int)threadIdx.x, n - 1)];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int e = base + i * BLOCK + threadIdx.x;
-        if (e < n) atomicAdd(&hist[(keys[e] >> bit_lo) & mask], 1u);
+        if (e < n) atomicAdd(&hist[(k[i] >> bit_lo) & mask], 1u);
     }
     __syncthreads();
     const uint32_t c = hist[threadIdx.x];
@@ -154,8 +157,13 @@ __global__ void __launch_bounds__(BLOCK) offsets_reduce_kernel(const uint32_t* _
     __shared__ uint32_t wsum[4];
     uint32_t v[8];
     const int base = blockIdx.x * SCAN_BLOCK_ELEMS + threadIdx.x * 8;
+    uint32_t oi[8];   // two rounds of independent loads instead of 8 dependent pairs
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? tiles[order[base + i]] : 0;
+    for (int i = 0; i < 8; i++) oi[i] = order[min(base + i, n - 1)];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = tiles[oi[i]];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? v[i] : 0u;
     uint32_t total;
     block_exclusive_scan_2048(v, wsum, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -170,8 +178,13 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
     __shared__ uint32_t psum[4];
     uint32_t v[8];
     const int base = blockIdx.x * SCAN_BLOCK_ELEMS + threadIdx.x * 8;
+    uint32_t oi[8];   // two rounds of independent loads instead of 8 dependent pairs
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? tiles[order[base + i]] : 0;
+    for (int i = 0; i < 8; i++) oi[i] = order[min(base + i, n - 1)];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = tiles[oi[i]];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? v[i] : 0u;
     // sum of the preceding blocks' totals (the block sums are few: every block adds them up itself, no scan kernel)
     uint32_t pre = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) pre += block_sums[b];

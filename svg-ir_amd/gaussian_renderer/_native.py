@@ -120,18 +120,26 @@ ALLOC_STATS = {"calls": 0, "seconds": 0.0, "max_seconds": 0.0}   # wall time spe
 
 
 class BlobAllocator:
-    """The three resizable byte blobs of the reference glue (rasterize_points.cu:27-33) as torch uint8 tensors."""
+    """The three resizable byte blobs of the reference glue (rasterize_points.cu:27-33) as torch uint8 tensors.
+
+    The ctypes thunks must not keep the allocator (and with it the blobs) alive through a reference cycle -- a cycle is
+    only collected by Python's cyclic GC, i.e. several generations of multi-GB blobs would pile up and every forward
+    would fall through the caching allocator to hipMalloc.  The closures therefore capture a plain dict, and `take()`
+    hands the tensors over and drops the thunks."""
 
     def __init__(self, device):
         self.device = device
         self.tensors = {}
-        self._fns = {}
+        self._fns = []
 
     def fn(self, name):
+        tensors, device = self.tensors, self.device
+
         def alloc(nbytes, _ctx):
             t0 = time.perf_counter()
-            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            self.tensors[name] = t
+            tensors[name] = None          # a speculative blob that turned out too small is released first
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            tensors[name] = t
             dt = time.perf_counter() - t0
             ALLOC_STATS["calls"] += 1
             ALLOC_STATS["seconds"] += dt
@@ -139,7 +147,7 @@ class BlobAllocator:
             return t.data_ptr()
 
         f = ALLOC_FN(alloc)
-        self._fns[name] = f  # keep the thunk alive
+        self._fns.append(f)  # keep the thunk alive for the duration of the call
         return f
 
     def get(self, name):
@@ -147,6 +155,12 @@ class BlobAllocator:
         if t is None:
             t = torch.empty(0, dtype=torch.uint8, device=self.device)
         return t
+
+    def take(self, *names):
+        out = tuple(self.get(n) for n in names)
+        self._fns = []
+        self.tensors = {}
+        return out
 
 
 def zeros_like_blob(device, shapes):

@@ -84,7 +84,7 @@ class _CBinding:
         else:
             n_contrib = torch.zeros((H, W), dtype=torch.int32, device=dev)
         return (rendered, n_contrib, out_color, out_normal, out_opacity, out_depth, out_feature, out_pseudo_normal,
-                out_surface_xyz, out_weights, radii, blobs.get("geom"), blobs.get("binning"), blobs.get("image"))
+                out_surface_xyz, out_weights, radii, *blobs.take("geom", "binning", "image"))
 
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, features, radii, colors, scales, rotations, scale_modifier,

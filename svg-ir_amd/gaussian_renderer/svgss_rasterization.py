@@ -80,7 +80,7 @@ class _CBinding:
                                                    blobs.fn("image"), None, N.stream_ptr(dev)), "forward")
         # note: C++ order is (..., depth, opac, ...) -- the Python wrapper re-orders (svgss_rasterization.py:175,183)
         return (rendered, out_color, out_normal, out_depth, out_opac, out_feature, out_vfeature, out_weights, radii,
-                blobs.get("geom"), blobs.get("binning"), blobs.get("image"))
+                *blobs.take("geom", "binning", "image"))
 
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, features, vfeatures, radii, colors, scales, rotations,
