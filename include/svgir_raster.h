@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 1
+#define SVGIR_ABI_VERSION 2
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -134,9 +134,12 @@ size_t svgir_binning_bytes(int32_t num_rendered, int32_t W, int32_t H, int32_t S
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H);
 
 /* Forward pass.  Replaces CudaRasterizer::Rasterizer::forward (svgss rasterizer_impl.cu:209-382,
- * rgss :209-407).  Calls geom(), image() and binning().  binning() is called speculatively -- sized for the
- * previous call's instance count -- while the GPU still computes the count, and once more after the one 4-byte
- * device->host read of the instance count if that guess was too small (only the LAST pointer it returned is used).
+ * rgss :209-407).  Calls geom(), image() and binning().  From the second call on, binning() is called -- and the
+ * count-dependent stages (emit, tile sort, ranges, composite) are launched -- speculatively for a capacity derived
+ * from the previous call's instance count, while the GPU still computes the count; the stages read the count on the
+ * device.  The one 4-byte device->host read of the count then only confirms the guess (no GPU idle time); if the
+ * guess was too small, binning() is called again and those stages are re-run (only the LAST pointer it returned is
+ * used).
  * Returns num_rendered (R >= 0) or a negative svgir_status. */
 int svgir_forward(const svgir_params* p, const svgir_outputs* o,
                   svgir_alloc_fn geom, void* geom_ctx,
@@ -146,9 +149,10 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o,
 
 /* Backward pass.  Replaces CudaRasterizer::Rasterizer::backward (svgss rasterizer_impl.cu:386-523,
  * rgss :411-535).  `R` and the three blobs are what the matching svgir_forward produced; `radii` is its
- * radii output. */
+ * radii output.  `binning_bytes` is the size the binning callback was last asked for: the blob is laid out for an
+ * instance capacity >= R that the backward recovers from it (the forward sizes the blob before it knows R). */
 int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii,
-                   char* geom_blob, char* binning_blob, char* image_blob, void* stream);
+                   char* geom_blob, char* binning_blob, size_t binning_bytes, char* image_blob, void* stream);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:141-153).  `present` is a byte per
  * Gaussian.  svgss: the reference kernel body is commented out, so `present` is left untouched (all false, Q14);

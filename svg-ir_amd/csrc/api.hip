@@ -26,7 +26,20 @@ thread_local std::string g_err;
 // HIP events recorded on the launch stream; they are resolved lazily (svgir_last_timings), so enabling profiling
 // adds no synchronisation to forward/backward.
 std::atomic<bool> g_prof{false};
-std::atomic<int> g_last_R{0};   // instance count of the previous forward: sizes the speculative binning blob
+std::atomic<int> g_last_R{0};
+// Pinned landing slots for the 4-byte instance-count read-back (a pageable destination would make the "async" copy a
+// blocking staged one).  A small ring: concurrent forwards on different threads/streams get different slots.
+uint32_t* g_pinned = nullptr;
+std::atomic<unsigned> g_pinned_next{0};
+constexpr unsigned kPinnedSlots = 64;
+std::once_flag g_pinned_once;
+uint32_t* pinned_slot() {
+    std::call_once(g_pinned_once, [] {
+        void* ptr = nullptr;
+        if (hipHostMalloc(&ptr, kPinnedSlots * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) g_pinned = (uint32_t*)ptr;
+    });
+    return g_pinned ? g_pinned + (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
+}   // instance count of the previous forward: sizes the speculative binning blob
 std::mutex g_times_mu;
 struct Pending { hipEvent_t a, b; const char* name; };
 std::vector<Pending> g_pending;
@@ -169,7 +182,7 @@ size_t svgir_geom_bytes(int32_t P) { return geom_layout(nullptr, P).bytes; }
 size_t svgir_image_bytes(int32_t W, int32_t H) { return image_layout(nullptr, W, H).bytes; }
 size_t svgir_binning_bytes(int32_t R, int32_t W, int32_t H, int32_t S, int32_t VS) {
     const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    return bin_layout(nullptr, R, T, seg_nstate(S, VS)).bytes;
+    return bin_layout(nullptr, binning_capacity(R), T, seg_nstate(S, VS)).bytes;
 }
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H) { return image_layout(nullptr, W, H).ncontrib_off; }
 const char* svgir_last_error(void) { return g_err.c_str(); }
@@ -249,70 +262,84 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     tm.mark("preprocess");
 
     // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in slot 0
-    launch_radix_sort(G.key, G.idx, P, 32, 8, G.radix_tbl, s);
+    launch_radix_sort(G.key, G.idx, P, nullptr, 32, 8, G.radix_tbl, s);
     if (int rc = check("depth sort")) return rc;
     tm.mark("sort_depth");
 
     launch_offsets_scan(G.tiles, G.idx[0], G.offsets, G.scan_tmp, P, G.counters, s);
     if (int rc = check("offsets scan")) return rc;
-    uint32_t R_host = 0;
-    HIP_OK(hipMemcpyAsync(&R_host, G.counters, 4, hipMemcpyDeviceToHost, s));
-    // While the GPU is still busy with the stages above, speculatively allocate the binning blob for the previous
-    // call's instance count (+12 %): the host work left after the synchronisation is then just the kernel launches.
-    const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
-    char* bblob = nullptr;
-    size_t bbytes = 0;
-    if (const int guess = g_last_R.load()) {
-        bbytes = bin_layout(nullptr, (int)std::min<long long>(0x7fffffffLL, (long long)guess + guess / 8 + 1024), T, nstate).bytes;
-        bblob = binning(bbytes, binning_ctx);
-        if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
-    }
-    HIP_OK(hipStreamSynchronize(s));
     tm.mark("scan");
-    if (R_host > 0x7fffffffu) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
-    const int R = (int)R_host;
-    g_last_R.store(R);
+    uint32_t R_pageable = 0;
+    uint32_t* R_slot = pinned_slot();
+    if (!R_slot) R_slot = &R_pageable;
+    HIP_OK(hipMemcpyAsync(R_slot, G.counters, 4, hipMemcpyDeviceToHost, s));
+    hipEvent_t evR;
+    HIP_OK(hipEventCreateWithFlags(&evR, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(evR, s));
 
-    const size_t need = bin_layout(nullptr, R, T, nstate).bytes;
-    if (!bblob || need > bbytes) {   // first call, or the scene grew: allocate the exact size now
-        bblob = binning(need, binning_ctx);
-        if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
-    }
-    const BinLayout B = bin_layout(bblob, R, T, nstate);
+    const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
     const TileSortPlan plan = tile_sort_plan(T);
+    const int fin = plan.passes & 1;
 
-    if (R > 0) {
-        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], I.ranges, B.seg_map,
+    // Everything from here on depends on the instance count R that the GPU is still computing.  The stages are
+    // launched for an instance CAPACITY `cap` and read R on the device (min(cap, R)); the binning blob is laid out
+    // for `cap`.  `timed`: stage marks are only recorded for the launch sequence that counts.
+    auto run_binning_and_render = [&](char* bblob, int cap, bool timed) -> int {
+        const BinLayout B = bin_layout(bblob, cap, T, nstate);
+        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges, B.seg_map,
                     B.seg_cap, s);
         if (int rc = check("emit")) return rc;
-    } else {
-        HIP_OK(hipMemsetAsync(I.ranges, 0, (size_t)T * 8, s));
-        HIP_OK(hipMemsetAsync(B.seg_map, 0xFF, B.seg_cap * 4, s));
-    }
-    tm.mark("emit");
-    launch_radix_sort(B.key, B.val, R, plan.bits, plan.bits_per_pass, B.radix_tbl, s);
-    if (int rc = check("tile sort")) return rc;
-    tm.mark("sort_tile");
-    const int fin = plan.passes & 1;
-    launch_ranges(R, B.key[fin], I.ranges, T, s);
-    launch_tile_order(I.ranges, T, I.tile_order, s);
-    if (int rc = check("ranges")) return rc;
-    tm.mark("ranges");
+        if (timed) tm.mark("emit");
+        launch_radix_sort(B.key, B.val, cap, G.counters, plan.bits, plan.bits_per_pass, B.radix_tbl, s);
+        if (int rc = check("tile sort")) return rc;
+        if (timed) tm.mark("sort_tile");
+        launch_ranges(cap, G.counters, B.key[fin], I.ranges, T, s);
+        launch_tile_order(I.ranges, T, I.tile_order, s);
+        if (int rc = check("ranges")) return rc;
+        if (timed) tm.mark("ranges");
 
-    RenderArgs ra;
-    ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = svgss ? p->VS : 0;
-    ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
-    ra.bg = p->background;
-    ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_count = I.sub_count; ra.tile_order = I.tile_order;
-    ra.sub_ndump = I.sub_ndump; ra.seg_map = B.seg_map; ra.seg_state = B.seg_state;
-    ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
-    ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
-    ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
-    if (launch_render_fwd(ra, svgss, s) < 0)
-        return fail(SVGIR_ERR_INVALID, "no forward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ra.VS,
-                    svgss ? "svgss" : "rgss");
-    if (int rc = check("render")) return rc;
-    tm.mark("render");
+        RenderArgs ra;
+        ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = svgss ? p->VS : 0;
+        ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
+        ra.bg = p->background;
+        ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_count = I.sub_count; ra.tile_order = I.tile_order;
+        ra.sub_ndump = I.sub_ndump; ra.seg_map = B.seg_map; ra.seg_state = B.seg_state;
+        ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
+        ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
+        ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
+        if (launch_render_fwd(ra, svgss, s) < 0)
+            return fail(SVGIR_ERR_INVALID, "no forward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ra.VS,
+                        svgss ? "svgss" : "rgss");
+        if (int rc = check("render")) return rc;
+        if (timed) tm.mark("render");
+        return 0;
+    };
+
+    // Speculative launch: capacity from the previous call's instance count (+12.5 %), no host round trip in between.
+    int cap = 0;
+    char* bblob = nullptr;
+    if (const int guess = g_last_R.load()) {
+        cap = binning_capacity((long long)guess + guess / 8 + 1024);
+        bblob = binning(bin_layout(nullptr, cap, T, nstate).bytes, binning_ctx);
+        if (!bblob) { (void)hipEventDestroy(evR); return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed"); }
+        if (int rc = run_binning_and_render(bblob, cap, true)) { (void)hipEventDestroy(evR); return rc; }
+    }
+    HIP_OK(hipEventSynchronize(evR));   // waits for the count only; the speculative stages keep running
+    (void)hipEventDestroy(evR);
+    const uint32_t R_host = *(volatile uint32_t*)R_slot;
+    if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
+    const int R = (int)R_host;
+    g_last_R.store(R);
+    if (!bblob || R > cap) {
+        // first call, or the scene grew past the guess: (re)do the dependent stages with the exact capacity
+        const bool redo = bblob != nullptr;
+        if (redo) HIP_OK(hipStreamSynchronize(s));
+        cap = binning_capacity(R);
+        bblob = binning(bin_layout(nullptr, cap, T, nstate).bytes, binning_ctx);
+        if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
+        if (redo && o->out_weights) HIP_OK(hipMemsetAsync(o->out_weights, 0, (size_t)P * 4, s));   // accumulated by atomics
+        if (int rc = run_binning_and_render(bblob, cap, !redo)) return rc;
+    }
 
     if (!svgss && p->computer_pseudo_normal) {
         launch_image_ops(W, H, p->viewmatrix, focal_x, focal_y, p->cx, p->cy, o->out_opacity, o->out_depth,
@@ -324,7 +351,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
 }
 
 int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii, char* geom_blob,
-                   char* binning_blob, char* image_blob, void* stream) {
+                   char* binning_blob, size_t binning_bytes, char* image_blob, void* stream) {
     if (int rc = validate(p, false)) return rc;
     if (p->P == 0) return 0;
     if (!g || !radii || !geom_blob || !binning_blob || !image_blob)
@@ -337,7 +364,11 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
     const GeomLayout G = geom_layout(geom_blob, P);
     const ImageLayout I = image_layout(image_blob, W, H);
-    const BinLayout B = bin_layout(binning_blob, R, T, seg_nstate(p->S, svgss ? p->VS : 0));
+    const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
+    const int cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
+    if (cap < R || bin_layout(nullptr, cap, T, nstate).bytes != binning_bytes)
+        return fail(SVGIR_ERR_INVALID, "binning blob of %zu bytes does not match any layout for R=%d", binning_bytes, R);
+    const BinLayout B = bin_layout(binning_blob, cap, T, nstate);
     const int fin = tile_sort_plan(T).passes & 1;
     StageTimer tm(s, g_prof.load());
 

@@ -27,16 +27,20 @@ namespace {
 constexpr int GS = 32;
 
 template <int ITEMS>
-__global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int bit_lo,
+__global__ void __launch_bounds__(BLOCK) radix_hist_kernel(const uint32_t* __restrict__ keys, int n_cap,
+                                                           const uint32_t* __restrict__ n_dev, int bit_lo,
                                                            uint32_t mask, uint32_t* __restrict__ table,
                                                            uint32_t* __restrict__ gtot) {
     __shared__ uint32_t hist[256];
+    // element count: launch-time bound n_cap, or -- when the count is still being computed on the device at launch
+    // time (speculative launch before the host has read it) -- the device-side value clamped to that bound
+    const int n = n_dev ? (int)min((uint32_t)n_cap, n_dev[0]) : n_cap;
     hist[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * (BLOCK * ITEMS);
     uint32_t k[ITEMS];   // all loads first (clamped index), then the LDS atomics: one memory latency, not ITEMS
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) k[i] = keys[min(base + i * BLOCK + (int)threadIdx.x, n - 1)];
+    for (int i = 0; i < ITEMS; i++) k[i] = keys[max(0, min(base + i * BLOCK + (int)threadIdx.x, n - 1))];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int e = base + i * BLOCK + threadIdx.x;
@@ -52,7 +56,7 @@ template <int ITEMS>
 __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __restrict__ kin,
                                                               const uint32_t* __restrict__ vin,
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                              int n, int bit_lo, int nbits,
+                                                              int n_cap, const uint32_t* __restrict__ n_dev, int bit_lo, int nbits,
                                                               const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ gtot, int ngroups) {
     __shared__ uint32_t running[256];     // global output cursor per digit for this block
@@ -60,6 +64,7 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
     __shared__ uint32_t wtot[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t mask = (1u << nbits) - 1;
+    const int n = n_dev ? (int)min((uint32_t)n_cap, n_dev[0]) : n_cap;
     const int base = blockIdx.x * (BLOCK * ITEMS);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // all loads of the block up front
@@ -209,7 +214,7 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
                                                      const uint32_t* __restrict__ offsets, const float* __restrict__ rec,
                                                      const int32_t* __restrict__ radii, int gx, int gy,
                                                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
-                                                     uint32_t* __restrict__ ranges, int n_ranges,
+                                                     uint32_t cap, uint32_t* __restrict__ ranges, int n_ranges,
                                                      uint32_t* __restrict__ seg_map, int n_seg) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     // piggy-backed initialisation of two small tables used by later stages (saves two memset launches)
@@ -226,15 +231,19 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
     uint32_t off = offsets[i];
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
-            tile_keys[off] = (uint32_t)(y * gx + x);
-            vals[off] = g;
+            if (off < cap) {   // only ever false for a speculative launch whose capacity guess was too small
+                tile_keys[off] = (uint32_t)(y * gx + x);
+                vals[off] = g;
+            }
             off++;
         }
 }
 
-__global__ void __launch_bounds__(BLOCK) ranges_kernel(int R, const uint32_t* __restrict__ tile_keys,
+__global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t* __restrict__ R_dev,
+                                                       const uint32_t* __restrict__ tile_keys,
                                                        uint32_t* __restrict__ ranges) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int R = R_dev ? (int)min((uint32_t)R_cap, R_dev[0]) : R_cap;
     if (i >= R) return;
     const uint32_t cur = tile_keys[i];
     if (i == 0) ranges[2 * cur] = 0;
@@ -295,8 +304,8 @@ void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream
 }
 
 template <int ITEMS>
-static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
-                            uint32_t* tbl, uint32_t* gtot, hipStream_t s) {
+static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, int total_bits,
+                            int bits_per_pass, uint32_t* tbl, uint32_t* gtot, hipStream_t s) {
     const int per = BLOCK * ITEMS;
     const int nb = (n + per - 1) / per;
     const int ng = (nb + GS - 1) / GS;
@@ -305,21 +314,23 @@ static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int 
     for (int p = 0; p < passes; p++) {
         const int lo = p * bits_per_pass, nbits = std::min(bits_per_pass, total_bits - lo);
         uint32_t* gt = gtot + (size_t)p * ng * 256;
-        hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], n, lo, (1u << nbits) - 1,
-                           tbl, gt);
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], n, n_dev, lo,
+                           (1u << nbits) - 1, tbl, gt);
         hipLaunchKernelGGL((radix_scatter_kernel<ITEMS>), dim3(nb), dim3(BLOCK), 0, s, key[p & 1], val[p & 1],
-                           key[(p + 1) & 1], val[(p + 1) & 1], n, lo, nbits, tbl, gt, ng);
+                           key[(p + 1) & 1], val[(p + 1) & 1], n, n_dev, lo, nbits, tbl, gt, ng);
     }
 }
 
 // Stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
-// the result lands in slot (passes & 1) of the ping/pong buffers.  `table` holds radix_table_words(n) counters.
-void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
-                       uint32_t* table, hipStream_t s) {
+// the result lands in slot (passes & 1) of the ping/pong buffers.  `n` sizes the launch and the scratch
+// (`table`: radix_table_words(n) counters); if `n_dev` is not null the element count is min(n, *n_dev), read on the
+// device (the count need not be known on the host at launch time).
+void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, int total_bits,
+                       int bits_per_pass, uint32_t* table, hipStream_t s) {
     if (n <= 0) return;
     uint32_t* gtot = table + (size_t)256 * sort_blocks(n);  // [passes <= 4][groups][256] group digit totals
-    if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, total_bits, bits_per_pass, table, gtot, s);
-    else radix_sort_impl<16>(key, val, n, total_bits, bits_per_pass, table, gtot, s);
+    if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, n_dev, total_bits, bits_per_pass, table, gtot, s);
+    else radix_sort_impl<16>(key, val, n, n_dev, total_bits, bits_per_pass, table, gtot, s);
 }
 
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
@@ -331,15 +342,15 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
 }
 
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
-                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, uint32_t* ranges,
+                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
                  uint32_t* seg_map, size_t seg_cap, hipStream_t s) {
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,
-                       radii, gx, gy, tile_keys, vals, ranges, 2 * gx * gy, seg_map, (int)seg_cap);
+                       radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy, seg_map, (int)seg_cap);
 }
 
 // `ranges` must already be zero (launch_emit clears it)
-void launch_ranges(int R, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s) {
-    if (R > 0) hipLaunchKernelGGL(ranges_kernel, dim3((R + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, R, tile_keys, ranges);
+void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s) {
+    if (R > 0) hipLaunchKernelGGL(ranges_kernel, dim3((R + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, R, R_dev, tile_keys, ranges);
 }
 
 }  // namespace svgir

@@ -113,6 +113,13 @@ constexpr int SEG = 128;
 inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
 constexpr int SEG_K_BITS = 14;   // seg_map entry = (sub-tile id << SEG_K_BITS) | k ; 0xFFFFFFFF = no segment
 
+// The binning blob is laid out for an instance CAPACITY (a multiple of 4096 >= R): the forward may size it from a
+// guess before the host knows R, and the backward recovers the capacity from the blob's byte size.
+inline int binning_capacity(long long R) {
+    const long long c = ((R > 0 ? R : 1) + 4095) / 4096 * 4096;
+    return (int)(c > 0x7ffff000LL ? 0x7ffff000LL : c);
+}
+
 struct BinLayout {
     uint32_t* key[2];  // [R] tile ids ping/pong
     uint32_t* val[2];  // [R] Gaussian ids ping/pong
@@ -141,6 +148,16 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     b.seg_state = (float*)take(b.seg_cap * (size_t)nstate * 64 * 4);
     b.bytes = off;
     return b;
+}
+
+// inverse of bin_layout(...).bytes over the capacities binning_capacity() produces (bytes is strictly increasing in it)
+inline int binning_capacity_from_bytes(size_t bytes, int T, int nstate) {
+    long long lo = 1, hi = 0x7ffff000LL / 4096;
+    while (lo < hi) {
+        const long long mid = (lo + hi) / 2;
+        if (bin_layout(nullptr, (int)(mid * 4096), T, nstate).bytes < bytes) lo = mid + 1; else hi = mid;
+    }
+    return (int)(lo * 4096);
 }
 
 // Tile-sort plan: #bits of the tile id split into equal passes of <= 8 bits (both fwd and bwd derive the final
@@ -222,16 +239,17 @@ void launch_preprocess(const PreArgs& a, bool svgss, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 // stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
 // input in slot 0 of the ping/pong buffers, result in slot (passes & 1); table: radix_table_words(n) counters
-void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, int total_bits, int bits_per_pass,
-                       uint32_t* table, hipStream_t s);
+// element count = n, or min(n, *n_dev) read on the device when n_dev != nullptr (n then only sizes launch + scratch)
+void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, int total_bits,
+                       int bits_per_pass, uint32_t* table, hipStream_t s);
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
                          uint32_t* total_out, hipStream_t s);
 // also clears ranges[2*gx*gy] and marks every seg_map[seg_cap] entry empty
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
-                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, uint32_t* ranges,
+                 const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
                  uint32_t* seg_map, size_t seg_cap, hipStream_t s);
-void launch_ranges(int R, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
+void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
 // order[] = tile ids sorted by descending list length (longest-processing-time-first dispatch of the composite waves)
 void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 if (S,VS) unsupported

@@ -123,6 +123,7 @@ class _CBinding:
             g.dL_drotations = dL_drotations.data_ptr()
             rad = radii.contiguous()
             N.check(N.lib.svgir_backward(p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                                         binningBuffer.numel(),
                                          imageBuffer.data_ptr(), N.stream_ptr(dev)), "backward")
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dcov3D, dL_dsh, dL_dscales,
                 dL_drotations)

@@ -125,6 +125,7 @@ class _CBinding:
             g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
             rad = radii.contiguous()
             N.check(N.lib.svgir_backward(p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                                         binningBuffer.numel(),
                                          imageBuffer.data_ptr(), N.stream_ptr(dev)), "backward")
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dvfeatures, dL_dcov3D, dL_dsh,
                 dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos)
