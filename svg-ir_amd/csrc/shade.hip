@@ -124,12 +124,21 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         }
         env_taps(dl, p.env_h, p.env_w, t);
         float E[3] = {0.f, 0.f, 0.f};
+        {   // 12 unconditional gathers (out-of-range taps: texel 0 with weight 0), one memory latency for all of them
+            float tex[4][3];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (t.idx[j] >= 0) {
+            for (int j = 0; j < 4; j++) {
+                const float* tp = p.env_work + (t.idx[j] >= 0 ? t.idx[j] : 0);
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) E[ch] += t.w[j] * p.env_work[t.idx[j] + ch];
+                for (int ch = 0; ch < 3; ch++) tex[j][ch] = tp[ch];
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float w = t.idx[j] >= 0 ? t.w[j] : 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) E[ch] += w * tex[j][ch];
+            }
+        }
         float* r = sS + lane * SREC;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -297,14 +306,21 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     const float fx = xx - x0f, fy = yy - y0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
     float E[3] = {0.f, 0.f, 0.f};
+    {   // 12 unconditional gathers (out-of-range taps: texel 0 with weight 0), one memory latency for all of them
+        float tex[4][3], tw[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int xi = x0 + (j & 1), yi = y0 + (j >> 1);
-        if (xi >= 0 && xi < We && yi >= 0 && yi < He) {
-            const float w = ((j & 1) ? fx : 1.f - fx) * ((j >> 1) ? fy : 1.f - fy);
-            const float* t = p.env_work + (yi * We + xi) * 3;
+        for (int j = 0; j < 4; j++) {
+            const int xi = x0 + (j & 1), yi = y0 + (j >> 1);
+            const bool ok = xi >= 0 && xi < We && yi >= 0 && yi < He;
+            tw[j] = ok ? ((j & 1) ? fx : 1.f - fx) * ((j >> 1) ? fy : 1.f - fy) : 0.f;
+            const float* t = p.env_work + (ok ? (yi * We + xi) * 3 : 0);
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) E[ch] += w * t[ch];
+            for (int ch = 0; ch < 3; ch++) tex[j][ch] = t[ch];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) E[ch] += tw[j] * tex[j][ch];
         }
     }
     float* r = sS + lane * BREC;
