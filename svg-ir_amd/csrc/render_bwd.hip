@@ -200,32 +200,36 @@ render_bwd_kernel(const RenderBwdArgs a) {
         else if (j < 6) { gbase = a.dL_dopacity; gstride = 1; }
     }
 
+    // Replay state.  The reference keeps, per channel, the blend of everything behind the current splat (accum_rec)
+    // and the last value, and adds (value - accum) * dL_dchannel to dL_dalpha for every channel.  The upstream
+    // gradient of a pixel is the same for every splat, so the per-channel recurrences
+    //     accum <- last_alpha * last + (1 - last_alpha) * accum
+    // collapse into ONE scalar recurrence on A = sum_ch accum_ch * g_ch with s = sum_ch value_ch * g_ch:
+    //     A <- last_alpha * s_last + (1 - last_alpha) * A ;   dL_dalpha += s - A.
     float T = T_final;
     float last_alpha = 0.f;
-    float acc_c[3] = {0.f, 0.f, 0.f}, last_c[3] = {0.f, 0.f, 0.f};
-    float acc_n[3] = {0.f, 0.f, 0.f}, last_n[3] = {0.f, 0.f, 0.f};
-    float acc_d = 0.f, last_d = 0.f;
-    float acc_f[SS], last_f[SS], acc_vf[VV], last_vf[VV];
-#pragma unroll
-    for (int i = 0; i < SS; i++) { acc_f[i] = 0.f; last_f[i] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < VV; i++) { acc_vf[i] = 0.f; last_vf[i] = 0.f; }
+    float A_acc = 0.f, s_last = 0.f;
     if (kseg < ndump) {
         // Not the deepest live segment: start from the forward state dumped at this segment's far end.  With
-        // last_alpha = 0 the replay recurrence takes acc = blend of everything behind = (final - prefix) / T_end.
+        // last_alpha = 0 the recurrence takes accum = blend of everything behind = (final - prefix) / T_end.
         constexpr int NST = 8 + S + VC;
         const uint32_t base = blockIdx.x - (uint32_t)kseg;   // state slot of (sub-tile, 0)
         const float* e = a.seg_state + ((size_t)(base + kseg) * NST) * 64 + lane;
         const float* f = a.seg_state + ((size_t)(base + ndump) * NST) * 64 + lane;   // final state
         T = e[0];
-        const float iT = __builtin_amdgcn_rcpf(T);
+        float dot = (f[7 * 64] - e[7 * 64]) * gDn;
 #pragma unroll
-        for (int i = 0; i < 3; i++) { acc_c[i] = (f[(1 + i) * 64] - e[(1 + i) * 64]) * iT; acc_n[i] = (f[(4 + i) * 64] - e[(4 + i) * 64]) * iT; }
-        acc_d = (f[7 * 64] - e[7 * 64]) * iT;
+        for (int i = 0; i < 3; i++) {
+            dot += (f[(1 + i) * 64] - e[(1 + i) * 64]) * gC[i];
+            dot += (f[(4 + i) * 64] - e[(4 + i) * 64]) * gN[i];   // zero unless `surface` (the forward leaves N at 0)
+        }
+        if (bgeom) {
 #pragma unroll
-        for (int i = 0; i < S; i++) acc_f[i] = (f[(8 + i) * 64] - e[(8 + i) * 64]) * iT;
+            for (int i = 0; i < S; i++) dot += (f[(8 + i) * 64] - e[(8 + i) * 64]) * gF[i];
+        }
 #pragma unroll
-        for (int i = 0; i < VC; i++) acc_vf[i] = (f[(8 + S + i) * 64] - e[(8 + S + i) * 64]) * iT;
+        for (int i = 0; i < VC; i++) dot += (f[(8 + S + i) * 64] - e[(8 + S + i) * 64]) * gVF[i];
+        A_acc = dot * __builtin_amdgcn_rcpf(T);
     }
 
     // The segment's list entries go to LDS once, deepest first (the replay walks back to front).
@@ -315,48 +319,32 @@ render_bwd_kernel(const RenderBwdArgs a) {
                             cw[0] = (1.f - u) * (1.f - v); cw[1] = u * (1.f - v); cw[2] = (1.f - u) * v; cw[3] = u * v;
                         }
                     }
-                    const float col[3] = {E.y, E.z, E.w};
+                    // s = sum over all blended channels of value * upstream gradient (see the replay-state comment)
+                    float sdot = E.y * gC[0] + E.z * gC[1] + E.w * gC[2];
+                    if (S > 0 && bgeom) {
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        acc_c[ch] = last_alpha * last_c[ch] + inv_keep * acc_c[ch];
-                        last_c[ch] = col[ch];
-                        dL_dalpha += (col[ch] - acc_c[ch]) * gC[ch];
-                    }
-                    if (S > 0) {
-#pragma unroll
-                        for (int ch = 0; ch < S; ch++) {
-                            acc_f[ch] = last_alpha * last_f[ch] + inv_keep * acc_f[ch];
-                            last_f[ch] = fl[ch];
-                            if (bgeom) dL_dalpha += (fl[ch] - acc_f[ch]) * gF[ch];
-                        }
+                        for (int ch = 0; ch < S; ch++) sdot += fl[ch] * gF[ch];
                     }
                     if (VC > 0) {
+                        // sum_ch (c4[ch] . cw) gVF[ch] = cw . (sum_ch c4[ch] gVF[ch])
                         const float4* vf = reinterpret_cast<const float4*>(r + SG::V_OFF);
+                        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
 #pragma unroll
                         for (int ch = 0; ch < VC; ch++) {
                             const float4 c4 = vf[ch];
-                            const float v = c4.x * cw[0] + c4.y * cw[1] + c4.z * cw[2] + c4.w * cw[3];
-                            acc_vf[ch] = last_alpha * last_vf[ch] + inv_keep * acc_vf[ch];
-                            last_vf[ch] = v;
-                            dL_dalpha += (v - acc_vf[ch]) * gVF[ch];
+                            h0 += c4.x * gVF[ch]; h1 += c4.y * gVF[ch]; h2 += c4.z * gVF[ch]; h3 += c4.w * gVF[ch];
                         }
+                        sdot += (h0 * cw[0] + h1 * cw[1]) + (h2 * cw[2] + h3 * cw[3]);
                     }
-                    if (surface) {
-                        const float nn[3] = {Nn.x, Nn.y, Nn.z};
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            acc_n[ch] = last_alpha * last_n[ch] + inv_keep * acc_n[ch];
-                            last_n[ch] = nn[ch];
-                            dL_dalpha += (nn[ch] - acc_n[ch]) * gN[ch];
-                        }
-                    }
+                    if (surface) sdot += Nn.x * gN[0] + Nn.y * gN[1] + Nn.z * gN[2];
                     {  // depth
                         float d_cur = B.z;
                         if (sp) d_cur -= du * B.w + dv * E.x;
-                        acc_d = last_alpha * last_d + inv_keep * acc_d;
-                        last_d = d_cur;
-                        dL_dalpha += kdn * inv_Told + (d_cur - acc_d) * gDn;
+                        sdot += d_cur * gDn;
                     }
+                    A_acc = last_alpha * s_last + inv_keep * A_acc;
+                    s_last = sdot;
+                    dL_dalpha += kdn * inv_Told + (sdot - A_acc);
                     dL_dalpha *= T;
                     const float tf_oma = T_final * inv_oma;
                     dL_dalpha += (gO - kbg) * tf_oma;
