@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-side sweep of the backward composite's register budget (waves per SIMD for svgss / rgss instantiations)
 cd svg-ir_amd/csrc
-for v in "2 3" "3 4" "4 5" "3 5" "2 4"; do
+for v in "2 4" "3 4" "3 5"; do
   set -- $v
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -I../../include -DBWD_WPE_V=$1 -DBWD_WPE_P=$2 -c render_bwd.hip -o render_bwd.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvgir_raster.so api.o binning.o geom_bwd.o image_ops.o preprocess.o render_bwd.o render_fwd.o shade.o

@@ -78,8 +78,8 @@ struct BwdGeom {
     static constexpr int PROWS = (VC > 0) ? 16 : SB;     // panel rows: (candidate, corner) or candidate
     static constexpr int PS = 68;                        // panel row stride (floats): 16-byte aligned rows
 #ifndef BWD_WPE_V
-#define BWD_WPE_V 2
-#define BWD_WPE_P 4
+#define BWD_WPE_V 3
+#define BWD_WPE_P 5
 #endif
     static constexpr int WPE = (VC > 0) ? BWD_WPE_V : BWD_WPE_P;   // waves per SIMD the register budget is held to
     static constexpr size_t off_q = (size_t)CHB * SG::NF * 4;
