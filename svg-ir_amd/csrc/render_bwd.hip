@@ -81,7 +81,8 @@ struct BwdGeom {
 #define BWD_WPE_V 3
 #define BWD_WPE_P 5
 #endif
-    static constexpr int WPE = (VC > 0) ? BWD_WPE_V : BWD_WPE_P;   // waves per SIMD the register budget is held to
+    // waves per SIMD the register budget is held to (measured: 5 rgss, 3 svgss-train; the eval widths need > 170 VGPRs)
+    static constexpr int WPE = (VC > 13 || S + VC > 17) ? 2 : ((VC > 0) ? BWD_WPE_V : BWD_WPE_P);
     static constexpr size_t off_q = (size_t)CHB * SG::NF * 4;
     static constexpr size_t off_p = off_q + (size_t)SEG * 8;   // the whole segment's {gid, slot} entries
     static constexpr size_t off_pg = off_p + (size_t)PROWS * PS * 4;
