@@ -52,6 +52,49 @@ def gather_metrics(vec):
     return out.reshape(world, vec.numel())
 
 
+class MetricsGatherer:
+    """One fused all_gather of a k-float metrics vector per step, issued asynchronously: the collective of step i
+    overlaps with the rendering of step i+1 and is waited for one step later (`results()` drains the last one).
+    Nothing in the data path depends on it, so no rank ever stalls on the collective."""
+
+    def __init__(self, k, device, dtype=torch.float32):
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.k = k
+        self.bufs = [torch.zeros(self.world * k, dtype=dtype, device=device) for _ in range(2)]
+        self.src = [torch.zeros(k, dtype=dtype, device=device) for _ in range(2)]
+        self.pending = [None, None]
+        self.step = 0
+        self.last = None
+
+    def submit(self, vec):
+        i = self.step & 1
+        if self.pending[i] is not None:          # the gather issued two steps ago used this slot
+            self.pending[i].wait()
+            self.pending[i] = None
+        self.src[i].copy_(vec.reshape(-1))
+        if self.world == 1:
+            self.bufs[i].copy_(self.src[i])
+        else:
+            self.pending[i] = dist.all_gather_into_tensor(self.bufs[i], self.src[i], async_op=True)
+        self.last = i
+        self.step += 1
+
+    def results(self):
+        """[world, k] table of the most recent submit (waits for it)."""
+        if self.last is None:
+            return None
+        if self.pending[self.last] is not None:
+            self.pending[self.last].wait()
+            self.pending[self.last] = None
+        return self.bufs[self.last].reshape(self.world, self.k)
+
+    def drain(self):
+        for i in (0, 1):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -44,6 +44,15 @@ def _worker(rank, world, port, q):
 
     table = vp.run_views(render_view, 5, rank, world, dev, 2)
     assert vp.shard_views(5, rank, world) == [v for v in range(5) if v % world == rank]
+    # asynchronous per-step metrics gather (what bench.py uses): results lag the submits by at most one step
+    g = vp.MetricsGatherer(3, dev)
+    for step in range(4):
+        g.submit(torch.tensor([float(rank), float(step), 10.0 * rank + step]))
+    got = g.results()
+    assert got.shape == (world, 3)
+    for r_ in range(world):
+        assert got[r_].tolist() == [float(r_), 3.0, 10.0 * r_ + 3.0], got
+    g.drain()
     vp.barrier()
     q.put((rank, table.numpy()))
 
