@@ -264,6 +264,15 @@ def main():
                       f"({shade_s:.2f} s/step)"
         res["cpu_baseline"] = {"value": P / per_step, "unit": "surfels/s", "cores": cores, "kind": "port",
                                "sample": sample}
+        # the same rasterizer step on ONE host thread (SURVEY 8d asks for both); 2 steps, a few seconds
+        o1 = orc.OracleRun(sc, var_id, num_threads=1)
+        tc = time.perf_counter()
+        for _ in range(2):
+            o1.forward()
+            o1.backward(grads["color"], grads["normal"], grads["depth"], grads["opacity"], grads["feature"],
+                        grads.get("vfeature"))
+        res["cpu_baseline"]["single_thread"] = {"value": 2 * P / (time.perf_counter() - tc), "unit": "surfels/s",
+                                                "cores": 1, "sample": "2 fwd+bwd rasterizer steps, 1 thread"}
     print(json.dumps(res))
 
 
