@@ -67,7 +67,21 @@ __device__ __forceinline__ uint32_t sh_to_rgb(const PreArgs& a, int idx, const f
     float dir[3] = {pos[0] - a.campos[0], pos[1] - a.campos[1], pos[2] - a.campos[2]};
     const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
     const float x = dir[0] / len, y = dir[1] / len, z = dir[2] / len;
-    const float* sh = a.shs + (size_t)idx * a.M * 3;
+    const float* shp = a.shs + (size_t)idx * a.M * 3;
+    // M = 16: the 48-float coefficient row is contiguous and 16-byte aligned -> 12 float4 loads instead of 48 dword
+    // loads (only the loads change, the arithmetic below is untouched)
+    float sh[48];
+    if (a.M == 16 && (((size_t)a.shs) & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const float4 v = reinterpret_cast<const float4*>(shp)[i];
+            sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+        }
+    } else {
+        const int n = 3 * (a.D + 1) * (a.D + 1);
+#pragma unroll
+        for (int i = 0; i < 48; i++) sh[i] = i < n ? shp[i] : 0.f;
+    }
     float res[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) res[c] = kC0 * sh[c];
