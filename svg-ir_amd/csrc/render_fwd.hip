@@ -131,6 +131,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
                 if (pass && test_T < 0.0001f) { done = true; pass = false; newly_done = true; }
                 if (__ballot(pass) != 0ull) {
                     const float w = pass ? alpha * T : 0.f;
+                    // the wave reduction for out_weights is issued first: its dependent DPP steps (2 wait states
+                    // each) interleave with the independent blend FMAs below instead of stalling at the end
+                    const float wsum = wave_scan_last(w);
                     float dep = B.z;
                     float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
                     if (sp) {
@@ -167,7 +170,6 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
                         T = test_T;
                         last_contributor = e.y + 1u;
                     }
-                    const float wsum = wave_scan_last(w);
                     if (lane == 63) atomic_add_f32(&a.out_weights[e.x], wsum);
                 }
                 if (__any(newly_done) && __all(done)) { wave_done = true; break; }
