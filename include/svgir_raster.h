@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 2
+#define SVGIR_ABI_VERSION 3
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -152,7 +152,13 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o,
  * radii output.  `binning_bytes` is the size the binning callback was last asked for: the blob is laid out for an
  * instance capacity >= R that the backward recovers from it (the forward sizes the blob before it knows R). */
 int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii,
-                   char* geom_blob, char* binning_blob, size_t binning_bytes, char* image_blob, void* stream);
+                   char* geom_blob, char* binning_blob, size_t binning_bytes, char* image_blob,
+                   char* scratch, size_t scratch_bytes, void* stream);
+/* Size of the optional backward scratch (device memory, contents irrelevant, only needed during the call).  With it
+ * the composite gradients are accumulated without atomics -- every (instance, sub-tile) pair stores one gradient row
+ * and a second kernel sums each Gaussian's rows in a fixed order: faster at the svgss widths and bit-reproducible.
+ * With scratch == NULL the kernels fall back to float atomics on the dL_d* tensors. */
+size_t svgir_backward_scratch_bytes(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:141-153).  `present` is a byte per
  * Gaussian.  svgss: the reference kernel body is commented out, so `present` is left untouched (all false, Q14);

@@ -3,7 +3,7 @@
 W=${1:-cfg2}
 cd svg-ir_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -I../../include -DRENDER_TIMING ${RENDER_DEFS:-} -c render_bwd.hip -o render_bwd.o 2>&1 | grep -E "error" -A5
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvgir_raster.so api.o binning.o geom_bwd.o image_ops.o preprocess.o render_bwd.o render_fwd.o shade.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvgir_raster.so api.o binning.o geom_bwd.o grad_reduce.o image_ops.o preprocess.o render_bwd.o render_fwd.o shade.o
 cd ../..
 python - $W <<'PY'
 import ctypes as C, sys, json, subprocess, io, contextlib

@@ -2,7 +2,7 @@
 # GPU-side: rebuild shade.o with in-kernel s_memtime phase counters and print the phase split of shade_bwd
 cd svg-ir_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -I../../include -DSHADE_TIMING ${SHADE_DEFS:-} -c shade.hip -o shade.o 2>&1 | grep -E "error" -A5
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvgir_raster.so api.o binning.o geom_bwd.o image_ops.o preprocess.o render_bwd.o render_fwd.o shade.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvgir_raster.so api.o binning.o geom_bwd.o grad_reduce.o image_ops.o preprocess.o render_bwd.o render_fwd.o shade.o
 cd ../..
 python - <<'PY'
 import ctypes as C, os, sys

@@ -350,8 +350,15 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     return R;
 }
 
+size_t svgir_backward_scratch_bytes(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS) {
+    const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const int cap = binning_capacity_from_bytes(binning_bytes, T, seg_nstate(S, VS));
+    return grad_scratch_bytes(cap, S, VS);
+}
+
 int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii, char* geom_blob,
-                   char* binning_blob, size_t binning_bytes, char* image_blob, void* stream) {
+                   char* binning_blob, size_t binning_bytes, char* image_blob, char* scratch, size_t scratch_bytes,
+                   void* stream) {
     if (int rc = validate(p, false)) return rc;
     if (p->P == 0) return 0;
     if (!g || !radii || !geom_blob || !binning_blob || !image_blob)
@@ -384,12 +391,33 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.g_opacity = g->dL_dout_opacity; ba.g_feature = g->dL_dout_feature; ba.g_vfeature = g->dL_dout_vfeature;
     ba.dL_dmean2D = g->dL_dmeans2D; ba.dL_dconic = g->dL_dconic; ba.dL_dopacity = g->dL_dopacity; ba.dL_dcolor = g->dL_dcolors;
     ba.dL_dfeature = g->dL_dfeatures; ba.dL_dvfeature = g->dL_dvfeatures; ba.dL_dnormal = g->dL_dnormal; ba.dL_ddepth = g->dL_ddepth;
+    // With scratch memory the composite writes gradient rows that grad_reduce sums per Gaussian (no atomics,
+    // deterministic); without it, it falls back to float atomics on the output tensors.
+    // (only worth it when a row is long: at the rgss widths the 18 atomics per pair cost less than the extra pass)
+    ba.grad_rows = nullptr; ba.row_flags = nullptr;
+    if (scratch && ba.VS > 0) {
+        if (scratch_bytes < grad_scratch_bytes(cap, p->S, ba.VS))
+            return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes()", scratch_bytes);
+        const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
+        ba.grad_rows = (float*)scratch;
+        ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
+        if (R > 0) HIP_OK(hipMemsetAsync(ba.row_flags, 0, (size_t)4 * cap, s));
+    }
     if (R > 0) {
         if (launch_render_bwd(ba, svgss, s) < 0)
             return fail(SVGIR_ERR_INVALID, "no backward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ba.VS,
                         svgss ? "svgss" : "rgss");
     }
     tm.mark("render_bwd");
+    if (R > 0 && ba.grad_rows) {
+        GradReduceArgs ra;
+        ra.P = P; ra.S = p->S; ra.VS = ba.VS; ra.radii = radii; ra.tiles = G.tiles; ra.rec = G.rec;
+        ra.grad_rows = ba.grad_rows; ra.row_flags = ba.row_flags;
+        ra.dL_dmean2D = g->dL_dmeans2D; ra.dL_dconic = g->dL_dconic; ra.dL_dopacity = g->dL_dopacity; ra.dL_dcolor = g->dL_dcolors;
+        ra.dL_dfeature = g->dL_dfeatures; ra.dL_dvfeature = g->dL_dvfeatures; ra.dL_dnormal = g->dL_dnormal; ra.dL_ddepth = g->dL_ddepth;
+        launch_grad_reduce(ra, s);
+        tm.mark("grad_reduce");
+    }
 
     GeomBwdArgs ga;
     ga.P = P; ga.D = p->D; ga.M = p->M;

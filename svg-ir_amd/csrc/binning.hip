@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
 // ---- emit --------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ tiles,
-                                                     const uint32_t* __restrict__ offsets, const float* __restrict__ rec,
+                                                     const uint32_t* __restrict__ offsets, float* __restrict__ rec,
                                                      const int32_t* __restrict__ radii, int gx, int gy,
                                                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
                                                      uint32_t cap, uint32_t* __restrict__ ranges, int n_ranges,
@@ -229,6 +229,9 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
     const int x0 = min(gx, max(0, (int)((px - r) / TILE))), y0 = min(gy, max(0, (int)((py - r) / TILE)));
     const int x1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE))), y1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
     uint32_t off = offsets[i];
+    // for the backward's gradient rows: first instance index (emit order) and tile rectangle of this Gaussian
+    rec[(size_t)g * REC + R_IBASE] = __builtin_bit_cast(float, off);
+    rec[(size_t)g * REC + R_RECT] = __builtin_bit_cast(float, (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20));
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             if (off < cap) {   // only ever false for a speculative launch whose capacity guess was too small
@@ -341,7 +344,7 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
                        total_out);
 }
 
-void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
+void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
                  uint32_t* seg_map, size_t seg_cap, hipStream_t s) {
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,

@@ -26,7 +26,9 @@ enum RecField {
     R_J0 = 8, R_J1 = 9, R_J2 = 10, R_J3 = 11,  // float4 #2: screen->tangent 2x2
     R_J9 = 12, R_R = 13, R_G = 14, R_B = 15,   // float4 #3: ax1.z, rgb
     R_NX = 16, R_NY = 17, R_NZ = 18, R_IU = 19,// float4 #4: view normal, 1/(0.5*scale.x+0.1)
-    R_IV = 20, R_PAD0 = 21, R_PAD1 = 22, R_PAD2 = 23  // float4 #5: 1/(0.5*scale.y+0.1)
+    R_IV = 20, R_IBASE = 21, R_RECT = 22, R_PAD2 = 23  // float4 #5: 1/(0.5*scale.y+0.1); [written by emit:] index of the
+                                                       // Gaussian's first instance in emit order (u32 bits); tile rect
+                                                       // x0 | y0 << 10 | (x1 - x0) << 20 (u32 bits)
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -102,6 +104,21 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.sub_ndump = (uint32_t*)take(T * 4 * 4);
     im.bytes = off;
     return im;
+}
+
+// Gradient rows.  Instead of one float atomic per (wave, splat, output), a backward wave writes the complete gradient
+// row of its (instance, sub-tile) pair -- slot 4 * (emit-order instance index) + sub-tile, so the rows of one Gaussian
+// are contiguous -- and a second kernel sums each Gaussian's valid rows: no atomics, deterministic gradients.
+// Row layout (floats): [0, NC0) colour3, normal3 (x10), depth, features S | pad to 4 | [P4, P4+VS) vfeatures |
+// [P4+VS, P4+VS+6) mean2D.xy, conic.xyz, opacity | pad to 4.
+struct GradRowGeom { int NC0, P4, VS, GEO, RS; };
+inline GradRowGeom grad_row_geom(int S, int VS) {
+    GradRowGeom g;
+    g.NC0 = 7 + S; g.P4 = (g.NC0 + 3) / 4 * 4; g.VS = VS; g.GEO = g.P4 + VS; g.RS = (g.GEO + 6 + 3) / 4 * 4;
+    return g;
+}
+inline size_t grad_scratch_bytes(int cap, int S, int VS) {   // rows + one validity byte per slot
+    return align_up((size_t)4 * cap * grad_row_geom(S, VS).RS * 4) + align_up((size_t)4 * cap);
 }
 
 // Backward segments.  The backward composite is parallelised over depth: one wave per SEG consecutive candidates of a
@@ -217,6 +234,14 @@ struct RenderBwdArgs {
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
+    float* grad_rows; uint8_t* row_flags;   // non-null: write gradient rows instead of issuing atomics
+};
+
+struct GradReduceArgs {
+    int P, S, VS;
+    const int32_t* radii; const uint32_t* tiles; const float* rec;
+    const float* grad_rows; const uint8_t* row_flags;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
 };
 
 struct GeomBwdArgs {
@@ -246,7 +271,7 @@ void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, co
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
                          uint32_t* total_out, hipStream_t s);
 // also clears ranges[2*gx*gy] and marks every seg_map[seg_cap] entry empty
-void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, const float* rec,
+void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
                  uint32_t* seg_map, size_t seg_cap, hipStream_t s);
 void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
@@ -254,6 +279,7 @@ void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint
 void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 if (S,VS) unsupported
 int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 if (S,VS) unsupported
+void launch_grad_reduce(const GradReduceArgs& a, hipStream_t s);
 void launch_geom_bwd(const GeomBwdArgs& a, hipStream_t s);
 void launch_image_ops(int W, int H, const float* view, float focal_x, float focal_y, float cx, float cy,
                       const float* opacity, const float* depth, float* pseudo_normal, float* surface_xyz,

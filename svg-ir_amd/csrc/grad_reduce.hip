@@ -1,0 +1,80 @@
+// svg-ir_amd/csrc/grad_reduce.hip -- per-Gaussian sum of the gradient rows written by the backward composite.
+//
+// The reference accumulates the composite's per-Gaussian gradients with one global float atomic per (pixel, splat,
+// output) (backward.cu:880-930); the first version here issued one per (wave, splat, output) -- still 18 / 69 / 84
+// memory-side atomics per pair, 30 % of the backward composite at the svgss widths.  Now a backward wave stores the
+// complete gradient row of its (instance, sub-tile) pair (common.hpp GradRowGeom; slot = 4 * emit-order instance index
+// + sub-tile, so all rows of one Gaussian are contiguous) and this kernel adds up each Gaussian's valid rows in slot
+// order: streaming stores + one coalesced pass, no atomics, bit-reproducible gradients.
+//
+// One wave per Gaussian: the 64 lanes first look at 64 validity bytes at a time (ballot), then walk the set bits;
+// lane l accumulates row element l (and l + 64 for rows longer than 64 floats).
+#include "common.hpp"
+
+namespace svgir {
+
+namespace {
+
+__global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs a, const GradRowGeom rg) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (g >= a.P) return;
+    // three independent loads first (one memory latency), then the early exits
+    const int32_t radius = a.radii[g];
+    const uint32_t ntiles = a.tiles[g];
+    const size_t base = (size_t)4 * __builtin_bit_cast(uint32_t, a.rec[(size_t)g * REC + R_IBASE]);
+    if (!(radius > 0) || ntiles == 0) return;
+    const uint32_t nslots = 4u * ntiles;
+    float acc0 = 0.f, acc1 = 0.f;
+    bool any = false;
+    for (uint32_t s0 = 0; s0 < nslots; s0 += 64) {
+        const uint32_t s = s0 + (uint32_t)lane;
+        unsigned long long m = __ballot(s < nslots && a.row_flags[base + s] != 0);
+        any = any || m != 0ull;
+        // up to four valid rows per step: all their loads are issued before the first add (one memory latency per
+        // four rows instead of one per row); the adds keep slot order, so the result is reproducible
+        while (m) {
+            int b[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                b[k] = m ? __builtin_ctzll(m) : -1;
+                m &= m - 1;   // (0 & anything stays 0)
+            }
+            float v0[4], v1[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float* row = a.grad_rows + (base + s0 + (uint32_t)(b[k] >= 0 ? b[k] : b[0])) * (size_t)rg.RS;
+                v0[k] = lane < rg.RS ? row[lane] : 0.f;
+                v1[k] = lane + 64 < rg.RS ? row[lane + 64] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (b[k] >= 0) { acc0 += v0[k]; acc1 += v1[k]; }
+        }
+    }
+    if (!any) return;   // outputs stay at the caller's zeros
+    // scatter the summed row to the output tensors (the caller zero-fills them; this is the only writer)
+    auto put = [&](int e, float v) {
+        if (e < 3) a.dL_dcolor[(size_t)g * 3 + e] = v;
+        else if (e < 6) a.dL_dnormal[(size_t)g * 3 + (e - 3)] = v;
+        else if (e < 7) a.dL_ddepth[g] = v;
+        else if (e < rg.NC0) a.dL_dfeature[(size_t)g * a.S + (e - 7)] = v;
+        else if (e < rg.P4) {}
+        else if (e < rg.GEO) a.dL_dvfeature[(size_t)g * a.VS + (e - rg.P4)] = v;
+        else if (e < rg.GEO + 2) a.dL_dmean2D[(size_t)g * 3 + (e - rg.GEO)] = v;
+        else if (e < rg.GEO + 5) { const int j = e - rg.GEO - 2; a.dL_dconic[(size_t)g * 4 + (j == 2 ? 3 : j)] = v; }
+        else if (e < rg.GEO + 6) a.dL_dopacity[g] = v;
+    };
+    if (lane < rg.RS) put(lane, acc0);
+    if (lane + 64 < rg.RS) put(lane + 64, acc1);
+}
+
+}  // namespace
+
+void launch_grad_reduce(const GradReduceArgs& a, hipStream_t s) {
+    const GradRowGeom rg = grad_row_geom(a.S, a.VS);
+    const int per = BLOCK / 64;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((a.P + per - 1) / per), dim3(BLOCK), 0, s, a, rg);
+}
+
+}  // namespace svgir

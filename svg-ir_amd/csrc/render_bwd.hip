@@ -396,7 +396,50 @@ render_bwd_kernel(const RenderBwdArgs a) {
                     if (VC > 0) accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Bv[kk], accV, 0, 0, 0);
                 }
                 // D layout: lane l, register r -> row 4*(l>>4) + r, column l&15
-                if (VC > 0) {
+                if (VC > 0 && a.grad_rows) {   // (rows are only used at the svgss widths, api.hip)
+                    // ---- gradient rows (common.hpp GradRowGeom): plain stores, summed per Gaussian afterwards ----
+                    constexpr int P4 = (NC0 + 3) / 4 * 4, GEO = P4 + VS, RS = (GEO + 6 + 3) / 4 * 4;
+                    // slot of candidate cb of this sub-batch: 4 * (first instance of the Gaussian + index of this tile
+                    // inside the Gaussian's tile rectangle, emit order) + sub-tile
+                    auto slot_of = [&](int cb) -> size_t {
+                        const float* rr = sD + (c0 + cb) * SG::NF;
+                        const uint32_t ib = __builtin_bit_cast(uint32_t, rr[R_IBASE]);
+                        const uint32_t rc = __builtin_bit_cast(uint32_t, rr[R_RECT]);
+                        const uint32_t x0 = rc & 1023u, y0 = (rc >> 10) & 1023u, wr = rc >> 20;
+                        return (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
+                    };
+                    if (VC > 0) {
+                        const bool mine = grpB < nsub && ((live >> grpB) & 1u);
+                        if (mine) {
+                            float* row = a.grad_rows + slot_of(grpB) * RS;
+                            if (colB < NC0) row[colB] = (accP[0] + accP[1]) + (accP[2] + accP[3]);
+                            if (colB < VC)
+                                reinterpret_cast<float4*>(row + P4)[colB] =
+                                    sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int cB = 4 * grpB + r;
+                            if (cB < nsub && ((live >> cB) & 1u) && colB < NC0) a.grad_rows[slot_of(cB) * RS + colB] = accP[r];
+                        }
+                    }
+                    {
+                        const int cB = lane >> 3, j = lane & 7;
+                        if (cB < nsub && ((live >> cB) & 1u)) {
+                            const size_t sl = slot_of(cB);
+                            if (j < 6) {
+                                float v = 0.f;
+#pragma unroll
+                                for (int p8 = 0; p8 < 8; p8++) v += sPg[(cB * 6 + j) * 8 + p8];
+                                a.grad_rows[sl * RS + GEO + j] = v;
+                            } else if (j == 6) {
+                                a.row_flags[sl] = 1;
+                            }
+                        }
+                    }
+                } else if (VC > 0) {
+
                     // rows = (candidate grpB, corner r)
                     const bool mine = grpB < nsub && ((live >> grpB) & 1u);
                     const int gidB = mine ? (int)sQ[base + c0 + grpB].x : 0;
@@ -419,7 +462,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
                     }
                 }
                 // --- geometric channels: finish the octant partials ---
-                {
+                if (!(VC > 0 && a.grad_rows)) {
                     const int cB = lane >> 3, j = lane & 7;
                     const bool mine = cB < nsub && ((live >> cB) & 1u) && j < 6;
                     if (mine) {

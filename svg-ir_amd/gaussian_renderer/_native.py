@@ -67,14 +67,16 @@ def _load():
                                   ALLOC_FN, C.c_void_p, C.c_void_p]
     lib.svgir_backward.restype = C.c_int
     lib.svgir_backward.argtypes = [C.POINTER(Params), C.POINTER(Grads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_size_t, C.c_void_p, C.c_void_p]
+                                   C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.svgir_backward_scratch_bytes.restype = C.c_size_t
+    lib.svgir_backward_scratch_bytes.argtypes = [C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.svgir_mark_visible.restype = C.c_int
     lib.svgir_mark_visible.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svgir_set_profiling.argtypes = [C.c_int]
     lib.svgir_last_timings.restype = C.c_int
     lib.svgir_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     lib.svgir_last_error.restype = C.c_char_p
-    if lib.svgir_abi_version() != 2:
+    if lib.svgir_abi_version() != 3:
         raise ImportError("libsvgir_raster.so ABI version mismatch")
     return lib
 
@@ -83,7 +85,7 @@ lib = _load()
 
 EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_binning_bytes",
            "svgir_image_ncontrib_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
-           "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
+           "svgir_backward_scratch_bytes", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
            "svgir_shade_backward")
 
 

@@ -269,3 +269,21 @@ def test_channel_widths_without_specialised_kernel(built, variant, S, VS):
     out, leaves, o, R = _run_both(sc, variant, grads)
     _check_forward(out, o, R, variant)
     _check_backward(leaves, o, variant)
+
+
+def test_svgss_gradients_bit_reproducible(built):
+    """The svgss backward accumulates the composite gradients without atomics (gradient rows summed per Gaussian in a
+    fixed order, csrc/grad_reduce.hip): two runs give bit-identical gradients."""
+    sc = scenes.surface_scene(P=6000, W=160, H=128, seed=71, sh_degree=2, variant="svgss", S=4, VS=52, scale_lo=0.02,
+                              scale_hi=0.08)
+    grads = scenes.upstream_grads(sc, "svgss", seed=3)
+    sct = runner.to_torch(sc, _dev())
+    runs = []
+    for _ in range(2):
+        out, leaves = runner.render(sct, "svgss", requires_grad=True)
+        runner.backward(out, grads, "svgss")
+        torch.cuda.synchronize()
+        runs.append({k: v.grad.clone() for k, v in leaves.items() if v.grad is not None})
+    assert set(runs[0]) == set(runs[1]) and len(runs[0]) >= 6
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
