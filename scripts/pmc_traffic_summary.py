@@ -18,7 +18,7 @@ def load(d):
 rd, wr = load(sys.argv[1]), load(sys.argv[2])
 out = {"workload": sys.argv[3], "method": __doc__.split("usage")[0].strip(), "kernels": {}}
 for k in rd:
-    if not any(p in k for p in ("render_", "shade_fwd", "shade_bwd")):
+    if not any(p in k for p in ("render_", "shade_fwd", "shade_bwd", "grad_reduce")):
         continue
     r, w = rd[k], wr.get(k, {})
     rq, r32 = r.get("TCC_EA0_RDREQ_sum", 0.0), r.get("TCC_EA0_RDREQ_32B_sum", 0.0)
