@@ -108,10 +108,10 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         const float d[3] = {p.incident_dirs[o * 3], p.incident_dirs[o * 3 + 1], p.incident_dirs[o * 3 + 2]};
         const float rad[3] = {p.radiance[o * 3], p.radiance[o * 3 + 1], p.radiance[o * 3 + 2]};
         const float vis = p.visibility[o], area = p.incident_areas[o];
-        const float il = 1.f / fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+        const float il = fminf(__builtin_amdgcn_rsqf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
         const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
         float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
-        const float ih = 1.f / fmaxf(sqrtf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e-12f);
+        const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
         H[0] *= ih; H[1] *= ih; H[2] *= ih;
         const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
         const float frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
 
     float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
     {
-        const float iv = 1.f / fmaxf(sqrtf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e-12f);
+        const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
         V[0] *= iv; V[1] *= iv; V[2] *= iv;
     }
     float m[10];
@@ -281,10 +281,10 @@ __device__ __forceinline__ RawSample load_raw(const svgir_shade_params& p, size_
 __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const RawSample& x, int lane, const float* V,
                                               float* __restrict__ sS) {
     const float* d = x.d;
-    const float il = 1.f / fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+    const float il = fminf(__builtin_amdgcn_rsqf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
     const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
     float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
-    const float ih = 1.f / fmaxf(sqrtf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e-12f);
+    const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
     H[0] *= ih; H[1] *= ih; H[2] *= ih;
     const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
     const float frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         const size_t gg = (size_t)g;
         float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
         {
-            const float iv = 1.f / fmaxf(sqrtf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e-12f);
+            const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
             V[0] *= iv; V[1] *= iv; V[2] *= iv;
         }
         GaussConst c;
