@@ -29,6 +29,7 @@ namespace {
 constexpr int SREC = 17;   // floats per staged sample: d(3) L(3) H(3) frac0 Lg(3) Ll(3) area
 constexpr int NRED = SVGIR_SHADE_REDUCED;
 constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
 
 struct ShadeArgs {
     svgir_shade_params p;
@@ -56,8 +57,8 @@ struct EnvTap { int idx[4]; float w[4]; };
 __device__ __forceinline__ void env_taps(const float* d, int He, int We, EnvTap& t) {
     const float phi = acosf(d[2]) - 1e-6f;
     const float theta = atan2f(d[1], d[0]);
-    const float gy = phi / kPi * 2.f - 1.f;
-    const float gx = -theta / kPi;
+    const float gy = phi * (2.f * kInvPi) - 1.f;
+    const float gx = -theta * kInvPi;
     const float x = (gx + 1.f) * 0.5f * (float)(We - 1);
     const float y = (gy + 1.f) * 0.5f * (float)(He - 1);
     const float x0f = floorf(x), y0f = floorf(y);
@@ -81,7 +82,7 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
     const float* n = p.normals + g * 12 + k * 3;
     c.nraw[0] = n[0]; c.nraw[1] = n[1]; c.nraw[2] = n[2];
     const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
-    c.inv_len = 1.f / len;
+    c.inv_len = __builtin_amdgcn_rcpf(len);
     float Nn[3] = {n[0] * c.inv_len, n[1] * c.inv_len, n[2] * c.inv_len};
     const float nov = V[0] * Nn[0] + V[1] * Nn[1] + V[2] * Nn[2];
     c.sgn = nov > 0.f ? 1.f : (nov < 0.f ? -1.f : 0.f);
@@ -94,7 +95,7 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
     c.kk = (a + 2.f * c.r + 1.0f) / 8.0f;
     c.nom1 = NoV * (1.f - c.kk) + c.kk;
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) c.fd[ch] = p.base_color[g * 12 + ch * 4 + k] / kPi;
+    for (int ch = 0; ch < 3; ch++) c.fd[ch] = p.base_color[g * 12 + ch * 4 + k] * kInvPi;
 }
 
 // phase 1 for one chunk of <= 64 samples [s0, s0+cnt) of one Gaussian: fills the wave's sample records (slot =
@@ -298,8 +299,8 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     }
     const float phi = acosf(dl[2]) - 1e-6f;
     const float theta = atan2f(dl[1], dl[0]);
-    const float gy = phi / kPi * 2.f - 1.f;
-    const float gx = -theta / kPi;
+    const float gy = phi * (2.f * kInvPi) - 1.f;
+    const float gx = -theta * kInvPi;
     const float xx = (gx + 1.f) * 0.5f * (float)(We - 1);
     const float yy = (gy + 1.f) * 0.5f * (float)(He - 1);
     const float x0f = floorf(xx), y0f = floorf(yy);
@@ -565,7 +566,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 a.d_normals[gg * 12 + k * 3 + j] = d_n[j] + dir_n[j];
-                a.d_base[gg * 12 + j * 4 + k] = d_fd[j] / kPi + dir_b[j];
+                a.d_base[gg * 12 + j * 4 + k] = d_fd[j] * kInvPi + dir_b[j];
             }
             a.d_rough[gg * 4 + k] = d_r + dir_r;
         }
