@@ -179,9 +179,9 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
     float o_pbr[3] = {0, 0, 0}, o_dif[3] = {0, 0, 0}, o_spe[3] = {0, 0, 0}, o_dir[3] = {0, 0, 0}, o_ind[3] = {0, 0, 0};
     for (int s0 = 0; s0 < Ns; s0 += 64) {
       const int cnt = min(64, Ns - s0);
-      __syncthreads();   // previous chunk consumed
+      wave_lds_sync();   // previous chunk consumed
       stage_samples(p, gg, lane, V, sS, m, s0, cnt);
-      __syncthreads();
+      wave_lds_sync();
       for (int s = sg; s < cnt; s += 16) {
         const float* r = sS + s * SREC;
         const float ndi = fmaxf(c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2], 0.f);
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
             sOut[36 + ch * 4 + k] = v3 * inv_ns; sOut[48 + ch * 4 + k] = v4 * inv_ns;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     if (!valid) return;
     // ---- epilogue: consecutive lanes write consecutive floats ----
     if (a.reduced) {
