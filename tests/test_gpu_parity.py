@@ -287,3 +287,22 @@ def test_svgss_gradients_bit_reproducible(built):
     assert set(runs[0]) == set(runs[1]) and len(runs[0]) >= 6
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k
+
+
+def test_speculative_capacity_small_large_small(built):
+    """The count-dependent forward stages are launched speculatively for a capacity guessed from the previous call's
+    instance count (csrc/api.hip): a much larger scene after a small one must take the re-run path, a small one after
+    a large one runs inside an over-sized blob -- all three must match the oracle, forward and backward."""
+    small = scenes.surface_scene(P=1500, W=80, H=64, seed=81, sh_degree=1, variant="rgss", S=5, VS=0, scale_lo=0.02,
+                                 scale_hi=0.06)
+    large = scenes.surface_scene(P=30000, W=256, H=192, seed=82, sh_degree=1, variant="rgss", S=5, VS=0, scale_lo=0.02,
+                                 scale_hi=0.08)
+    last_R = None
+    for sc in (small, large, small):
+        grads = scenes.upstream_grads(sc, "rgss", seed=17)
+        out, leaves, o, R = _run_both(sc, "rgss", grads)
+        _check_forward(out, o, R, "rgss")
+        _check_backward(leaves, o, "rgss")
+        if last_R is not None:
+            assert R > 3 * last_R or last_R > 3 * R, "the scenes should differ a lot in instance count"
+        last_R = R
