@@ -26,7 +26,16 @@ thread_local std::string g_err;
 // HIP events recorded on the launch stream; they are resolved lazily (svgir_last_timings), so enabling profiling
 // adds no synchronisation to forward/backward.
 std::atomic<bool> g_prof{false};
-std::atomic<int> g_last_R{0};
+// Instance counts of the last eight forwards (any view / size): the speculative launch is sized for their maximum, so
+// a training loop that cycles through cameras with different footprints rarely has to re-run the dependent stages.
+std::atomic<int> g_R_hist[8];
+std::atomic<unsigned> g_R_next{0};
+int guess_R() {
+    int m = 0;
+    for (auto& r : g_R_hist) m = std::max(m, r.load());
+    return m;
+}
+void record_R(int R) { g_R_hist[g_R_next.fetch_add(1) % 8].store(R); }
 // Pinned landing slots for the 4-byte instance-count read-back (a pageable destination would make the "async" copy a
 // blocking staged one).  A small ring: concurrent forwards on different threads/streams get different slots.
 uint32_t* g_pinned = nullptr;
@@ -318,7 +327,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     // Speculative launch: capacity from the previous call's instance count (+12.5 %), no host round trip in between.
     int cap = 0;
     char* bblob = nullptr;
-    if (const int guess = g_last_R.load()) {
+    if (const int guess = guess_R()) {
         cap = binning_capacity((long long)guess + guess / 8 + 1024);
         bblob = binning(bin_layout(nullptr, cap, T, nstate).bytes, binning_ctx);
         if (!bblob) { (void)hipEventDestroy(evR); return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed"); }
@@ -329,7 +338,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     const uint32_t R_host = *(volatile uint32_t*)R_slot;
     if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
     const int R = (int)R_host;
-    g_last_R.store(R);
+    record_R(R);
     if (!bblob || R > cap) {
         // first call, or the scene grew past the guess: (re)do the dependent stages with the exact capacity
         const bool redo = bblob != nullptr;
