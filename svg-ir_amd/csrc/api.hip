@@ -71,28 +71,6 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(SVGIR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-// Stage timer: one event per stage boundary; consecutive pairs are queued for lazy resolution.
-struct StageTimer {
-    hipStream_t s;
-    bool on;
-    hipEvent_t prev = nullptr;
-    StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
-        if (on) mark(nullptr);
-    }
-    void mark(const char* name) {
-        if (!on) return;
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
-        (void)hipEventRecord(e, s);
-        if (prev && name) {
-            std::lock_guard<std::mutex> lk(g_times_mu);
-            g_pending.push_back({prev, e, name});
-        }
-        prev = e;  // events are destroyed when the pair that ends with them is resolved (the first one leaks into
-                   // the pair as `a`; every event is destroyed exactly once in resolve_pending)
-    }
-};
-
 // Resolve queued event pairs into per-stage sums.  Each event appears as `b` of one pair and possibly `a` of the
 // next; destroy an event after its last use.
 void resolve_pending() {
@@ -146,6 +124,15 @@ void stage_mark(StageMarks& t, const char* name) {
 }  // namespace svgir
 
 namespace {
+
+// Stage timer (stage_begin / stage_mark above): one event per stage boundary; consecutive pairs are queued for
+// lazy resolution.
+struct StageTimer {
+    StageMarks t;
+    explicit StageTimer(hipStream_t s) : t(stage_begin(s)) {}
+    void mark(const char* name) { stage_mark(t, name); }
+};
+
 
 CfgRef cfg_ref(const svgir_params* p) {
     CfgRef c;
@@ -244,7 +231,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     const GeomLayout G = geom_layout(gblob, P);
     const ImageLayout I = image_layout(iblob, W, H);
 
-    StageTimer tm(s, g_prof.load());
+    StageTimer tm(s);
     auto check = [&](const char* what) -> int {
         if (!p->debug) {
             hipError_t e = hipGetLastError();
@@ -386,7 +373,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         return fail(SVGIR_ERR_INVALID, "binning blob of %zu bytes does not match any layout for R=%d", binning_bytes, R);
     const BinLayout B = bin_layout(binning_blob, cap, T, nstate);
     const int fin = tile_sort_plan(T).passes & 1;
-    StageTimer tm(s, g_prof.load());
+    StageTimer tm(s);
 
     RenderBwdArgs ba;
     ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = svgss ? p->VS : 0;

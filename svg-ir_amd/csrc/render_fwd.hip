@@ -27,11 +27,6 @@ namespace svgir {
 
 namespace {
 
-#ifdef FWD_USE_BARRIER
-#define FWD_SYNC() __syncthreads()
-#else
-#define FWD_SYNC() wave_lds_sync()
-#endif
 
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
@@ -109,10 +104,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
         // ---- stage + blend queued candidates, CH at a time ----
         while (!wave_done && (tail - head >= (uint32_t)SG::CH || (last_scan && tail != head))) {
             const int m = min((int)SG::CH, (int)(tail - head));
-            FWD_SYNC();  // ring writes visible; previous batch fully consumed
+            wave_lds_sync();  // ring writes visible; previous batch fully consumed
             stage_candidates<S, VC, SG::CH>(sD, m, [&](int s) { return sQ[(head + s) & (SG::QN - 1)].x; }, lane, a.rec,
                                     a.features, a.vfeatures);
-            FWD_SYNC();
+            wave_lds_sync();
             for (int c = 0; c < m; c++) {
                 const float4* q = reinterpret_cast<const float4*>(sD + c * SG::NF);
                 const float4 A = q[0];   // x, y, conic.x, conic.y
