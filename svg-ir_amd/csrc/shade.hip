@@ -176,7 +176,10 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
     const int k = lane >> 4, sg = lane & 15;
     GaussConst c;
     load_corner(p, gg, k, V, c);
-    float o_pbr[3] = {0, 0, 0}, o_dif[3] = {0, 0, 0}, o_spe[3] = {0, 0, 0}, o_dir[3] = {0, 0, 0}, o_ind[3] = {0, 0, 0};
+    // per channel four sums: A_d = sum(Lg*ge), A_l = sum(Ll*ge), B_d = sum(fs*Lg*ge), B_l = sum(fs*Ll*ge); with
+    // f = f_d + fs the five outputs are  diffuse = A_d + A_l, specular = B_d + B_l, direct = f_d*A_d + B_d,
+    // indirect = f_d*A_l + B_l, pbr = direct + indirect
+    float Ad[3] = {0, 0, 0}, Al[3] = {0, 0, 0}, Bd[3] = {0, 0, 0}, Bl[3] = {0, 0, 0};
     for (int s0 = 0; s0 < Ns; s0 += 64) {
       const int cnt = min(64, Ns - s0);
       wave_lds_sync();   // previous chunk consumed
@@ -193,9 +196,8 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
         const float ge = r[16] * ndi;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const float td = r[10 + ch] * ge, tl = r[13 + ch] * ge, ti = td + tl;
-            const float f = c.fd[ch] + fs;
-            o_pbr[ch] += f * ti; o_dif[ch] += ti; o_spe[ch] += fs * ti; o_dir[ch] += f * td; o_ind[ch] += f * tl;
+            const float td = r[10 + ch] * ge, tl = r[13 + ch] * ge;
+            Ad[ch] += td; Al[ch] += tl; Bd[ch] += fs * td; Bl[ch] += fs * tl;
         }
       }
     }
@@ -210,8 +212,8 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        const float v0 = row16_sum(o_pbr[ch]), v1 = row16_sum(o_dif[ch]), v2 = row16_sum(o_spe[ch]),
-                    v3 = row16_sum(o_dir[ch]), v4 = row16_sum(o_ind[ch]);
+        const float ad = row16_sum(Ad[ch]), al = row16_sum(Al[ch]), bd = row16_sum(Bd[ch]), bl = row16_sum(Bl[ch]);
+        const float v1 = ad + al, v2 = bd + bl, v3 = c.fd[ch] * ad + bd, v4 = c.fd[ch] * al + bl, v0 = v3 + v4;
         if (sg == 0) {
             sOut[0 + ch * 4 + k] = v0 * inv_ns; sOut[12 + ch * 4 + k] = v1 * inv_ns; sOut[24 + ch * 4 + k] = v2 * inv_ns;
             sOut[36 + ch * 4 + k] = v3 * inv_ns; sOut[48 + ch * 4 + k] = v4 * inv_ns;
