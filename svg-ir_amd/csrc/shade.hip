@@ -451,6 +451,13 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             gp[ch] *= inv_ns; gd[ch] *= inv_ns; gs[ch] *= inv_ns; gdi[ch] *= inv_ns; gin[ch] *= inv_ns;
             gmi[ch] *= inv_ns; gml[ch] *= inv_ns; gmg[ch] *= inv_ns;
         }
+        float kAd[3], kAl[3], kBd[3], kBl[3], qd[3], ql[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            qd[ch] = gdi[ch] + gp[ch]; ql[ch] = gin[ch] + gp[ch];            // d/df_d = qd * A_d + ql * A_l
+            kAd[ch] = gd[ch] + c.fd[ch] * qd[ch]; kAl[ch] = gd[ch] + c.fd[ch] * ql[ch];
+            kBd[ch] = gs[ch] + qd[ch]; kBl[ch] = gs[ch] + ql[ch];
+        }
         // lane k owns channel k (< 3) of dL/dradiance: constant part
         const float grad_const = k == 0 ? gmi[0] + gml[0] : (k == 1 ? gmi[1] + gml[1] : gmi[2] + gml[2]);
         float d_fd[3] = {0, 0, 0}, d_r = 0.f, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
@@ -489,19 +496,19 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 const float fs = r[9] * c.a2 * inv_nom;
                 const float area = act ? r[16] : 0.f, ge = area * ndi;
                 float d_fs = 0.f, d_ndi = 0.f;
-                float xi[3], xg[3], xl[3];
+                float xg[3], xl[3];   // d/d(global light), d/d(local light) of this (corner, sample)
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const float Lg = r[10 + ch], Ll = r[13 + ch], Li = Lg + Ll;
-                    const float f = c.fd[ch] + fs;
-                    // outputs: pbr = f*Li*ge, dif = Li*ge, spe = fs*Li*ge, dir = f*Lg*ge, ind = f*Ll*ge
-                    const float cLi = gp[ch] * f + gd[ch] + gs[ch] * fs;   // d/d(Li*ge)
-                    const float cLg = gdi[ch] * f, cLl = gin[ch] * f;
-                    xi[ch] = cLi * ge; xg[ch] = cLg * ge; xl[ch] = cLl * ge;
-                    const float df = (gp[ch] * Li + gdi[ch] * Lg + gin[ch] * Ll) * ge;   // d/df
-                    d_fd[ch] += df;
-                    d_fs += df + gs[ch] * Li * ge;
-                    d_ndi += (cLi * Li + cLg * Lg + cLl * Ll) * area;
+                    // The five outputs are linear in  A_d = Lg*ge, A_l = Ll*ge, B_d = fs*A_d, B_l = fs*A_l  (see the
+                    // forward): dL/dA_d = kAd, dL/dA_l = kAl, dL/dB_d = kBd, dL/dB_l = kBl are per-(corner, channel)
+                    // constants computed once per Gaussian.
+                    const float Lg = r[10 + ch], Ll = r[13 + ch];
+                    const float td = Lg * ge, tl = Ll * ge;
+                    const float cg = kAd[ch] + fs * kBd[ch], cl = kAl[ch] + fs * kBl[ch];
+                    xg[ch] = cg * ge; xl[ch] = cl * ge;
+                    d_fd[ch] += qd[ch] * td + ql[ch] * tl;
+                    d_fs += kBd[ch] * td + kBl[ch] * tl;
+                    d_ndi += (cg * Lg + cl * Ll) * area;
                 }
                 if (ndr > 0.f) {
 #pragma unroll
@@ -526,11 +533,11 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 
                 // ---- adjoint of the sample: sum the four corners (one quad), then lane k takes channel / tap k ----
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) { xi[ch] = quad_sum(xi[ch]); xg[ch] = quad_sum(xg[ch]); xl[ch] = quad_sum(xl[ch]); }
+                for (int ch = 0; ch < 3; ch++) { xg[ch] = quad_sum(xg[ch]); xl[ch] = quad_sum(xl[ch]); }
                 if (act) {
                     const size_t o = gg * Ns + s0 + s;
                     if (k < 3) {
-                        const float v = k == 0 ? xi[0] + xl[0] : (k == 1 ? xi[1] + xl[1] : xi[2] + xl[2]);
+                        const float v = k == 0 ? xl[0] : (k == 1 ? xl[1] : xl[2]);
                         a.d_radiance[o * 3 + k] = v + grad_const;
                     }
                     const uint32_t xy = __builtin_bit_cast(uint32_t, r[20]);
@@ -541,7 +548,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                         const int idx = (ty * We + tx) * 3;
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
-                            const float dt = (xi[ch] + xg[ch] + gmi[ch] + gmg[ch]) * r[17 + ch] * w;
+                            const float dt = (xg[ch] + gmi[ch] + gmg[ch]) * r[17 + ch] * w;
                             if (dt != 0.f) {
                                 // (ds_add_f32 is ~10x slower than the integer LDS atomics on gfx950 -- measured
                                 // ~500 cycles per wave instruction; still far cheaper than L2 atomics on 6144 texels)
