@@ -458,9 +458,11 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             kAd[ch] = gd[ch] + c.fd[ch] * qd[ch]; kAl[ch] = gd[ch] + c.fd[ch] * ql[ch];
             kBd[ch] = gs[ch] + qd[ch]; kBl[ch] = gs[ch] + ql[ch];
         }
+        const float gmig[3] = {gmi[0] + gmg[0], gmi[1] + gmg[1], gmi[2] + gmg[2]};   // constant part of the env gradient
         // lane k owns channel k (< 3) of dL/dradiance: constant part
         const float grad_const = k == 0 ? gmi[0] + gml[0] : (k == 1 ? gmi[1] + gml[1] : gmi[2] + gml[2]);
-        float d_fd[3] = {0, 0, 0}, d_r = 0.f, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
+        float d_fd[3] = {0, 0, 0}, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
+        float s_a2 = 0.f, s_nom1 = 0.f, s_kk2 = 0.f, s_nov = 0.f;   // per-Gaussian sums whose chain rule is applied once, below
         const float NoV = fminf(1.f, fmaxf(1e-6f, c.NoV_raw));
         const bool nov_in = c.NoV_raw >= 1e-6f && c.NoV_raw <= 1.f;
         for (int s0 = 0; s0 < Ns; s0 += 64) {
@@ -521,15 +523,13 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 const float d_nom1 = d_nom * t4 * nom0 * nom0 * nom2;
                 const float d_nom2 = d_nom * t4 * nom0 * nom0 * c.nom1;
                 // a2 enters frac (fs/a2) and nom0; kk enters nom1, nom2
-                const float d_a2 = d_fs * r[9] * inv_nom + d_nom0 * NoH * NoH;
-                const float d_kk = d_nom1 * (1.f - NoV) + d_nom2 * (1.f - NoL);
-                // a2 = r^4, kk = (r^2 + 2r + 1)/8
-                d_r += d_a2 * 4.f * c.r * c.r * c.r + d_kk * (2.f * c.r + 2.f) / 8.f;
+                s_a2 += d_fs * r[9] * inv_nom + d_nom0 * NoH * NoH;   // dL/da2
+                s_nom1 += d_nom1;                                      // nom1 = NoV (1 - kk) + kk is per-Gaussian
+                s_kk2 += d_nom2 * (1.f - NoL);                         // kk through nom2
                 const float d_NoH = (NoHr >= 1e-6f && NoHr <= 1.f) ? d_nom0 * 2.f * NoH * (c.a2 - 1.f) : 0.f;
                 const float d_NoL = (NoLr >= 1e-6f && NoLr <= 1.f) ? d_nom2 * (1.f - c.kk) : 0.f;
-                const float d_NoV = nov_in ? d_nom1 * (1.f - c.kk) : 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; j++) d_Nh[j] += d_NoH * r[6 + j] + d_NoL * r[3 + j] + d_NoV * V[j];
+                for (int j = 0; j < 3; j++) d_Nh[j] += d_NoH * r[6 + j] + d_NoL * r[3 + j];
 
                 // ---- adjoint of the sample: sum the four corners (one quad), then lane k takes channel / tap k ----
 #pragma unroll
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                         const int idx = (ty * We + tx) * 3;
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
-                            const float dt = (xg[ch] + gmi[ch] + gmg[ch]) * r[17 + ch] * w;
+                            const float dt = (xg[ch] + gmig[ch]) * r[17 + ch] * w;
                             if (dt != 0.f) {
                                 // (ds_add_f32 is ~10x slower than the integer LDS atomics on gfx950 -- measured
                                 // ~500 cycles per wave instruction; still far cheaper than L2 atomics on 6144 texels)
@@ -561,6 +561,15 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             }
         }
         TM_MARK(4);
+        // per-Gaussian chain rule of the sums: a2 = r^4, kk = (r^2 + 2r + 1)/8 (through nom1 and nom2), NoV -> Nh
+        float d_r;
+        {
+            const float d_kk = s_nom1 * (1.f - NoV) + s_kk2;
+            d_r = s_a2 * 4.f * c.r * c.r * c.r + d_kk * (2.f * c.r + 2.f) / 8.f;
+            const float d_NoV = nov_in ? s_nom1 * (1.f - c.kk) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; j++) d_Nh[j] += d_NoV * V[j];
+        }
         // Nh = sgn * n / |n|  =>  dn += sgn/|n| * (dNh - Nn (Nn . dNh)),  Nn = n/|n|
         {
             const float Nn[3] = {c.nraw[0] * c.inv_len, c.nraw[1] * c.inv_len, c.nraw[2] * c.inv_len};
