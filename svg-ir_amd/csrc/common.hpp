@@ -126,7 +126,7 @@ inline size_t grad_scratch_bytes(int cap, int S, int VS) {   // rows + one valid
 // candidate and once at the end; a backward segment starts its back-to-front replay from the state at its far end
 // (transmittance there, and "everything behind" = (final - prefix) / T) instead of from the end of the list.
 // Segment / state slot of sub-tile i = 4*tile+w, segment k:  (4*r0 + w*len) / SEG + i + k   (disjoint by construction).
-constexpr int SEG = 128;
+constexpr int SEG = 64;
 inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
 constexpr int SEG_K_BITS = 14;   // seg_map entry = (sub-tile id << SEG_K_BITS) | k ; 0xFFFFFFFF = no segment
 
