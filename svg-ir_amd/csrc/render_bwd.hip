@@ -70,7 +70,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int S, int VC>
 struct BwdGeom {
     using SG = StageGeom<S, VC>;
-    static constexpr int CHB = 16;                       // candidates staged per batch
+    static constexpr int CHB = (VC > 0) ? 16 : 8;        // candidates staged per batch (measured: 8 / 16 / 32 -> 203 / 212 /
+                                                         // 227 us rgss cfg2, 426 / 415 / 488 us svgss cfg3)
     static constexpr int SB = (VC > 0) ? 4 : 8;          // candidates per phase-A/phase-B sub-batch
     static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S  (<= 16)
     static constexpr int NG = NC0 + VC;                  // columns of G
