@@ -190,3 +190,26 @@ def test_envlight_hdr_map_with_transform(built):
     _close("mean_global", ex["global_incident_lights"].mean(-2), ref["mean_global"])
     for k in names:
         _close("grad_" + k, lg[k].grad, lo[k].grad, tol=3e-4)
+
+
+@pytest.mark.parametrize("Ns,He,We", [(1, 32, 64), (5, 16, 32), (65, 64, 128), (130, 32, 64)])
+def test_shading_odd_sample_counts_and_env_sizes(built, Ns, He, We):
+    """Partial 64-sample chunks, a single sample, and an env map too large for the LDS gradient image (64x128: the
+    backward falls back to global atomics on the env-gradient table)."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _random_case(120, Ns, 40 + Ns, He=He, We=We, rough_lo=0.3)
+    names = ("base", "rough", "normals", "radiance", "env")
+    lo = {k: d[k].clone().requires_grad_(True) for k in names}
+    ref = so.shade(lo["base"], lo["rough"], lo["normals"], d["viewdirs"], lo["radiance"], d["vis"], d["dirs"], d["areas"], lo["env"])
+    (ref["pbr"].sum() + ref["diffuse_light"].sum() + ref["mean_global"].sum()).backward()
+    lg = {k: d[k].float().to(dev).requires_grad_(True) for k in names}
+    c = {k: d[k].float().to(dev) for k in ("viewdirs", "vis", "dirs", "areas")}
+    pbr, ex = shading.rendering_equation4(lg["base"], lg["rough"], lg["normals"], c["viewdirs"], lg["radiance"], _Light(lg["env"]),
+                                          visibility_precompute=c["vis"], incident_dirs_precompute=c["dirs"],
+                                          incident_areas_precompute=c["areas"])
+    (pbr.sum() + ex["diffuse_light"].sum() + ex["global_incident_lights"].mean(-2).sum()).backward()
+    _close("pbr", pbr, ref["pbr"])
+    _close("diffuse_light", ex["diffuse_light"], ref["diffuse_light"])
+    for k in names:
+        _close("grad_" + k, lg[k].grad, lo[k].grad, tol=3e-4)
