@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 3
+#define SVGIR_ABI_VERSION 4
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -154,11 +154,16 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o,
 int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii,
                    char* geom_blob, char* binning_blob, size_t binning_bytes, char* image_blob,
                    char* scratch, size_t scratch_bytes, void* stream);
-/* Size of the optional backward scratch (device memory, contents irrelevant, only needed during the call).  With it
- * the composite gradients are accumulated without atomics -- every (instance, sub-tile) pair stores one gradient row
- * and a second kernel sums each Gaussian's rows in a fixed order: faster at the svgss widths and bit-reproducible.
- * With scratch == NULL the kernels fall back to float atomics on the dL_d* tensors. */
-size_t svgir_backward_scratch_bytes(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS);
+/* Size of the backward scratch (device memory, contents irrelevant on entry, only needed during the call; REQUIRED).
+ * The composite backward reduces every per-Gaussian gradient over the 64 pixels of a wave and then
+ *   svgss: stores one complete gradient row per (instance, sub-tile) pair, summed per Gaussian in a fixed order by a
+ *          second kernel (no atomics, bit-reproducible gradients): 4 * capacity rows + one validity byte per row;
+ *   rgss : accumulates with float atomics into ONE packed row per Gaussian (P rows), unpacked into the dL_d* tensors
+ *          by the per-Gaussian backward kernel.
+ * The reference accumulates with one global float atomic per (pixel, splat, output) straight into its dL_d* tensors
+ * (backward.cu:880-930) and needs no scratch; a binder allocates this buffer next to them. */
+size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_bytes, int32_t W, int32_t H, int32_t S,
+                                    int32_t VS);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:141-153).  `present` is a byte per
  * Gaussian.  svgss: the reference kernel body is commented out, so `present` is left untouched (all false, Q14);

@@ -282,15 +282,14 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     // for `cap`.  `timed`: stage marks are only recorded for the launch sequence that counts.
     auto run_binning_and_render = [&](char* bblob, int cap, bool timed) -> int {
         const BinLayout B = bin_layout(bblob, cap, T, nstate);
-        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges, B.seg_map,
-                    B.seg_cap, s);
+        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
+                    I.counters, s);
         if (int rc = check("emit")) return rc;
         if (timed) tm.mark("emit");
         launch_radix_sort(B.key, B.val, cap, G.counters, plan.bits, plan.bits_per_pass, B.radix_tbl, s);
         if (int rc = check("tile sort")) return rc;
         if (timed) tm.mark("sort_tile");
         launch_ranges(cap, G.counters, B.key[fin], I.ranges, T, s);
-        launch_tile_order(I.ranges, T, I.tile_order, s);
         if (int rc = check("ranges")) return rc;
         if (timed) tm.mark("ranges");
 
@@ -298,11 +297,16 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = svgss ? p->VS : 0;
         ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
         ra.bg = p->background;
-        ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_count = I.sub_count; ra.tile_order = I.tile_order;
-        ra.sub_ndump = I.sub_ndump; ra.seg_map = B.seg_map; ra.seg_state = B.seg_state;
+        ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_total = I.sub_total; ra.sub_order = I.sub_order;
+        ra.sub_count = I.sub_count;
+        ra.sub_ndump = I.sub_ndump; ra.seg_list = B.seg_list; ra.seg_count = I.counters; ra.seg_state = B.seg_state;
         ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
         ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
         ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
+        launch_cull(ra, s);
+        launch_order_desc(I.sub_total, 4 * T, I.sub_order, s);
+        if (int rc = check("cull")) return rc;
+        if (timed) tm.mark("cull");
         if (launch_render_fwd(ra, svgss, s) < 0)
             return fail(SVGIR_ERR_INVALID, "no forward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ra.VS,
                         svgss ? "svgss" : "rgss");
@@ -346,7 +350,10 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     return R;
 }
 
-size_t svgir_backward_scratch_bytes(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS) {
+size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_bytes, int32_t W, int32_t H, int32_t S,
+                                    int32_t VS) {
+    if (variant != SVGIR_SVGSS || VS == 0)   // one packed gradient row per Gaussian
+        return align_up((size_t)(P > 0 ? P : 1) * grad_row_geom(S, 0).RS * 4);
     const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const int cap = binning_capacity_from_bytes(binning_bytes, T, seg_nstate(S, VS));
     return grad_scratch_bytes(cap, S, VS);
@@ -379,25 +386,31 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = svgss ? p->VS : 0;
     ba.ranges = I.ranges; ba.point_list = B.val[fin]; ba.rec = G.rec; ba.features = p->features; ba.vfeatures = p->vfeatures;
     ba.bg = p->background;
-    ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count; ba.tile_order = I.tile_order;
-    ba.sub_ndump = I.sub_ndump; ba.seg_map = B.seg_map; ba.seg_state = B.seg_state; ba.seg_cap = (int)B.seg_cap;
+    ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count;
+    ba.sub_ndump = I.sub_ndump; ba.seg_list = B.seg_list; ba.seg_count = I.counters; ba.seg_state = B.seg_state;
+    ba.seg_cap = (int)B.seg_cap;
     ba.backward_geometry = p->backward_geometry;
     ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;
     ba.g_color = g->dL_dout_color; ba.g_normal = g->dL_dout_normal; ba.g_depth = g->dL_dout_depth;
     ba.g_opacity = g->dL_dout_opacity; ba.g_feature = g->dL_dout_feature; ba.g_vfeature = g->dL_dout_vfeature;
     ba.dL_dmean2D = g->dL_dmeans2D; ba.dL_dconic = g->dL_dconic; ba.dL_dopacity = g->dL_dopacity; ba.dL_dcolor = g->dL_dcolors;
     ba.dL_dfeature = g->dL_dfeatures; ba.dL_dvfeature = g->dL_dvfeatures; ba.dL_dnormal = g->dL_dnormal; ba.dL_ddepth = g->dL_ddepth;
-    // With scratch memory the composite writes gradient rows that grad_reduce sums per Gaussian (no atomics,
-    // deterministic); without it, it falls back to float atomics on the output tensors.
-    // (only worth it when a row is long: at the rgss widths the 18 atomics per pair cost less than the extra pass)
-    ba.grad_rows = nullptr; ba.row_flags = nullptr;
-    if (scratch && ba.VS > 0) {
-        if (scratch_bytes < grad_scratch_bytes(cap, p->S, ba.VS))
-            return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes()", scratch_bytes);
-        const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
-        ba.grad_rows = (float*)scratch;
+    // Composite gradients go through the scratch: svgss (VS > 0) -> one row per (instance, sub-tile) pair, summed per
+    // Gaussian by grad_reduce (no atomics, deterministic); otherwise one packed row per Gaussian accumulated with float
+    // atomics and unpacked by geom_bwd.
+    const size_t need = svgir_backward_scratch_bytes(p->variant, P, binning_bytes, W, H, p->S, ba.VS);
+    if (!scratch || scratch_bytes < need)
+        return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes() = %zu",
+                    scratch ? scratch_bytes : (size_t)0, need);
+    const bool rows = ba.VS > 0;
+    const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
+    ba.grad_rows = (float*)scratch;
+    ba.row_flags = nullptr;
+    if (rows) {
         ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
         if (R > 0) HIP_OK(hipMemsetAsync(ba.row_flags, 0, (size_t)4 * cap, s));
+    } else {
+        HIP_OK(hipMemsetAsync(ba.grad_rows, 0, (size_t)P * rg.RS * 4, s));
     }
     if (R > 0) {
         if (launch_render_bwd(ba, svgss, s) < 0)
@@ -405,7 +418,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
                         svgss ? "svgss" : "rgss");
     }
     tm.mark("render_bwd");
-    if (R > 0 && ba.grad_rows) {
+    if (R > 0 && rows) {
         GradReduceArgs ra;
         ra.P = P; ra.S = p->S; ra.VS = ba.VS; ra.radii = radii; ra.tiles = G.tiles; ra.rec = G.rec;
         ra.grad_rows = ba.grad_rows; ra.row_flags = ba.row_flags;
@@ -424,6 +437,8 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ga.cfg = cfg; ga.svgss = svgss;
     ga.dL_dmean2D = g->dL_dmeans2D; ga.dL_dconic = g->dL_dconic; ga.dL_dcolor = g->dL_dcolors; ga.dL_dnormal = g->dL_dnormal;
     ga.dL_ddepth = g->dL_ddepth;
+    ga.packed = rows ? nullptr : ba.grad_rows; ga.S = p->S;
+    ga.dL_dopacity = g->dL_dopacity; ga.dL_dfeature = g->dL_dfeatures;
     ga.dL_dmean3D = g->dL_dmeans3D; ga.dL_dcov3D = g->dL_dcov3D; ga.dL_dsh = g->dL_dsh; ga.dL_dscale = g->dL_dscales;
     ga.dL_drot = g->dL_drotations; ga.dL_dviewmat = g->dL_dviewmat; ga.dL_dprojmat = g->dL_dprojmat; ga.dL_dcampos = g->dL_dcampos;
     if (ga.scales && !ga.rotations) return fail(SVGIR_ERR_INVALID, "rotations missing");

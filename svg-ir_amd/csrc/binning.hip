@@ -215,11 +215,11 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
                                                      const int32_t* __restrict__ radii, int gx, int gy,
                                                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
                                                      uint32_t cap, uint32_t* __restrict__ ranges, int n_ranges,
-                                                     uint32_t* __restrict__ seg_map, int n_seg) {
+                                                     uint32_t* __restrict__ seg_count) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     // piggy-backed initialisation of two small tables used by later stages (saves two memset launches)
     for (int j = i; j < n_ranges; j += gridDim.x * BLOCK) ranges[j] = 0u;
-    for (int j = i; j < n_seg; j += gridDim.x * BLOCK) seg_map[j] = 0xFFFFFFFFu;
+    if (i == 0) seg_count[0] = 0u;
     if (i >= P) return;
     const uint32_t g = order[i];
     if (tiles[g] == 0) return;
@@ -257,8 +257,8 @@ __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t
     if (i == R - 1) ranges[2 * cur + 1] = (uint32_t)R;
 }
 
-// One-block counting sort of the T tiles by descending list length (1024 length buckets).
-__global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ ranges, int T,
+// One-block counting sort of n work items by descending size (1024 size buckets): order[] = item ids, largest first.
+__global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __restrict__ counts, int n,
                                                           uint32_t* __restrict__ order) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
@@ -268,14 +268,21 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __rest
     if (t == 0) maxlen_s = 0;
     __syncthreads();
     uint32_t mx = 0;
-    for (int i = t; i < T; i += 1024) mx = max(mx, ranges[2 * i + 1] - ranges[2 * i]);
+    for (int i = t; i < n; i += 1024) mx = max(mx, counts[i]);
     atomicMax(&maxlen_s, mx);
     __syncthreads();
     const uint32_t maxlen = maxlen_s + 1;
-    for (int i = t; i < T; i += 1024) {
-        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
-        const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
-        atomicAdd(&hist[b], 1u);
+    // Items of size 0 (most of an image is usually empty) all land in the last bucket: they are counted with one
+    // atomic per wave instead of one per item, and placed in index order at the very end.
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + t;
+        const uint32_t len = i < n ? counts[i] : 1u;
+        const unsigned long long zero = __ballot(i < n && len == 0u);
+        if (i < n && len != 0u) {
+            const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
+            atomicAdd(&hist[b], 1u);
+        }
+        if (lane == 0 && zero) atomicAdd(&hist[1023], (uint32_t)__popcll(zero));
     }
     __syncthreads();
     // exclusive scan of hist over the 1024 threads
@@ -293,17 +300,27 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __rest
     __syncthreads();
     hist[t] = woff + incl - v;  // becomes the bucket cursor
     __syncthreads();
-    for (int i = t; i < T; i += 1024) {
-        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
-        const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
-        order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + t;
+        const uint32_t len = i < n ? counts[i] : 1u;
+        const bool z = i < n && len == 0u;
+        const unsigned long long zero = __ballot(z);
+        if (i < n && len != 0u) {
+            const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
+            order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
+        }
+        uint32_t zbase = 0;
+        if (lane == 0 && zero) zbase = atomicAdd(&hist[1023], (uint32_t)__popcll(zero));
+        zbase = (uint32_t)__shfl((int)zbase, 0);
+        if (z) order[zbase + (uint32_t)__popcll(zero & lt_mask)] = (uint32_t)i;
     }
 }
 
 }  // namespace
 
-void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, T, order);
+void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s) {
+    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order);
 }
 
 template <int ITEMS>
@@ -346,9 +363,9 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
 
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
-                 uint32_t* seg_map, size_t seg_cap, hipStream_t s) {
+                 uint32_t* seg_count, hipStream_t s) {
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,
-                       radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy, seg_map, (int)seg_cap);
+                       radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy, seg_count);
 }
 
 // `ranges` must already be zero (launch_emit clears it)

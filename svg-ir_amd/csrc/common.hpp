@@ -22,9 +22,12 @@ constexpr int REC = 24;  // floats per splat record
 // Record field offsets (floats).  First 6 floats = the "header" the composite kernels stage in LDS.
 enum RecField {
     R_X = 0, R_Y = 1, R_CX = 2, R_CY = 3,      // float4 #0: mean2D, conic.x, conic.y
-    R_CZ = 4, R_OP = 5, R_DEPTH = 6, R_J6 = 7, // float4 #1: conic.z, opacity, view depth, ax0.z
+    R_CZ = 4, R_OP = 5, R_DEPTH = 6, R_DA = 7, // float4 #1: conic.z, opacity, view depth, d(depth)/d(dx)
     R_J0 = 8, R_J1 = 9, R_J2 = 10, R_J3 = 11,  // float4 #2: screen->tangent 2x2
-    R_J9 = 12, R_R = 13, R_G = 14, R_B = 15,   // float4 #3: ax1.z, rgb
+    R_DB = 12, R_R = 13, R_G = 14, R_B = 15,   // float4 #3: d(depth)/d(dy), rgb
+                                               //   depth differencing (auxiliary.h:390-397, .z): (dx J0 + dy J1) ax0.z +
+                                               //   (dx J2 + dy J3) ax1.z = dx DA + dy DB, DA = J0 ax0.z + J2 ax1.z,
+                                               //   DB = J1 ax0.z + J3 ax1.z -- the only way ax0.z / ax1.z are ever used
     R_NX = 16, R_NY = 17, R_NZ = 18, R_IU = 19,// float4 #4: view normal, 1/(0.5*scale.x+0.1)
     R_IV = 20, R_IBASE = 21, R_RECT = 22, R_PAD2 = 23  // float4 #5: 1/(0.5*scale.y+0.1); [written by emit:] index of the
                                                        // Gaussian's first instance in emit order (u32 bits); tile rect
@@ -82,9 +85,11 @@ struct ImageLayout {
     float* final_D;      // [N]
     int32_t* n_contrib;  // [N]
     uint32_t* ranges;    // [2*T]
-    uint32_t* tile_order; // [T] tiles sorted by descending list length (heaviest work is dispatched first)
-    uint32_t* sub_count; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the forward)
+    uint32_t* sub_total; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the cull kernel)
+    uint32_t* sub_order; // [4*T] sub-tiles sorted by descending candidate count (heaviest work is dispatched first)
+    uint32_t* sub_count; // [4*T] #candidates the forward composite consumed before every pixel was done (<= sub_total)
     uint32_t* sub_ndump; // [4*T] #segment-boundary states the forward dumped for the sub-tile (see SEG)
+    uint32_t* counters;  // [4]: [0] = number of live backward segments (entries of BinLayout::seg_list)
     size_t ncontrib_off;
     size_t bytes;
 };
@@ -99,9 +104,11 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.ncontrib_off = off;
     im.n_contrib = (int32_t*)take(N * 4);
     im.ranges = (uint32_t*)take(T * 8);
-    im.tile_order = (uint32_t*)take(T * 4);
+    im.sub_total = (uint32_t*)take(T * 4 * 4);
+    im.sub_order = (uint32_t*)take(T * 4 * 4);
     im.sub_count = (uint32_t*)take(T * 4 * 4);
     im.sub_ndump = (uint32_t*)take(T * 4 * 4);
+    im.counters = (uint32_t*)take(16);
     im.bytes = off;
     return im;
 }
@@ -125,10 +132,18 @@ inline size_t grad_scratch_bytes(int cap, int S, int VS) {   // rows + one valid
 // sub-tile's compact list.  The forward dumps its per-pixel blend state (T and every accumulator) after each SEG-th
 // candidate and once at the end; a backward segment starts its back-to-front replay from the state at its far end
 // (transmittance there, and "everything behind" = (final - prefix) / T) instead of from the end of the list.
-// Segment / state slot of sub-tile i = 4*tile+w, segment k:  (4*r0 + w*len) / SEG + i + k   (disjoint by construction).
+// State slot of sub-tile i = 4*tile+w, segment k:  (4*r0 + w*len) / SEG + i + k   (disjoint by construction).
+// The live segments are appended by the forward to a compact list (seg_list, seg_count) that the backward's
+// persistent waves walk.
 constexpr int SEG = 64;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t seg_state_base(uint32_t r0, uint32_t len, int tile, int sub) {
+    return (uint32_t)(((size_t)4 * r0 + (size_t)sub * len) / SEG) + (uint32_t)(4 * tile + sub);
+}
 inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
-constexpr int SEG_K_BITS = 14;   // seg_map entry = (sub-tile id << SEG_K_BITS) | k ; 0xFFFFFFFF = no segment
+constexpr int SEG_K_BITS = 14;   // seg_list entry = (sub-tile id << SEG_K_BITS) | k
 
 // The binning blob is laid out for an instance CAPACITY (a multiple of 4096 >= R): the forward may size it from a
 // guess before the host knows R, and the backward recovers the capacity from the blob's byte size.
@@ -143,7 +158,7 @@ struct BinLayout {
     uint32_t* radix_tbl;
     uint2* sub_list;   // [4*R] compact per-sub-tile candidate lists {Gaussian id, slot in the tile list}; sub-tile w
                        // of a tile with range [r0,r1) owns entries [4*r0 + w*(r1-r0), 4*r0 + (w+1)*(r1-r0))
-    uint32_t* seg_map; // [seg_capacity] live backward segments (written by the forward)
+    uint32_t* seg_list; // [seg_capacity] live backward segments, compact (appended by the forward)
     float* seg_state;  // [seg_capacity][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
     size_t seg_cap;
     size_t bytes;
@@ -161,7 +176,7 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     b.radix_tbl = (uint32_t*)take(radix_table_words(R) * 4);
     b.sub_list = (uint2*)take(r * 4 * 8);
     b.seg_cap = seg_capacity(R, T);
-    b.seg_map = (uint32_t*)take(b.seg_cap * 4);
+    b.seg_list = (uint32_t*)take(b.seg_cap * 4);
     b.seg_state = (float*)take(b.seg_cap * (size_t)nstate * 64 * 4);
     b.bytes = off;
     return b;
@@ -217,8 +232,8 @@ struct RenderArgs {
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
     CfgRef cfg;
-    uint2* sub_list; uint32_t* sub_count; const uint32_t* tile_order;
-    uint32_t* sub_ndump; uint32_t* seg_map; float* seg_state;
+    uint2* sub_list; uint32_t* sub_total; uint32_t* sub_order; uint32_t* sub_count;
+    uint32_t* sub_ndump; uint32_t* seg_list; uint32_t* seg_count; float* seg_state;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
 };
@@ -229,12 +244,12 @@ struct RenderBwdArgs {
     const float* rec; const float* features; const float* vfeatures;
     const float* bg;
     CfgRef cfg; int backward_geometry;
-    const uint2* sub_list; const uint32_t* sub_count; const uint32_t* tile_order;
-    const uint32_t* sub_ndump; const uint32_t* seg_map; const float* seg_state; int seg_cap;
+    const uint2* sub_list; const uint32_t* sub_count;
+    const uint32_t* sub_ndump; const uint32_t* seg_list; const uint32_t* seg_count; const float* seg_state; int seg_cap;
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
-    float* grad_rows; uint8_t* row_flags;   // non-null: write gradient rows instead of issuing atomics
+    float* grad_rows; uint8_t* row_flags;   // svgss (VS > 0): gradient rows + validity bytes; else: packed rows [P][RS]
 };
 
 struct GradReduceArgs {
@@ -250,7 +265,10 @@ struct GeomBwdArgs {
     const int32_t* radii; const uint32_t* clamped;
     float scale_modifier, tanx, tany, focal_x, focal_y;
     CfgRef cfg; int svgss;
-    const float *dL_dmean2D, *dL_dconic, *dL_dcolor, *dL_dnormal, *dL_ddepth;
+    // composite gradients: the caller's tensors; when `packed` is set (one GradRowGeom(S, 0) row per Gaussian, written by
+    // the backward composite) the kernel first unpacks the Gaussian's row into them
+    float *dL_dmean2D, *dL_dconic, *dL_dcolor, *dL_dnormal, *dL_ddepth, *dL_dopacity, *dL_dfeature;
+    const float* packed; int S;
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot, *dL_dviewmat, *dL_dprojmat, *dL_dcampos;
 };
 
@@ -270,13 +288,15 @@ void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, co
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
                          uint32_t* total_out, hipStream_t s);
-// also clears ranges[2*gx*gy] and marks every seg_map[seg_cap] entry empty
+// also clears ranges[2*gx*gy] and the live-segment counter
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
-                 uint32_t* seg_map, size_t seg_cap, hipStream_t s);
+                 uint32_t* seg_count, hipStream_t s);
 void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
-// order[] = tile ids sorted by descending list length (longest-processing-time-first dispatch of the composite waves)
-void launch_tile_order(const uint32_t* ranges, int T, uint32_t* order, hipStream_t s);
+// order[] = item ids sorted by descending counts[] (longest-processing-time-first dispatch of the composite waves)
+void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s);
+// per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
+void launch_cull(const RenderArgs& a, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 if (S,VS) unsupported
 int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 if (S,VS) unsupported
 void launch_grad_reduce(const GradReduceArgs& a, hipStream_t s);

@@ -45,6 +45,19 @@ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    if (a.packed) {
+        // rgss: the backward composite accumulated this Gaussian's gradients in one packed row (common.hpp GradRowGeom:
+        // colour3, normal3, depth, feature S | pad | mean2D.xy, conic.xyz, opacity); unpack it into the caller's tensors
+        const int P4 = (7 + a.S + 3) / 4 * 4, RS = (P4 + 6 + 3) / 4 * 4;
+        const float* row = a.packed + (size_t)idx * RS;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { a.dL_dcolor[3 * idx + c] = row[c]; a.dL_dnormal[3 * idx + c] = row[3 + c]; }
+        a.dL_ddepth[idx] = row[6];
+        for (int c = 0; c < a.S; c++) a.dL_dfeature[(size_t)idx * a.S + c] = row[7 + c];
+        a.dL_dmean2D[3 * idx] = row[P4]; a.dL_dmean2D[3 * idx + 1] = row[P4 + 1];
+        a.dL_dconic[4 * idx] = row[P4 + 2]; a.dL_dconic[4 * idx + 1] = row[P4 + 3]; a.dL_dconic[4 * idx + 3] = row[P4 + 4];
+        a.dL_dopacity[idx] = row[P4 + 5];
+    }
     const bool surface = cfg_flag(a.cfg, 0);
     const bool lrn_cam = a.svgss && a.cfg.len >= 0 && cfg_flag(a.cfg, 3);
     const float* V = a.view;

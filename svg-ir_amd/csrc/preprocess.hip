@@ -276,9 +276,11 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     }
     float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC);
     rec[0] = make_float4(pix[0], pix[1], conic[0], conic[1]);
-    rec[1] = make_float4(conic[2], a.opacities[idx], pv[2], J[6]);
+    // depth-differencing coefficients (common.hpp R_DA / R_DB)
+    const float da = J[0] * J[6] + J[2] * J[9], db = J[1] * J[6] + J[3] * J[9];
+    rec[1] = make_float4(conic[2], a.opacities[idx], pv[2], da);
     rec[2] = make_float4(J[0], J[1], J[2], J[3]);
-    rec[3] = make_float4(J[9], rgb[0], rgb[1], rgb[2]);
+    rec[3] = make_float4(db, rgb[0], rgb[1], rgb[2]);
     rec[4] = make_float4(nv[0], nv[1], nv[2], iu);
     rec[5] = make_float4(iv, 0.f, 0.f, 0.f);
 }

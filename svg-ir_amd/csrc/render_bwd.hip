@@ -7,90 +7,86 @@
 //
 // CDNA4 mapping
 //   * one wave64 per depth segment of an 8x8-pixel sub-tile (one wave per workgroup, no barriers across waves): SEG
-//     consecutive entries of the compact candidate list {Gaussian id, slot} that the forward kernel wrote for the
+//     consecutive entries of the compact candidate list {Gaussian id, slot} that the cull kernel wrote for the
 //     sub-tile (nothing is culled twice), walked in reverse.  The deepest live segment starts from final_T like the
 //     reference; every other one starts from the forward state dumped at its far end (T there, and the blend of
 //     everything behind = (final accumulators - prefix accumulators) / T), which turns the reference's strictly
-//     sequential per-pixel replay into ~2x more, much shorter and evenly sized work items;
-//   * candidates are staged CHB at a time into LDS like in the forward (stage.hpp); LDS per wave is kept small
-//     (9 KB rgss / 18 KB svgss-train) because the kernel is latency-bound and lives off waves per SIMD;
+//     sequential per-pixel replay into many short, evenly sized work items.  The waves stride over the compact list
+//     of live segments the forward appended (seg_list / seg_count, read on the device), so no workgroup is
+//     launched for a dead segment;
+//   * candidates are staged CHB at a time into LDS like in the forward (stage.hpp), the gathers of the next batch in
+//     flight while the current one is replayed;
 //   * per-pixel replay state (running accumulators, last values, upstream gradients) lives in VGPRs thanks to
 //     compile-time channel counts (the reference keeps ~330 floats per thread in scratch, backward.cu:617-635);
+//   * the replay is written in lock-step over groups of KB candidates and without branches: alphas, corner weights
+//     and the dot products with the upstream gradients are KB independent instruction streams, only the (T, A)
+//     recurrence is sequential;
 //   * gradient accumulation.  The reference issues 13 + S + VS global float atomics per (pixel, splat) pair
-//     (18 / 69 / 84).  All per-Gaussian gradients except the 6 geometric ones have the form
-//         dL/dq[g][ch] = sum over pixels of  a_v[pixel] * G[pixel][ch]
-//     with a per-sub-tile-constant matrix G (upstream image gradients) and only 1 (+4 for the bilinear corners)
-//     per-pair scalars a_v.  The replay is therefore split in two phases per sub-batch of SB candidates:
-//       phase A (lane = pixel): replay, alpha gradient; the 1+4 per-pair scalars go to an LDS panel
-//                [candidate][vector][pixel]; the 6 geometric gradients are pre-reduced over 8-lane octants with 3
-//                DPP steps and stored as [candidate][6][8];
-//       phase B: the contraction panel[rows][64 pixels] x G[64 pixels][channels] runs on the matrix pipe as
-//                16 (+16 for the vfeature channels) v_mfma_f32_16x16x4_f32 per sub-batch -- exact fp32, G held in
-//                registers in the B-operand layout -- and each lane issues the atomics of the (row, channel)
-//                results it ends up holding.  (This is the one genuinely dense contraction of the path; the
-//                blending itself stays scalar.)
+//     (18 / 69 / 84).  Here every per-Gaussian gradient is first reduced over the 64 pixels of the wave:
+//       - all gradients except the 6 geometric ones have the form  dL/dq[g][ch] = sum_pixels a_v[pixel] G[pixel][ch]
+//         with a per-sub-tile-constant matrix G (upstream image gradients) and only 1 (+4 for the bilinear corners)
+//         per-pair scalars a_v: phase A (lane = pixel) writes the scalars to an LDS panel [row][64 pixels], phase B
+//         runs the contraction panel[rows][64] x G[64][channels] on the matrix pipe (v_mfma_f32_16x16x4_f32, exact
+//         fp32; the one genuinely dense contraction of the path -- the blending itself stays scalar);
+//       - the 6 geometric gradients (mean2D.xy, conic.xyz, opacity) are written to a second LDS panel
+//         [candidate][6][64 pixels] and summed lane-parallel: 2-4 lanes per (candidate, value) row read 16-32 pixels
+//         with ds_read_b128 and finish with 1-2 DPP adds (instead of 18 DPP steps + masked stores per candidate);
+//     the per-(wave, splat) results then go to memory as
+//       - rgss: float atomics into ONE packed row per Gaussian (common.hpp GradRowGeom, 20 floats at S=5): a single
+//         scalar base + 32-bit offset per atomic, one atomic instruction per 16 candidates x 4 register rows;
+//         geom_bwd.hip unpacks the rows into the caller's tensors;
+//       - svgss: plain stores of the complete gradient row of the (instance, sub-tile) pair, summed per Gaussian by
+//         grad_reduce.hip (no atomics, bit-reproducible).
+#include <algorithm>
+
 #include "common.hpp"
 #include "stage.hpp"
+#include "dev_trace.hpp"
 
 namespace svgir {
 
 namespace {
 
-
-// sum over the 8 lanes of an aligned octant (lanes differing in their low 3 bits); result in all 8 lanes
-__device__ __forceinline__ float octant_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
-    return v;
-}
-
-#ifdef RENDER_TIMING
-__device__ unsigned long long g_bwd_tm[16];
-#define TM_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_acc[i] += t_ - tm_prev; tm_prev = t_; } while (0)
-#define TM_COUNT(i, n) tm_acc[i] += (unsigned long long)(n)
-#ifdef RENDER_TIMING_FINE
-#define TM_FINE(i) TM_MARK(i)
-#else
-#define TM_FINE(i)
-#endif
-#else
-#define TM_FINE(i)
-#define TM_MARK(i)
-#define TM_COUNT(i, n)
-#endif
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifdef EXP_NO_ATOMICS   // timing experiment: keep the arithmetic alive, drop (almost) every atomic
-#define BWD_ATOMIC(p, v) do { if ((v) == 123.456f) atomic_add_f32((p), (v)); } while (0)
-#else
-#define BWD_ATOMIC(p, v) atomic_add_f32((p), (v))
-#endif
-
 template <int S, int VC>
 struct BwdGeom {
     using SG = StageGeom<S, VC>;
-    static constexpr int CHB = (VC > 0) ? 16 : 8;        // candidates staged per batch (measured: 8 / 16 / 32 -> 203 / 212 /
-                                                         // 227 us rgss cfg2, 426 / 415 / 488 us svgss cfg3)
-    static constexpr int SB = (VC > 0) ? 4 : 8;          // candidates per phase-A/phase-B sub-batch
+#ifndef BWD_KB_V
+#define BWD_KB_V 2
+#endif
+#ifndef BWD_KB_P
+#define BWD_KB_P 4
+#endif
+    static constexpr int KB = (VC > 0) ? BWD_KB_V : BWD_KB_P;   // candidates replayed per branch-free group
+    static constexpr int CHB = 16;                       // candidates staged per batch
+    static constexpr int SB = (VC > 0) ? 4 : 8;          // candidates per phase-B contraction (<= 16 panel rows)
     static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S  (<= 16)
     static constexpr int NG = NC0 + VC;                  // columns of G
-    static constexpr int GROW = NG + 1;
-    static constexpr int PROWS = (VC > 0) ? 16 : SB;     // panel rows: (candidate, corner) or candidate
-    static constexpr int PS = 68;                        // panel row stride (floats): 16-byte aligned rows
+    static constexpr int GROW = NG + 1;                  // odd or even, padded so that lanes hit different banks
+    static constexpr int PS = 68;                        // panel row stride (floats): 16-byte aligned, bank-staggered rows
+    static constexpr int GEO_ROWS = KB * 6;              // geometric panel rows of one group
+    static constexpr int LPR = KB >= 4 ? 2 : (KB == 2 ? 4 : 8);   // lanes that share one geometric row
 #ifndef BWD_WPE_V
-#define BWD_WPE_V 3
-#define BWD_WPE_P 5
+#define BWD_WPE_V 2
 #endif
-    // waves per SIMD the register budget is held to (measured: 5 rgss, 3 svgss-train; the eval widths need > 170 VGPRs)
-    static constexpr int WPE = (VC > 13 || S + VC > 17) ? 2 : ((VC > 0) ? BWD_WPE_V : BWD_WPE_P);
+#ifndef BWD_WPE_P
+#define BWD_WPE_P 3
+#endif
+    // waves per SIMD the register budget is held to
+    static constexpr int WPE = (VC > 0) ? BWD_WPE_V : BWD_WPE_P;
     static constexpr size_t off_q = (size_t)CHB * SG::NF * 4;
-    static constexpr size_t off_p = off_q + (size_t)SEG * 8;   // the whole segment's {gid, slot} entries
+    static constexpr size_t off_p = off_q + (size_t)SEG * 8;          // the whole segment's {gid, slot} entries
+    static constexpr int PROWS = (VC > 0) ? 16 : SB;                  // weight panel rows: (candidate, corner) or candidate
     static constexpr size_t off_pg = off_p + (size_t)PROWS * PS * 4;
-    static constexpr size_t run_bytes = off_pg + (size_t)SB * 6 * 8 * 4;
-    static constexpr size_t g_bytes = (size_t)64 * GROW * 4;   // G is only staged through LDS once, at setup
-    static constexpr size_t lds_bytes = run_bytes > g_bytes ? run_bytes : g_bytes;
+    static constexpr size_t geo_bytes = (size_t)GEO_ROWS * PS * 4;
+    static constexpr size_t g_bytes = (size_t)64 * GROW * 4;
+    // G (the MFMA B operand): svgss keeps it in LDS for the whole segment (two column groups, 32 VGPRs otherwise);
+    // rgss transposes it once through LDS (aliasing the geometric panel) into 16 VGPRs -- its LDS budget decides
+    // how many waves a CU holds.
+    static constexpr bool G_IN_REGS = (VC == 0);
+    static constexpr size_t off_g = G_IN_REGS ? off_pg : off_pg + geo_bytes;
+    static constexpr size_t lds_bytes = G_IN_REGS ? off_pg + (geo_bytes > g_bytes ? geo_bytes : g_bytes) : off_g + g_bytes;
     static_assert(NC0 <= 16 && VC <= 16, "one 16-wide MFMA column tile per channel group");
+    static_assert(SB % KB == 0 && CHB % SB == 0 && GEO_ROWS * LPR <= 64, "batch nesting");
 };
 
 template <int S, int VC, bool SVGSS>
@@ -99,40 +95,52 @@ render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int VS = VC * 4;
     using SG = StageGeom<S, VC>;
     using BG = BwdGeom<S, VC>;
-    constexpr int SB = BG::SB, NC0 = BG::NC0, GROW = BG::GROW, CHB = BG::CHB, PS = BG::PS;
+    constexpr int SB = BG::SB, KB = BG::KB, NC0 = BG::NC0, GROW = BG::GROW, CHB = BG::CHB, PS = BG::PS, LPR = BG::LPR;
     constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
+    constexpr int P4 = (NC0 + 3) / 4 * 4, GEO = P4 + VS, RS = (GEO + 6 + 3) / 4 * 4;   // common.hpp GradRowGeom
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sD = reinterpret_cast<float*>(smem);                    // [CHB][NF] staged candidates
     uint2* sQ = reinterpret_cast<uint2*>(smem + BG::off_q);        // [SEG] {gid, slot} of the segment, deepest first
-    float* sG = reinterpret_cast<float*>(smem);                    // [64][GROW] upstream gradients (setup only; aliases sD..)
-    float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [PROWS][PS] blend-weight panel (MFMA A operand)
-    float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [SB][6][8] octant-reduced geometric gradients
+    float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [16][PS] blend-weight panel (MFMA A operand)
+    float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [KB*6][PS] geometric gradients per pixel
+    float* sG = reinterpret_cast<float*>(smem + BG::off_g);        // [64][GROW] upstream gradients of the sub-tile (MFMA B operand)
 
-    // one wave per live depth segment (common.hpp SEG): seg_map[b] = (sub-tile id << SEG_K_BITS) | k
-    const uint32_t sm = a.seg_map[blockIdx.x];
-    if (sm == 0xFFFFFFFFu) return;
-#ifdef RENDER_TIMING
-    unsigned long long tm_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tm_prev = __builtin_amdgcn_s_memtime();
-#endif
+    const int lane = threadIdx.x;
+    const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
+    const bool sp = surface && cfg_flag(a.cfg, 2);
+    const bool bgeom = SVGSS ? true : (a.backward_geometry != 0);
+    const size_t N_ = (size_t)a.W * a.H;
+    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    const int colB = lane & 15, grpB = lane >> 4;
+
+    // The staging buffer and the weight panel start as zeros: slots beyond a batch's size then always hold finite values
+    // (zeros or an older candidate), so the replay needs no per-candidate bounds branches -- such slots get weight 0.
+    for (int i = lane; i < (int)(BG::off_q / 16); i += 64) reinterpret_cast<float4*>(sD)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < BG::PROWS * PS / 4; i += 64) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // the waves stride over the compact list of live depth segments (common.hpp SEG) the forward appended;
+    // entry = (sub-tile id << SEG_K_BITS) | k
+    const uint32_t nlive = min(a.seg_count[0], (uint32_t)a.seg_cap);
+    if (blockIdx.x >= nlive) return;
+    DEV_TRACE_DECL();
+    unsigned dev_items = 0, dev_cands = 0;
+    for (uint32_t item = blockIdx.x; item < nlive; item += gridDim.x) {
+    DEV_TRACE_MARK(3);
+    wave_lds_sync();   // the previous segment's LDS traffic is complete before its buffers are reused
+    const uint32_t sm = a.seg_list[item];
     const int sid = (int)(sm >> SEG_K_BITS), kseg = (int)(sm & ((1u << SEG_K_BITS) - 1u));
     const int tile = sid >> 2, sub = sid & 3;
     const int count = (int)a.sub_count[sid];
     const int ndump = (int)a.sub_ndump[sid];
     const int seg_lo = kseg * SEG, seg_hi = min(count, seg_lo + SEG);
-    if (seg_hi <= seg_lo) return;
+    if (seg_hi <= seg_lo) continue;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int lane = threadIdx.x;
     const int px = tx * TILE + (sub & 1) * 8 + (lane & 7);
     const int py = ty * TILE + (sub >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const uint2* __restrict__ sub_in = a.sub_list + (size_t)4 * r0 + (size_t)sub * (r1 - r0);
-    const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
-    const bool sp = surface && cfg_flag(a.cfg, 2);
-    const bool bgeom = SVGSS ? true : (a.backward_geometry != 0);
-    const size_t N_ = (size_t)a.W * a.H;
     const size_t pid = inside ? (size_t)a.W * py + px : 0;
 
     const float T_final = inside ? a.final_T[pid] : 0.f;
@@ -147,21 +155,22 @@ render_bwd_kernel(const RenderBwdArgs a) {
     for (int i = 0; i < VV; i++) gVF[i] = (inside && i < VC) ? a.g_vfeature[i * N_ + pid] : 0.f;
     if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
     const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
-    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const float omt = 1.f - T_final;
     const float gDn = normalize_depth ? gD / omt : gD;  // depth gradient seen by the blended depth
     // d(depth normalisation)/d alpha of the reference, gD*D_final/(1-Tf)^2 * -Tf/(1-alpha)/T_new, equals kdn / T_old
     const float kdn = normalize_depth ? -gD * D_final * T_final / (omt * omt) : 0.f;
-    const float kbg = bgdot + (normalize_depth ? 0.f : 10.f * gD);   // background (+ un-normalised depth) term
-    const float q5 = sp ? -gD : 0.f;
+    const float gO_kbg = gO - (bgdot + (normalize_depth ? 0.f : 10.f * gD));   // opacity minus background (+ un-normalised depth) term
+    const float q5g = sp ? -gD : 0.f;   // Q5: un-weighted depth-differencing term
 
     // deepest contributor of the wave
     uint32_t wmax = last_contributor;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
-    if (wmax == 0) return;
+    if (wmax == 0) continue;
 
-    // G matrix of this sub-tile: row = pixel (lane), columns = [colour3 | normal3 x10 (Q4) | depth | feature S | vfeature VC]
+    // G matrix of this sub-tile: row = pixel (lane), columns = [colour3 | normal3 x10 (Q4) | depth | feature S | vfeature VC].
+    // Phase B needs it as the MFMA B operand (lane l: G[pixel = 16*(l>>4) + kk][channel = l&15], kk = 0..15): svgss reads
+    // it from LDS right before the MFMAs, rgss keeps the 16 values in registers (BwdGeom::G_IN_REGS).
     {
         float* g = sG + lane * GROW;
         g[0] = gC[0]; g[1] = gC[1]; g[2] = gC[2];
@@ -173,33 +182,13 @@ render_bwd_kernel(const RenderBwdArgs a) {
         for (int i = 0; i < VC; i++) g[NC0 + i] = gVF[i];
     }
 
-    // Phase B is the contraction  out[row][ch] = sum_pixel panel[row][pixel] * G[pixel][ch]  on the matrix pipe
-    // (v_mfma_f32_16x16x4_f32, exact fp32).  G is transposed once through LDS into the B-operand layout and then
-    // lives in registers: lane l holds G[pixel = 16*(l>>4) + kk][channel = l&15] for kk = 0..15, one set for the
-    // plain channels and one for the vfeature channels.
-    wave_lds_sync();
-    const int colB = lane & 15, grpB = lane >> 4;
-    float Bp[16], Bv[16];
+    float Bp[16];
+    if (BG::G_IN_REGS) {
+        wave_lds_sync();
+        const float* gB = sG + (16 * grpB) * GROW + (colB < NC0 ? colB : 0);
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        const float* g = sG + (16 * grpB + kk) * GROW;
-        Bp[kk] = colB < NC0 ? g[colB] : 0.f;
-        Bv[kk] = (VC > 0 && colB < VC) ? g[NC0 + (VC > 0 ? colB : 0)] : 0.f;
-    }
-    wave_lds_sync();   // sG is dead from here on (its LDS is reused by the staging buffers and the panel)
-    // destination of the plain channel colB
-    float* pbase = nullptr; int pstride = 0;
-    if (colB < 3) { pbase = a.dL_dcolor + colB; pstride = 3; }
-    else if (colB < 6) { pbase = a.dL_dnormal + (colB - 3); pstride = 3; }
-    else if (colB < 7) { pbase = a.dL_ddepth; pstride = 1; }
-    else if (colB < NC0) { pbase = a.dL_dfeature + (colB - 7); pstride = S; }
-    // geometric channel owned by this lane in phase B: lane = (candidate lane>>3, value lane&7 < 6)
-    float* gbase = nullptr; int gstride = 0;
-    {
-        const int j = lane & 7;
-        if (j < 2) { gbase = a.dL_dmean2D + j; gstride = 3; }
-        else if (j < 5) { gbase = a.dL_dconic + (j == 4 ? 3 : j - 2); gstride = 4; }
-        else if (j < 6) { gbase = a.dL_dopacity; gstride = 1; }
+        for (int kk = 0; kk < 16; kk++) Bp[kk] = colB < NC0 ? gB[kk * GROW] : 0.f;
+        wave_lds_sync();   // sG aliases the geometric panel
     }
 
     // Replay state.  The reference keeps, per channel, the blend of everything behind the current splat (accum_rec)
@@ -215,9 +204,9 @@ render_bwd_kernel(const RenderBwdArgs a) {
         // Not the deepest live segment: start from the forward state dumped at this segment's far end.  With
         // last_alpha = 0 the recurrence takes accum = blend of everything behind = (final - prefix) / T_end.
         constexpr int NST = 8 + S + VC;
-        const uint32_t base = blockIdx.x - (uint32_t)kseg;   // state slot of (sub-tile, 0)
-        const float* e = a.seg_state + ((size_t)(base + kseg) * NST) * 64 + lane;
-        const float* f = a.seg_state + ((size_t)(base + ndump) * NST) * 64 + lane;   // final state
+        const uint32_t sbase = seg_state_base(r0, r1 - r0, tile, sub);   // state slot of (sub-tile, 0)
+        const float* e = a.seg_state + ((size_t)(sbase + kseg) * NST) * 64 + lane;
+        const float* f = a.seg_state + ((size_t)(sbase + ndump) * NST) * 64 + lane;   // final state
         T = e[0];
         float dot = (f[7 * 64] - e[7 * 64]) * gDn;
 #pragma unroll
@@ -239,11 +228,13 @@ render_bwd_kernel(const RenderBwdArgs a) {
     int nskip = 0;   // entries that lie behind every pixel of this wave (a prefix: slots descend)
     for (int i = lane; i < SEG; i += 64) {
         uint2 e = make_uint2(0u, 0u);
-        if (i < nent) { e = sub_in[seg_hi - 1 - i]; sQ[i] = e; }
+        if (i < nent) e = sub_in[seg_hi - 1 - i];
+        sQ[i] = e;
         nskip += __popcll(__ballot(i < nent && e.y >= wmax));
     }
     wave_lds_sync();
-    TM_MARK(0);   // setup: upstream gradients, G matrix, start state
+    DEV_TRACE_MARK(0);   // segment setup
+    dev_items++; dev_cands += (unsigned)nent;
     // Batches of CHB candidates; the gathers of batch b+1 are in flight (registers) while batch b is replayed, so
     // neither their latency nor the completion of this batch's gradient atomics is waited for.
     StageRegs<S, VC, CHB> sr;
@@ -262,232 +253,236 @@ render_bwd_kernel(const RenderBwdArgs a) {
                                        a.features, a.vfeatures);
         }
         wave_lds_sync();
-        TM_MARK(1);   // staging (LDS stores, prefetch issue)
-        TM_COUNT(5, m);
+        DEV_TRACE_MARK(1);   // staging
 
         for (int c0 = 0; c0 < m; c0 += SB) {
-            const int nsub = min(SB, m - c0);
             uint32_t live = 0;  // bit cs set: candidate c0+cs has at least one blending pixel (wave-uniform)
-            // ---------------- phase A: lane = pixel ----------------
-            for (int cs = 0; cs < nsub; cs++) {
-                const int c = c0 + cs;
-                const float* r = sD + c * SG::NF;
-                const float4* q = reinterpret_cast<const float4*>(r);
-                // all LDS reads of the candidate are issued up front (one latency exposure)
-                const uint32_t slot = sQ[base + c].y;
-                const float4 A = q[0];   // x, y, conic.x, conic.y
-                const float4 B = q[1];   // conic.z, opacity, depth, J6
-                const float4 Jv = q[2];  // J0..J3
-                const float4 E = q[3];   // J9, r, g, b
-                const float4 Nn = q[4];  // nx, ny, nz, 1/umax
-                const float ivm = q[5].x;
-                float fl[SS];
+            // ---------------- phase A: lane = pixel, KB candidates per branch-free group, lock-step ----------------
+#pragma unroll 1
+            for (int cs0 = 0; cs0 < SB && c0 + cs0 < m; cs0 += KB) {
+                const int cb = c0 + cs0;   // first candidate of the group (slot in the staging buffer)
+                // (1) loads + independent per-candidate work: alpha, corner weights, s = sum_ch value_ch * g_ch
+                float4 A[KB], B[KB], E[KB], Nn[KB];
+                uint32_t slot[KB];
 #pragma unroll
-                for (int ch = 0; ch < S; ch++) fl[ch] = r[SG::F_OFF + ch];
-                if (slot >= wmax) continue;  // uniform: behind every pixel of this wave
-                TM_FINE(8);    // loop overhead + slot read
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                float power;
-                if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
-                else power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(0.99f, B.y * G);
-                const bool pass = slot < last_contributor && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                TM_FINE(9);    // alpha
-                if (__ballot(pass) == 0ull) continue;
-                live |= 1u << cs;
-#ifdef EXP_NO_REPLAY
-                if (live != 0xdeadbeefu) { T *= 0.999f; continue; }
-#endif
-
-                float vw = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
-                float ge[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (pass) {
-                    const float oma = 1.f - alpha;
-                    const float inv_oma = __builtin_amdgcn_rcpf(oma);
-                    const float inv_Told = __builtin_amdgcn_rcpf(T);
-                    T = T * inv_oma;
-                    const float dch = alpha * T;
-                    const float inv_keep = 1.f - last_alpha;
-                    float dL_dalpha = 0.f;
-                    float du = 0.f, dv = 0.f;
-                    float cw[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (sp) {
-                        du = dx * Jv.x + dy * Jv.y; dv = dx * Jv.z + dy * Jv.w;
-                        if (SVGSS && VC > 0) {
-                            float u = du * Nn.w * 0.5f + 0.5f, v = dv * ivm * 0.5f + 0.5f;
+                for (int k = 0; k < KB; k++) {
+                    const float4* q = reinterpret_cast<const float4*>(sD + (cb + k) * SG::NF);
+                    A[k] = q[0];    // x, y, conic.x, conic.y
+                    B[k] = q[1];    // conic.z, opacity, depth, DA
+                    E[k] = q[3];    // DB, r, g, b
+                    Nn[k] = q[4];   // nx, ny, nz, 1/umax
+                    slot[k] = sQ[base + cb + k].y;
+                }
+                float dx[KB], dy[KB], pw[KB], Gs[KB], al[KB], ioma[KB], sd[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) { dx[k] = A[k].x - pxf; dy[k] = A[k].y - pyf; }
+#pragma unroll
+                for (int k = 0; k < KB; k++) pw[k] = pair_power(A[k].z, A[k].w, B[k].x, dx[k], dy[k]);
+#pragma unroll
+                for (int k = 0; k < KB; k++) { Gs[k] = exp_nonpos(pw[k]); al[k] = fminf(0.99f, B[k].y * Gs[k]); }
+                bool pre[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    pre[k] = (cb + k < m) && slot[k] < last_contributor && pw[k] <= 0.0f && al[k] >= (1.0f / 255.0f);
+                    ioma[k] = __builtin_amdgcn_rcpf(1.f - al[k]);
+                }
+                float cw0[KB], cw1[KB], cw2[KB], cw3[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    cw0[k] = cw1[k] = cw2[k] = cw3[k] = 0.f;
+                    if (SVGSS && VC > 0) {
+                        if (sp) {
+                            const float4* q = reinterpret_cast<const float4*>(sD + (cb + k) * SG::NF);
+                            const float4 Jv = q[2];  // J0..J3
+                            const float ivm = q[5].x;
+                            const float du = dx[k] * Jv.x + dy[k] * Jv.y, dv = dx[k] * Jv.z + dy[k] * Jv.w;
+                            float u = du * Nn[k].w * 0.5f + 0.5f, v = dv * ivm * 0.5f + 0.5f;
                             u = fminf(0.999f, fmaxf(0.001f, u));
                             v = fminf(0.999f, fmaxf(0.001f, v));
-                            cw[0] = (1.f - u) * (1.f - v); cw[1] = u * (1.f - v); cw[2] = (1.f - u) * v; cw[3] = u * v;
+                            cw0[k] = (1.f - u) * (1.f - v); cw1[k] = u * (1.f - v); cw2[k] = (1.f - u) * v; cw3[k] = u * v;
                         }
                     }
-                    // s = sum over all blended channels of value * upstream gradient (see the replay-state comment)
-                    float sdot = E.y * gC[0] + E.z * gC[1] + E.w * gC[2];
-                    if (S > 0 && bgeom) {
+                }
 #pragma unroll
-                        for (int ch = 0; ch < S; ch++) sdot += fl[ch] * gF[ch];
+                for (int k = 0; k < KB; k++) {
+                    float sdot = E[k].y * gC[0] + E[k].z * gC[1] + E[k].w * gC[2];
+                    if (surface) sdot += Nn[k].x * gN[0] + Nn[k].y * gN[1] + Nn[k].z * gN[2];
+                    float d_cur = B[k].z;
+                    if (sp) d_cur -= dx[k] * B[k].w + dy[k] * E[k].x;   // depth differencing (common.hpp R_DA / R_DB)
+                    sdot += d_cur * gDn;
+                    sd[k] = sdot;
+                }
+                if (S > 0 && bgeom) {
+#pragma unroll
+                    for (int k = 0; k < KB; k++) {
+                        const float* f = sD + (cb + k) * SG::NF + SG::F_OFF;
+#pragma unroll
+                        for (int ch = 0; ch < S; ch++) sd[k] += f[ch] * gF[ch];
                     }
-                    if (VC > 0) {
+                }
+                if (VC > 0) {
+#pragma unroll
+                    for (int k = 0; k < KB; k++) {
                         // sum_ch (c4[ch] . cw) gVF[ch] = cw . (sum_ch c4[ch] gVF[ch])
-                        const float4* vf = reinterpret_cast<const float4*>(r + SG::V_OFF);
+                        const float4* vf = reinterpret_cast<const float4*>(sD + (cb + k) * SG::NF + SG::V_OFF);
                         float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
 #pragma unroll
                         for (int ch = 0; ch < VC; ch++) {
                             const float4 c4 = vf[ch];
                             h0 += c4.x * gVF[ch]; h1 += c4.y * gVF[ch]; h2 += c4.z * gVF[ch]; h3 += c4.w * gVF[ch];
                         }
-                        sdot += (h0 * cw[0] + h1 * cw[1]) + (h2 * cw[2] + h3 * cw[3]);
+                        sd[k] += (h0 * cw0[k] + h1 * cw1[k]) + (h2 * cw2[k] + h3 * cw3[k]);
                     }
-                    if (surface) sdot += Nn.x * gN[0] + Nn.y * gN[1] + Nn.z * gN[2];
-                    {  // depth
-                        float d_cur = B.z;
-                        if (sp) d_cur -= du * B.w + dv * E.x;
-                        sdot += d_cur * gDn;
-                    }
-                    A_acc = last_alpha * s_last + inv_keep * A_acc;
-                    s_last = sdot;
-                    dL_dalpha += kdn * inv_Told + (sdot - A_acc);
-                    dL_dalpha *= T;
-                    const float tf_oma = T_final * inv_oma;
-                    dL_dalpha += (gO - kbg) * tf_oma;
-                    last_alpha = alpha;
-                    const float dL_ddist = dL_dalpha * B.y * -0.5f * G;
-                    vw = dch;
-                    vc0 = cw[0] * dch; vc1 = cw[1] * dch; vc2 = cw[2] * dch; vc3 = cw[3] * dch;
-                    ge[0] = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx + q5 * (B.w * Jv.x + E.x * Jv.z);  // + Q5
-                    ge[1] = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy + q5 * (B.w * Jv.y + E.x * Jv.w);
-                    ge[2] = dL_ddist * (dx * dx);
-                    ge[3] = dL_ddist * (dx * dy);
-                    ge[4] = dL_ddist * (dy * dy);
-                    ge[5] = G * dL_dalpha;
                 }
-                TM_FINE(10);   // replay math
-                if (VC > 0) {   // rows (candidate, corner); the four corner weights sum to the blend weight
-                    float* pr = sP + (cs * 4) * PS + lane;
-                    pr[0] = sp ? vc0 : vw; pr[PS] = vc1; pr[2 * PS] = vc2; pr[3 * PS] = vc3;
-                } else {
-                    sP[cs * PS + lane] = vw;
+                // (2) the sequential part: T <- T / (1 - alpha) and the scalar replay recurrence (backward.cu:700-850)
+                float dLa[KB], vw[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const bool pass = pre[k];
+                    const float inv_Told = __builtin_amdgcn_rcpf(T);
+                    const float Tn = T * ioma[k];
+                    const float An = last_alpha * s_last + (1.f - last_alpha) * A_acc;
+                    float dL_dalpha = kdn * inv_Told + (sd[k] - An);
+                    dL_dalpha *= Tn;
+                    dL_dalpha += gO_kbg * (T_final * ioma[k]);
+                    T = pass ? Tn : T;
+                    A_acc = pass ? An : A_acc;
+                    s_last = pass ? sd[k] : s_last;
+                    last_alpha = pass ? al[k] : last_alpha;
+                    dLa[k] = pass ? dL_dalpha : 0.f;
+                    vw[k] = pass ? al[k] * Tn : 0.f;
+                }
+                // (3) independent again: weight panel rows and the six geometric gradients per pixel
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    if (VC > 0) {   // rows (candidate, corner); the four corner weights sum to the blend weight
+                        float* pr = sP + ((cs0 + k) * 4) * PS + lane;
+                        pr[0] = sp ? cw0[k] * vw[k] : vw[k]; pr[PS] = cw1[k] * vw[k];
+                        pr[2 * PS] = cw2[k] * vw[k]; pr[3 * PS] = cw3[k] * vw[k];
+                    } else {
+                        sP[(cs0 + k) * PS + lane] = vw[k];
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const float s8 = octant_sum(ge[k]);
-                    if ((lane & 7) == 0) sPg[(cs * 6 + k) * 8 + (lane >> 3)] = s8;
+                for (int k = 0; k < KB; k++) {
+                    const float dL_ddist = dLa[k] * (B[k].y * -0.5f) * Gs[k];
+                    float ge0 = dL_ddist * 2.f * (A[k].z * dx[k] + A[k].w * dy[k]) * ddelx_dx;
+                    float ge1 = dL_ddist * 2.f * (B[k].x * dy[k] + A[k].w * dx[k]) * ddely_dy;
+                    if (sp) { ge0 += q5g * B[k].w; ge1 += q5g * E[k].x; }   // + Q5, d(depth offset)/d(mean2D) = (DA, DB)
+                    const float ge2 = dL_ddist * (dx[k] * dx[k]);
+                    const float ge3 = dL_ddist * (dx[k] * dy[k]);
+                    const float ge4 = dL_ddist * (dy[k] * dy[k]);
+                    const float ge5 = Gs[k] * dLa[k];
+                    float* pg = sPg + (k * 6) * PS + lane;
+                    pg[0] = pre[k] ? ge0 : 0.f; pg[PS] = pre[k] ? ge1 : 0.f; pg[2 * PS] = pre[k] ? ge2 : 0.f;
+                    pg[3 * PS] = pre[k] ? ge3 : 0.f; pg[4 * PS] = pre[k] ? ge4 : 0.f; pg[5 * PS] = pre[k] ? ge5 : 0.f;
                 }
-                TM_FINE(11);   // panel + octant writes
+                uint32_t glive = 0;
+#pragma unroll
+                for (int k = 0; k < KB; k++) glive |= (__ballot(pre[k]) != 0ull ? 1u : 0u) << k;
+                live |= glive << cs0;
+                wave_lds_sync();   // geometric panel visible
+                // (4) geometric sums: LPR lanes per (candidate, value) row, 64 / LPR pixels each
+                {
+                    constexpr int EPL = 64 / LPR;
+                    const int row = lane / LPR, part = lane % LPR;
+                    const int kq = row / 6, jq = row - kq * 6;
+                    float v = 0.f;
+                    if (row < KB * 6) {
+                        const float4* src = reinterpret_cast<const float4*>(sPg + row * PS + part * EPL);
+                        float4 t[EPL / 4];
+#pragma unroll
+                        for (int i = 0; i < EPL / 4; i++) t[i] = src[i];
+#pragma unroll
+                        for (int i = 0; i < EPL / 4; i++) v += (t[i].x + t[i].y) + (t[i].z + t[i].w);
+                    }
+                    // partner lanes are adjacent: quad_perm [1,0,3,2] (+ [2,3,0,1], + row_half_mirror)
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+                    if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+                    if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+                    const bool mine = row < KB * 6 && part == 0 && ((glive >> kq) & 1u);
+                    if (mine) {
+                        if (VC > 0) {
+                            // gradient row of the (instance, sub-tile) pair (see phase B)
+                            const float* rr = sD + (cb + kq) * SG::NF;
+                            const uint32_t ib = __builtin_bit_cast(uint32_t, rr[R_IBASE]);
+                            const uint32_t rc = __builtin_bit_cast(uint32_t, rr[R_RECT]);
+                            const uint32_t x0 = rc & 1023u, y0 = (rc >> 10) & 1023u, wr = rc >> 20;
+                            const size_t sl = (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
+                            a.grad_rows[sl * RS + GEO + jq] = v;
+                            if (jq == 0) a.row_flags[sl] = 1;
+                        } else if (v != 0.f) {
+                            atomic_add_f32(a.grad_rows + ((size_t)sQ[base + cb + kq].x * RS + (uint32_t)(GEO + jq)), v);
+                        }
+                    }
+                }
+                wave_lds_sync();   // geometric panel consumed before the next group overwrites it
             }
-            TM_MARK(2);   // phase A
-            TM_COUNT(6, __popc(live));
-#ifdef EXP_NO_PHASEB
-            if (live != 0xdeadbeefu) continue;
-#endif
+            DEV_TRACE_MARK(2);   // phase A
             if (live == 0) continue;  // uniform
-            wave_lds_sync();          // panel (and, the first time, G) visible to the phase-B lanes
+            // (the weight panel was made visible by the fences of the last group)
 
             // ---------------- phase B: panel x G on the matrix pipe ----------------
             {
-                const int rowA = VC > 0 ? colB : min(colB, SB - 1);
-                const float4* ap = reinterpret_cast<const float4*>(sP + rowA * PS + 16 * grpB);
+                const float4* ap = reinterpret_cast<const float4*>(sP + colB * PS + 16 * grpB);
                 const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
                 const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w,
                                       a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
                 f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
+                const float* gB = sG + (16 * grpB) * GROW;
+                const int colP = colB < NC0 ? colB : 0, colV = NC0 + ((VC > 0 && colB < VC) ? colB : 0);
 #pragma unroll
                 for (int kk = 0; kk < 16; kk++) {
-                    accP = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Bp[kk], accP, 0, 0, 0);
-                    if (VC > 0) accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Bv[kk], accV, 0, 0, 0);
+                    const float bp = BG::G_IN_REGS ? Bp[kk] : gB[kk * GROW + colP];
+                    accP = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], colB < NC0 ? bp : 0.f, accP, 0, 0, 0);
+                    if (VC > 0) {
+                        const float bv = gB[kk * GROW + colV];
+                        accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], colB < VC ? bv : 0.f, accV, 0, 0, 0);
+                    }
                 }
                 // D layout: lane l, register r -> row 4*(l>>4) + r, column l&15
-                if (VC > 0 && a.grad_rows) {   // (rows are only used at the svgss widths, api.hip)
-                    // ---- gradient rows (common.hpp GradRowGeom): plain stores, summed per Gaussian afterwards ----
-                    constexpr int P4 = (NC0 + 3) / 4 * 4, GEO = P4 + VS, RS = (GEO + 6 + 3) / 4 * 4;
-                    // slot of candidate cb of this sub-batch: 4 * (first instance of the Gaussian + index of this tile
-                    // inside the Gaussian's tile rectangle, emit order) + sub-tile
-                    auto slot_of = [&](int cb) -> size_t {
-                        const float* rr = sD + (c0 + cb) * SG::NF;
+                if (VC > 0) {
+                    // ---- svgss: gradient rows (common.hpp GradRowGeom): plain stores, summed per Gaussian afterwards ----
+                    // rows of the panel = (candidate grpB, corner r); slot of the candidate: 4 * (first instance of the
+                    // Gaussian + index of this tile inside the Gaussian's tile rectangle, emit order) + sub-tile
+                    const bool mine = c0 + grpB < m && ((live >> grpB) & 1u);
+                    if (mine) {
+                        const float* rr = sD + (c0 + grpB) * SG::NF;
                         const uint32_t ib = __builtin_bit_cast(uint32_t, rr[R_IBASE]);
                         const uint32_t rc = __builtin_bit_cast(uint32_t, rr[R_RECT]);
                         const uint32_t x0 = rc & 1023u, y0 = (rc >> 10) & 1023u, wr = rc >> 20;
-                        return (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
-                    };
-                    if (VC > 0) {
-                        const bool mine = grpB < nsub && ((live >> grpB) & 1u);
-                        if (mine) {
-                            float* row = a.grad_rows + slot_of(grpB) * RS;
-                            if (colB < NC0) row[colB] = (accP[0] + accP[1]) + (accP[2] + accP[3]);
-                            if (colB < VC)
-                                reinterpret_cast<float4*>(row + P4)[colB] =
-                                    sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int cB = 4 * grpB + r;
-                            if (cB < nsub && ((live >> cB) & 1u) && colB < NC0) a.grad_rows[slot_of(cB) * RS + colB] = accP[r];
-                        }
-                    }
-                    {
-                        const int cB = lane >> 3, j = lane & 7;
-                        if (cB < nsub && ((live >> cB) & 1u)) {
-                            const size_t sl = slot_of(cB);
-                            if (j < 6) {
-                                float v = 0.f;
-#pragma unroll
-                                for (int p8 = 0; p8 < 8; p8++) v += sPg[(cB * 6 + j) * 8 + p8];
-                                a.grad_rows[sl * RS + GEO + j] = v;
-                            } else if (j == 6) {
-                                a.row_flags[sl] = 1;
-                            }
-                        }
-                    }
-                } else if (VC > 0) {
-
-                    // rows = (candidate grpB, corner r)
-                    const bool mine = grpB < nsub && ((live >> grpB) & 1u);
-                    const int gidB = mine ? (int)sQ[base + c0 + grpB].x : 0;
-                    const float v = (accP[0] + accP[1]) + (accP[2] + accP[3]);
-                    if (mine && colB < NC0 && v != 0.f) BWD_ATOMIC(pbase + (size_t)gidB * pstride, v);
-                    if (mine && sp && colB < VC) {
-                        float* dst = a.dL_dvfeature + (size_t)gidB * VS + colB * 4;
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            if (accV[r] != 0.f) BWD_ATOMIC(dst + r, accV[r]);
+                        const size_t sl = (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
+                        float* row = a.grad_rows + sl * RS;
+                        if (colB < NC0) row[colB] = (accP[0] + accP[1]) + (accP[2] + accP[3]);
+                        if (colB < VC)
+                            reinterpret_cast<float4*>(row + P4)[colB] =
+                                sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 } else {
-                    // rows = candidates 4*grpB + r (only rows < SB exist)
+                    // ---- rgss: one packed gradient row per Gaussian, float atomics; rows of the panel = candidates ----
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int cB = 4 * grpB + r;
-                        const bool mine = cB < nsub && ((live >> cB) & 1u);
-                        if (mine && colB < NC0 && accP[r] != 0.f)
-                            BWD_ATOMIC(pbase + (size_t)sQ[base + c0 + cB].x * pstride, accP[r]);
-                    }
-                }
-                // --- geometric channels: finish the octant partials ---
-                if (!(VC > 0 && a.grad_rows)) {
-                    const int cB = lane >> 3, j = lane & 7;
-                    const bool mine = cB < nsub && ((live >> cB) & 1u) && j < 6;
-                    if (mine) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int p8 = 0; p8 < 8; p8++) v += sPg[(cB * 6 + j) * 8 + p8];
-                        if (v != 0.f) BWD_ATOMIC(gbase + (size_t)sQ[base + c0 + cB].x * gstride, v);
+                        const bool mine = c0 + cB < m && ((live >> cB) & 1u) && colB < NC0 && accP[r] != 0.f;
+                        if (mine) atomic_add_f32(a.grad_rows + ((size_t)sQ[base + c0 + cB].x * RS + (uint32_t)colB), accP[r]);
                     }
                 }
             }
-            wave_lds_sync();  // panel consumed before the next phase A overwrites it
-            TM_MARK(3);   // phase B
+            DEV_TRACE_MARK(3);   // phase B
         }
     }
-#ifdef RENDER_TIMING
-    tm_acc[7] += 1;
-    if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_bwd_tm[i], tm_acc[i]);
-#endif
+    }   // loop over live segments
+    DEV_TRACE_END(1, dev_items, dev_cands, blockIdx.x);
 }
 
 template <int S, int VC, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
     using BG = BwdGeom<S, VC>;
-    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(a.seg_cap), dim3(64), BG::lds_bytes, s, a);
+    // The live-segment count only exists on the device: launch a few waves per resident slot (256 CUs x 4 SIMDs x WPE),
+    // capped by the list's upper bound, and let them stride over the list.  Small workloads get one segment per wave
+    // (the dispatcher balances), large ones several; waves beyond the count exit after one scalar load.
+    const int grid = std::min(a.seg_cap, 4 * 256 * 4 * BG::WPE);
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(grid), dim3(64), BG::lds_bytes, s, a);
 }
 
 }  // namespace
@@ -501,11 +496,16 @@ int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s) {
     return -1;
 }
 
-#ifdef RENDER_TIMING
-extern "C" int svgir_debug_bwd_timing(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(svgir::g_bwd_tm), 128) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_bwd_tm), z, 128); }
-    return 0;
+#if defined(SVGIR_DEV)
+extern "C" int svgir_dev_trace_read_bwd(unsigned long long* out, int cap_records) {
+    unsigned int n[2];
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(svgir::g_dev_trace_n), sizeof(n)) != hipSuccess) return -1;
+    int cnt = (int)std::min<unsigned>(n[1], (unsigned)std::min(cap_records, svgir::DEV_TRACE_CAP));
+    if (cnt > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(svgir::g_dev_trace), (size_t)cnt * svgir::DEV_TRACE_WORDS * 8,
+                                       (size_t)svgir::DEV_TRACE_CAP * svgir::DEV_TRACE_WORDS * 8) != hipSuccess) return -1;
+    n[1] = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_dev_trace_n), n, sizeof(n));
+    return cnt;
 }
 #endif
 

@@ -4,54 +4,138 @@
 // depth-ordered splat list of each 16x16 tile; per-pixel depth by depth differencing; svgss additionally blends
 // VS/4 "vfeature" channels, each the bilinear interpolation of 4 corner values in the surfel's tangent plane.
 //
-// CDNA4 mapping (see stage.hpp for the staging details)
-//   * one wave64 per 8x8-pixel sub-tile, one wave per workgroup: 4x more independent work items than the
-//     reference's 256-thread tile blocks, no workgroup barriers, and a compact pixel footprint so that a splat is
-//     only visited by the waves it can actually touch (measured: ~17 % of the (wave, splat) pairs of a tile list);
-//   * the wave scans the tile list 64 entries per step, one splat per lane: coalesced id load, 32-byte header
-//     gather, exact minimum of the conic form over the 8x8 rectangle against the 1/255 alpha threshold; survivors are
-//     compacted with a ballot + popcount into an LDS ring and -- with their slot in the tile list -- into a global
-//     per-sub-tile list that the backward kernel reuses (it never re-culls);
-//   * candidates are staged CH at a time into LDS (record + features + vfeatures, 16-byte loads, all in flight
-//     together) and consumed with wave-uniform broadcast reads; channel counts are template parameters so every
-//     accumulator lives in a VGPR (the reference keeps >640 floats per thread in scratch, forward.cu:483-493);
-//   * the per-(pixel,splat) out_weights atomic of the reference (forward.cu:653) becomes one DPP wave reduction
-//     + one atomic per (wave, splat);
+// CDNA4 mapping (see stage.hpp for the staging details): two kernels.
+//   cull_kernel: one 256-thread workgroup per tile walks the tile's depth-ordered list 256 entries per round, one
+//     splat per lane: coalesced id load, 32-byte header gather, exact minimum of the conic form over each of the
+//     tile's four 8x8 pixel rectangles against the 1/255 alpha threshold (the per-splat part of the test is shared by
+//     the four rectangles, the header is gathered once instead of once per sub-tile).  Survivors are compacted in
+//     order (ballot + popcount in the wave, per-wave counts through LDS across the waves) into one list per sub-tile
+//     {Gaussian id, slot in the tile list}; forward and backward composite both consume these lists.
+//   render_fwd_kernel: one wave64 per 8x8 sub-tile (one wave per workgroup, no barriers), sub-tiles dispatched by
+//     descending candidate count.  Candidates are staged CH at a time into LDS (record + features + vfeatures, 16-byte
+//     loads, all in flight together and issued one batch AHEAD: the gathers of batch b+1 fly while batch b is blended)
+//     and consumed KB at a time with wave-uniform broadcast reads.  A group of KB candidates is blended without
+//     branches and written in lock-step (the same operation for all KB candidates, then the next one), so the wave's
+//     instruction stream carries KB independent dependency chains: the alphas are independent, only the
+//     transmittance chain (T <- T (1 - alpha), the 1e-4 cut-off) is sequential, and the accumulations are independent
+//     FMAs again;
+//   * channel counts are template parameters so every accumulator lives in a VGPR (the reference keeps >640 floats
+//     per thread in scratch, forward.cu:483-493);
+//   * the per-(pixel,splat) out_weights atomic of the reference (forward.cu:653) becomes one DPP wave reduction per
+//     (wave, splat) parked in LDS and ONE atomic instruction per staging batch (lane = candidate);
 //   * after every SEG-th candidate (and once at the end) the wave dumps its blend state -- T and every accumulator,
-//     [state][channel][64 pixels] -- and registers the live backward segments of its sub-tile (common.hpp SEG): the
-//     backward is parallel over depth segments and starts each one from these states.
+//     [state][channel][64 pixels] -- and appends the live backward segments of its sub-tile to a compact list
+//     (common.hpp SEG): the backward is parallel over depth segments and starts each one from these states.
+//
+// Numerics: alpha is evaluated in exactly the operation order of the reference's source (no FMA contraction in the
+// quadratic form) with a ~1 ulp exp, so the alpha >= 1/255 and T < 1e-4 decisions agree with a plain fp32
+// evaluation of the reference's formulas except where exp itself differs in the last bit.
+#include <algorithm>
+
 #include "common.hpp"
 #include "stage.hpp"
+#include "dev_trace.hpp"
 
 namespace svgir {
 
 namespace {
 
+// ---- cull: tile list -> four compact sub-tile lists -----------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) cull_kernel(const RenderArgs a) {
+    __shared__ uint32_t wcnt[4][4];   // [wave][sub-tile] survivors of the current round
+    const int tile = blockIdx.x;
+    const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+    const int len = (int)(r1 - r0);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    if (len == 0) {
+        // Empty tile: nothing will ever be blended here.  The 256 threads write the background result of the whole
+        // 16x16 tile (64-byte rows) and the four composite waves of the tile exit at once (render_fwd_kernel).
+        if (t < 4) { a.sub_total[4 * tile + t] = 0u; a.sub_count[4 * tile + t] = 0u; a.sub_ndump[4 * tile + t] = 0u; }
+        const int px = tx * TILE + (t & 15), py = ty * TILE + (t >> 4);
+        if (px < a.W && py < a.H) {
+            const size_t N_ = (size_t)a.W * a.H;
+            const size_t pid = (size_t)a.W * py + px;
+            const float T = (float)(1 - 0.000001);   // forward.cu:671
+            a.final_T[pid] = T; a.final_D[pid] = 0.f; a.n_contrib[pid] = 0;
+            a.out_color[pid] = T * a.bg[0]; a.out_color[N_ + pid] = T * a.bg[1]; a.out_color[2 * N_ + pid] = T * a.bg[2];
+            for (int ch = 0; ch < a.S; ch++) a.out_feature[ch * N_ + pid] = 0.f;
+            for (int ch = 0; ch < a.VS / 4; ch++) a.out_vfeature[ch * N_ + pid] = 0.f;
+            a.out_normal[pid] = 0.f; a.out_normal[N_ + pid] = 0.f; a.out_normal[2 * N_ + pid] = 0.f;
+            a.out_depth[pid] = cfg_flag(a.cfg, 1) ? 0.f / (1.f - T) : 0.f + T * 10.f;
+            a.out_opacity[pid] = 1.f - T;
+        }
+        return;
+    }
+    const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
+    const float4* __restrict__ rec4 = reinterpret_cast<const float4*>(a.rec);
+    uint2* __restrict__ out = a.sub_list + (size_t)4 * r0;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t run[4] = {0u, 0u, 0u, 0u};   // survivors so far per sub-tile (uniform)
+    for (int base = 0; base < len; base += BLOCK) {
+        const int i = base + t;
+        bool m[4] = {false, false, false, false};
+        uint32_t gid = 0;
+        if (i < len) {
+            gid = a.point_list[r0 + i];
+            const float4 A = rec4[(size_t)gid * 6];
+            const float4 B = rec4[(size_t)gid * 6 + 1];
+            const SplatCull sc = cull_prepare(A.x, A.y, A.z, A.w, B.x, B.y);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float x0 = X0 + (float)((w & 1) * 8), y0 = Y0 + (float)((w >> 1) * 8);
+                m[w] = cull_test(sc, x0, y0, x0 + 7.f, y0 + 7.f);
+            }
+        }
+        unsigned long long mask[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            mask[w] = __ballot(m[w]);
+            if (lane == 0) wcnt[wave][w] = (uint32_t)__popcll(mask[w]);
+        }
+        __syncthreads();
+        const uint2 e = make_uint2(gid, (uint32_t)i);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int v = 0; v < 4; v++) { const uint32_t c = wcnt[v][w]; all += c; before += v < wave ? c : 0u; }
+            if (m[w]) out[(size_t)w * len + run[w] + before + (uint32_t)__popcll(mask[w] & lt_mask)] = e;
+            run[w] += all;
+        }
+        __syncthreads();   // counts consumed before the next round overwrites them
+    }
+    if (t < 4) a.sub_total[4 * tile + t] = run[t];
+}
 
+// ---- blend --------------------------------------------------------------------------------------------------
 template <int S, int VC, bool SVGSS>
-__global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(StageGeom<S, VC>::WPE, StageGeom<S, VC>::WPE)))
+render_fwd_kernel(const RenderArgs a) {
     using SG = StageGeom<S, VC>;
+    constexpr int KB = SG::KB, CH = SG::CH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sD = reinterpret_cast<float*>(smem);                              // [CH][NF]
-    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)SG::CH * SG::NF * 4);  // [QN] {gid, slot}
+    float* sD = reinterpret_cast<float*>(smem);                              // [CH][NF] staged candidates
+    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)CH * SG::NF * 4);    // [2][CH] {gid, slot}: this batch / next batch
+    float* sW = reinterpret_cast<float*>(smem + (size_t)CH * SG::NF * 4 + (size_t)SG::QN * 8);   // [2][CH] blend-weight sums
 
-    int tile, sub;
-    sub_tile_of_block(blockIdx.x, a.gx * a.gy, a.tile_order, tile, sub);
-    if (tile < 0) return;
+    if ((int)blockIdx.x >= 4 * a.gx * a.gy) return;
+    const uint32_t sid = a.sub_order[blockIdx.x];
+    const int tile = (int)(sid >> 2), sub = (int)(sid & 3u);
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int lane = threadIdx.x;
     const int bx = tx * TILE + (sub & 1) * 8, by = ty * TILE + (sub >> 1) * 8;
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float wx0 = (float)bx, wy0 = (float)by;
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int len = (int)(r1 - r0);
+    if (len == 0) return;   // empty tile: the cull kernel has written its background pixels
+    DEV_TRACE_DECL();
+    const int total = (int)a.sub_total[sid];
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
     const bool sp = surface && cfg_flag(a.cfg, 2);
-    const float4* __restrict__ rec4 = reinterpret_cast<const float4*>(a.rec);
-    uint2* __restrict__ sub_out = a.sub_list + (size_t)4 * r0 + (size_t)sub * len;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint2* __restrict__ list = a.sub_list + (size_t)4 * r0 + (size_t)sub * len;
 
     bool done = !inside;
     float T = 1.0f, D = 0.f;
@@ -66,7 +150,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
 
     // segment-boundary state dumps (see common.hpp SEG)
     constexpr int NST = 8 + S + VC;
-    const uint32_t dump_base = (uint32_t)(((size_t)4 * r0 + (size_t)sub * len) / SEG) + (uint32_t)(4 * tile + sub);
+    const uint32_t dump_base = seg_state_base(r0, (uint32_t)len, tile, sub);
     uint32_t ndump = 0;
     auto dump_state = [&](uint32_t j) {
         float* d = a.seg_state + ((size_t)(dump_base + j) * NST) * 64 + lane;
@@ -78,110 +162,167 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
         for (int ch = 0; ch < VC; ch++) d[(8 + S + ch) * 64] = VF[ch];
     };
 
-    uint32_t head = 0, tail = 0;  // candidate ring indices (wave-uniform)
-    bool wave_done = __all(done);
-    for (int scan = 0; scan < len && !wave_done; scan += 64) {
-        // ---- lane-parallel cull of 64 list entries ----
-        const int i = scan + lane;
-        bool cand = false;
-        uint32_t gid = 0;
-        if (i < len) {
-            gid = a.point_list[r0 + i];
-            const float4 A = rec4[(size_t)gid * 6];
-            const float4 B = rec4[(size_t)gid * 6 + 1];
-            cand = splat_may_touch(A.x, A.y, A.z, A.w, B.x, B.y, wx0, wy0, wx0 + 7.f, wy0 + 7.f);
-        }
-        const unsigned long long mask = __ballot(cand);
-        if (cand) {
-            const uint32_t pos = tail + (uint32_t)__popcll(mask & lt_mask);
-            const uint2 e = make_uint2(gid, (uint32_t)i);
-            sQ[pos & (SG::QN - 1)] = e;
-            sub_out[pos] = e;
-        }
-        tail += (uint32_t)__popcll(mask);
-        const bool last_scan = scan + 64 >= len;
-
-        // ---- stage + blend queued candidates, CH at a time ----
-        while (!wave_done && (tail - head >= (uint32_t)SG::CH || (last_scan && tail != head))) {
-            const int m = min((int)SG::CH, (int)(tail - head));
-            wave_lds_sync();  // ring writes visible; previous batch fully consumed
-            stage_candidates<S, VC, SG::CH>(sD, m, [&](int s) { return sQ[(head + s) & (SG::QN - 1)].x; }, lane, a.rec,
-                                    a.features, a.vfeatures);
+    uint32_t head = 0;   // candidates consumed so far (wave-uniform)
+    if (total > 0) {
+        // The staging buffer starts as zeros: slots beyond a batch's size then always hold finite values (zeros or an
+        // older candidate), so the blend loop needs no per-candidate bounds branches -- such slots get weight 0.
+        for (int i = lane; i < CH * SG::NF / 4; i += 64) reinterpret_cast<float4*>(sD)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // software pipeline: {gid, slot} entries are fetched two batches ahead, records one batch ahead
+        auto load_entries = [&](int b) -> uint2 {
+            const int i = b * CH + lane;
+            return (lane < CH && i < total) ? list[i] : make_uint2(0u, 0u);
+        };
+        const int nb = (total + CH - 1) / CH;
+        if (lane < CH) sQ[lane] = load_entries(0);
+        uint2 e_next = load_entries(1);
+        wave_lds_sync();
+        StageRegs<S, VC, CH> sr;
+        stage_load<S, VC, CH>(sr, min(CH, total), [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
+        bool wave_done = __all(done);
+        int nflush = 0;   // candidates of the previous batch whose out_weights sums are still parked in LDS
+        // out_weights of a batch: one atomic instruction, lane = candidate.  It is issued one batch late, BEFORE the next
+        // batch's gathers: a wait for those gathers then never waits for an atomic that was issued after them.
+        auto flush_weights = [&](int bprev) {
+            if (lane < nflush) {
+                const float wsum = sW[(bprev & 1) * CH + lane];
+                if (wsum != 0.f) atomic_add_f32(&a.out_weights[sQ[(bprev & 1) * CH + lane].x], wsum);
+            }
+        };
+        int b = 0;
+        for (; b < nb && !wave_done; b++) {
+            const int m = min(CH, total - b * CH);
+            const uint2* q_cur = sQ + (b & 1) * CH;
+            float* w_cur = sW + (b & 1) * CH;
+            wave_lds_sync();   // previous batch fully consumed
+            stage_store<S, VC, CH>(sr, sD, m, lane);
+            flush_weights(b - 1);
+            wave_lds_sync();   // ... before its {gid, slot} entries are overwritten
+            if (lane < CH) sQ[((b + 1) & 1) * CH + lane] = e_next;
+            e_next = load_entries(b + 2);
             wave_lds_sync();
-            for (int c = 0; c < m; c++) {
-                const float4* q = reinterpret_cast<const float4*>(sD + c * SG::NF);
-                const float4 A = q[0];   // x, y, conic.x, conic.y
-                const float4 B = q[1];   // conic.z, opacity, depth, J6
-                const float4 J = q[2];   // J0..J3
-                const float4 E = q[3];   // J9, r, g, b
-                const float4 Nn = q[4];  // nx, ny, nz, 1/umax
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                float power;
-                if (SVGSS) power = -0.5f * ((A.z * dx * dx + B.x * dy * dy) + 2.f * A.w * dx * dy);
-                else power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float alpha = fminf(0.99f, B.y * __expf(power));
-                bool pass = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                const float test_T = T * (1.f - alpha);
-                bool newly_done = false;
-                if (pass && test_T < 0.0001f) { done = true; pass = false; newly_done = true; }
-                if (__ballot(pass) != 0ull) {
-                    const float w = pass ? alpha * T : 0.f;
-                    // the wave reduction for out_weights is issued first: its dependent DPP steps (2 wait states
-                    // each) interleave with the independent blend FMAs below instead of stalling at the end
-                    const float wsum = wave_scan_last(w);
-                    float dep = B.z;
-                    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+            if (b + 1 < nb) {
+                const uint2* q_nxt = sQ + ((b + 1) & 1) * CH;
+                stage_load<S, VC, CH>(sr, min(CH, total - (b + 1) * CH), [&](int s) { return q_nxt[s].x; }, lane, a.rec,
+                                      a.features, a.vfeatures);
+            }
+            DEV_TRACE_MARK(1);   // staging
+            int nproc = m;   // candidates of this batch whose weight sums are valid
+            for (int c0 = 0; c0 < m; c0 += KB) {
+                // ---- (1) KB independent alphas, lock-step ----
+                float4 A[KB], B[KB];
+                uint32_t slot[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const float4* q = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF);
+                    A[k] = q[0];   // x, y, conic.x, conic.y
+                    B[k] = q[1];   // conic.z, opacity, depth, DA
+                    slot[k] = q_cur[c0 + k].y;
+                }
+                float dx[KB], dy[KB], pw[KB], al[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) { dx[k] = A[k].x - pxf; dy[k] = A[k].y - pyf; }
+#pragma unroll
+                for (int k = 0; k < KB; k++) pw[k] = pair_power(A[k].z, A[k].w, B[k].x, dx[k], dy[k]);
+#pragma unroll
+                for (int k = 0; k < KB; k++) al[k] = fminf(0.99f, B[k].y * exp_nonpos(pw[k]));
+                bool pre[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) pre[k] = (c0 + k < m) && pw[k] <= 0.0f && al[k] >= (1.0f / 255.0f);
+                // ---- (2) the sequential part: transmittance chain and cut-off (forward.cu:541-560) ----
+                float w[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const bool live = pre[k] && !done;
+                    const float test_T = T * (1.f - al[k]);
+                    const bool term = live && test_T < 0.0001f;
+                    const bool pass = live && !term;
+                    done = done || term;
+                    w[k] = pass ? al[k] * T : 0.f;
+                    T = pass ? test_T : T;
+                    last_contributor = pass ? slot[k] + 1u : last_contributor;
+                }
+                // ---- (3) independent accumulations (weight 0 for everything that did not pass) ----
+                float4 E[KB], Nn[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const float4* q = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF);
+                    E[k] = q[3];    // DB, r, g, b
+                    Nn[k] = q[4];   // nx, ny, nz, 1/umax
+                }
+                float w0[KB], w1[KB], w2[KB], w3[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    float dep = B[k].z;
+                    w0[k] = w1[k] = w2[k] = w3[k] = 0.f;
                     if (sp) {
-                        const float du = dx * J.x + dy * J.y;
-                        const float dv = dx * J.z + dy * J.w;
-                        dep -= du * B.w + dv * E.x;
+                        dep -= dx[k] * B[k].w + dy[k] * E[k].x;   // depth differencing (common.hpp R_DA / R_DB)
                         if (SVGSS && VC > 0) {
+                            const float4* q = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF);
+                            const float4 J = q[2];   // J0..J3
                             const float iv = q[5].x;
-                            float u = du * Nn.w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
+                            const float du = dx[k] * J.x + dy[k] * J.y;
+                            const float dv = dx[k] * J.z + dy[k] * J.w;
+                            float u = du * Nn[k].w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
                             u = fminf(0.999f, fmaxf(0.001f, u));
                             v = fminf(0.999f, fmaxf(0.001f, v));
                             // pre-multiplied by the blend weight
-                            w0 = (1.f - u) * (1.f - v) * w; w1 = u * (1.f - v) * w; w2 = (1.f - u) * v * w; w3 = u * v * w;
+                            w0[k] = (1.f - u) * (1.f - v) * w[k]; w1[k] = u * (1.f - v) * w[k];
+                            w2[k] = (1.f - u) * v * w[k]; w3[k] = u * v * w[k];
                         }
                     }
-                    D += dep * w;
-                    C[0] += E.y * w; C[1] += E.z * w; C[2] += E.w * w;
-                    if (surface) { N[0] += Nn.x * w; N[1] += Nn.y * w; N[2] += Nn.z * w; }
-                    if (S > 0) {
-                        const float* f = sD + c * SG::NF + SG::F_OFF;
+                    D += dep * w[k];
+                }
 #pragma unroll
-                        for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w;
+                for (int k = 0; k < KB; k++) { C[0] += E[k].y * w[k]; C[1] += E[k].z * w[k]; C[2] += E[k].w * w[k]; }
+                if (surface) {
+#pragma unroll
+                    for (int k = 0; k < KB; k++) { N[0] += Nn[k].x * w[k]; N[1] += Nn[k].y * w[k]; N[2] += Nn[k].z * w[k]; }
+                }
+                if (S > 0) {
+#pragma unroll
+                    for (int k = 0; k < KB; k++) {
+                        const float* f = sD + (c0 + k) * SG::NF + SG::F_OFF;
+#pragma unroll
+                        for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w[k];
                     }
-                    if (VC > 0) {
-                        const float4* vf = reinterpret_cast<const float4*>(sD + c * SG::NF + SG::V_OFF);
+                }
+                if (VC > 0) {
+#pragma unroll
+                    for (int k = 0; k < KB; k++) {
+                        const float4* vf = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF + SG::V_OFF);
 #pragma unroll
                         for (int ch = 0; ch < VC; ch++) {
                             const float4 c4 = vf[ch];
-                            VF[ch] += c4.x * w0 + c4.y * w1 + c4.z * w2 + c4.w * w3;
+                            VF[ch] += c4.x * w0[k] + c4.y * w1[k] + c4.z * w2[k] + c4.w * w3[k];
                         }
                     }
-                    const uint2 e = sQ[(head + c) & (SG::QN - 1)];
-                    if (pass) {
-                        T = test_T;
-                        last_contributor = e.y + 1u;
-                    }
-                    if (lane == 63) atomic_add_f32(&a.out_weights[e.x], wsum);
                 }
-                if (__any(newly_done) && __all(done)) { wave_done = true; break; }
+                // ---- (4) out_weights: KB interleaved wave reductions, parked in LDS ----
+                float ws[KB];
+#pragma unroll
+                for (int k = 0; k < KB; k++) ws[k] = wave_scan_last(w[k]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < KB; k++) w_cur[c0 + k] = ws[k];
+                }
+                if (__all(done)) { wave_done = true; nproc = min(m, c0 + KB); break; }
             }
+            nflush = nproc;
             head += (uint32_t)m;
+            DEV_TRACE_MARK(2);   // blending
             // batches are CH-aligned and CH divides SEG: segment boundaries are batch ends
             if (!wave_done && (head & (uint32_t)(SEG - 1)) == 0u) dump_state(ndump++);
         }
+        wave_lds_sync();
+        flush_weights(b - 1);
     }
-    if (lane == 0) { a.sub_count[4 * tile + sub] = tail; a.sub_ndump[4 * tile + sub] = ndump; }
-    if (tail != 0) {
-        if (ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
-        // live segments: those that hold at least one processed candidate
-        const uint32_t nseg = min((tail + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u);
-        for (uint32_t k = lane; k < nseg; k += 64)
-            a.seg_map[dump_base + k] = ((uint32_t)(4 * tile + sub) << SEG_K_BITS) | k;
-    }
+    // live segments (those that hold at least one consumed candidate) are appended to the compact list the backward's
+    // waves walk; the list position comes from a returning atomic whose latency is covered by the output stores below
+    const uint32_t nseg = head != 0 ? min((head + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u) : 0u;
+    uint32_t seg_at = 0;
+    if (lane == 0 && nseg != 0) seg_at = atomicAdd(a.seg_count, nseg);
+    if (lane == 0) { a.sub_count[sid] = head; a.sub_ndump[sid] = ndump; }
+    if (head != 0 && ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
 
     if (inside) {
         const size_t N_ = (size_t)a.W * a.H;
@@ -203,16 +344,28 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(const RenderArgs a) {
         a.out_opacity[pid] = 1.f - T;
         a.final_D[pid] = D;
     }
+    seg_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_at);
+    for (uint32_t k = lane; k < nseg; k += 64) a.seg_list[seg_at + k] = (sid << SEG_K_BITS) | k;
+    DEV_TRACE_MARK(3);   // dumps + epilogue
+    DEV_TRACE_END(0, (unsigned)total, head, blockIdx.x);
 }
 
+// The LDS request doubles as a residency control for experiments (build_variant.sh -DFWD_LDS_MIN=...).
+#ifndef FWD_LDS_MIN
+#define FWD_LDS_MIN 0
+#endif
 template <int S, int VC, bool SVGSS>
 void launch(const RenderArgs& a, hipStream_t s) {
     using SG = StageGeom<S, VC>;
-    hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(sub_tile_grid(a.gx * a.gy)), dim3(64), SG::lds_bytes(),
-                       s, a);
+    hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(4 * a.gx * a.gy), dim3(64),
+                       std::max(SG::lds_bytes(), (size_t)FWD_LDS_MIN), s, a);
 }
 
 }  // namespace
+
+void launch_cull(const RenderArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(cull_kernel, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+}
 
 // Channel-count specialisations: the widths the reference's callers use (render.py:91 S=5; svgss.py:148-166
 // train S=4,VS=52 / eval S=7,VS=64), the no-feature case, and small generic widths for tests.
@@ -224,5 +377,19 @@ int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s) {
 #undef CASE
     return -1;
 }
+
+#if defined(SVGIR_DEV)
+// development builds only: copies the per-wave records of kernel slot 0 (forward) / 1 (backward) and resets the slot
+extern "C" int svgir_dev_trace_read(int slot, unsigned long long* out, int cap_records) {
+    unsigned int n[2];
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(svgir::g_dev_trace_n), sizeof(n)) != hipSuccess) return -1;
+    int cnt = (int)std::min<unsigned>(n[slot], (unsigned)std::min(cap_records, svgir::DEV_TRACE_CAP));
+    if (cnt > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(svgir::g_dev_trace), (size_t)cnt * svgir::DEV_TRACE_WORDS * 8,
+                                       (size_t)slot * svgir::DEV_TRACE_CAP * svgir::DEV_TRACE_WORDS * 8) != hipSuccess) return -1;
+    n[slot] = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_dev_trace_n), n, sizeof(n));
+    return cnt;
+}
+#endif
 
 }  // namespace svgir

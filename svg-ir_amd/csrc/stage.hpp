@@ -1,12 +1,12 @@
 // svg-ir_amd/csrc/stage.hpp -- wave-level culling and LDS staging shared by the forward and backward composite
 // kernels.
 //
-// Work decomposition: ONE wave64 per 8x8-pixel sub-tile (4 per 16x16 tile), no workgroup barriers.  A wave scans its
-// tile's depth-ordered splat list 64 entries at a time, culls lane-parallel (one splat per lane) against its 8x8
-// pixel rectangle, and queues the survivors ("candidates") in a small LDS ring.  Candidates are then staged CH at a
-// time: the 96-byte record written by preprocess.hip plus the S feature and VS vfeature floats are gathered into LDS
-// with 16-byte loads (all loads of a batch in flight before the first LDS store) and every candidate is then consumed
-// with wave-uniform (broadcast) ds_read_b128.
+// Work decomposition: ONE wave64 per 8x8-pixel sub-tile (4 per 16x16 tile), no workgroup barriers.  A cull kernel
+// (render_fwd.hip) tests every entry of a tile's depth-ordered splat list lane-parallel (one splat per lane) against the
+// four 8x8 pixel rectangles of the tile and writes the survivors ("candidates") to one compact list per sub-tile.
+// Candidates are then staged CH at a time: the 96-byte record written by preprocess.hip plus the S feature and VS
+// vfeature floats are gathered into LDS with 16-byte loads (all loads of a batch in flight before the first LDS store,
+// issued one batch ahead of their use) and every candidate is consumed with wave-uniform (broadcast) ds_read_b128.
 //
 // Staged layout of one candidate (floats):  [0,24) the record (common.hpp RecField), [24, 24+S4) the S feature
 // floats padded to a float4 boundary, [24+S4, NFD) the VS vfeature floats; slot stride NF = an odd number of float4s.
@@ -23,37 +23,90 @@ struct StageGeom {
     static constexpr int NF = NF4 * 4;
     static constexpr int C4 = 6 + VC;                // 16-byte chunks gathered per candidate (record + vfeatures)
     static constexpr int CH = NF <= 48 ? 64 : 32;    // candidates staged per batch (<= ~13 KB of LDS per wave)
-    static constexpr int QN = 128;                   // candidate ring (>= CH + 64)
+    static constexpr int QN = 2 * CH;                // {gid, slot} entries of the current and the next staging batch
+#ifndef FWD_KB_V
+#define FWD_KB_V 2
+#endif
+#ifndef FWD_KB_P
+#define FWD_KB_P 4
+#endif
+    static constexpr int KB = VC > 0 ? FWD_KB_V : FWD_KB_P;   // candidates blended per branch-free group (divides CH)
+#ifndef FWD_WPE_V
+#define FWD_WPE_V 2
+#endif
+#ifndef FWD_WPE_P
+#define FWD_WPE_P 3
+#endif
+    static constexpr int WPE = VC > 0 ? FWD_WPE_V : FWD_WPE_P;   // waves per SIMD the forward's register budget is held to
     static constexpr int F_OFF = REC;
     static constexpr int V_OFF = REC + S4;
-    static constexpr size_t lds_bytes() { return (size_t)CH * NF * 4 + (size_t)QN * 8; }
+    static constexpr size_t lds_bytes() { return (size_t)CH * NF * 4 + (size_t)QN * 8 + (size_t)2 * CH * 4; }   // + per-candidate weight sums (this / previous batch)
     static_assert(SEG % CH == 0, "segment boundaries must fall on staging-batch boundaries");
+    static_assert(CH % KB == 0, "a staging batch is a whole number of blend batches");
 };
 
 #if defined(__HIPCC__)
-// Conservative wave-level cull.  Lane-parallel over splats: does the splat with mean (mx,my), conic (a,b,c) and
-// opacity `op` reach alpha >= 1/255 anywhere inside the pixel rectangle [X0,X1]x[Y0,Y1]?  The per-pixel test is
+// Exponent of the Gaussian falloff of a (pixel, splat) pair, rounded exactly like a plain fp32 evaluation of the
+// reference's source (svgss forward.cu:534-535: -0.5 * ((a dx dx + c dy dy) + 2 b dx dy); rgss forward.cu:430:
+// -0.5 * (a dx dx + c dy dy) - b dx dy) without FMA contraction of the products: forward and backward must take
+// identical alpha >= 1/255 decisions, and that evaluation is what the parity oracle computes.  Both variants round
+// the same real number once in their last step (scaling by 2 or 0.5 is exact), so one formula serves both:
+// s = ((a dx) dx + (c dy) dy), m = (b dx) dy, power = round(-0.5 s - m).
+__device__ __forceinline__ float pair_power(float a, float b, float c, float dx, float dy) {
+    float s, m;
+    {
+#pragma clang fp contract(off)
+        s = a * dx * dx + c * dy * dy;
+        m = b * dx * dy;
+    }
+    return __builtin_fmaf(-0.5f, s, -m);
+}
+
+// exp(x) for x <= 0 to ~1 ulp in 6 instructions: the hardware exp2 is evaluated at the rounded product t = x log2(e)
+// and corrected to first order for the rounding of t (residual r = x log2(e) - t, exact through an FMA and the low
+// word of log2(e)): 2^(t + r) = 2^t (1 + r ln 2 + O(r^2)), |r| < 2^-21.  No range reduction is needed: v_exp_f32
+// covers the whole range and flushes to 0 where exp underflows.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    const float L2E_HI = 1.44269502162933349609375f;    // fp32(log2 e)
+    const float L2E_LO = 1.92596299112661746e-8f;       // log2 e - fp32(log2 e)
+    const float t = x * L2E_HI;
+    float r = __builtin_fmaf(x, L2E_HI, -t);
+    r = __builtin_fmaf(x, L2E_LO, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
+}
+
+// Conservative cull of a splat against pixel rectangles.  Does the splat with mean (mx,my), conic (a,b,c) and opacity
+// `op` reach alpha >= 1/255 anywhere inside the pixel rectangle [X0,X1]x[Y0,Y1]?  The per-pixel test is
 // q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 op); the minimum of the convex form over the rectangle is 0 when
 // the mean is inside, else it lies on one of the four edges.  A slack absorbs fp32 rounding of the per-pixel
-// evaluation, so a splat is only ever dropped when no pixel of the rectangle can pass the exact test.
-__device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, float b, float c, float op, float X0,
-                                                float Y0, float X1, float Y1) {
-    const float u0 = mx - X1, u1 = mx - X0, v0 = my - Y1, v1 = my - Y0;  // ranges of dx, dy
-    const float tau2 = 2.f * __logf(255.f * op);                         // NaN / -inf for op <= 0 => never passes
-    if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f)) return tau2 == tau2;  // degenerate conic: keep
-    float qmin = 0.f;
+// evaluation (and of the hardware reciprocal / logarithm used here), so a splat is only ever dropped when no pixel
+// of the rectangle can pass the exact test.  The per-splat part is computed once and tested against several rectangles.
+struct SplatCull {
+    float mx, my, a, b, c, tau2, ia, ic;
+    bool degenerate;   // not a positive-definite conic: keep whenever the threshold is a number
+};
+__device__ __forceinline__ SplatCull cull_prepare(float mx, float my, float a, float b, float c, float op) {
+    SplatCull s;
+    s.mx = mx; s.my = my; s.a = a; s.b = b; s.c = c;
+    s.tau2 = 2.f * 0.693147182f * __builtin_amdgcn_logf(255.f * op);   // NaN / -inf for op <= 0 => never passes
+    s.degenerate = !(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f);
+    s.ia = __builtin_amdgcn_rcpf(a); s.ic = __builtin_amdgcn_rcpf(c);
+    return s;
+}
+__device__ __forceinline__ bool cull_test(const SplatCull& s, float X0, float Y0, float X1, float Y1) {
+    const float u0 = s.mx - X1, u1 = s.mx - X0, v0 = s.my - Y1, v1 = s.my - Y0;  // ranges of dx, dy
+    const float a = s.a, b = s.b, c = s.c;
     const bool in = (u0 <= 0.f) && (u1 >= 0.f) && (v0 <= 0.f) && (v1 >= 0.f);
-    if (!in) {
-        const float ic = 1.f / c, ia = 1.f / a;
-        float v, u, q;
-        v = fminf(v1, fmaxf(v0, -b * u0 * ic)); qmin = a * u0 * u0 + 2.f * b * u0 * v + c * v * v;
-        v = fminf(v1, fmaxf(v0, -b * u1 * ic)); q = a * u1 * u1 + 2.f * b * u1 * v + c * v * v; qmin = fminf(qmin, q);
-        u = fminf(u1, fmaxf(u0, -b * v0 * ia)); q = a * u * u + 2.f * b * u * v0 + c * v0 * v0; qmin = fminf(qmin, q);
-        u = fminf(u1, fmaxf(u0, -b * v1 * ia)); q = a * u * u + 2.f * b * u * v1 + c * v1 * v1; qmin = fminf(qmin, q);
-    }
+    float v, u, q, qmin;
+    v = fminf(v1, fmaxf(v0, -b * u0 * s.ic)); qmin = a * u0 * u0 + 2.f * b * u0 * v + c * v * v;
+    v = fminf(v1, fmaxf(v0, -b * u1 * s.ic)); q = a * u1 * u1 + 2.f * b * u1 * v + c * v * v; qmin = fminf(qmin, q);
+    u = fminf(u1, fmaxf(u0, -b * v0 * s.ia)); q = a * u * u + 2.f * b * u * v0 + c * v0 * v0; qmin = fminf(qmin, q);
+    u = fminf(u1, fmaxf(u0, -b * v1 * s.ia)); q = a * u * u + 2.f * b * u * v1 + c * v1 * v1; qmin = fminf(qmin, q);
+    qmin = in ? 0.f : qmin;
     const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
     const float slack = 0.02f + 4e-5f * (a * um * um + 2.f * fabsf(b) * um * vm + c * vm * vm);
-    return qmin <= tau2 + slack;
+    return s.degenerate ? (s.tau2 == s.tau2) : (qmin <= s.tau2 + slack);
 }
 
 // Wave-level gather of m (<= CHN) candidates into LDS slots [0, m), split in two halves so that the global loads of
@@ -63,12 +116,16 @@ __device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, flo
 //                with clamped indices, which keeps everything in registers);
 //   stage_store: registers -> LDS (predicated).
 // The caller separates the stores from the subsequent LDS reads with wave_lds_sync().
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int S, int VC, int CHN>
 struct StageRegs {
     using SG = StageGeom<S, VC>;
     static constexpr int KV = (CHN * SG::C4 + 63) / 64;  // 16-byte loads per lane per batch
     static constexpr int KF = (CHN * S + 63) / 64;       // feature floats per lane per batch
-    float4 v[KV];
+    // native vector type: a HIP float4 is a struct, and struct copies global -> register array -> LDS are lowered to
+    // memcpys that keep the whole array in scratch (every gather then waits for its own latency before it is spilled)
+    f32x4 v[KV];
     float fv[KF > 0 ? KF : 1];
 };
 
@@ -78,15 +135,15 @@ __device__ __forceinline__ void stage_load(StageRegs<S, VC, CHN>& r, int m, GidO
                                            const float* __restrict__ vfeat) {
     using SG = StageGeom<S, VC>;
     using SR = StageRegs<S, VC, CHN>;
-    const float4* rec4 = reinterpret_cast<const float4*>(rec);
-    const float4* vf4 = reinterpret_cast<const float4*>(vfeat);
+    const f32x4* rec4 = reinterpret_cast<const f32x4*>(rec);
+    const f32x4* vf4 = reinterpret_cast<const f32x4*>(vfeat);
     const int total = m * SG::C4;  // >= C4 (m >= 1)
 #pragma unroll
     for (int u = 0; u < SR::KV; u++) {
         const int k = min(u * 64 + lane, total - 1);
         const int s = k / SG::C4, part = k - s * SG::C4;
         const size_t id = (size_t)gid_of(s);
-        const float4* src = part < 6 ? rec4 + id * 6 + part : vf4 + id * VC + (part - 6);
+        const f32x4* src = part < 6 ? rec4 + id * 6 + part : vf4 + id * VC + (part - 6);
         r.v[u] = *src;
     }
     if (S > 0) {
@@ -104,7 +161,7 @@ template <int S, int VC, int CHN>
 __device__ __forceinline__ void stage_store(const StageRegs<S, VC, CHN>& r, float* __restrict__ sD, int m, int lane) {
     using SG = StageGeom<S, VC>;
     using SR = StageRegs<S, VC, CHN>;
-    float4* sD4 = reinterpret_cast<float4*>(sD);
+    f32x4* sD4 = reinterpret_cast<f32x4*>(sD);
     const int total = m * SG::C4;
 #pragma unroll
     for (int u = 0; u < SR::KV; u++) {
@@ -137,7 +194,7 @@ __device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, 
     // per 16-byte chunk): every loaded value has to be live here, so all loads of the batch are in flight together.
 #pragma unroll
     for (int u = 0; u < StageRegs<S, VC, CHN>::KV; u++)
-        asm volatile("" : "+v"(r.v[u].x), "+v"(r.v[u].y), "+v"(r.v[u].z), "+v"(r.v[u].w));
+        asm volatile("" : "+v"(r.v[u]));
     if (S > 0) {
 #pragma unroll
         for (int u = 0; u < StageRegs<S, VC, CHN>::KF; u++) asm volatile("" : "+v"(r.fv[u]));
@@ -145,18 +202,6 @@ __device__ __forceinline__ void stage_candidates(float* __restrict__ sD, int m, 
     stage_store<S, VC, CHN>(r, sD, m, lane);
 }
 
-// Block -> (tile, sub-tile) mapping: the four waves of a tile get block ids congruent mod 8, i.e. they run on the
-// same XCD (blocks are dispatched round-robin over the 8 XCDs) and share that XCD's L2 for the records they gather.
-// Tiles are taken in descending order of their list length (tile_order), so the longest sequential walks start
-// first and the short ones fill the tail of the launch.
-__device__ __forceinline__ void sub_tile_of_block(int b, int T, const uint32_t* __restrict__ tile_order, int& tile,
-                                                  int& sub) {
-    const int grp = b >> 5, r = b & 31;  // 32 blocks = 8 tiles x 4 sub-tiles
-    const int k = grp * 8 + (r & 7);
-    sub = r >> 3;
-    tile = k < T ? (int)tile_order[k] : -1;
-}
-inline int sub_tile_grid(int T) { return ((T + 7) / 8) * 32; }
 #endif
 
 }  // namespace svgir

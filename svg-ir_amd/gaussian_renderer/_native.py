@@ -13,6 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
 
 RGSS, SVGSS = 0, 1
+ABI_VERSION = 4
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -69,14 +70,14 @@ def _load():
     lib.svgir_backward.argtypes = [C.POINTER(Params), C.POINTER(Grads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.svgir_backward_scratch_bytes.restype = C.c_size_t
-    lib.svgir_backward_scratch_bytes.argtypes = [C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.svgir_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.svgir_mark_visible.restype = C.c_int
     lib.svgir_mark_visible.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svgir_set_profiling.argtypes = [C.c_int]
     lib.svgir_last_timings.restype = C.c_int
     lib.svgir_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     lib.svgir_last_error.restype = C.c_char_p
-    if lib.svgir_abi_version() != 3:
+    if lib.svgir_abi_version() != ABI_VERSION:
         raise ImportError("libsvgir_raster.so ABI version mismatch")
     return lib
 

@@ -122,9 +122,11 @@ class _CBinding:
             g.dL_dcov3D, g.dL_dsh, g.dL_dscales = dL_dcov3D.data_ptr(), N.ptr(dL_dsh), dL_dscales.data_ptr()
             g.dL_drotations = dL_drotations.data_ptr()
             rad = radii.contiguous()
-            # (no scratch: at the rgss widths the gradient atomics are cheaper than the row pass, include/svgir_raster.h)
+            # scratch: one packed gradient row per Gaussian (include/svgir_raster.h)
+            nscr = N.lib.svgir_backward_scratch_bytes(N.RGSS, P, binningBuffer.numel(), W, H, S, 0)
+            scratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
             N.check(N.lib.svgir_backward(p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
-                                         binningBuffer.numel(), imageBuffer.data_ptr(), None, 0,
+                                         binningBuffer.numel(), imageBuffer.data_ptr(), scratch.data_ptr(), nscr,
                                          N.stream_ptr(dev)), "backward")
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dcov3D, dL_dsh, dL_dscales,
                 dL_drotations)

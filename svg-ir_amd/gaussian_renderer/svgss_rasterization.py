@@ -124,8 +124,8 @@ class _CBinding:
             g.dL_drotations = dL_drotations.data_ptr()
             g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
             rad = radii.contiguous()
-            # scratch for the atomic-free gradient accumulation (rows per (instance, sub-tile), summed per Gaussian)
-            nscr = N.lib.svgir_backward_scratch_bytes(binningBuffer.numel(), W, H, S, VS)
+            # scratch for the gradient accumulation (rows per (instance, sub-tile), summed per Gaussian)
+            nscr = N.lib.svgir_backward_scratch_bytes(N.SVGSS, P, binningBuffer.numel(), W, H, S, VS)
             scratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
             N.check(N.lib.svgir_backward(p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
                                          binningBuffer.numel(), imageBuffer.data_ptr(), scratch.data_ptr(), nscr,
