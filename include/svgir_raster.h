@@ -165,6 +165,13 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
 size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_bytes, int32_t W, int32_t H, int32_t S,
                                     int32_t VS);
 
+/* Introspection of the state blobs for tests / debugging (the blobs stay opaque to the rendering path): byte offset of
+ * the depth-sorted instance list `point_list` (uint32 Gaussian ids, R entries; BinningState::point_list,
+ * rasterizer_impl.h:66-76) inside the binning blob, and of the per-tile `ranges` (uint2 per tile; ImageState::ranges,
+ * rasterizer_impl.h:49-63) inside the image blob. */
+size_t svgir_binning_point_list_offset(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS);
+size_t svgir_image_ranges_offset(int32_t W, int32_t H);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:141-153).  `present` is a byte per
  * Gaussian.  svgss: the reference kernel body is commented out, so `present` is left untouched (all false, Q14);
  * rgss: present = view-space z > 0.2. */

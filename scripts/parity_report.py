@@ -1,0 +1,60 @@
+"""Measured HIP-vs-oracle error per tensor and config -> gpurun_out/parity_<tag>.json (copied to profiles/ by hand).
+    python scripts/parity_report.py [tag] [configs...]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "svg-ir_amd"), ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import parity_util as pu
+from oracle import oracle as orc
+from svgir_harness import runner, scenes
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+cfgs = sys.argv[2:] or ["cfg1", "cfg2", "cfg3_train", "cfg3_eval", "cfg4"]
+dev = torch.device("cuda:0")
+rep = {}
+for cfg in cfgs:
+    variant = scenes.CONFIGS[cfg][1]["variant"]
+    sc = scenes.make(cfg)
+    train = cfg in ("cfg2", "cfg3_train", "cfg4")
+    grads = scenes.upstream_grads(sc, variant) if train else None
+    sct = runner.to_torch(sc, dev)
+    t0 = time.time()
+    raw = runner.forward_raw(sct, variant)
+    out, leaves = runner.render(sct, variant, requires_grad=train)
+    if train:
+        runner.backward(out, grads, variant)
+    torch.cuda.synchronize()
+    o = orc.OracleRun(sc, orc.SVGSS if variant == "svgss" else orc.RGSS)
+    R = o.forward()
+    if train:
+        o.backward(grads["color"], grads["normal"], grads["depth"], grads["opacity"], grads["feature"], grads.get("vfeature"))
+    im = o.images()
+    r = {"num_rendered": [int(out["num_rendered"]), int(R)], "radii_equal": bool(np.array_equal(out["radii"].cpu().numpy(), im["radii"])),
+         "point_list_equal": bool(np.array_equal(raw["point_list"], o.get("point_list")[:R])),
+         "ranges_equal": bool(np.array_equal(raw["ranges"].reshape(-1), o.get("ranges").reshape(-1))),
+         "n_contrib_mismatch_frac": float((raw["n_contrib"] != o.get("n_contrib").reshape(raw["n_contrib"].shape)).mean()),
+         "forward": {}, "backward": {}}
+    for k in ["color", "normal", "depth", "opacity", "feature", "weights"] + (["vfeature"] if variant == "svgss" else []):
+        r["forward"][k] = pu.stats(out[k].detach().cpu().numpy(), im[k])
+    if train:
+        gr = o.grads()
+        pairs = [("means3D", "means3D"), ("scales", "scales"), ("rotations", "rotations"), ("opacities", "opacity"),
+                 ("shs", "sh"), ("features", "features"), ("means2D", "means2D")] + ([("vfeatures", "vfeatures")] if variant == "svgss" else [])
+        for lk, ok in pairs:
+            if leaves[lk].grad is not None:
+                r["backward"][lk] = pu.stats(leaves[lk].grad.cpu().numpy(), gr[ok])
+    r["seconds"] = time.time() - t0
+    rep[cfg] = r
+    print(cfg, "R", r["num_rendered"], "point_list", r["point_list_equal"], "ranges", r["ranges_equal"], "ncontrib mismatch %.2e" % r["n_contrib_mismatch_frac"])
+    for ph in ("forward", "backward"):
+        for k, v in r[ph].items():
+            print("   %-8s %-10s max_norm %.2e p99.99 %.2e flip_frac %.2e rel_frac %.2e p99.99_rel %.2e" % (ph, k, v["max_norm"], v["p9999_norm"], v["flip_frac"], v["rel_frac"], v.get("p9999_rel", 0)))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", f"parity_{tag}.json"), "w") as f:
+    json.dump(rep, f, indent=1)

@@ -181,6 +181,17 @@ size_t svgir_binning_bytes(int32_t R, int32_t W, int32_t H, int32_t S, int32_t V
     return bin_layout(nullptr, binning_capacity(R), T, seg_nstate(S, VS)).bytes;
 }
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H) { return image_layout(nullptr, W, H).ncontrib_off; }
+size_t svgir_image_ranges_offset(int32_t W, int32_t H) {
+    const ImageLayout I = image_layout((char*)256, W, H);   // (non-null dummy base: the layout returns pointers)
+    return (size_t)((char*)I.ranges - (char*)256);
+}
+size_t svgir_binning_point_list_offset(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS) {
+    const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const int nstate = seg_nstate(S, VS);
+    const int cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
+    const BinLayout B = bin_layout((char*)256, cap, T, nstate);
+    return (size_t)((char*)B.val[tile_sort_plan(T).passes & 1] - (char*)256);
+}
 const char* svgir_last_error(void) { return g_err.c_str(); }
 void svgir_set_profiling(int enabled) {
     resolve_pending();

@@ -63,6 +63,10 @@ def _load():
     lib.svgir_binning_bytes.argtypes = [C.c_int32] * 5
     lib.svgir_image_ncontrib_offset.restype = C.c_size_t
     lib.svgir_image_ncontrib_offset.argtypes = [C.c_int32, C.c_int32]
+    lib.svgir_image_ranges_offset.restype = C.c_size_t
+    lib.svgir_image_ranges_offset.argtypes = [C.c_int32, C.c_int32]
+    lib.svgir_binning_point_list_offset.restype = C.c_size_t
+    lib.svgir_binning_point_list_offset.argtypes = [C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.svgir_forward.restype = C.c_int
     lib.svgir_forward.argtypes = [C.POINTER(Params), C.POINTER(Outputs), ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
                                   ALLOC_FN, C.c_void_p, C.c_void_p]
@@ -85,7 +89,7 @@ def _load():
 lib = _load()
 
 EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_binning_bytes",
-           "svgir_image_ncontrib_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
+           "svgir_image_ncontrib_offset", "svgir_image_ranges_offset", "svgir_binning_point_list_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
            "svgir_backward_scratch_bytes", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
            "svgir_shade_backward")
 

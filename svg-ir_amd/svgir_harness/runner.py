@@ -75,3 +75,44 @@ def backward(out, grads, variant):
             continue
         loss = loss + (out[k] * g.to(dev)).sum()
     loss.backward()
+
+
+def forward_raw(sc, variant):
+    """Forward through the `_C` binding (no autograd) keeping the three state blobs; also decodes the depth-sorted instance
+    list and the tile ranges from them (include/svgir_raster.h introspection offsets).  `sc` is a to_torch() scene."""
+    from gaussian_renderer import _native as N
+    dev = sc["means3D"].device
+    st = settings(sc, variant)
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+    S = sc["features"].shape[1]
+    if variant == "svgss":
+        from gaussian_renderer.svgss_rasterization import _C
+        VS = sc["vfeatures"].shape[1]
+        out = _C.rasterize_gaussians(st.bg, sc["means3D"], sc["features"], sc["vfeatures"], empty, sc["opacities"],
+                                     sc["scales"], sc["rotations"], st.scale_modifier, empty, st.viewmatrix,
+                                     st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy,
+                                     st.image_height, st.image_width, sc["shs"], st.sh_degree, st.campos, False, False,
+                                     st.config)
+        (R, color, normal, depth, opac, feat, vfeat, weights, radii, gb, bb, ib) = out
+        res = dict(num_rendered=R, color=color, normal=normal, depth=depth, opacity=opac, feature=feat, vfeature=vfeat,
+                   weights=weights, radii=radii)
+    else:
+        from gaussian_renderer.rgss_rasterization import _C
+        VS = 0
+        out = _C.rasterize_gaussians(st.bg, sc["means3D"], sc["features"], empty, sc["opacities"], sc["scales"],
+                                     sc["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix,
+                                     st.tanfovx, st.tanfovy, st.cx, st.cy, st.image_height, st.image_width, sc["shs"],
+                                     st.sh_degree, st.campos, False, False, False)
+        (R, ncontrib, color, normal, opac, depth, feat, pn, sx, weights, radii, gb, bb, ib) = out
+        res = dict(num_rendered=R, color=color, normal=normal, depth=depth, opacity=opac, feature=feat, weights=weights,
+                   radii=radii)
+    W, H = st.image_width, st.image_height
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    off = N.lib.svgir_binning_point_list_offset(bb.numel(), W, H, S, VS)
+    res["point_list"] = bb[off:off + 4 * R].view(torch.int32).cpu().numpy().astype("uint32")
+    roff = N.lib.svgir_image_ranges_offset(W, H)
+    res["ranges"] = ib[roff:roff + 8 * T].view(torch.int32).cpu().numpy().astype("uint32").reshape(T, 2)
+    noff = N.lib.svgir_image_ncontrib_offset(W, H)
+    res["n_contrib"] = ib[noff:noff + 4 * W * H].view(torch.int32).cpu().numpy().reshape(H, W)
+    res["blobs"] = (gb, bb, ib)
+    return res

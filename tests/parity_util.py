@@ -1,0 +1,25 @@
+"""Error statistics shared by the GPU parity tests and scripts/parity_report.py.
+
+north_star: "match the reference within 1e-4 relative fp32".  Two views of the same comparison:
+  * normalised: |a-b| <= tol * (max|b| + |b|) -- what a consumer of the image / gradient tensor sees;
+  * element-wise relative on the entries that carry signal (|b| > 1e-3 max|b|): |a-b| <= rel_tol * |b|.
+Entries outside either band are "flips": an alpha >= 1/255 or T < 1e-4 decision that fell the other way for an isolated
+(pixel, splat) pair because exp differs in its last bit.  Their share and their size are both bounded."""
+import numpy as np
+
+
+def stats(a, b, tol=1e-4, rel_tol=1e-3):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.size == 0:
+        return dict(n=0, scale=0.0, max_abs=0.0, max_norm=0.0, p9999_norm=0.0, flip_frac=0.0, rel_frac=0.0, finite=True)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    err = np.abs(a - b)
+    norm = err / (scale + np.abs(b))
+    big = np.abs(b) > 1e-3 * scale
+    rel = err[big] / np.abs(b[big]) if big.any() else np.zeros(0)
+    return dict(n=int(b.size), scale=scale, max_abs=float(err.max()), max_norm=float(norm.max()),
+                p9999_norm=float(np.quantile(norm, 0.9999)), flip_frac=float((norm > tol).mean()),
+                rel_frac=float((rel > rel_tol).mean()) if rel.size else 0.0,
+                p9999_rel=float(np.quantile(rel, 0.9999)) if rel.size else 0.0, finite=bool(np.isfinite(a).all()))

@@ -1,22 +1,28 @@
 """GPU parity tests: the HIP path (through the C ABI and the drop-in bindings) against the CPU oracle.
 
-Tolerance: north_star asks for 1e-4 relative fp32 agreement.  Integer outputs (num_rendered, radii, n_contrib) must
-match exactly.  Float images/gradients are compared with |a-b| <= 1e-4*(scale + |b|) where scale = max|b| of the
-tensor; because exp() implementations differ by an ulp between glibc and the GPU, an (alpha >= 1/255) or
-(T < 1e-4) decision can flip for isolated (pixel, splat) pairs (SURVEY 7 "hard parts"), so up to FLIP_FRAC of the
-entries may exceed the tolerance, and those are bounded by the size of one threshold contribution.
+Tolerance: north_star asks for 1e-4 relative fp32 agreement.  Integer outputs (num_rendered, radii, n_contrib, the
+depth-sorted instance list, the tile ranges) must match EXACTLY.  Float images / gradients are compared two ways
+(tests/parity_util.py): normalised, |a-b| <= 1e-4 (max|b| + |b|), and element-wise relative on the entries that carry
+signal.  The composite kernels evaluate alpha in exactly the operation order of the reference's source with a ~1 ulp
+exp, so the alpha >= 1/255 and T < 1e-4 decisions agree with the oracle's; the measured flip share is 0 on every
+BASELINE config (profiles/parity_r02.json), and the tests allow at most FLIP_FRAC isolated outliers, each bounded.
 """
 import numpy as np
 import pytest
 import torch
 
+import parity_util as pu
 from oracle import oracle as orc
 from svgir_harness import runner, scenes
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
-FLIP_FRAC = 2e-4
+TOL = 1e-4          # normalised tolerance (north_star)
+FLIP_FRAC = 2e-5    # share of forward entries that may exceed it (threshold flips), each bounded by FLIP_BOUND * max|ref|
+GRAD_FLIP_FRAC = 3e-4
+FLIP_BOUND = 0.05
+REL_TOL = 5e-3      # element-wise relative tolerance on entries > 1e-3 max|ref| ...
+REL_FRAC = 1e-3     # ... for all but this share (differences of nearly cancelling sums)
 
 
 def _dev():
@@ -24,20 +30,17 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _cmp(name, a, b, tol=TOL, flip_frac=FLIP_FRAC, flip_bound=None):
-    a = np.asarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float64).reshape(-1)
-    b = np.asarray(b, dtype=np.float64).reshape(-1)
-    assert a.shape == b.shape, (name, a.shape, b.shape)
-    if b.size == 0:
-        return
-    assert np.isfinite(a).all(), name
-    scale = max(np.abs(b).max(), 1e-30)
-    err = np.abs(a - b)
-    bad = err > tol * (scale + np.abs(b))
-    frac = bad.mean()
-    assert frac <= flip_frac, f"{name}: {bad.sum()}/{bad.size} entries beyond 1e-4 (max err {err.max():.3e}, scale {scale:.3e})"
-    if flip_bound is not None and bad.any():
-        assert err.max() <= flip_bound * scale, f"{name}: outlier {err.max():.3e} exceeds flip bound"
+def _cmp(name, a, b, tol=TOL, flip_frac=FLIP_FRAC, flip_bound=FLIP_BOUND, rel=True):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    st = pu.stats(a, b, tol=tol, rel_tol=REL_TOL)
+    if st["n"] == 0:
+        return st
+    assert st["finite"], name
+    assert st["flip_frac"] <= flip_frac, f"{name}: {st['flip_frac']:.2e} of the entries beyond {tol:g} (max {st['max_norm']:.2e} of scale {st['scale']:.3e})"
+    assert st["max_abs"] <= max(flip_bound, tol * 2) * st["scale"], f"{name}: outlier {st['max_abs']:.3e} exceeds the flip bound"
+    if rel:
+        assert st["rel_frac"] <= REL_FRAC, f"{name}: {st['rel_frac']:.2e} of the signal-carrying entries beyond {REL_TOL:g} relative"
+    return st
 
 
 def _run_both(sc, variant, grads=None):
@@ -54,13 +57,23 @@ def _run_both(sc, variant, grads=None):
     return out, leaves, o, R
 
 
+def _check_binning(sc, variant, o, R):
+    """Integer state compared directly with the oracle: instance list (a5), tile ranges (a6), last contributors (a7)."""
+    raw = runner.forward_raw(runner.to_torch(sc, _dev()), variant)
+    assert raw["num_rendered"] == R
+    assert np.array_equal(raw["point_list"], o.get("point_list")[:R]), "depth-sorted instance list differs from the oracle's"
+    assert np.array_equal(raw["ranges"].reshape(-1), o.get("ranges").reshape(-1)), "tile ranges differ"
+    nc = o.get("n_contrib").reshape(raw["n_contrib"].shape)
+    assert (raw["n_contrib"] != nc).mean() <= FLIP_FRAC, "n_contrib differs"
+
+
 def _check_forward(out, o, R, variant):
     im = o.images()
     assert out["num_rendered"] == R
     assert np.array_equal(out["radii"].cpu().numpy(), im["radii"])
     for k in ["color", "normal", "depth", "opacity", "feature"] + (["vfeature"] if variant == "svgss" else []):
         assert tuple(out[k].shape) == im[k].shape, k
-        _cmp(k, out[k], im[k], flip_bound=0.05)
+        _cmp(k, out[k], im[k])
     _cmp("weights", out["weights"], im["weights"])
     return im
 
@@ -76,8 +89,7 @@ def _check_backward(leaves, o, variant):
         if g is None:
             assert gr[ok].size == 0 or np.abs(gr[ok]).max() == 0, lk
             continue
-        # float atomics / different summation order: a slightly larger share of tiny entries may deviate
-        _cmp("grad_" + lk, g, gr[ok], tol=2e-4, flip_frac=3e-3)
+        _cmp("grad_" + lk, g, gr[ok], flip_frac=GRAD_FLIP_FRAC)
 
 
 CASES = [
@@ -99,21 +111,55 @@ def test_forward_backward_parity_small(built, name, kw):
     out, leaves, o, R = _run_both(sc, variant, grads)
     assert R > 0
     im = _check_forward(out, o, R, variant)
-    if variant == "rgss":
-        assert (out["n_contrib"].cpu().numpy() == im["n_contrib"]).mean() > 1 - FLIP_FRAC
+    _check_binning(sc, variant, o, R)
     _check_backward(leaves, o, variant)
 
 
-@pytest.mark.parametrize("cfg,variant", [("cfg1", "svgss"), ("cfg2", "rgss"), ("cfg3_train", "svgss"), ("cfg3_eval", "svgss")])
+@pytest.mark.parametrize("cfg,variant", [("cfg1", "svgss"), ("cfg2", "rgss"), ("cfg3_train", "svgss"), ("cfg3_eval", "svgss"),
+                                         ("cfg4", "svgss")])
 def test_baseline_configs_full_size(built, cfg, variant):
-    """BASELINE.json configs 0-2 at full size (the oracle finishes them in seconds)."""
+    """BASELINE.json configs 0-3 at full size (the oracle finishes them in seconds).  cfg4 = one of the eight armadillo
+    views at the eval widths (the other seven only differ in the camera: test_cfg4_all_eight_views)."""
     sc = scenes.make(cfg)
     train = cfg != "cfg3_eval"
     grads = scenes.upstream_grads(sc, variant) if train else None
     out, leaves, o, R = _run_both(sc, variant, grads)
     _check_forward(out, o, R, variant)
+    _check_binning(sc, variant, o, R)
     if train:
         _check_backward(leaves, o, variant)
+
+
+def test_cfg4_all_eight_views(built):
+    """BASELINE configs[3]: the eight test views (azimuth k * 45 degrees, elevation 30 degrees) that the view-parallel
+    driver shards over 8 GPUs, each forward against the oracle on this one GPU."""
+    from svgir_harness import cameras
+    base = scenes.make("cfg4")
+    for k in range(8):
+        sc = dict(base)
+        sc.update(cameras.make_camera(sc["W"], sc["H"], cameras.orbit_eye(4.0, 45.0 * k, 30.0)))
+        out, leaves, o, R = _run_both(sc, "svgss", None)
+        _check_forward(out, o, R, "svgss")
+
+
+def test_cfg5_stress_full_size(built):
+    """BASELINE configs[4]: 2 M surfels, 1600x1600, eval widths -- forward and backward against the oracle at full size,
+    plus the size-independent properties (idempotence, linearity in the feature channels)."""
+    sc = scenes.make("cfg5")
+    grads = scenes.upstream_grads(sc, "svgss")
+    out, leaves, o, R = _run_both(sc, "svgss", grads)
+    assert R > 3_000_000
+    _check_forward(out, o, R, "svgss")
+    _check_binning(sc, "svgss", o, R)
+    _check_backward(leaves, o, "svgss")
+    del o
+    sct = runner.to_torch(sc, _dev())
+    out2, _ = runner.render(sct, "svgss")
+    for k in ("color", "normal", "depth", "opacity", "feature", "vfeature"):
+        assert torch.equal(out[k].detach(), out2[k]), k
+    sct["features"] = sct["features"] * 2.0
+    out3, _ = runner.render(sct, "svgss")
+    torch.testing.assert_close(out3["feature"], out2["feature"] * 2.0, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("variant,S,VS", [("rgss", 5, 0), ("svgss", 3, 8)])
@@ -158,9 +204,9 @@ def test_config_flags_and_quirks(built):
     o.forward()
     o.backward(grads["color"], grads["normal"], grads["depth"], grads["opacity"], grads["feature"], grads["vfeature"])
     gr = o.grads()
-    _cmp("viewmat", vm.grad, gr["viewmat"], tol=5e-4, flip_frac=0.0)
-    _cmp("projmat", pm.grad, gr["projmat"], tol=5e-4, flip_frac=0.0)
-    _cmp("campos", cp.grad, gr["campos"], tol=5e-4, flip_frac=0.0)
+    _cmp("viewmat", vm.grad, gr["viewmat"], tol=5e-4, flip_frac=0.0, rel=False)
+    _cmp("projmat", pm.grad, gr["projmat"], tol=5e-4, flip_frac=0.0, rel=False)
+    _cmp("campos", cp.grad, gr["campos"], tol=5e-4, flip_frac=0.0, rel=False)
 
 
 def test_rgss_pseudo_normal_ncontrib_view_and_backward_geometry(built):
@@ -170,7 +216,7 @@ def test_rgss_pseudo_normal_ncontrib_view_and_backward_geometry(built):
     grads = scenes.upstream_grads(sc, "rgss", seed=3)
     out, leaves, o, R = _run_both(sc, "rgss", grads)
     im = _check_forward(out, o, R, "rgss")
-    _cmp("surface_xyz", out["surface_xyz"], im["surface_xyz"], flip_bound=0.05)
+    _cmp("surface_xyz", out["surface_xyz"], im["surface_xyz"])
     # the stencil normal amplifies per-pixel depth flips: compare where the neighbourhood agrees
     pn, pr = out["pseudo_normal"].cpu().numpy(), im["pseudo_normal"]
     assert (np.abs(pn - pr).max(0) < 1e-3).mean() > 0.995
@@ -233,7 +279,7 @@ def test_colors_precomp_and_cov3d_precomp_paths(built):
                colors_precomp=sct["colors_precomp"], scales=sct["scales"], rotations=sct["rotations"],
                features=sct["features"], vfeatures=sct["vfeatures"])
     assert res[0] == R
-    _cmp("color_precomp", res[1], o2.images()["color"], flip_bound=0.05)
+    _cmp("color_precomp", res[1], o2.images()["color"])
 
 
 def test_full_size_properties_cfg3_eval(built):
