@@ -26,16 +26,42 @@ thread_local std::string g_err;
 // HIP events recorded on the launch stream; they are resolved lazily (svgir_last_timings), so enabling profiling
 // adds no synchronisation to forward/backward.
 std::atomic<bool> g_prof{false};
-// Instance counts of the last eight forwards (any view / size): the speculative launch is sized for their maximum, so
-// a training loop that cycles through cameras with different footprints rarely has to re-run the dependent stages.
-std::atomic<int> g_R_hist[8];
-std::atomic<unsigned> g_R_next{0};
-int guess_R() {
+// Speculative-capacity history: the instance counts of the last eight forwards PER WORKLOAD KEY (device, image size,
+// Gaussian count, channel widths, variant), so that scenes / resolutions that alternate in one process (a 256x256
+// preview next to a 1600x1600 render, several scenes, several devices) neither re-run each other's dependent stages nor
+// over-allocate each other's blobs.  A small fixed table, least-recently-used replacement.
+struct CapKey { int dev, W, H, P, S, VS, variant; };
+struct CapEntry { CapKey key; int hist[8]; unsigned next; unsigned long long stamp; bool used; };
+std::mutex g_cap_mu;
+CapEntry g_cap[16];
+unsigned long long g_cap_clock = 0;
+bool same_key(const CapKey& a, const CapKey& b) {
+    return a.dev == b.dev && a.W == b.W && a.H == b.H && a.P == b.P && a.S == b.S && a.VS == b.VS && a.variant == b.variant;
+}
+CapEntry* cap_entry(const CapKey& k, bool create) {
+    CapEntry* lru = &g_cap[0];
+    for (auto& e : g_cap) {
+        if (e.used && same_key(e.key, k)) { e.stamp = ++g_cap_clock; return &e; }
+        if (!e.used) { if (lru->used) lru = &e; }
+        else if (lru->used && e.stamp < lru->stamp) lru = &e;
+    }
+    if (!create) return nullptr;
+    *lru = CapEntry{};
+    lru->key = k; lru->used = true; lru->stamp = ++g_cap_clock;
+    return lru;
+}
+int guess_R(const CapKey& k) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    const CapEntry* e = cap_entry(k, false);
     int m = 0;
-    for (auto& r : g_R_hist) m = std::max(m, r.load());
+    if (e) for (int r : e->hist) m = std::max(m, r);
     return m;
 }
-void record_R(int R) { g_R_hist[g_R_next.fetch_add(1) % 8].store(R); }
+void record_R(const CapKey& k, int R) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    CapEntry* e = cap_entry(k, true);
+    e->hist[e->next++ % 8] = R;
+}
 // Pinned landing slots for the 4-byte instance-count read-back (a pageable destination would make the "async" copy a
 // blocking staged one).  A small ring: concurrent forwards on different threads/streams get different slots.
 uint32_t* g_pinned = nullptr;
@@ -45,9 +71,9 @@ std::once_flag g_pinned_once;
 uint32_t* pinned_slot() {
     std::call_once(g_pinned_once, [] {
         void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, kPinnedSlots * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) g_pinned = (uint32_t*)ptr;
+        if (hipHostMalloc(&ptr, kPinnedSlots * 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) g_pinned = (uint32_t*)ptr;
     });
-    return g_pinned ? g_pinned + (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
+    return g_pinned ? g_pinned + 2 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
 }   // instance count of the previous forward: sizes the speculative binning blob
 std::mutex g_times_mu;
 struct Pending { hipEvent_t a, b; const char* name; };
@@ -145,6 +171,13 @@ int validate(const svgir_params* p, bool fwd) {
     if (!p) return fail(SVGIR_ERR_INVALID, "params is NULL");
     if (p->variant != SVGIR_RGSS && p->variant != SVGIR_SVGSS) return fail(SVGIR_ERR_INVALID, "unknown variant %d", p->variant);
     if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(SVGIR_ERR_INVALID, "bad sizes P=%d W=%d H=%d", p->P, p->W, p->H);
+    {   // packing limits of the state blobs: tile rectangle x0 | y0 << 10 | width << 20 (common.hpp R_RECT) and
+        // (sub-tile id << SEG_K_BITS) | segment (seg_list)
+        const long long gx = (p->W + TILE - 1) / TILE, gy = (p->H + TILE - 1) / TILE;
+        if (gx > 1023 || gy > 1023 || 4 * gx * gy >= (1ll << (32 - SEG_K_BITS)))
+            return fail(SVGIR_ERR_INVALID, "image %dx%d exceeds the supported size (at most 1023 tiles per side, %lld tiles in total)",
+                        p->W, p->H, (1ll << (32 - SEG_K_BITS)) / 4 - 1);
+    }
     if (p->P == 0) return 0;
     if (!p->means3D || !p->viewmatrix || !p->projmatrix || !p->background)
         return fail(SVGIR_ERR_INVALID, "means3D/viewmatrix/projmatrix/background must be provided");
@@ -264,6 +297,11 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     pa.focal_x = focal_x; pa.focal_y = focal_y; pa.cfg = cfg;
     pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
     pa.radii = o->radii;
+    pa.prefilter_violation = nullptr;
+    if (p->prefiltered) {   // the violation flag sits next to the instance counter and is read back with it
+        HIP_OK(hipMemsetAsync(G.counters, 0, 16, s));
+        pa.prefilter_violation = G.counters + 1;
+    }
     launch_preprocess(pa, svgss, s);
     if (int rc = check("preprocess")) return rc;
     tm.mark("preprocess");
@@ -276,10 +314,10 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     launch_offsets_scan(G.tiles, G.idx[0], G.offsets, G.scan_tmp, P, G.counters, s);
     if (int rc = check("offsets scan")) return rc;
     tm.mark("scan");
-    uint32_t R_pageable = 0;
+    uint32_t R_pageable[2] = {0, 0};
     uint32_t* R_slot = pinned_slot();
-    if (!R_slot) R_slot = &R_pageable;
-    HIP_OK(hipMemcpyAsync(R_slot, G.counters, 4, hipMemcpyDeviceToHost, s));
+    if (!R_slot) R_slot = R_pageable;
+    HIP_OK(hipMemcpyAsync(R_slot, G.counters, p->prefiltered ? 8 : 4, hipMemcpyDeviceToHost, s));
     hipEvent_t evR;
     HIP_OK(hipEventCreateWithFlags(&evR, hipEventDisableTiming));
     HIP_OK(hipEventRecord(evR, s));
@@ -326,21 +364,33 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         return 0;
     };
 
-    // Speculative launch: capacity from the previous call's instance count (+12.5 %), no host round trip in between.
+    // Speculative launch: capacity from this workload's recent instance counts (+12.5 %), no host round trip in between.
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
     int cap = 0;
     char* bblob = nullptr;
-    if (const int guess = guess_R()) {
+    if (const int guess = guess_R(ckey)) {
         cap = binning_capacity((long long)guess + guess / 8 + 1024);
         bblob = binning(bin_layout(nullptr, cap, T, nstate).bytes, binning_ctx);
-        if (!bblob) { (void)hipEventDestroy(evR); return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed"); }
-        if (int rc = run_binning_and_render(bblob, cap, true)) { (void)hipEventDestroy(evR); return rc; }
+        // (a failed speculative allocation is not an error: the guess may be far larger than this view needs; fall
+        // through to the exact-size path below)
+        if (bblob) {
+            if (int rc = run_binning_and_render(bblob, cap, true)) { (void)hipEventDestroy(evR); return rc; }
+        } else {
+            cap = 0;
+        }
     }
     HIP_OK(hipEventSynchronize(evR));   // waits for the count only; the speculative stages keep running
     (void)hipEventDestroy(evR);
     const uint32_t R_host = *(volatile uint32_t*)R_slot;
+    if (p->prefiltered && ((volatile uint32_t*)R_slot)[1] != 0u) {
+        (void)hipStreamSynchronize(s);
+        return fail(SVGIR_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");   // auxiliary.h:163-167
+    }
     if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
     const int R = (int)R_host;
-    record_R(R);
+    record_R(ckey, R);
     if (!bblob || R > cap) {
         // first call, or the scene grew past the guess: (re)do the dependent stages with the exact capacity
         const bool redo = bblob != nullptr;

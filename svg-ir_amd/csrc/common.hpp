@@ -224,6 +224,7 @@ struct PreArgs {
     float scale_modifier, tanx, tany, focal_x, focal_y;
     CfgRef cfg;
     float* rec; float* cov3D; uint32_t* clamped; uint32_t* tiles; uint32_t* key; uint32_t* idx; int32_t* radii;
+    uint32_t* prefilter_violation;   // non-null <=> `prefiltered`: set to 1 when a frustum / back-face cull fires (auxiliary.h:163-167)
 };
 
 struct RenderArgs {

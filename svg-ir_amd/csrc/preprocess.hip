@@ -142,10 +142,15 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     if (SVGSS) {
         const float x0 = a.patchbbox[1], y0 = a.patchbbox[0], x1 = a.patchbbox[3], y1 = a.patchbbox[2];
         const float w = x1 - x0, h = y1 - y0, e = (float)0.2;
-        if (pv[2] < 0 || pix[0] < x0 - w * e || pix[0] >= x1 + w * e || pix[1] < y0 - h * e || pix[1] >= y1 + h * e)
+        if (pv[2] < 0 || pix[0] < x0 - w * e || pix[0] >= x1 + w * e || pix[1] < y0 - h * e || pix[1] >= y1 + h * e) {
+            if (a.prefilter_violation) *a.prefilter_violation = 1u;   // the reference traps here (auxiliary.h:163-167)
             return;
+        }
     } else {
-        if (pv[2] <= 0.2f) return;
+        if (pv[2] <= 0.2f) {
+            if (a.prefilter_violation) *a.prefilter_violation = 1u;
+            return;
+        }
     }
 
     float q[4] = {1.f, 0.f, 0.f, 0.f};
@@ -174,7 +179,10 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
             a1[i] = V[i] * a1w[0] + V[4 + i] * a1w[1] + V[8 + i] * a1w[2];
         }
         const float dot = pv[0] * nv[0] + pv[1] * nv[1] + pv[2] * nv[2];
-        if ((double)dot > -0.01) return;  // back-facing
+        if ((double)dot > -0.01) {  // back-facing
+            if (a.prefilter_violation) *a.prefilter_violation = 1u;   // auxiliary.h:195-199
+            return;
+        }
         if (pix_depth) {
             // local homography between the screen and the tangent plane (auxiliary.h:291-388)
             const float qx = pv[0] / pv[2], qy = pv[1] / pv[2];

@@ -148,18 +148,6 @@ def _env_of(light):
     raise TypeError("direct_light_env_light must expose .env (DirectLightMap) or .envmap (EnvLight)")
 
 
-class MeanOnly:
-    """Stand-in for a per-sample [n, Ns, 3] tensor of the reference's extra_results that its callers only consume
-    through `.mean(-2)` (svgss.py:143-151); the fused kernel never materialises the per-sample values."""
-
-    def __init__(self, mean):
-        self._mean = mean
-
-    def mean(self, dim=-2, *a, **k):
-        assert dim in (-2, 1), "only the mean over the incident samples is available from the fused kernel"
-        return self._mean
-
-
 def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light=None,
                         visibility_precompute=None, incident_dirs_precompute=None, incident_areas_precompute=None):
     """Drop-in for gaussian_renderer/svgss.py:537-593.  Returns (pbr [n,12], extra_results)."""
@@ -169,9 +157,13 @@ def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, dire
                        softplus, scale, transform)
     extra_results = {
         "incident_dirs": dirs,
-        "incident_lights": MeanOnly(red[:, 60:63]),
+        # The reference returns the per-sample [n, Ns, 3] light here; its callers only ever take `.mean(-2)` of it
+        # (svgss.py:143-151), possibly after `torch.cat(..., dim=0)` over 100k-surfel chunks (svgss.py:121-136).  The fused
+        # kernel never materialises the per-sample values: the tensor carries the mean as its single "sample", so both
+        # the concatenation and the mean (exactly) keep working.
+        "incident_lights": red[:, 60:63].unsqueeze(-2),
         "local_incident_lights": radiance,
-        "global_incident_lights": MeanOnly(red[:, 66:69]),
+        "global_incident_lights": red[:, 66:69].unsqueeze(-2),
         "incident_visibility": visibility_precompute,
         "diffuse_light": red[:, 12:24],
         "specular": red[:, 24:36],

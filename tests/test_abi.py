@@ -113,3 +113,24 @@ def test_cpu_tensors_fail_loudly_no_fallback(built):
     sc = scenes.random_cloud(P=16, W=32, H=32, variant="rgss")
     with pytest.raises(RuntimeError, match="must live on the GPU"):
         runner.render(runner.to_torch(sc, torch.device("cpu")), "rgss")
+
+
+def test_image_size_limits_are_validated(built):
+    """The state blobs pack tile coordinates into 10 bits and sub-tile ids into 18: larger images are rejected up
+    front (before any HIP call) instead of corrupting silently."""
+    from gaussian_renderer import _native as N
+    p = N.Params()
+    p.variant, p.P, p.W, p.H = N.SVGSS, 10, 16 * 1024, 64
+    cb = N.ALLOC_FN(lambda n, c: 0)
+    rc = N.lib.svgir_forward(p, N.Outputs(), cb, None, cb, None, cb, None, None)
+    assert rc == -1 and "exceeds the supported size" in N.last_error()
+    p.W, p.H = 16 * 300, 16 * 300      # 90 000 tiles: too many sub-tile ids
+    rc = N.lib.svgir_forward(p, N.Outputs(), cb, None, cb, None, cb, None, None)
+    assert rc == -1 and "exceeds the supported size" in N.last_error()
+
+
+def test_backward_requires_scratch(built):
+    from gaussian_renderer import _native as N
+    assert N.lib.svgir_backward_scratch_bytes(N.RGSS, 1000, 0, 64, 64, 5, 0) >= 1000 * 20 * 4
+    assert N.lib.svgir_backward_scratch_bytes(N.SVGSS, 1000, N.lib.svgir_binning_bytes(5000, 64, 64, 4, 52), 64, 64, 4, 52) > \
+        N.lib.svgir_backward_scratch_bytes(N.RGSS, 1000, 0, 64, 64, 5, 0)

@@ -352,3 +352,25 @@ def test_speculative_capacity_small_large_small(built):
         if last_R is not None:
             assert R > 3 * last_R or last_R > 3 * R, "the scenes should differ a lot in instance count"
         last_R = R
+
+
+def test_prefiltered_flag_reports_culled_points(built):
+    """`prefiltered=True` asserts that the caller has already removed every point the frustum / back-face tests would
+    cull; the reference traps the device when one is culled anyway (auxiliary.h:163-167, 195-199).  Here the forward
+    returns an error through the C ABI (RuntimeError in the binding) -- and runs normally when nothing is culled."""
+    from gaussian_renderer.svgss_rasterization import GaussianRasterizer
+    dev = _dev()
+    sc = scenes.surface_scene(P=800, W=64, H=48, seed=91, sh_degree=0, variant="svgss", S=0, VS=0, scale_lo=0.03, scale_hi=0.1)
+    sct = runner.to_torch(sc, dev)
+    st = runner.settings(sct, "svgss")._replace(prefiltered=True)
+    kw = dict(means3D=sct["means3D"], means2D=torch.zeros_like(sct["means3D"]), opacities=sct["opacities"], shs=sct["shs"],
+              scales=sct["scales"], rotations=sct["rotations"], features=sct["features"], vfeatures=sct["vfeatures"])
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        GaussianRasterizer(st)(**kw)   # half of the surfels face away from the camera
+    # keep only what survives the culls: the same call now succeeds and matches the unfiltered render
+    out_all, _ = runner.render(sct, "svgss")
+    keep = out_all["radii"] > 0
+    kw2 = {k: (v[keep] if v.shape[0] == keep.shape[0] else v) for k, v in kw.items()}
+    res = GaussianRasterizer(st)(**kw2)
+    assert res[0] == out_all["num_rendered"]
+    assert torch.equal(res[1], out_all["color"])

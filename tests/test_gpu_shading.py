@@ -24,7 +24,7 @@ class _Light:
 
 def _close(name, a, b, tol=1e-4):
     a = a.detach().double().cpu().reshape(-1)
-    b = b.detach().double().cpu().reshape(-1)
+    b = (b if torch.is_tensor(b) else torch.from_numpy(np.asarray(b))).detach().double().cpu().reshape(-1)
     scale = max(float(b.abs().max()), 1e-30)
     err = float((a - b).abs().max())
     assert err <= tol * scale + 1e-7, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
@@ -213,3 +213,51 @@ def test_shading_odd_sample_counts_and_env_sizes(built, Ns, He, We):
     _close("diffuse_light", ex["diffuse_light"], ref["diffuse_light"])
     for k in names:
         _close("grad_" + k, lg[k].grad, lo[k].grad, tol=3e-4)
+
+
+def test_rendering_equation4_survives_the_reference_eval_chunk_loop(built):
+    """gaussian_renderer/svgss.py:121-151 (is_training=False): rendering_equation4 per 100k-surfel chunk, then
+    `torch.cat` over EVERY key of extra_results, then the features / vfeatures assembly.  The fused kernel returns the
+    per-sample light tensors reduced to their mean; the concatenation and `.mean(-2)` must still give the reference's
+    features (pinned by tests/golden/render_view.npz, recorded at the reference's rasterizer call)."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_view.npz"))
+    t = lambda k: torch.from_numpy(g[k]).to(dev)  # noqa: E731
+    base, rough, normal = t("pc_get_base_color"), t("pc_get_roughness"), t("pc_get_shading_normal")
+    inc, vis, dirs, areas = t("pc_get_radiances"), t("pc_visibility_tracing"), t("pc_incident_dirs"), t("pc_incident_areas")
+    viewdirs = torch.nn.functional.normalize(t("eval_settings_campos") - t("pc_get_xyz"), dim=-1)
+    light = _Light(t("env"))
+    chunk = 100
+    brdf, extras = [], []
+    with torch.no_grad():
+        for i in range(0, base.shape[0], chunk):
+            b, e = shading.rendering_equation4(base[i:i + chunk], rough[i:i + chunk], normal[i:i + chunk].detach(),
+                                               viewdirs[i:i + chunk], inc[i:i + chunk], light,
+                                               visibility_precompute=vis[i:i + chunk],
+                                               incident_dirs_precompute=dirs[i:i + chunk],
+                                               incident_areas_precompute=areas[i:i + chunk])
+            brdf.append(b)
+            extras.append(e)
+    brdf = torch.cat(brdf, dim=0)
+    extra = {k: torch.cat([e[k] for e in extras], dim=0) for k in extras[0]}      # svgss.py:136
+    features = torch.cat([extra["incident_lights"].mean(-2), extra["local_incident_lights"].mean(-2),
+                          extra["incident_visibility"].mean(-2)], dim=-1)            # svgss.py:148-151
+    nv = (normal @ t("eval_settings_viewmatrix")[:3, :3]).transpose(1, 2).reshape(normal.shape[0], -1)
+    vfeatures = torch.cat([brdf, base, nv, rough, extra["direct"], extra["indirect"]], dim=-1)
+    _close("features", features, g["eval_features"], tol=2e-4)
+    _close("vfeatures", vfeatures, g["eval_vfeatures"], tol=2e-3)
+    # the training branch consumes the same dict without concatenation (svgss.py:143-147, 157-158)
+    with torch.no_grad():
+        b, e = shading.rendering_equation4(base, rough, normal, torch.nn.functional.normalize(t("train_settings_campos") - t("pc_get_xyz"), dim=-1),
+                                           inc, light, visibility_precompute=vis, incident_dirs_precompute=dirs,
+                                           incident_areas_precompute=areas)
+    f_tr = torch.cat([e["incident_visibility"].mean(-2), e["local_incident_lights"].mean(-2)], dim=-1)
+    _close("train_features", f_tr, g["train_features"], tol=2e-4)
+    # and the fused packing kernel against the same recording
+    for tag, training in (("train", True), ("eval", False)):
+        vd = torch.nn.functional.normalize(t(f"{tag}_settings_campos") - t("pc_get_xyz"), dim=-1)
+        with torch.no_grad():
+            f, vf, _ = shading.shade_and_pack(base, rough, normal, vd, inc, light, vis, dirs, areas, t(f"{tag}_settings_viewmatrix"), training)
+        _close(tag + "_packed_features", f, g[f"{tag}_features"], tol=2e-4)
+        _close(tag + "_packed_vfeatures", vf, g[f"{tag}_vfeatures"], tol=2e-3)

@@ -160,6 +160,69 @@ def test_forward_matches_independent_torch_restatement(variant, S, VS, nd):
         assert (np.diff(rank[ids]) > 0).all()
 
 
+@pytest.mark.parametrize("variant,seed,P,W,H", [("svgss", 11, 4000, 160, 112), ("rgss", 12, 4000, 144, 128),
+                                                ("svgss", 13, 600, 72, 56)])
+def test_preprocess_binning_match_oracle_free_construction(variant, seed, P, W, H):
+    """a2 / a4-a6 pinned without the oracle: radii, tile rectangles, cull decisions, the local homography, the
+    instance count and the complete depth-sorted instance list of the oracle (fp32) equal an independent fp64
+    construction from the geometry (tests/torch_ref.py consts_independent)."""
+    sc = scenes.surface_scene(P=P, W=W, H=H, seed=seed, sh_degree=1, variant=variant, S=1, VS=4 if variant == "svgss" else 0,
+                              scale_lo=0.01, scale_hi=0.12)
+    sc["means3D"][: P // 20] *= 3.0     # some centres off screen / behind the patch border
+    o = orc.OracleRun(sc, orc.SVGSS if variant == "svgss" else orc.RGSS)
+    R = o.forward()
+    ind = torch_ref.consts_independent(sc, variant)
+    radii = o.get("radii")
+    # decisions that sit within fp32 rounding of a threshold may legitimately differ between fp32 and fp64
+    sure = ind["margin"] > 1e-4
+    assert ((radii > 0) == (ind["radii"] > 0)).mean() > 0.999
+    both = (radii > 0) & (ind["radii"] > 0)
+    assert both.sum() > 0.3 * P
+    assert np.array_equal(radii[both & sure], ind["radii"][both & sure])
+    m2 = o.get("means2D").reshape(P, 2)
+    np.testing.assert_allclose(m2[both], ind["pix"][both], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(o.get("depths")[both], ind["depth"][both], rtol=2e-6)
+    J = o.get("Jinv").reshape(P, 10)
+    np.testing.assert_allclose(J[both], ind["Jinv"][both], rtol=2e-4, atol=2e-5)
+    # tile rectangles -> instance count and per-tile membership
+    oc = torch_ref.consts_from_oracle(o, sc)
+    same = both & sure & (np.abs(m2 - ind["pix"]).max(1) < 1e-3)
+    assert (oc["rect"][same] == ind["rect"][same]).mean() > 0.9995
+    tiles = o.get("tiles_touched")
+    area = (oc["rect"][:, 2] - oc["rect"][:, 0]) * (oc["rect"][:, 3] - oc["rect"][:, 1])
+    assert np.array_equal(tiles[radii > 0], area[radii > 0]) and R == int(tiles.sum())
+    # the instance list, rebuilt from first principles: for every tile, the visible Gaussians whose rectangle covers it,
+    # in (depth, id) order
+    gx = (W + 15) // 16
+    pl, rg = o.get("point_list"), o.get("ranges").reshape(-1, 2)
+    key = o.get("depths").astype(np.float32).view(np.uint32).astype(np.uint64) * (1 << 32) + np.arange(P).astype(np.uint64)
+    vis_ids = np.nonzero(radii > 0)[0]
+    checked = 0
+    for t in range(rg.shape[0]):
+        tx, ty = t % gx, t // gx
+        rc = oc["rect"][vis_ids]
+        ids = vis_ids[(rc[:, 0] <= tx) & (tx < rc[:, 2]) & (rc[:, 1] <= ty) & (ty < rc[:, 3])]
+        ids = ids[np.argsort(key[ids], kind="stable")]
+        assert np.array_equal(pl[rg[t, 0]:rg[t, 1]], ids.astype(pl.dtype)), t
+        checked += len(ids)
+    assert checked == R
+
+
+@pytest.mark.parametrize("variant,S,VS", [("svgss", 3, 8), ("rgss", 5, 0)])
+def test_forward_matches_restatement_with_oracle_free_constants(variant, S, VS):
+    """The dense fp64 forward fed ONLY with the oracle-free constants reproduces the oracle's images."""
+    sc = _small_scene(variant, 7, S, VS)
+    o = orc.OracleRun(sc, orc.SVGSS if variant == "svgss" else orc.RGSS, fp64=True)
+    o.forward()
+    ind = torch_ref.consts_independent(sc, variant)
+    assert np.array_equal(o.get("radii"), ind["radii"])
+    with torch.no_grad():
+        ref = torch_ref.forward(_torch_leaves(sc, variant), sc, ind, variant)
+    im = o.images()
+    for k in ["color", "normal", "depth", "opacity", "feature"] + (["vfeature"] if variant == "svgss" else []):
+        np.testing.assert_allclose(im[k], ref[k].numpy(), rtol=1e-7, atol=1e-9, err_msg=k)
+
+
 @pytest.mark.parametrize("variant,S,VS,nd", [("svgss", 3, 8, 1.0), ("svgss", 2, 4, 0.0), ("rgss", 5, 0, 1.0)])
 def test_backward_equals_autograd_of_restatement(variant, S, VS, nd):
     """Oracle backward == torch.autograd of the independent forward, plus the explicit non-derivative term Q5."""

@@ -8,8 +8,12 @@ Used to pin the oracle (oracle/svgir_oracle.cpp):
     same stop-gradients (bilinear corner weights and the depth-differencing offset are constants; the local
     homography is a constant) and the tests account for the explicit extra terms (Q4 x10 on normals, Q5).
 
-Integer decisions (visibility, tile rectangles, depth order) are taken from the oracle run and are not
-differentiated.
+Integer decisions (visibility, tile rectangles, depth order) and the local homography are constants of the
+differentiation.  They come either from the oracle run (`consts_from_oracle`) or -- oracle-free -- from
+`consts_independent`, an fp64 construction from the geometry itself (ray / tangent-plane intersection for the
+homography, eigenvalues of the 2D covariance for the radius, floor arithmetic for the tile rectangle, the cull
+conditions of auxiliary.h / forward.cu stated as geometric predicates), which is what pins the oracle's `local_homo`,
+`getRect`, radius formula and cull thresholds by test instead of by inspection.
 """
 import numpy as np
 import torch
@@ -182,3 +186,107 @@ def consts_from_oracle(o, sc):
     order = np.argsort(key, kind="stable")
     return dict(radii=radii, rect=rect, order=order, Jinv=o.get("Jinv").reshape(P, 10).astype(np.float64),
                 **{"lambda": o.get("lambda").reshape(P, 2).astype(np.float64)})
+
+
+def consts_independent(sc, variant):
+    """The same constants as consts_from_oracle, derived WITHOUT the oracle in fp64 numpy.
+
+    Geometry (camera space: x right, y down, z forward; V = W2C^T as stored by the reference):
+      * a surfel is a planar Gaussian in the plane through its centre c (camera space) spanned by its local axes
+        a0, a1 with normal n = a0 x a1 (third column of R(q), rotated into camera space);
+      * culls: behind the near plane (svgss: c.z < 0 or projected centre outside the patch box grown by 20 %; rgss:
+        c.z <= 0.2), back-facing (c . n > -0.01), grazing (the two probe rays below make |cos| < 0.01 with n),
+        singular 2D covariance, empty tile rectangle;
+      * local homography: probe rays through (qx + 1/1000, qy) and (qx, qy + 1/1000) on the z = 1 plane, q = c.xy / c.z,
+        are intersected with the tangent plane; the offsets of the two hit points from c, expressed in (a0, a1) and
+        divided by (mean focal length / 1000), are the columns of the 2x2 screen -> tangent map J; the depth offset of a
+        tangent displacement (du, dv) is du a0.z + dv a1.z;
+      * radius = ceil(3 sqrt(larger eigenvalue of the low-pass-filtered 2D covariance)), eigenvalues from the trace /
+        determinant with the reference's floor of 0.1 under the root;
+      * tile rectangle = tiles whose 16 px cells meet [centre - radius, centre + radius + 15] (truncating division).
+    """
+    W, H = sc["W"], sc["H"]
+    svgss = variant == "svgss"
+    cfg = [float(c) for c in sc["config"]] if svgss else [1.0, 1.0, 1.0]
+    surface, pix_depth = cfg[0] > 0, cfg[2] > 0
+    f64 = lambda k: np.asarray(sc[k], dtype=np.float64)  # noqa: E731
+    V, PM = f64("viewmatrix"), f64("projmatrix")
+    m, q, sc3 = f64("means3D"), f64("rotations"), f64("scales")
+    P = m.shape[0]
+    fx, fy = W / (2.0 * sc["tanfovx"]), H / (2.0 * sc["tanfovy"])
+    mod = float(sc.get("scale_modifier", 1.0))
+    hom = np.concatenate([m, np.ones((P, 1))], -1)
+    c = (hom @ V)[:, :3]                                      # centre in camera space
+    clip = hom @ PM
+    ndc = clip[:, :2] / (clip[:, 3:4] + 0.0000001)
+    pix = np.stack([((ndc[:, 0] + 1) * W - 1) * 0.5, ((ndc[:, 1] + 1) * H - 1) * 0.5], -1)
+    r_, x, y, z = q.T
+    Rq = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r_ * z), 2 * (x * z + r_ * y),
+                   2 * (x * y + r_ * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r_ * x),
+                   2 * (x * z - r_ * y), 2 * (y * z + r_ * x), 1 - 2 * (x * x + y * y)], -1).reshape(P, 3, 3)
+    Wrot = V[:3, :3].T
+    axes = np.einsum("ij,pjk->pik", Wrot, Rq)                 # columns = a0, a1, n in camera space
+    a0, a1, n = axes[:, :, 0], axes[:, :, 1], axes[:, :, 2]
+    vis = np.ones(P, dtype=bool)
+    if svgss:
+        y0, x0, y1, x1 = [float(v) for v in np.asarray(sc["patch_bbox"]).reshape(-1)[:4]]
+        gw, gh = (x1 - x0) * 0.2, (y1 - y0) * 0.2
+        vis &= ~((c[:, 2] < 0) | (pix[:, 0] < x0 - gw) | (pix[:, 0] >= x1 + gw) | (pix[:, 1] < y0 - gh) | (pix[:, 1] >= y1 + gh))
+    else:
+        vis &= c[:, 2] > 0.2
+    Jinv = np.zeros((P, 10))
+    if surface:
+        vis &= ~(np.einsum("pi,pi->p", c, n) > -0.01)
+        if pix_depth:
+            qxy = c[:, :2] / c[:, 2:3]
+            k = ((fx + fy) / 2) / 1000.0
+            hits = []
+            for e in (np.array([1 / 1000.0, 0.0]), np.array([0.0, 1 / 1000.0])):
+                ray = np.concatenate([qxy + e[None], np.ones((P, 1))], -1)
+                length = np.linalg.norm(ray, axis=-1)
+                ray = ray / length[:, None]
+                cosang = np.einsum("pi,pi->p", ray, n)
+                vis &= ~(np.abs(cosang / length) < 0.01)
+                t = np.einsum("pi,pi->p", c, n) / cosang        # ray parameter of the plane hit
+                hits.append(ray * t[:, None] - c)
+            Jinv[:, 0] = np.einsum("pi,pi->p", hits[0], a0) / k
+            Jinv[:, 1] = np.einsum("pi,pi->p", hits[1], a0) / k
+            Jinv[:, 2] = np.einsum("pi,pi->p", hits[0], a1) / k
+            Jinv[:, 3] = np.einsum("pi,pi->p", hits[1], a1) / k
+            Jinv[:, 4:7], Jinv[:, 7:10] = a0, a1
+    # 2D covariance of the (flattened) Gaussian under the local affine approximation of the projection
+    s = sc3 * mod
+    sz = np.zeros(P) if (mod * (1.0 if surface else 0.0)) != 0 else sc3[:, 2]
+    Sd = np.stack([s[:, 0], s[:, 1], sz], -1)
+    Sigma = np.einsum("pij,pj,pkj->pik", Rq, Sd * Sd, Rq)
+    limx, limy = 1.3 * sc["tanfovx"], 1.3 * sc["tanfovy"]
+    tz = c[:, 2]
+    txc = np.clip(c[:, 0] / tz, -limx, limx) * tz
+    tyc = np.clip(c[:, 1] / tz, -limy, limy) * tz
+    Jp = np.zeros((P, 2, 3))
+    Jp[:, 0, 0], Jp[:, 0, 2] = fx / tz, -fx * txc / (tz * tz)
+    Jp[:, 1, 1], Jp[:, 1, 2] = fy / tz, -fy * tyc / (tz * tz)
+    Tm = Jp @ Wrot
+    cov = Tm @ Sigma @ Tm.transpose(0, 2, 1)
+    ca, cb, cc = cov[:, 0, 0] + 0.3, cov[:, 0, 1], cov[:, 1, 1] + 0.3
+    det = ca * cc - cb * cb
+    vis &= det != 0
+    mid = 0.5 * (ca + cc)
+    lam_max = mid + np.sqrt(np.maximum(0.1, mid * mid - det))
+    radius = np.ceil(3.0 * np.sqrt(np.maximum(lam_max, mid - np.sqrt(np.maximum(0.1, mid * mid - det)))))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    rect = np.zeros((P, 4), dtype=np.int64)
+    with np.errstate(invalid="ignore"):
+        rect[:, 0] = np.clip(np.trunc((pix[:, 0] - radius) / 16), 0, gx)
+        rect[:, 1] = np.clip(np.trunc((pix[:, 1] - radius) / 16), 0, gy)
+        rect[:, 2] = np.clip(np.trunc((pix[:, 0] + radius + 15) / 16), 0, gx)
+        rect[:, 3] = np.clip(np.trunc((pix[:, 1] + radius + 15) / 16), 0, gy)
+    vis &= (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1]) > 0
+    radii = np.where(vis, radius, 0).astype(np.int32)
+    rect[~vis] = 0
+    key = c[:, 2].astype(np.float32).view(np.uint32).astype(np.uint64)
+    key[~vis] = 0xFFFFFFFF
+    order = np.argsort(key, kind="stable")
+    return dict(radii=radii, rect=rect, order=order, Jinv=np.where(vis[:, None], Jinv, 0.0), pix=pix, depth=c[:, 2],
+                margin=np.abs(3.0 * np.sqrt(lam_max) - np.round(3.0 * np.sqrt(lam_max))),
+                **{"lambda": sc3[:, :2].copy()})
