@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Gaussian-surfels/s, forward + backward, one 800x800 view per step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3_train|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3_train|cfg3_eval|cfg4|cfg5]
 
-One process per GPU (launched by torchrun for N > 1).  A "step" is one forward+backward pass of the rasterizer
-over one synthetic view (inputs resident in HBM before the timed region), through the drop-in binding layer
-(`_C.rasterize_gaussians` + `_C.rasterize_gaussians_backward` -> C ABI -> HIP kernels).  For N > 1 the views are
-sharded (each rank renders its own camera; weak scaling) and the only collective is one fused all_gather of a
-3-float metrics vector per step (RCCL over xGMI).
+One process per GPU.  Launched under torchrun (WORLD_SIZE set) every process is a rank; launched plainly with
+`--gpus N > 1` the script starts N rank processes itself BEFORE anything touches the GPU (fresh child processes, no
+re-exec) and relays rank 0's line.  A "step" is one forward+backward pass of the rasterizer over one synthetic view
+(inputs resident in HBM before the timed region), through the drop-in binding layer (`_C.rasterize_gaussians` +
+`_C.rasterize_gaussians_backward` -> C ABI -> HIP kernels); the svgss workloads run the per-surfel SV-BRDF shading in
+every step too.  N = 1 times BASELINE.json configs[1] (cfg2); N > 1 times configs[3] (cfg4: the eight armadillo test
+views, rank r renders view r, azimuth 45 r degrees) -- views are sharded, weak scaling, and the only collective is one
+fused all_gather of a 3-float metrics vector per step (RCCL over xGMI).
+
+Timing: W warm-up steps, then the K-step timed region (barrier + synchronize on both sides, max over ranks) is repeated
+`--repeats` times; `ms_per_step` / `value` are the MEDIAN region, min / max are reported beside it.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline":     dominant kernel (backward composite): algorithmic bytes (SURVEY 8d formula with the measured R)
                   / average kernel time from HIP events recorded on the launch stream DURING the timed steps,
-                  against the 8 TB/s HBM peak;
+                  against the 8 TB/s HBM peak; `traffic` = PMC bytes per launch from profiles/traffic_<workload>.json,
+                  nulled when the kernel sources changed since that measurement (source hash);
+  "shaded":       (N = 1, default workload only) the same measurement on cfg3_train -- shading + rasterizer forward +
+                  backward, the "shaded + blended" number of north_star -- with its own roofline;
   "cpu_baseline": the CPU oracle (port of the reference kernels; the reference has no CPU path) timed on the host
                   cores on a bounded number of the same steps (rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,9 +38,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "svg-ir_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -43,89 +52,145 @@ def algorithmic_bytes(P, R, W, H, S, VS, svgss):
     return dict(G=G, fwd=fwd, bwd=bwd)
 
 
-def main():
+def kernel_source_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "svg-ir_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--repeats", type=int, default=25, help="repetitions of the K-step timed region (median reported)")
+    ap.add_argument("--workload", default=None, help="default: cfg2 (N = 1), cfg4 (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shaded", action="store_true", help="skip the extra cfg3_train (shaded + blended) record")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-oracle steps (0 = as many as fit ~12 s)")
     ap.add_argument("--no-shade", action="store_true", help="svgss workloads: skip the SV-BRDF shading stage")
+    ap.add_argument("--streamed-dirs", action="store_true", help="shading reads [P,Ns,3] incident directions from HBM "
+                    "instead of generating the lattice in the kernels")
     ap.add_argument("--samples", type=int, default=0, help="incident samples per surfel (default 64 train / 384 eval)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise launch / collective / reporting logic with "
+                    "gloo on the CPU (the rendering step is replaced by a token computation)")
+    return ap.parse_args()
 
-    from svgir_harness import cameras, runner, scenes, view_parallel as vp
-    rank, world, local = vp.init_from_env()
-    assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the rasterizer has no CPU path)"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    from gaussian_renderer import _native
 
-    gen_kw = dict(scenes.CONFIGS[args.workload][1])
-    variant = gen_kw["variant"]
-    sc = scenes.make(args.workload)
-    # every rank renders its own view of the (replicated) scene: azimuth 30 + 45*rank degrees
-    sc.update(cameras.make_camera(sc["W"], sc["H"], cameras.orbit_eye(4.0, 30.0 + 45.0 * rank, 25.0)))
-    grads = scenes.upstream_grads(sc, variant)
-    sct = runner.to_torch(sc, dev)
-    per_gaussian = {k: sct[k] for k in ("means3D", "scales", "rotations", "opacities", "shs", "features") if k in sct}
-    if variant == "svgss":
-        per_gaussian["vfeatures"] = sct["vfeatures"]
-    vp.broadcast_scene(per_gaussian)  # one-time replication (identical seeds already; exercised for N > 1)
-    gt = {k: torch.from_numpy(v).to(dev) for k, v in grads.items()}
-    P, W, H = int(sc["means3D"].shape[0]), sc["W"], sc["H"]
-    S = int(sc["features"].shape[1])
-    VS = int(sc["vfeatures"].shape[1]) if variant == "svgss" else 0
+def launch_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (nothing here has touched the GPU)."""
+    import torch
+    n = args.gpus
+    if not args.dry_run:
+        have = torch.cuda.device_count()   # (does not initialise the GPU)
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
-    if variant == "svgss":
-        from gaussian_renderer.svgss_rasterization import _C
-    else:
-        from gaussian_renderer.rgss_rasterization import _C
-    empty = torch.empty(0, dtype=torch.float32, device=dev)
-    st = runner.settings(sct, variant)
 
-    # svgss workloads: the per-surfel SV-BRDF shading (rendering_equation4 + feature packing) produces the rasterizer's
-    # features / vfeatures every step, and its backward consumes the rasterizer's dL_dfeatures / dL_dvfeatures.
-    shade = variant == "svgss" and not args.no_shade
-    if shade:
-        from gaussian_renderer import shading
-        from svgir_harness import shade_inputs
-        training = S == 4
-        Ns = args.samples or (64 if training else 384)
-        q = torch.nn.functional.normalize(sct["rotations"], dim=-1)
-        r, x, y, z = q.unbind(-1)   # local z axis of the surfel = geometric normal
-        geo_n = torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y)], dim=-1)
-        sd = shade_inputs.make(P, Ns, seed=5 + rank, device=dev, geo_normals=geo_n)
-        sd["viewdirs"] = torch.nn.functional.normalize(st.campos[None, :] - sct["means3D"], dim=-1)
-        leaves = {k: sd[k].clone().requires_grad_(training) for k in ("base_color", "roughness", "normals", "radiance", "env")}
-        light = shade_inputs.Light(leaves["env"])
+class Workload:
+    """One synthetic view of a BASELINE config resident on the device, and a step() that runs it once."""
 
-    def step():
-        """One forward + backward through the binding layer; returns (R, checksum tensor)."""
+    def __init__(self, name, dev, rank, world, args):
+        import torch
+        from svgir_harness import cameras, runner, scenes, view_parallel as vp
+        self.name, self.dev = name, dev
+        gen_kw = dict(scenes.CONFIGS[name][1])
+        self.variant = variant = gen_kw["variant"]
+        sc = scenes.make(name)
+        if name == "cfg4":     # SURVEY 8e: eight cameras at azimuth k * 45 degrees, elevation 30 degrees, one per rank
+            sc.update(cameras.make_camera(sc["W"], sc["H"], cameras.orbit_eye(4.0, 45.0 * rank, 30.0)))
+        elif world > 1:        # other workloads under N > 1: every rank its own view of the replicated scene
+            sc.update(cameras.make_camera(sc["W"], sc["H"], cameras.orbit_eye(4.0, 30.0 + 45.0 * rank, 25.0)))
+        self.sc = sc
+        self.train = True   # the metric is fwd+bwd: the rasterizer backward is part of every workload's step (the shading
+                            # backward only at the training widths)
+        self.grads = scenes.upstream_grads(sc, variant)
+        sct = self.sct = runner.to_torch(sc, dev)
+        per_gaussian = {k: sct[k] for k in ("means3D", "scales", "rotations", "opacities", "shs", "features") if k in sct}
         if variant == "svgss":
+            per_gaussian["vfeatures"] = sct["vfeatures"]
+        vp.broadcast_scene(per_gaussian)  # one-time replication (identical seeds already; exercised for N > 1)
+        self.gt = {k: torch.from_numpy(v).to(dev) for k, v in self.grads.items()}
+        self.P, self.W, self.H = int(sc["means3D"].shape[0]), sc["W"], sc["H"]
+        self.S = int(sc["features"].shape[1])
+        self.VS = int(sc["vfeatures"].shape[1]) if variant == "svgss" else 0
+        if variant == "svgss":
+            from gaussian_renderer.svgss_rasterization import _C
+        else:
+            from gaussian_renderer.rgss_rasterization import _C
+        self._C = _C
+        self.empty = torch.empty(0, dtype=torch.float32, device=dev)
+        self.st = runner.settings(sct, variant)
+        # svgss workloads: the per-surfel SV-BRDF shading (rendering_equation4 + feature packing) produces the rasterizer's
+        # features / vfeatures every step, and its backward consumes the rasterizer's dL_dfeatures / dL_dvfeatures.
+        self.shade = variant == "svgss" and not args.no_shade
+        if self.shade:
+            from gaussian_renderer import shading
+            from svgir_harness import shade_inputs
+            self.shading = shading
+            self.training = self.S == 4
+            self.Ns = args.samples or (64 if self.training else 384)
+            q = torch.nn.functional.normalize(sct["rotations"], dim=-1)
+            r, x, y, z = q.unbind(-1)   # local z axis of the surfel = geometric normal
+            geo_n = torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y)], dim=-1)
+            self.sd = sd = shade_inputs.make(self.P, self.Ns, seed=5 + rank, device=dev, geo_normals=geo_n, with_dirs=args.streamed_dirs)
+            sd["viewdirs"] = torch.nn.functional.normalize(self.st.campos[None, :] - sct["means3D"], dim=-1)
+            if args.streamed_dirs:
+                self.dirs, self.areas = sd["dirs"], sd["areas"]
+            else:   # incident directions generated in the kernels (SURVEY 8f row f1); training lattices carry random offsets
+                offs = torch.rand(self.P, device=dev) * 6.2831855 if self.training else None
+                self.dirs, self.areas = shading.FibonacciLattice(torch.nn.functional.normalize(geo_n, dim=-1), self.Ns, offs), None
+            self.leaves = {k: sd[k].clone().requires_grad_(self.training) for k in ("base_color", "roughness", "normals", "radiance", "env")}
+            self.light = shade_inputs.Light(self.leaves["env"])
+
+    def step(self):
+        """One forward (+ backward) through the binding layer; returns (R, colour image, a gradient tensor)."""
+        import torch
+        st, sct, gt, _C, empty = self.st, self.sct, self.gt, self._C, self.empty
+        if self.variant == "svgss":
             feats_in, vfeats_in = sct["features"], sct["vfeatures"]
-            if shade:
-                for v in leaves.values():
+            if self.shade:
+                for v in self.leaves.values():
                     v.grad = None
-                with torch.set_grad_enabled(training):
-                    feats_in, vfeats_in, _ = shading.shade_and_pack(
-                        leaves["base_color"], leaves["roughness"], leaves["normals"], sd["viewdirs"], leaves["radiance"],
-                        light, sd["visibility"], sd["dirs"], sd["areas"], st.viewmatrix, training)
+                lv, sd = self.leaves, self.sd
+                with torch.set_grad_enabled(self.training):
+                    feats_in, vfeats_in, _ = self.shading.shade_and_pack(
+                        lv["base_color"], lv["roughness"], lv["normals"], sd["viewdirs"], lv["radiance"], self.light,
+                        sd["visibility"], self.dirs, self.areas, st.viewmatrix, self.training)
             out = _C.rasterize_gaussians(st.bg, sct["means3D"], feats_in.detach(), vfeats_in.detach(), empty,
                                          sct["opacities"], sct["scales"], sct["rotations"], st.scale_modifier, empty,
                                          st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
                                          st.tanfovy, st.image_height, st.image_width, sct["shs"], st.sh_degree,
                                          st.campos, False, False, st.config)
             (R, color, normal, depth, opac, feat, vfeat, weights, radii, gb, bb, ib) = out
+            if not self.train:
+                return R, color, weights
             g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], feats_in.detach(), vfeats_in.detach(), radii, empty,
                                                 sct["scales"], sct["rotations"], st.scale_modifier, empty,
                                                 st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
                                                 st.tanfovy, gt["color"], gt["normal"], gt["depth"], gt["opacity"],
                                                 gt["feature"], gt["vfeature"], sct["shs"], st.sh_degree, st.campos,
                                                 gb, R, bb, ib, False, st.config)
-            if shade and training:
+            if self.shade and self.training:
                 torch.autograd.backward([feats_in, vfeats_in], [g[4], g[5]])
         else:
             out = _C.rasterize_gaussians(st.bg, sct["means3D"], sct["features"], empty, sct["opacities"],
@@ -140,6 +205,12 @@ def main():
                                                 st.campos, gb, R, bb, ib, True, False)
         return R, color, g[3]
 
+
+def timed(wl, args, world, dev, dry=None):
+    """warm-up, then `repeats` x (barrier, sync, K steps, barrier, sync); returns (per-region seconds [max over ranks], R,
+    stage timings)."""
+    import torch
+    from svgir_harness import view_parallel as vp
     mvec = torch.zeros(3, dtype=torch.float32, device=dev)
 
     def metrics(R, color, gmean):
@@ -150,136 +221,217 @@ def main():
         mvec[2].fill_(float(R))
         return mvec
 
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    step = dry or wl.step
     gatherer = vp.MetricsGatherer(3, dev)   # async: the collective of step i overlaps with step i+1
+    R = 0
     for _ in range(args.warmup):
         R, color, gm = step()
         gatherer.submit(metrics(R, color, gm))
     gatherer.drain()
-    vp.barrier()
-    torch.cuda.synchronize()
-    _native.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        R, color, gm = step()
-        gatherer.submit(metrics(R, color, gm))
-    allm = gatherer.results()   # inside the timed region: the last collective has completed
-    vp.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    stage = {n: (ms, cnt) for n, ms, cnt in _native.last_timings(with_counts=True)}
-    if os.environ.get("SVGIR_BENCH_MEMSTATS"):
-        ms_ = torch.cuda.memory_stats(dev)
-        print("memstats:", {k: ms_[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries",
-                                                "reserved_bytes.all.peak", "allocated_bytes.all.peak")},
-              "blob callbacks:", _native.ALLOC_STATS, file=sys.stderr)
-    _native.set_profiling(False)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if not dry:
+        from gaussian_renderer import _native
+        _native.set_profiling(True)
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        vp.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            R, color, gm = step()
+            gatherer.submit(metrics(R, color, gm))
+        gatherer.results()   # inside the timed region: the last collective has completed
+        vp.barrier()
+        sync()
+        regions.append(time.perf_counter() - t0)
+    stage = {}
+    if not dry:
+        stage = {n: (ms, cnt) for n, ms, cnt in _native.last_timings(with_counts=True)}
+        _native.set_profiling(False)
+    el = torch.tensor(regions, dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(el.item())
+    return el.cpu().numpy(), int(R), stage, gatherer.results().cpu().numpy()
 
-    if rank != 0:
-        return
-    value = world * P * args.steps / elapsed
-    ab = algorithmic_bytes(P, R, W, H, S, VS, variant == "svgss")
-    dom = "render_bwd"
-    dom_ms = stage[dom][0]
-    dom_name = "render_bwd_kernel (backward composite)"
-    if "grad_reduce" in stage:
-        # svgss: the gradient read-modify-write part of B_bwd is carried out by the row stores of render_bwd plus the
-        # per-Gaussian reduce kernel; the roofline is taken over both so that the byte model stays comparable
-        dom_ms += stage["grad_reduce"][0]
-        dom_name = "render_bwd_kernel + grad_reduce_kernel (backward composite incl. its gradient accumulation)"
-    achieved = ab["bwd"] / (dom_ms * 1e-3) / 1e9
-    fwd_ms = stage["render"][0]
+
+def roofline_of(wl, R, stage, workload):
+    ab = algorithmic_bytes(wl.P, R, wl.W, wl.H, wl.S, wl.VS, wl.variant == "svgss")
+    out = {}
+    if "render_bwd" in stage:
+        dom_ms = stage["render_bwd"][0]
+        dom_name = "render_bwd_kernel (backward composite)"
+        if "grad_reduce" in stage:
+            # svgss: the gradient read-modify-write part of B_bwd is carried out by the row stores of render_bwd plus the
+            # per-Gaussian reduce kernel; the roofline is taken over both so that the byte model stays comparable
+            dom_ms += stage["grad_reduce"][0]
+            dom_name = "render_bwd_kernel + grad_reduce_kernel (backward composite incl. its gradient accumulation)"
+        achieved = ab["bwd"] / (dom_ms * 1e-3) / 1e9
+        out = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": ab["bwd"],
+               "avg_launch_ms": dom_ms, "launches": stage["render_bwd"][1]}
+    fwd_ms = stage["render"][0] + stage.get("cull", (0.0, 0))[0]
+    fwd = {"kernel": "cull_kernel + render_fwd_kernel (forward composite)", "achieved": ab["fwd"] / (fwd_ms * 1e-3) / 1e9,
+           "frac": ab["fwd"] / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": fwd_ms,
+           "algorithmic_bytes_per_launch": ab["fwd"]}
+    if not out:   # forward-only workload: the forward composite is the dominant kernel
+        out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "launches": stage["render"][1], **fwd}
+    else:
+        out["fwd_composite"] = fwd
     # HBM bytes per launch of the dominant kernel from the PMC counters: a committed measurement of this workload
-    # (scripts/pmc_traffic.sh -> profiles/traffic_<workload>.json: separate rocprofv3 --pmc passes, gfx950 correction)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    # (scripts/pmc_traffic.sh -> profiles/traffic_<workload>.json: separate rocprofv3 --pmc passes, gfx950 correction),
+    # valid only for the kernel sources it was taken with
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
-            for kname, kv in json.load(f).get("kernels", {}).items():
+            tj = json.load(f)
+        if tj.get("kernel_source_hash") == kernel_source_hash():
+            tr = 0
+            for kname, kv in tj.get("kernels", {}).items():
                 if kname.startswith("render_bwd_kernel") or kname.startswith("grad_reduce_kernel"):
-                    traffic = (traffic or 0) + kv["read_bytes"] + kv["write_bytes"]
-    res = {
-        "metric": "Gaussian-surfels/sec fwd+bwd @800x800 (1 view)",
-        "value": value, "unit": "surfels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {variant} path, P={P} surfels, {W}x{H}, SH degree {sc['sh_degree']}, "
-                               f"S={S}, VS={VS}, fwd+bwd, one view per step per GPU (BASELINE.json configs[1] for cfg2)",
-                   "num_rendered": int(R), "views_per_step": world, "parallelism": f"view-parallel x{world}"},
-        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": ab["bwd"], "avg_launch_ms": dom_ms, "launches": stage[dom][1],
-                     "fwd_composite": {"achieved": ab["fwd"] / (fwd_ms * 1e-3) / 1e9, "avg_launch_ms": fwd_ms,
-                                       "algorithmic_bytes_per_launch": ab["fwd"]}},
-        "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
-    }
-    if shade:
-        # shading kernels: HBM bytes = per-sample inputs (dirs 12 + area 4 + visibility 4 + radiance 12 = 32 B) x Ns
-        # + per-surfel inputs (31 floats) + outputs (reduced 70 floats [+ features/vfeatures in the no-grad path])
-        sf = P * Ns * 32 + P * (31 + 70 + (0 if training else S + VS)) * 4
-        res["config"]["shading"] = f"rendering_equation4 + packing, Ns={Ns} incident samples/surfel, env 32x64, " \
-                                   f"{'forward+backward' if training else 'forward only (eval)'}"
-        res["shading"] = {"fwd": {"avg_launch_ms": stage["shade_fwd"][0], "algorithmic_bytes_per_launch": sf,
-                                  "achieved": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
-                                  "frac": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-        if training and "shade_bwd" in stage:
-            sb = P * Ns * (32 + 12) + P * (31 + 70 + 28) * 4   # + dL_dradiance per sample, per-surfel gradients
-            res["shading"]["bwd"] = {"avg_launch_ms": stage["shade_bwd"][0], "algorithmic_bytes_per_launch": sb,
-                                     "achieved": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
-                                     "frac": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as orc
-        var_id = orc.SVGSS if variant == "svgss" else orc.RGSS
-        cores = orc.max_threads()
-        o = orc.OracleRun(sc, var_id)
+                    tr += kv["read_bytes"] + kv["write_bytes"]
+            out["traffic"] = tr or None
+        else:
+            out["traffic_note"] = "profiles/traffic_%s.json was measured with different kernel sources" % workload
+    return out
 
-        def cpu_step():
-            o.forward()
-            o.backward(grads["color"], grads["normal"], grads["depth"], grads["opacity"], grads["feature"],
-                       grads.get("vfeature"))
 
-        tc = time.perf_counter()
-        cpu_step()  # warm-up (thread pool, page faults); also sizes the sample
-        one = time.perf_counter() - tc
-        n_cpu = args.cpu_steps or max(2, min(200, int(12.0 / max(one, 1e-3))))
-        tc = time.perf_counter()
-        for _ in range(n_cpu):
-            cpu_step()
-        cpu_el = time.perf_counter() - tc
-        per_step = cpu_el / n_cpu
-        sample = f"{n_cpu} fwd+bwd rasterizer steps of the same {args.workload} view ({cpu_el:.1f} s, OpenMP " \
-                 f"oracle/svgir_oracle.cpp, {cores} threads)"
-        if shade:
-            # shading oracle (torch fp64 restatement of the reference's PyTorch code) on the first P/10 surfels, x10
-            from oracle import shading_oracle as so
-            n = max(1, P // 10)
-            cd = {k: v[:n].double().cpu() for k, v in sd.items() if k != "env"}
-            cl = {k: leaves[k].detach()[:n].double().cpu().requires_grad_(training) for k in ("base_color", "roughness", "normals", "radiance")}
-            cenv = leaves["env"].detach().double().cpu().requires_grad_(training)
-            ts = time.perf_counter()
-            r = so.shade(cl["base_color"], cl["roughness"], cl["normals"], cd["viewdirs"], cl["radiance"], cd["visibility"],
-                         cd["dirs"], cd["areas"], cenv)
-            if training:
-                (r["pbr"].sum() + r["diffuse_light"].sum() + r["mean_local"].sum()).backward()
-            shade_s = (time.perf_counter() - ts) * (P / n)
-            per_step += shade_s
-            sample += f" + shading oracle (torch fp64, {torch.get_num_threads()} threads) on {n} surfels scaled to P " \
-                      f"({shade_s:.2f} s/step)"
-        res["cpu_baseline"] = {"value": P / per_step, "unit": "surfels/s", "cores": cores, "kind": "port",
-                               "sample": sample}
-        # the same rasterizer step on ONE host thread (SURVEY 8d asks for both); 2 steps, a few seconds
-        o1 = orc.OracleRun(sc, var_id, num_threads=1)
-        tc = time.perf_counter()
-        for _ in range(2):
-            o1.forward()
-            o1.backward(grads["color"], grads["normal"], grads["depth"], grads["opacity"], grads["feature"],
-                        grads.get("vfeature"))
-        res["cpu_baseline"]["single_thread"] = {"value": 2 * P / (time.perf_counter() - tc), "unit": "surfels/s",
-                                                "cores": 1, "sample": "2 fwd+bwd rasterizer steps, 1 thread"}
-    print(json.dumps(res))
+def shading_record(wl, stage):
+    sf_per_sample = 32 if not isinstance(wl.dirs, wl.shading.FibonacciLattice) else 16
+    sf = wl.P * wl.Ns * sf_per_sample + wl.P * (31 + 70 + (0 if wl.training else wl.S + wl.VS) + (0 if sf_per_sample == 32 else 4)) * 4
+    rec = {"config": f"rendering_equation4 + packing, Ns={wl.Ns} incident samples/surfel, env 32x64, incident directions "
+                     f"{'streamed from HBM' if sf_per_sample == 32 else 'generated in the kernels (Fibonacci lattice)'}, "
+                     f"{'forward+backward' if wl.training else 'forward only (eval)'}",
+           "fwd": {"avg_launch_ms": stage["shade_fwd"][0], "algorithmic_bytes_per_launch": sf, "bytes_per_sample": sf_per_sample,
+                   "achieved": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
+                   "frac": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if wl.training and "shade_bwd" in stage:
+        sb = wl.P * wl.Ns * (sf_per_sample + 12) + wl.P * (31 + 70 + 28) * 4   # + dL_dradiance per sample, per-surfel gradients
+        rec["bwd"] = {"avg_launch_ms": stage["shade_bwd"][0], "algorithmic_bytes_per_launch": sb,
+                      "achieved": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
+                      "frac": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return rec
+
+
+def cpu_baseline(wl, args):
+    """The CPU oracle on the host cores: `-O3 -march=native` build (compiled here, on the machine that
+    runs it) when the compiler is available, else the parity build."""
+    import torch
+    from oracle import oracle as orc
+    fast = orc.build_fast()
+    var_id = orc.SVGSS if wl.variant == "svgss" else orc.RGSS
+    cores = orc.max_threads()
+    o = orc.OracleRun(wl.sc, var_id, fast=fast)
+    g = wl.grads
+
+    def cpu_step(oo):
+        oo.forward()
+        oo.backward(g["color"], g["normal"], g["depth"], g["opacity"], g["feature"], g.get("vfeature"))
+
+    tc = time.perf_counter()
+    cpu_step(o)  # warm-up (thread pool, page faults); also sizes the sample
+    one = time.perf_counter() - tc
+    n_cpu = args.cpu_steps or max(2, min(200, int(12.0 / max(one, 1e-3))))
+    tc = time.perf_counter()
+    for _ in range(n_cpu):
+        cpu_step(o)
+    cpu_el = time.perf_counter() - tc
+    per_step = cpu_el / n_cpu
+    build = "-O3 -march=native" if fast else "-O2 (parity build)"
+    sample = f"{n_cpu} fwd+bwd rasterizer steps of the same {wl.name} view ({cpu_el:.1f} s, OpenMP oracle/svgir_oracle.cpp " \
+             f"{build}, {cores} threads)"
+    res = {"value": wl.P / per_step, "unit": "surfels/s", "cores": cores, "kind": "port", "sample": sample}
+    # the same rasterizer step on ONE host thread (SURVEY 8d asks for both); 2 steps, a few seconds
+    o1 = orc.OracleRun(wl.sc, var_id, num_threads=1, fast=fast)
+    tc = time.perf_counter()
+    for _ in range(2):
+        cpu_step(o1)
+    res["single_thread"] = {"value": 2 * wl.P / (time.perf_counter() - tc), "unit": "surfels/s", "cores": 1,
+                            "sample": "2 fwd+bwd rasterizer steps, 1 thread"}
+    return res
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
+    import torch
+    from svgir_harness import view_parallel as vp
+    rank, world, local = vp.init_from_env(backend="gloo" if args.dry_run else None)
+    if world != max(1, args.gpus):
+        print(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    name = args.workload or ("cfg2" if world == 1 else "cfg4")
+
+    if args.dry_run:
+        dev = torch.device("cpu")
+        tok = torch.arange(8, dtype=torch.float32) + rank
+
+        def dry_step():
+            return 100 + rank, tok * 2.0, tok + 1.0
+
+        regions, R, stage, table = timed(None, args, world, dev, dry=dry_step)
+        if rank == 0:
+            med = float(np.median(regions))
+            print(json.dumps({"metric": "dry-run (no GPU work)", "value": world * args.steps / med, "unit": "steps/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "repeats": len(regions), "ms_per_step": med / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": name + " (dry run)", "views_per_step": world},
+                              "per_rank_R": [int(r[2]) for r in table]}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    if torch.cuda.device_count() <= local or not torch.cuda.is_available():
+        print("bench.py needs a GPU per rank (the rasterizer has no CPU path)", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    wl = Workload(name, dev, rank, world, args)
+    regions, R, stage, table = timed(wl, args, world, dev)
+    res = None
+    if rank == 0:
+        med = float(np.median(regions))
+        res = {
+            "metric": "Gaussian-surfels/sec fwd+bwd @800x800 (1 view)",
+            "value": world * wl.P * args.steps / med, "unit": "surfels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": len(regions), "ms_per_step_min": float(regions.min()) / args.steps * 1e3,
+            "ms_per_step_max": float(regions.max()) / args.steps * 1e3,
+            "config": {"workload": f"{name}: {wl.variant} path, P={wl.P} surfels, {wl.W}x{wl.H}, SH degree {wl.sc['sh_degree']}, "
+                                   f"S={wl.S}, VS={wl.VS}, {'fwd+bwd' if wl.train else 'fwd'}, one view per step per GPU "
+                                   f"(BASELINE.json configs[1] = cfg2 at N=1; configs[3] = cfg4, view r on rank r, at N>1)",
+                       "num_rendered": int(R), "views_per_step": world, "parallelism": f"view-parallel x{world}",
+                       "per_rank_num_rendered": [int(r[2]) for r in table]},
+            "roofline": roofline_of(wl, R, stage, name),
+            "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
+        }
+        if wl.shade:
+            res["config"]["shading"] = shading_record(wl, stage)["config"]
+            res["shading"] = {k: v for k, v in shading_record(wl, stage).items() if k != "config"}
+    # the "shaded + blended" number of north_star: cfg3_train with the shading stage, same measurement, extra keys
+    if world == 1 and args.workload is None and not args.no_shaded:
+        wl.sct = wl.gt = None
+        torch.cuda.empty_cache()
+        sa = argparse.Namespace(**vars(args))
+        sa.repeats = max(1, args.repeats // 5)
+        w3 = Workload("cfg3_train", dev, rank, world, sa)
+        reg3, R3, st3, _ = timed(w3, sa, world, dev)
+        m3 = float(np.median(reg3))
+        res["shaded"] = {"workload": f"cfg3_train: svgss path, P={w3.P}, {w3.W}x{w3.H}, S={w3.S}, VS={w3.VS}, SV-BRDF shading "
+                                     f"(Ns={w3.Ns}) + rasterizer, fwd+bwd (BASELINE.json configs[2])",
+                         "value": w3.P * sa.steps / m3, "unit": "surfels/s", "ms_per_step": m3 / sa.steps * 1e3, "repeats": len(reg3),
+                         "num_rendered": int(R3), "roofline": roofline_of(w3, R3, st3, "cfg3_train"),
+                         "shading": shading_record(w3, st3), "stage_ms": {k: round(v[0], 4) for k, v in st3.items()}}
+        del w3
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(wl, args)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -215,6 +215,15 @@ typedef struct svgir_shade_params {
     float* env_work;
     const float* env_transform; /* [9] row-major 3x3 or NULL: the env lookup uses transform * dir (EnvLight.transform,
                                  * scene/envmap.py:57-60); every other term keeps the untransformed direction */
+    /* Incident directions generated in the kernels instead of streamed: when incident_dirs is
+     * NULL, sample i of surfel g is the reference's Fibonacci hemisphere lattice around lattice_normals[g]
+     * (fibonacci_sphere_sampling + rotation_between_z, utils/graphics_utils.py:9-37, utils/sh_utils.py:36-68; what
+     * sample_incident_rays stores in pc._incident_dirs, scene/gaussian_model.py:23-31), with the per-surfel random
+     * azimuth offset lattice_offsets[g] of the training branch (NULL: evaluation lattice).  incident_areas may then be
+     * NULL too (the lattice's areas are the constant 2 pi).  lattice_work: scratch of 4 * Ns floats. */
+    const float* lattice_normals;   /* [P,3] unit */
+    const float* lattice_offsets;   /* [P] radians or NULL */
+    float* lattice_work;
 } svgir_shade_params;
 
 #define SVGIR_SHADE_REDUCED 70
@@ -232,6 +241,18 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
                          const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
                          float* env_grad_work, void* stream);
+
+/* Materialises the incident-direction lattice: dirs [P,Ns,3] and / or areas [P,Ns,1] (either may be NULL), the return
+ * values of the reference's fibonacci_sphere_sampling(normals, Ns, random_rotate) with `offsets` [P] standing for its
+ * random draw (NULL = random_rotate False).  lattice_work: scratch of 4 * Ns floats. */
+int svgir_incident_dirs(int32_t P, int32_t Ns, const float* normals, const float* offsets, float* lattice_work,
+                        float* dirs, float* areas, void* stream);
+
+/* Bilinear resize of an [H,W,C] image to [out_h,out_w,C] with the half-pixel convention of
+ * F.interpolate(mode='bilinear', align_corners=False): EnvLight.direct_light's 32x64 down-sample of its HDR map
+ * (scene/envmap.py:62-63). */
+int svgir_resample_bilinear(const float* src, int32_t H, int32_t W, int32_t C, float* dst, int32_t out_h, int32_t out_w,
+                            void* stream);
 
 /* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
  * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,

@@ -3,9 +3,10 @@
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 The product package (svg-ir_amd/) must never import this module.
 
-Parity status: see the header of svgir_oracle.cpp ("parity unpinned" for the rasterizer: the reference has no
-tests/golden vectors for this path and is CUDA-only; pinned indirectly through tests/golden fixtures generated
-from the reference's importable Python helpers, an autograd fp64 restatement and finite differences).
+Parity status: see the header of svgir_oracle.cpp (the reference has no tests / golden vectors for the rasterizer and
+is CUDA-only; the restatement is pinned by fixtures generated from the reference's importable Python helpers, by an
+oracle-free fp64 construction of every per-Gaussian decision and of the instance list, by torch.autograd of an
+independent forward, and by finite differences -- tests/test_oracle.py).
 """
 import ctypes as C
 import os
@@ -15,7 +16,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsvgir_oracle.so")
+_FAST_PATH = os.path.join(_HERE, "libsvgir_oracle_fast.so")
 _lib = None
+_lib_fast = None
 
 RGSS, SVGSS = 0, 1
 
@@ -44,11 +47,34 @@ def build(force=False):
     return _LIB_PATH
 
 
-def lib():
-    global _lib
+def build_fast():
+    """`-O3 -march=native -fopenmp` build for the CPU-baseline timing: compiled on the machine that runs
+    it, never used for parity.  Returns False when it cannot be built here."""
+    src = os.path.join(_HERE, "svgir_oracle.cpp")
+    try:
+        if not os.path.exists(_FAST_PATH) or os.path.getmtime(_FAST_PATH) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "libsvgir_oracle_fast.so"], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL)
+        lib(fast=True)
+        return True
+    except Exception:
+        return False
+
+
+def lib(fast=False):
+    global _lib, _lib_fast
+    if fast:
+        if _lib_fast is None:
+            _lib_fast = _bind(C.CDLL(_FAST_PATH))
+        return _lib_fast
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
+        _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(_lib):
+    if True:
         _lib.orc_create.restype = C.c_void_p
         _lib.orc_create.argtypes = [C.POINTER(_Params)]
         _lib.orc_destroy.argtypes = [C.c_void_p]
@@ -77,8 +103,8 @@ class OracleRun:
     computer_pseudo_normal (rgss).
     """
 
-    def __init__(self, scene, variant, fp64=False, num_threads=0):
-        self.L = lib()
+    def __init__(self, scene, variant, fp64=False, num_threads=0, fast=False):
+        self.L = lib(fast=fast)
         self.dt = np.float64 if fp64 else np.float32
         self.variant = variant
         self._keep = {}

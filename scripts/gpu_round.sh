@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU session: tests, bench lines and rocprofv3 kernel-trace summaries.  usage: scripts/gpu_round.sh <tag> [quick]
+# One GPU session: tests, PMC traffic, bench lines and rocprofv3 kernel-trace summaries.  usage: scripts/gpu_round.sh <tag> [quick]
 set -u
 export TMPDIR=/tmp
 R=$PWD
@@ -9,15 +9,17 @@ if [ "${2:-}" != "quick" ]; then
   python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/${TAG}_tests.log
   cat gpurun_out/${TAG}_tests.log
 fi
-for W in cfg2 cfg3_train; do   # PMC traffic first: bench.py reports it as roofline.traffic
-  scripts/pmc_traffic.sh $W ${TAG}_$W > /dev/null 2>&1 && cp gpurun_out/${TAG}_${W}_traffic.json profiles/traffic_$W.json
+for W in cfg2 cfg3_train; do   # PMC traffic first: bench.py reports it as roofline.traffic (stamped with the kernel-source hash)
+  scripts/pmc_traffic.sh $W ${TAG}_$W > /dev/null 2>&1 && cp gpurun_out/${TAG}_${W}_traffic.json profiles/traffic_$W.json && cp gpurun_out/${TAG}_${W}_traffic.json gpurun_out/traffic_$W.json
 done
-for W in cfg2 cfg3_train cfg3_eval; do
-  python bench.py --workload $W > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err
-  tail -c 2500 gpurun_out/${TAG}_bench_$W.json; tail -3 gpurun_out/${TAG}_bench_$W.err
+python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+tail -c 6000 gpurun_out/${TAG}_bench_default.json; tail -3 gpurun_out/${TAG}_bench_default.err
+for W in cfg3_train cfg3_eval cfg4 cfg5; do
+  python bench.py --workload $W --no-cpu-baseline --repeats 5 > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err
+  tail -c 3000 gpurun_out/${TAG}_bench_$W.json; tail -3 gpurun_out/${TAG}_bench_$W.err
 done
-for W in cfg2 cfg3_train; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$W -o p -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $W > $R/gpurun_out/${TAG}_prof_$W.log 2>&1)
+for W in cfg2 cfg3_train cfg5; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$W -o p -- python3 $R/bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --workload $W > $R/gpurun_out/${TAG}_prof_$W.log 2>&1)
   DB=$(find gpurun_out/${TAG}_prof_$W -name "*.db" | head -1)
-  python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_${W}_kernel_stats.txt "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $W" | head -30
+  python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_${W}_kernel_stats.txt "python3 bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --workload $W" | head -30
 done

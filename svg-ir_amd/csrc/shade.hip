@@ -73,6 +73,104 @@ __device__ __forceinline__ void env_taps(const float* d, int He, int We, EnvTap&
     }
 }
 
+// ---- incident-direction lattice -----------------------------------------------------------
+// `fibonacci_sphere_sampling` (utils/graphics_utils.py:9-37) + `rotation_between_z` (utils/sh_utils.py:36-68), as
+// called by `sample_incident_rays` (scene/gaussian_model.py:23-31): sample i of a surfel = R(n) * (sin t_i rad_i,
+// cos t_i rad_i, z_i), re-normalised, with z_i = max(1 - 2 i / (2 Ns - 1), sin 10 deg), rad_i = sqrt(1 - z_i^2),
+// t_i = delta * i (+ the surfel's random azimuth offset in training), areas = 2 pi.  The reference materialises
+// [P,Ns,3] + [P,Ns,1] tensors (16 of the 32 bytes per sample the shading kernels stream); here the per-index part
+// {sin t_i, cos t_i, z_i, rad_i} is a tiny table (one launch per call) and the kernels build the directions in
+// registers from 3 (+1) floats per SURFEL.
+// The reference evaluates t_i in fp32 (one ulp is 6e-5 rad at t = 900); the table is built from exactly that rounded
+// product, and the offset is added with the rounding error of the fp32 sum carried to first order.
+constexpr float kLatticeDelta = 2.39996322972865332f;   // fp32(pi * (3 - sqrt(5)))
+constexpr float kTwoPi = 6.28318530717958647692f;
+
+__global__ void __launch_bounds__(BLOCK) lattice_table_kernel(int Ns, float4* __restrict__ tab) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= Ns) return;
+    const float fi = (float)i;
+    const float z = fmaxf(1.f - 2.f * fi / (float)(2 * Ns - 1), 0.17364817766693033f);   // sin(10 deg)
+    const float rad = sqrtf(1.f - z * z);
+    const float t = kLatticeDelta * fi;
+    float sn, cs;
+    sincosf(t, &sn, &cs);
+    tab[i] = make_float4(sn, cs, z, rad);
+}
+
+struct LatticeFrame { float R[9]; float so, co, off; };   // rotation taking +z to the surfel's normal; offset angle
+__device__ __forceinline__ LatticeFrame lattice_frame(const float* __restrict__ normals, const float* __restrict__ offsets,
+                                                      size_t g) {
+    LatticeFrame f;
+    const float nx = normals[g * 3], ny = normals[g * 3 + 1], nz = normals[g * 3 + 2];
+    const float v1 = -ny, v2 = nx;
+    const float ic = 1.f / fmaxf(nz + 1.f, 1e-7f);
+    const bool ok = nz + 1.f > 0.f;
+    f.R[0] = ok ? 1.f - v2 * v2 * ic : -1.f; f.R[1] = ok ? v1 * v2 * ic : 0.f; f.R[2] = ok ? v2 : 0.f;
+    f.R[3] = ok ? v1 * v2 * ic : 0.f; f.R[4] = ok ? 1.f - v1 * v1 * ic : -1.f; f.R[5] = ok ? -v1 : 0.f;
+    f.R[6] = ok ? -v2 : 0.f; f.R[7] = ok ? v1 : 0.f; f.R[8] = ok ? 1.f - (v2 * v2 + v1 * v1) * ic : -1.f;
+    f.off = offsets ? offsets[g] : 0.f;
+    f.so = 0.f; f.co = 1.f;
+    if (offsets) sincosf(f.off, &f.so, &f.co);
+    return f;
+}
+__device__ __forceinline__ void lattice_dir(const LatticeFrame& f, const float4 t, int i, bool has_offset, float* d) {
+    float sn = t.x, cs = t.y;
+    if (has_offset) {
+        // the reference takes sin / cos of th = fl(offset + t_i).  With e = (offset + t_i) - th exactly (two-sum):
+        // sin th = sin(offset + t_i) - e cos(offset + t_i) + O(e^2), and the sine / cosine of the exact sum come from the
+        // table and the surfel's (sin, cos)(offset) by the addition theorems.
+        float ti, th, e;
+        {
+#pragma clang fp contract(off)
+            ti = kLatticeDelta * (float)i;
+            th = f.off + ti;
+            const float bb = th - f.off;
+            e = (f.off - (th - bb)) + (ti - bb);
+        }
+        const float se = f.so * t.y + f.co * t.x, ce = f.co * t.y - f.so * t.x;
+        sn = se - e * ce; cs = ce + e * se;
+    }
+    const float x = sn * t.w, y = cs * t.w, z = t.z;
+    float v[3] = {f.R[0] * x + f.R[1] * y + f.R[2] * z, f.R[3] * x + f.R[4] * y + f.R[5] * z, f.R[6] * x + f.R[7] * y + f.R[8] * z};
+    const float il = fminf(__builtin_amdgcn_rsqf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+    d[0] = v[0] * il; d[1] = v[1] * il; d[2] = v[2] * il;
+}
+
+// materialises the lattice: the drop-in for fibonacci_sphere_sampling's return values
+__global__ void __launch_bounds__(BLOCK) incident_dirs_kernel(int P, int Ns, const float* __restrict__ normals,
+                                                              const float* __restrict__ offsets,
+                                                              const float4* __restrict__ tab, float* __restrict__ dirs,
+                                                              float* __restrict__ areas) {
+    const size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (o >= (size_t)P * Ns) return;
+    const size_t g = o / Ns;
+    const int i = (int)(o - g * Ns);
+    const LatticeFrame f = lattice_frame(normals, offsets, g);
+    float d[3];
+    lattice_dir(f, tab[i], i, offsets != nullptr, d);
+    if (dirs) { dirs[o * 3] = d[0]; dirs[o * 3 + 1] = d[1]; dirs[o * 3 + 2] = d[2]; }
+    if (areas) areas[o] = kTwoPi;
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) of an [H,W,C] image to [oh,ow,C] (EnvLight.direct_light's 32x64
+// down-sample, scene/envmap.py:62-63): source coordinate (dst + 0.5) * scale - 0.5 clamped at 0, neighbours clamped
+__global__ void __launch_bounds__(BLOCK) resample_kernel(const float* __restrict__ src, int H, int W, int C,
+                                                         float* __restrict__ dst, int oh, int ow) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= oh * ow * C) return;
+    const int c = i % C, x = (i / C) % ow, y = i / (C * ow);
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)H / (float)oh) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)W / (float)ow) - 0.5f, 0.f);
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    const float a = src[((size_t)y0 * W + x0) * C + c], b = src[((size_t)y0 * W + x1) * C + c];
+    const float e = src[((size_t)y1 * W + x0) * C + c], f = src[((size_t)y1 * W + x1) * C + c];
+    dst[i] = (a * (1.f - fx) + b * fx) * (1.f - fy) + (e * (1.f - fx) + f * fx) * fy;
+}
+
 struct GaussConst {  // per-(Gaussian, corner) constants of a phase-2 lane
     float nraw[3], Nh[3], a2, kk, nom1, fd[3], r;
     float sgn, inv_len, NoV_raw;  // for the backward
@@ -101,14 +199,16 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
 // phase 1 for one chunk of <= 64 samples [s0, s0+cnt) of one Gaussian: fills the wave's sample records (slot =
 // sample - s0) and adds this lane's sample to the per-lane light sums m[10].
 __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_t g, int lane, const float* V,
-                                              float* __restrict__ sS, float* m, int s0, int cnt) {
+                                              float* __restrict__ sS, float* m, int s0, int cnt, const LatticeFrame& lf) {
     const int Ns = p.Ns;
     if (lane < cnt) {
         const int s = s0 + lane;
         const size_t o = g * Ns + s;
-        const float d[3] = {p.incident_dirs[o * 3], p.incident_dirs[o * 3 + 1], p.incident_dirs[o * 3 + 2]};
+        float d[3];
+        if (p.incident_dirs) { d[0] = p.incident_dirs[o * 3]; d[1] = p.incident_dirs[o * 3 + 1]; d[2] = p.incident_dirs[o * 3 + 2]; }
+        else lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[s], s, p.lattice_offsets != nullptr, d);
         const float rad[3] = {p.radiance[o * 3], p.radiance[o * 3 + 1], p.radiance[o * 3 + 2]};
-        const float vis = p.visibility[o], area = p.incident_areas[o];
+        const float vis = p.visibility[o], area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
         const float il = fminf(__builtin_amdgcn_rsqf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
         const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
         float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
@@ -180,10 +280,12 @@ __global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
     // f = f_d + fs the five outputs are  diffuse = A_d + A_l, specular = B_d + B_l, direct = f_d*A_d + B_d,
     // indirect = f_d*A_l + B_l, pbr = direct + indirect
     float Ad[3] = {0, 0, 0}, Al[3] = {0, 0, 0}, Bd[3] = {0, 0, 0}, Bl[3] = {0, 0, 0};
+    LatticeFrame lf = {};
+    if (!p.incident_dirs) lf = lattice_frame(p.lattice_normals, p.lattice_offsets, gg);
     for (int s0 = 0; s0 < Ns; s0 += 64) {
       const int cnt = min(64, Ns - s0);
       wave_lds_sync();   // previous chunk consumed
-      stage_samples(p, gg, lane, V, sS, m, s0, cnt);
+      stage_samples(p, gg, lane, V, sS, m, s0, cnt, lf);
       wave_lds_sync();
       for (int s = sg; s < cnt; s += 16) {
         const float* r = sS + s * SREC;
@@ -266,6 +368,8 @@ struct ShadeBwdArgs {
 constexpr int BREC = 23;
 #ifndef SHADE_BWAVES
 #define SHADE_BWAVES 4   // measured on MI355X (P=200k, Ns=64): 4 waves x 3/SIMD 0.71 ms, 8x4 0.79, 8x2 0.83, 4x4 1.05
+#endif
+#ifndef SHADE_BWPE
 #define SHADE_BWPE 3
 #endif
 constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
@@ -273,11 +377,19 @@ constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
 struct RawSample { float d[3], rad[3], vis, area; };
 
 __device__ __forceinline__ RawSample load_raw(const svgir_shade_params& p, size_t g, int s, int lane, int cnt) {
-    const size_t o = g * (size_t)p.Ns + (size_t)(s + (lane < cnt ? lane : 0));
+    const int si = s + (lane < cnt ? lane : 0);
+    const size_t o = g * (size_t)p.Ns + (size_t)si;
     RawSample r;
+    if (p.incident_dirs) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) { r.d[j] = p.incident_dirs[o * 3 + j]; r.rad[j] = p.radiance[o * 3 + j]; }
-    r.vis = p.visibility[o]; r.area = p.incident_areas[o];
+        for (int j = 0; j < 3; j++) r.d[j] = p.incident_dirs[o * 3 + j];
+    } else {   // directions from the lattice (3 (+1) floats per surfel instead of 12 bytes per sample)
+        const LatticeFrame lf = lattice_frame(p.lattice_normals, p.lattice_offsets, g);
+        lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[si], si, p.lattice_offsets != nullptr, r.d);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.rad[j] = p.radiance[o * 3 + j];
+    r.vis = p.visibility[o]; r.area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
     return r;
 }
 
@@ -354,12 +466,6 @@ __device__ __forceinline__ float stride4_sum(float v) {
     v += __shfl_xor(v, 32);
     return v;
 }
-#ifdef SHADE_TIMING
-__device__ unsigned long long g_shade_tm[8];
-#define TM_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm_acc[i] += t_ - tm_prev; tm_prev = t_; } while (0)
-#else
-#define TM_MARK(i)
-#endif
 
 // Persistent workgroups of BWAVES waves; every wave owns one Gaussian at a time and never synchronises with the other
 // waves (its sample records are wave-private LDS).  Lane = (sample group sg = lane / 4, corner k = lane % 4): the
@@ -388,12 +494,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 
     RawSample raw;
     if (g < P) raw = load_raw(p, (size_t)g, 0, lane, min(64, Ns));
-#ifdef SHADE_TIMING
-    unsigned long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tm_prev = __builtin_amdgcn_s_memtime();
-#endif
     for (; g < P; g += gstep) {
-        TM_MARK(0);
         const size_t gg = (size_t)g;
         float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
         {
@@ -468,9 +569,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         for (int s0 = 0; s0 < Ns; s0 += 64) {
             const int cnt = min(64, Ns - s0);
             wave_lds_sync();   // previous chunk consumed
-            TM_MARK(1);
             if (lane < cnt) stage_raw_bwd(p, raw, lane, V, sS);
-            TM_MARK(2);
             {   // prefetch the next chunk (of this Gaussian or of the wave's next one)
                 const bool more = s0 + 64 < Ns;
                 const int gn = more ? g : g + gstep;
@@ -478,7 +577,6 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 if (gn < P) raw = load_raw(p, (size_t)gn, sn, lane, min(64, Ns - sn));
             }
             wave_lds_sync();
-            TM_MARK(3);
 #pragma unroll 1
             for (int it = 0; it < 4; it++) {
                 const int s = sg + 16 * it;
@@ -560,7 +658,6 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 }
             }
         }
-        TM_MARK(4);
         // per-Gaussian chain rule of the sums: a2 = r^4, kk = (r^2 + 2r + 1)/8 (through nom1 and nom2), NoV -> Nh
         float d_r;
         {
@@ -588,20 +685,14 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             }
             a.d_rough[gg * 4 + k] = d_r + dir_r;
         }
-        TM_MARK(5);
     }
     __syncthreads();
-    TM_MARK(6);
     if (env_in_lds) {
         for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) {
             const float v = sEnv[i];
             if (v != 0.f) atomic_add_f32(&a.d_envtab[i], v);
         }
     }
-    TM_MARK(7);
-#ifdef SHADE_TIMING
-    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_shade_tm[i], tm_acc[i]);
-#endif
 }
 
 // dL/d env_raw = dL/d f(env) * f'(env);  softplus' = sigmoid
@@ -625,11 +716,14 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     if (!p || p->P < 0 || p->Ns <= 0 || p->env_h <= 0 || p->env_w <= 0) return SVGIR_ERR_INVALID;
     if (p->P == 0) return 0;
     if (!p->base_color || !p->roughness || !p->normals || !p->viewdirs || !p->radiance || !p->visibility ||
-        !p->incident_dirs || !p->incident_areas || !p->env || !p->env_work || (vfeatures && !p->viewmatrix))
+        !p->env || !p->env_work || (vfeatures && !p->viewmatrix))
         return SVGIR_ERR_INVALID;
+    if (!p->incident_dirs && !(p->lattice_normals && p->lattice_work)) return SVGIR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
+    if (!p->incident_dirs)
+        hipLaunchKernelGGL(lattice_table_kernel, dim3((p->Ns + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->Ns, (float4*)p->lattice_work);
     hipLaunchKernelGGL(env_table_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, p->env_work, ntex,
                        p->env_softplus);
     stage_mark(tm, "shade_env_table");
@@ -650,9 +744,12 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     if ((!dL_dreduced && !dL_dfeatures && !dL_dvfeatures) || (dL_dvfeatures && !p->viewmatrix) || !dL_dbase_color || !dL_droughness || !dL_dnormals || !dL_dradiance || !dL_denv ||
         !env_grad_work || !p->env_work)
         return SVGIR_ERR_INVALID;
+    if (!p->incident_dirs && !(p->lattice_normals && p->lattice_work)) return SVGIR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
+    if (!p->incident_dirs)
+        hipLaunchKernelGGL(lattice_table_kernel, dim3((p->Ns + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->Ns, (float4*)p->lattice_work);
     hipLaunchKernelGGL(env_table_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, p->env_work, ntex,
                        p->env_softplus);
     if (hipMemsetAsync(env_grad_work, 0, (size_t)ntex * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
@@ -674,12 +771,25 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 
-#ifdef SHADE_TIMING
-int svgir_debug_shade_timing(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_shade_tm), 64) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_tm), z, 64); }
-    return 0;
+int svgir_incident_dirs(int32_t P, int32_t Ns, const float* normals, const float* offsets, float* lattice_work,
+                        float* dirs, float* areas, void* stream) {
+    if (P < 0 || Ns <= 0 || (P > 0 && (!normals || !lattice_work))) return SVGIR_ERR_INVALID;
+    if (P == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lattice_table_kernel, dim3((Ns + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, Ns, (float4*)lattice_work);
+    const size_t n = (size_t)P * Ns;
+    hipLaunchKernelGGL(incident_dirs_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, P, Ns, normals,
+                       offsets, (const float4*)lattice_work, dirs, areas);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
-#endif
+
+int svgir_resample_bilinear(const float* src, int32_t H, int32_t W, int32_t C, float* dst, int32_t out_h, int32_t out_w,
+                            void* stream) {
+    if (!src || !dst || H <= 0 || W <= 0 || C <= 0 || out_h <= 0 || out_w <= 0) return SVGIR_ERR_INVALID;
+    const int n = out_h * out_w * C;
+    hipLaunchKernelGGL(resample_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, src, H, W, C, dst,
+                       out_h, out_w);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
 
 }  // extern "C"

@@ -26,13 +26,67 @@ class ShadeParams(C.Structure):
                 ("base_color", C.c_void_p), ("roughness", C.c_void_p), ("normals", C.c_void_p),
                 ("viewdirs", C.c_void_p), ("radiance", C.c_void_p), ("visibility", C.c_void_p),
                 ("incident_dirs", C.c_void_p), ("incident_areas", C.c_void_p), ("env", C.c_void_p),
-                ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p), ("env_transform", C.c_void_p)]
+                ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p), ("env_transform", C.c_void_p),
+                ("lattice_normals", C.c_void_p), ("lattice_offsets", C.c_void_p), ("lattice_work", C.c_void_p)]
 
 
 N.lib.svgir_shade_forward.restype = C.c_int
 N.lib.svgir_shade_forward.argtypes = [C.POINTER(ShadeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 N.lib.svgir_shade_backward.restype = C.c_int
 N.lib.svgir_shade_backward.argtypes = [C.POINTER(ShadeParams)] + [C.c_void_p] * 10
+N.lib.svgir_incident_dirs.restype = C.c_int
+N.lib.svgir_incident_dirs.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 6
+N.lib.svgir_resample_bilinear.restype = C.c_int
+N.lib.svgir_resample_bilinear.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+
+
+class FibonacciLattice:
+    """The incident directions of `sample_incident_rays` (scene/gaussian_model.py:23-31) WITHOUT the [P,Ns,3] tensor:
+    the Fibonacci hemisphere lattice of utils/graphics_utils.py:9-37 around `normals` [P,3], with the per-surfel random
+    azimuth `offsets` [P] of the training branch (None: evaluation lattice).  Passed as `incident_dirs_precompute` the
+    shading kernels build the directions in registers (12 + 4 bytes per SURFEL instead of 16 bytes per sample);
+    `.dirs()` / `.areas()` materialise the reference's tensors for other consumers (ray tracer, visibility baking)."""
+
+    def __init__(self, normals, sample_num, offsets=None):
+        self.normals = N.f32c(normals.detach(), normals.device)
+        self.offsets = None if offsets is None else N.f32c(offsets.detach().reshape(-1), normals.device)
+        self.sample_num = int(sample_num)
+
+    @property
+    def shape(self):
+        return (self.normals.shape[0], self.sample_num, 3)
+
+    def __getitem__(self, idx):   # chunking along the surfel axis (svgss.py:121-136)
+        return FibonacciLattice(self.normals[idx], self.sample_num, None if self.offsets is None else self.offsets[idx])
+
+    def _materialise(self, want_dirs, want_areas):
+        dev = self.normals.device
+        if dev.type != "cuda":
+            raise RuntimeError("FibonacciLattice: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
+        P, Ns = self.normals.shape[0], self.sample_num
+        dirs = torch.empty((P, Ns, 3), dtype=torch.float32, device=dev) if want_dirs else None
+        areas = torch.empty((P, Ns, 1), dtype=torch.float32, device=dev) if want_areas else None
+        work = torch.empty(4 * Ns, dtype=torch.float32, device=dev)
+        if P:
+            N.check(N.lib.svgir_incident_dirs(P, Ns, N.ptr(self.normals), N.ptr(self.offsets), work.data_ptr(), N.ptr(dirs),
+                                              N.ptr(areas), N.stream_ptr(dev)), "incident_dirs")
+        return dirs, areas
+
+    def dirs(self):
+        return self._materialise(True, False)[0]
+
+    def areas(self):
+        return self._materialise(False, True)[1]
+
+
+def sample_incident_rays(normals, is_training=False, sample_num=24, materialize=True):
+    """Drop-in for scene/gaussian_model.py:23-31.  Returns (incident_dirs [N,S,3], incident_areas [N,S,1]) like the
+    reference, or -- materialize=False -- (FibonacciLattice, None) for the fused shading kernels."""
+    offsets = torch.rand(normals.shape[0], device=normals.device) * (2 * torch.pi) if is_training else None
+    lat = FibonacciLattice(normals, sample_num, offsets)
+    if not materialize:
+        return lat, None
+    return lat._materialise(True, True)
 
 
 def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
@@ -40,10 +94,11 @@ def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs
     dev = base_color.device
     if dev.type != "cuda":
         raise RuntimeError("shading: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
-    keep = [N.f32c(t, dev) for t in (base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env,
-                                      viewmatrix, env_transform)]
+    lattice = dirs if isinstance(dirs, FibonacciLattice) else None
+    keep = [N.f32c(t, dev) for t in (base_color, roughness, normals, viewdirs, radiance, visibility,
+                                      None if lattice else dirs, areas, env, viewmatrix, env_transform)]
     bc, ro, nr, vd, ra, vi, di, ar, en, vm, et = keep
-    P, Ns = di.shape[0], di.shape[1]
+    P, Ns = ra.shape[0], ra.shape[1]
     env_h, env_w = en.shape[-3], en.shape[-2]
     work = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
     p = ShadeParams()
@@ -53,6 +108,12 @@ def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs
     p.radiance, p.visibility, p.incident_dirs, p.incident_areas = N.ptr(ra), N.ptr(vi), N.ptr(di), N.ptr(ar)
     p.env, p.viewmatrix, p.env_work, p.env_transform = N.ptr(en), N.ptr(vm), work.data_ptr(), N.ptr(et)
     keep.append(work)
+    if lattice is not None:
+        if lattice.sample_num != Ns or lattice.normals.shape[0] != P:
+            raise RuntimeError("FibonacciLattice does not match the radiance tensor's [P, Ns]")
+        lwork = torch.empty(4 * Ns, dtype=torch.float32, device=dev)
+        p.lattice_normals, p.lattice_offsets, p.lattice_work = N.ptr(lattice.normals), N.ptr(lattice.offsets), lwork.data_ptr()
+        keep += [lattice, lwork]
     return p, keep, dev, P, Ns, env_h, env_w
 
 
@@ -68,16 +129,18 @@ class _Shade(torch.autograd.Function):
         reduced = torch.empty((P, NRED), dtype=torch.float32, device=dev)
         if P:
             N.check(N.lib.svgir_shade_forward(p, reduced.data_ptr(), None, None, N.stream_ptr(dev)), "shade_forward")
-        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env)
-        ctx.cfg = (softplus, scale, env_transform)
+        lat = dirs if isinstance(dirs, FibonacciLattice) else None
+        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, None if lat else dirs, areas, env)
+        ctx.cfg = (softplus, scale, env_transform, lat)
         return reduced
 
     @staticmethod
     def backward(ctx, g_reduced):
         base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env = ctx.saved_tensors
-        softplus, scale, env_transform = ctx.cfg
-        p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs,
-                                                    areas, env, softplus, scale, env_transform=env_transform)
+        softplus, scale, env_transform, lat = ctx.cfg
+        p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility,
+                                                    lat if lat is not None else dirs, areas, env, softplus, scale,
+                                                    env_transform=env_transform)
         g = N.f32c(g_reduced, dev)
         d_base, d_rough, d_norm, d_rad, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 4, 8))  # all overwritten
         gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
@@ -108,18 +171,20 @@ class _ShadePack(torch.autograd.Function):
         if P:
             N.check(N.lib.svgir_shade_forward(p, red.data_ptr(), feats.data_ptr(), vfeats.data_ptr(), N.stream_ptr(dev)),
                     "shade_forward")
-        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix)
-        ctx.cfg = (softplus, scale, training, env_transform)
+        lat = dirs if isinstance(dirs, FibonacciLattice) else None
+        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, None if lat else dirs, areas, env,
+                              viewmatrix)
+        ctx.cfg = (softplus, scale, training, env_transform, lat)
         ctx.set_materialize_grads(False)
         return feats, vfeats, red
 
     @staticmethod
     def backward(ctx, g_feat, g_vfeat, g_red):
         base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix = ctx.saved_tensors
-        softplus, scale, training, env_transform = ctx.cfg
-        p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs,
-                                                    areas, env, softplus, scale, viewmatrix=viewmatrix, training=training,
-                                                    env_transform=env_transform)
+        softplus, scale, training, env_transform, lat = ctx.cfg
+        p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility,
+                                                    lat if lat is not None else dirs, areas, env, softplus, scale,
+                                                    viewmatrix=viewmatrix, training=training, env_transform=env_transform)
         if g_feat is None and g_vfeat is None and g_red is None:
             return (None,) * 14
         gf, gv, gr = (N.f32c(t, dev) for t in (g_feat, g_vfeat, g_red))
@@ -141,9 +206,10 @@ def _env_of(light):
     if hasattr(light, "env"):       # scene/direct_light_map.py: learnable map, softplus, x2
         return light.env, True, 2.0, None
     if hasattr(light, "envmap"):    # scene/envmap.py: HDR map, bilinear down-sample to 32x64, optional rotation
-        envmap = light.envmap.permute(2, 0, 1).unsqueeze(0)
-        envmap = F.interpolate(envmap, size=(32, 64), mode="bilinear", align_corners=False)
-        env = envmap[0].permute(1, 2, 0).contiguous()
+        src = N.f32c(light.envmap, light.envmap.device)
+        env = torch.empty((32, 64, src.shape[2]), dtype=torch.float32, device=src.device)
+        N.check(N.lib.svgir_resample_bilinear(src.data_ptr(), src.shape[0], src.shape[1], src.shape[2], env.data_ptr(), 32, 64,
+                                              N.stream_ptr(src.device)), "resample_bilinear")
         return env, False, 1.0, getattr(light, "transform", None)   # lookup direction = dirs @ transform.T
     raise TypeError("direct_light_env_light must expose .env (DirectLightMap) or .envmap (EnvLight)")
 
@@ -156,7 +222,9 @@ def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, dire
     red = _Shade.apply(base_color, roughness, normals, viewdirs, radiance, visibility_precompute, dirs, areas, env,
                        softplus, scale, transform)
     extra_results = {
-        "incident_dirs": dirs,
+        # (with a FibonacciLattice the [n, Ns, 3] tensor is never built: an empty stand-in keeps the chunk loop's
+        #  torch.cat over every key working, `incident_dirs_precompute.dirs()` materialises the real thing)
+        "incident_dirs": dirs if torch.is_tensor(dirs) else radiance.new_empty((radiance.shape[0], 0, 3)),
         # The reference returns the per-sample [n, Ns, 3] light here; its callers only ever take `.mean(-2)` of it
         # (svgss.py:143-151), possibly after `torch.cat(..., dim=0)` over 100k-surfel chunks (svgss.py:121-136).  The fused
         # kernel never materialises the per-sample values: the tensor carries the mean as its single "sample", so both

@@ -29,7 +29,7 @@ def fibonacci_dirs(normals, Ns):
     return local[None, :, 0:1] * t0[:, None] + local[None, :, 1:2] * t1[:, None] + local[None, :, 2:3] * n[:, None]
 
 
-def make(P, Ns, seed=2, device="cpu", geo_normals=None, env_res=32):
+def make(P, Ns, seed=2, device="cpu", geo_normals=None, env_res=32, with_dirs=True):
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
     if geo_normals is None:
@@ -42,9 +42,10 @@ def make(P, Ns, seed=2, device="cpu", geo_normals=None, env_res=32):
         "viewdirs": torch.nn.functional.normalize(geo_normals + 0.5 * rnd(P, 3), dim=-1),
         "visibility": (torch.rand(P, Ns, 1, generator=g) > 0.3).float(),
         "radiance": (0.2 * rnd(P, Ns, 3)).abs(),
-        "areas": torch.full((P, Ns, 1), 2 * math.pi),
         "env": 3.0 * torch.rand(1, env_res, 2 * env_res, 3, generator=g),
     }
     d = {k: v.to(device) for k, v in d.items()}
-    d["dirs"] = fibonacci_dirs(geo_normals.to(device), Ns).contiguous()
+    if with_dirs:   # (omitted when the shading kernels generate the lattice themselves: 16 bytes per sample less)
+        d["areas"] = torch.full((P, Ns, 1), 2 * math.pi, device=device)
+        d["dirs"] = fibonacci_dirs(geo_normals.to(device), Ns).contiguous()
     return d

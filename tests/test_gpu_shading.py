@@ -261,3 +261,71 @@ def test_rendering_equation4_survives_the_reference_eval_chunk_loop(built):
             f, vf, _ = shading.shade_and_pack(base, rough, normal, vd, inc, light, vis, dirs, areas, t(f"{tag}_settings_viewmatrix"), training)
         _close(tag + "_packed_features", f, g[f"{tag}_features"], tol=2e-4)
         _close(tag + "_packed_vfeatures", vf, g[f"{tag}_vfeatures"], tol=2e-3)
+
+
+def test_incident_direction_lattice_matches_reference(built):
+    """svgir_incident_dirs against the reference's fibonacci_sphere_sampling / sample_incident_rays
+    outputs (tests/golden/incident_dirs.npz), evaluation lattice and training lattice with the recorded random offsets."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "incident_dirs.npz"))
+    normals = torch.from_numpy(g["normals"]).to(dev)
+    for Ns in (8, 64, 384):
+        lat = shading.FibonacciLattice(normals, Ns)
+        d, a = lat.dirs(), lat.areas()
+        assert tuple(d.shape) == (300, Ns, 3) and tuple(a.shape) == (300, Ns, 1)
+        np.testing.assert_allclose(d.cpu().numpy(), g[f"dirs_{Ns}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a.cpu().numpy(), g[f"areas_{Ns}"], rtol=1e-6)
+    lat = shading.FibonacciLattice(normals, 24, offsets=torch.from_numpy(g["sample_train_24_offsets"]).to(dev))
+    np.testing.assert_allclose(lat.dirs().cpu().numpy(), g["sample_train_24"], rtol=0, atol=3e-6)
+    d, a = shading.sample_incident_rays(normals, is_training=False, sample_num=24)
+    np.testing.assert_allclose(d.cpu().numpy(), g["sample_eval_24"], rtol=0, atol=2e-6)
+    d, a = shading.sample_incident_rays(normals, is_training=True, sample_num=24)      # random offsets: unit, upper hemisphere
+    assert torch.allclose(d.norm(dim=-1), torch.ones_like(d[..., 0]), atol=1e-5)
+    assert ((d * normals[:, None]).sum(-1) > 0.1).all()
+
+
+@pytest.mark.parametrize("training,Ns", [(True, 64), (False, 384), (True, 7)])
+def test_shading_with_in_kernel_directions_equals_streamed_directions(built, training, Ns):
+    """The shading kernels fed with a FibonacciLattice (directions built in registers, areas = 2 pi) against the same
+    kernels fed with the materialised [P,Ns,3] / [P,Ns,1] tensors, forward and backward."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _random_case(400, Ns, 11, rough_lo=0.3)
+    geo = torch.nn.functional.normalize(d["normals"][:, 0].float(), dim=-1).to(dev)
+    offs = torch.rand(400, device=dev) * 6.2831855 if training else None
+    lat = shading.FibonacciLattice(geo, Ns, offs)
+    dirs, areas = lat.dirs(), lat.areas()
+    names = ("base", "rough", "normals", "radiance", "env")
+    res = []
+    for mode in ("lattice", "streamed"):
+        lv = {k: d[k].float().to(dev).requires_grad_(True) for k in names}
+        vm = torch.eye(4, device=dev)
+        f, vf, red = shading.shade_and_pack(lv["base"], lv["rough"], lv["normals"], d["viewdirs"].float().to(dev), lv["radiance"],
+                                            _Light(lv["env"]), d["vis"].float().to(dev),
+                                            lat if mode == "lattice" else dirs, None if mode == "lattice" else areas, vm, training)
+        (f.sum() + (vf * vf).sum() + red[:, :60].sum()).backward()
+        res.append((f, vf, red, {k: lv[k].grad for k in names}))
+    for a_, b_ in zip(res[0][:3], res[1][:3]):
+        _close("fwd", a_, b_, tol=2e-5)
+    for k in names:
+        _close("grad_" + k, res[0][3][k], res[1][3][k], tol=5e-5)
+
+
+def test_envlight_resample_matches_reference(built):
+    """EnvLight.direct_light's 32x64 down-sample (scene/envmap.py:62-63) as a HIP kernel, and the lookups through it,
+    against the outputs of the reference's own class (tests/golden/lights.npz)."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lights.npz"))
+
+    class EnvLight:
+        def __init__(self, envmap, transform=None):
+            self.envmap, self.transform = envmap, transform
+
+    env, softplus, scale, tr = shading._env_of(EnvLight(torch.from_numpy(g["el_envmap"]).to(dev)))
+    assert not softplus and scale == 1.0 and tr is None
+    np.testing.assert_allclose(env.cpu().numpy(), g["el_resampled"], rtol=2e-6, atol=2e-7)
+    # lookups: a single white surfel whose `global light` mean is the env lookup itself is awkward; use the oracle path
+    got = so.env_lookup(env.double().cpu(), torch.from_numpy(g["dirs"]).double(), softplus=False, scale=1.0)
+    np.testing.assert_allclose(got.numpy(), g["el_light"], rtol=2e-5, atol=2e-6)

@@ -87,3 +87,24 @@ def test_view_parallel_world2_gloo():
         R = o.forward()
         assert res[0][v, 0] == R
         np.testing.assert_allclose(res[0][v, 1], o.images()["color"].sum(), rtol=1e-6)
+
+
+def test_bench_self_launches_ranks_dry_run():
+    """`python bench.py --gpus 2` without torchrun starts the two ranks itself (fresh processes, before anything touches
+    the GPU), runs the timed regions with the per-step metrics all_gather (gloo here, RCCL on the GPUs) and prints ONE
+    JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1",
+                          "--repeats", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["repeats"] == 3 and d["scaling"] == "weak"
+    assert d["per_rank_R"] == [100, 101] and d["config"]["workload"].startswith("cfg4")
+    # a request for more GPUs than the machine has fails loudly instead of silently running one rank
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "GPU(s) are visible" in out.stderr
