@@ -254,6 +254,26 @@ int svgir_incident_dirs(int32_t P, int32_t Ns, const float* normals, const float
 int svgir_resample_bilinear(const float* src, int32_t H, int32_t W, int32_t C, float* dst, int32_t out_h, int32_t out_w,
                             void* stream);
 
+/* ---- image-space epilogue right after the svgss rasterizer ----------------------------------
+ * Fused replacement of the PyTorch tail of render_view (gaussian_renderer/svgss.py:187-246): feature / vfeature planes
+ * divided by the rendered opacity (clamp_min 1e-5), channel split, rgb_to_srgb (utils/graphics_utils.py:198-215),
+ * compositing over `bg` [3].  opacity [1,H,W], feature [S,H,W], vfeature [VS/4,H,W] are the rasterizer's outputs at the
+ * training (S=4, VS=52) or evaluation (S=7, VS=64) widths; `out` receives svgir_unpack_planes(training) planes [.,H,W]:
+ *   training  (21): pbr | normal | base_color | roughness | diffuse | local_lights | visibility
+ *   evaluation(27): pbr | normal | base_color | roughness | direct | indirect | lights | local_lights | visibility
+ * (three planes per quantity; one-channel quantities are broadcast over the three background channels as in the
+ * reference).  The backward maps dL/d(out) to dL/d(opacity, feature, vfeature); all outputs are overwritten. */
+int svgir_unpack_planes(int32_t training);
+int svgir_unpack_forward(int32_t W, int32_t H, int32_t training, const float* bg, const float* opacity, const float* feature,
+                         const float* vfeature, float* out, void* stream);
+int svgir_unpack_backward(int32_t W, int32_t H, int32_t training, const float* bg, const float* opacity, const float* feature,
+                          const float* vfeature, const float* dL_dout, float* dL_dopacity, float* dL_dfeature,
+                          float* dL_dvfeature, void* stream);
+/* depth2normal (utils/image_utils.py:61-125): depth, mask [1,H,W] -> normal [3,H,W]; fovx / fovy in radians, prcp = the
+ * camera's principal point as a fraction of the image (Camera.prcppoint). */
+int svgir_depth2normal(int32_t W, int32_t H, const float* depth, const float* mask, float fovx, float fovy, float prcp_x,
+                       float prcp_y, float* normal, void* stream);
+
 /* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
  * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,
  * the AVERAGE duration in milliseconds and the number of samples since profiling was (re-)enabled.

@@ -142,3 +142,34 @@ def depth2normal(depth, mask, fovx, fovy, prcppoint=(0.5, 0.5)):
     n = np.cross(u, l_) + np.cross(r, u) + np.cross(b, r) + np.cross(l_, b)
     n = n / np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-12)
     return (n * mk[1:-1, 1:-1]).transpose(2, 0, 1)
+
+
+def unpack_svgss_torch(opacity, feature, vfeature, bg, training):
+    """The same as unpack_svgss in differentiable torch (any dtype / device): torch.autograd of this is the reference for
+    the backward of the fused epilogue kernel."""
+    import torch
+
+    def srgb(img):
+        out = torch.where(img > 0.0031308, torch.pow(torch.clamp(img, min=0.0031308), 1.0 / 2.4) * 1.055 - 0.055, 12.92 * img)
+        return out.clamp(0.0, 1.0)
+
+    f = feature / opacity.clamp_min(1e-5)
+    vf = vfeature / opacity.clamp_min(1e-5)
+    bgc = bg[:, None, None]
+
+    def over(r):
+        return r * opacity + (1 - opacity) * bgc
+
+    res = {}
+    if training:
+        vis, local = f.split([1, 3], dim=0)
+        pbr, base, normal, rough, diffuse = vf.split([3, 3, 3, 1, 3], dim=0)
+        res.update(local_lights=over(srgb(local)), visibility=over(vis), base_color=over(srgb(base)), diffuse=over(srgb(diffuse)),
+                   roughness=over(rough))
+    else:
+        light, local, vis = f.split([3, 3, 1], dim=0)
+        pbr, base, normal, rough, direct, indirect = vf.split([3, 3, 3, 1, 3, 3], dim=0)
+        res.update(lights=over(srgb(light)), local_lights=over(srgb(local)), visibility=over(vis), base_color=over(srgb(base)),
+                   direct=srgb(direct), indirect=srgb(indirect), roughness=over(rough))
+    res.update(pbr=srgb(over(pbr)), normal=normal.expand(3, -1, -1))
+    return res

@@ -1,0 +1,208 @@
+// svg-ir_amd/csrc/epilogue.hip -- image-space epilogue right after the svgss rasterizer.
+//
+// Replaces the PyTorch tail of `render_view` (gaussian_renderer/svgss.py:187-246): division of the feature / vfeature
+// planes by the rendered opacity (clamp_min 1e-5), channel split, `rgb_to_srgb` (utils/graphics_utils.py:198-215) and
+// compositing over the background, and `depth2normal` (utils/image_utils.py:61-125).  The reference runs ~40 elementwise
+// torch kernels over [C,H,W] planes (and autograd keeps their inputs); here one pass reads the rasterizer's planes once
+// and writes every result plane, and one pass maps the upstream gradients of those planes back to
+// dL/d(opacity, feature, vfeature) -- both pure HBM streams: 4 (1 + S + VS/4) bytes in, 4 NOUT bytes out per pixel.
+//
+// Result planes [NOUT,H,W] in this order (each group 3 planes; one-channel quantities are broadcast over the three
+// background channels exactly like `r * opacity + (1 - opacity) * bg[:, None, None]` does in the reference):
+//   training (S=4: visibility, local light; VS/4=13: pbr, base colour, normal, roughness, diffuse)     NOUT = 21
+//     pbr | normal | base_color | roughness | diffuse | local_lights | visibility
+//   evaluation (S=7: light, local light, visibility; VS/4=16: pbr, base, normal, roughness, direct, indirect)  NOUT = 27
+//     pbr | normal | base_color | roughness | direct | indirect | lights | local_lights | visibility
+// with x = plane / max(opacity, 1e-5):
+//   pbr = srgb(x o + (1 - o) bg)      normal = x      direct, indirect = srgb(x)
+//   base_color, diffuse, lights, local_lights = srgb(x) o + (1 - o) bg      roughness, visibility = x o + (1 - o) bg
+#include "common.hpp"
+
+namespace svgir {
+
+namespace {
+
+enum PlaneKind { K_SRGB_OF_OVER = 0, K_PLAIN = 1, K_OVER_SRGB = 2, K_OVER_LIN = 3, K_SRGB = 4 };
+struct PlaneGroup { int kind, src, vf, n; };   // src: first source channel; vf: source is vfeature; n: source channels (1 or 3)
+
+__device__ __forceinline__ float srgb(float x) {
+    const float y = x > 0.0031308f ? powf(fmaxf(x, 0.0031308f), 1.0f / 2.4f) * 1.055f - 0.055f : 12.92f * x;
+    return fminf(1.f, fmaxf(0.f, y));
+}
+// d srgb / dx (0 where the final clip to [0,1] is active)
+__device__ __forceinline__ float dsrgb(float x) {
+    const float y = x > 0.0031308f ? powf(fmaxf(x, 0.0031308f), 1.0f / 2.4f) * 1.055f - 0.055f : 12.92f * x;
+    if (y < 0.f || y > 1.f) return 0.f;
+    return x > 0.0031308f ? (1.055f / 2.4f) * powf(fmaxf(x, 0.0031308f), 1.0f / 2.4f - 1.0f) : 12.92f;
+}
+
+template <bool TRAINING> struct Groups;
+template <> struct Groups<true> {
+    static constexpr int N = 7, S = 4, VC = 13;
+    static constexpr PlaneGroup g[7] = {{K_SRGB_OF_OVER, 0, 1, 3}, {K_PLAIN, 6, 1, 3}, {K_OVER_SRGB, 3, 1, 3}, {K_OVER_LIN, 9, 1, 1},
+                                        {K_OVER_SRGB, 10, 1, 3}, {K_OVER_SRGB, 1, 0, 3}, {K_OVER_LIN, 0, 0, 1}};
+};
+template <> struct Groups<false> {
+    static constexpr int N = 9, S = 7, VC = 16;
+    static constexpr PlaneGroup g[9] = {{K_SRGB_OF_OVER, 0, 1, 3}, {K_PLAIN, 6, 1, 3}, {K_OVER_SRGB, 3, 1, 3}, {K_OVER_LIN, 9, 1, 1},
+                                        {K_SRGB, 10, 1, 3}, {K_SRGB, 13, 1, 3}, {K_OVER_SRGB, 0, 0, 3}, {K_OVER_SRGB, 3, 0, 3},
+                                        {K_OVER_LIN, 6, 0, 1}};
+};
+
+struct UnpackArgs {
+    int W, H, training;
+    const float *bg, *opacity, *feature, *vfeature;
+    float* out;                                        // forward
+    const float* g_out; float *d_opacity, *d_feature, *d_vfeature;   // backward
+};
+
+template <bool BWD, bool TRAINING>
+__global__ void __launch_bounds__(BLOCK) unpack_kernel(const UnpackArgs a) {
+    using G = Groups<TRAINING>;
+    const size_t N = (size_t)a.W * a.H;
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= N) return;
+    constexpr int S = G::S, VC = G::VC;
+    const float o = a.opacity[i];
+    const bool clamped = !(o > 1e-5f);
+    const float inv = 1.f / fmaxf(o, 1e-5f);
+    const float dinv = clamped ? 0.f : -inv * inv;     // d inv / d o
+    const float bg[3] = {a.bg[0], a.bg[1], a.bg[2]};
+    float d_o = 0.f;
+    float dS[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dV[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) dV[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < G::N; k++) {
+        constexpr const PlaneGroup* g = G::g;
+        const float* src = g[k].vf ? a.vfeature : a.feature;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int sc = g[k].src + (g[k].n == 3 ? c : 0);
+            const float raw = src[(size_t)sc * N + i];
+            const float x = raw * inv;
+            const size_t oi = (size_t)(3 * k + c) * N + i;
+            if (!BWD) {
+                float y;
+                switch (g[k].kind) {
+                    case K_SRGB_OF_OVER: y = srgb(x * o + (1.f - o) * bg[c]); break;
+                    case K_PLAIN: y = x; break;
+                    case K_OVER_SRGB: y = srgb(x) * o + (1.f - o) * bg[c]; break;
+                    case K_OVER_LIN: y = x * o + (1.f - o) * bg[c]; break;
+                    default: y = srgb(x); break;
+                }
+                a.out[oi] = y;
+            } else {
+                const float gy = a.g_out[oi];
+                float dx = 0.f, dopac = 0.f;    // dy/dx, explicit dy/do
+                switch (g[k].kind) {
+                    case K_SRGB_OF_OVER: { const float ds = dsrgb(x * o + (1.f - o) * bg[c]); dx = ds * o; dopac = ds * (x - bg[c]); break; }
+                    case K_PLAIN: dx = 1.f; break;
+                    case K_OVER_SRGB: dx = dsrgb(x) * o; dopac = srgb(x) - bg[c]; break;
+                    case K_OVER_LIN: dx = o; dopac = x - bg[c]; break;
+                    default: dx = dsrgb(x); break;
+                }
+                const float draw = gy * dx * inv;
+                d_o += gy * (dopac + dx * raw * dinv);
+                if (g[k].vf) dV[sc] += draw; else dS[sc] += draw;
+            }
+        }
+    }
+    if (BWD) {
+        a.d_opacity[i] = d_o;
+#pragma unroll
+        for (int c = 0; c < 7; c++) if (c < S) a.d_feature[(size_t)c * N + i] = dS[c];
+#pragma unroll
+        for (int c = 0; c < 16; c++) if (c < VC) a.d_vfeature[(size_t)c * N + i] = dV[c];
+    }
+}
+
+// depth2normal (utils/image_utils.py:61-125): back-project the pixel and its four neighbours (replicate padding) with
+// the reference's intrinsics -- K = diag(focal(FoVy, H), focal(FoVx, W)), i.e. x is divided by the y focal length and
+// vice versa, as in the reference --, mask, sum of the four cross products of neighbouring differences, normalise, mask.
+__global__ void __launch_bounds__(BLOCK) depth2normal_kernel(const float* __restrict__ depth, const float* __restrict__ mask,
+                                                             int W, int H, float k00, float k11, float ppx, float ppy,
+                                                             float* __restrict__ normal) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = i % W, y = i / W;
+    auto cam = [&](int xx, int yy, float* p, float& m) {
+        xx = min(max(xx, 0), W - 1); yy = min(max(yy, 0), H - 1);
+        const float d = depth[yy * W + xx];
+        m = mask[yy * W + xx] != 0.f ? 1.f : 0.f;
+        p[0] = ((float)xx - ppx) * d / k00; p[1] = ((float)yy - ppy) * d / k11; p[2] = d;
+    };
+    float pc[3], pu[3], pl[3], pb[3], pr[3], mc, mu, ml, mb, mr;
+    cam(x, y, pc, mc); cam(x, y - 1, pu, mu); cam(x - 1, y, pl, ml); cam(x, y + 1, pb, mb); cam(x + 1, y, pr, mr);
+    float c[3], u[3], l[3], b[3], r[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        c[j] = pc[j] * mc;
+        u[j] = (pu[j] - c[j]) * mu; l[j] = (pl[j] - c[j]) * ml; b[j] = (pb[j] - c[j]) * mb; r[j] = (pr[j] - c[j]) * mr;
+    }
+    auto cross = [](const float* a, const float* b_, float* o) {
+        o[0] = a[1] * b_[2] - a[2] * b_[1]; o[1] = a[2] * b_[0] - a[0] * b_[2]; o[2] = a[0] * b_[1] - a[1] * b_[0];
+    };
+    float n1[3], n2[3], n3[3], n4[3];
+    cross(u, l, n1); cross(r, u, n2); cross(b, r, n3); cross(l, b, n4);
+    float n[3] = {n1[0] + n2[0] + n3[0] + n4[0], n1[1] + n2[1] + n3[1] + n4[1], n1[2] + n2[2] + n3[2] + n4[2]};
+    const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+    const size_t N = (size_t)W * H;
+#pragma unroll
+    for (int j = 0; j < 3; j++) normal[(size_t)j * N + i] = n[j] / len * mc;
+}
+
+}  // namespace
+
+}  // namespace svgir
+
+using namespace svgir;
+
+extern "C" {
+
+int svgir_unpack_planes(int32_t training) { return training ? 21 : 27; }
+
+int svgir_unpack_forward(int32_t W, int32_t H, int32_t training, const float* bg, const float* opacity, const float* feature,
+                         const float* vfeature, float* out, void* stream) {
+    if (W <= 0 || H <= 0 || !bg || !opacity || !feature || !vfeature || !out) return SVGIR_ERR_INVALID;
+    UnpackArgs a{};
+    a.W = W; a.H = H; a.training = training; a.bg = bg; a.opacity = opacity; a.feature = feature; a.vfeature = vfeature; a.out = out;
+    const size_t N = (size_t)W * H;
+    hipStream_t s = (hipStream_t)stream;
+    StageMarks tm = stage_begin(s);
+    if (training) hipLaunchKernelGGL((unpack_kernel<false, true>), dim3((unsigned)((N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((unpack_kernel<false, false>), dim3((unsigned)((N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+    stage_mark(tm, "unpack_fwd");
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_unpack_backward(int32_t W, int32_t H, int32_t training, const float* bg, const float* opacity, const float* feature,
+                          const float* vfeature, const float* dL_dout, float* dL_dopacity, float* dL_dfeature,
+                          float* dL_dvfeature, void* stream) {
+    if (W <= 0 || H <= 0 || !bg || !opacity || !feature || !vfeature || !dL_dout || !dL_dopacity || !dL_dfeature || !dL_dvfeature)
+        return SVGIR_ERR_INVALID;
+    UnpackArgs a{};
+    a.W = W; a.H = H; a.training = training; a.bg = bg; a.opacity = opacity; a.feature = feature; a.vfeature = vfeature;
+    a.g_out = dL_dout; a.d_opacity = dL_dopacity; a.d_feature = dL_dfeature; a.d_vfeature = dL_dvfeature;
+    const size_t N = (size_t)W * H;
+    hipStream_t s = (hipStream_t)stream;
+    StageMarks tm = stage_begin(s);
+    if (training) hipLaunchKernelGGL((unpack_kernel<true, true>), dim3((unsigned)((N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((unpack_kernel<true, false>), dim3((unsigned)((N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+    stage_mark(tm, "unpack_bwd");
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_depth2normal(int32_t W, int32_t H, const float* depth, const float* mask, float fovx, float fovy, float prcp_x,
+                       float prcp_y, float* normal, void* stream) {
+    if (W <= 0 || H <= 0 || !depth || !mask || !normal) return SVGIR_ERR_INVALID;
+    const float k00 = (float)H / (2.f * tanf(fovy * 0.5f)), k11 = (float)W / (2.f * tanf(fovx * 0.5f));
+    hipStream_t s = (hipStream_t)stream;
+    StageMarks tm = stage_begin(s);
+    hipLaunchKernelGGL(depth2normal_kernel, dim3((W * H + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, depth, mask, W, H, k00, k11,
+                       prcp_x * (float)W, prcp_y * (float)H, normal);
+    stage_mark(tm, "depth2normal");
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+}  // extern "C"

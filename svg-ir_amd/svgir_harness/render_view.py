@@ -6,44 +6,81 @@ Only the parts that belong to the hot path and its immediate callers are reprodu
 (:188-246: division by the rendered opacity, channel split, sRGB, compositing over the background).  The
 `depth2normal` pseudo normal and the environment backdrop of the eval branch need the reference's camera class and
 are left to the caller."""
+import ctypes as C
+
 import torch
 
+from gaussian_renderer import _native as N
 from gaussian_renderer import shading
 from gaussian_renderer.svgss_rasterization import GaussianRasterizer
 
 from . import runner
 
+N.lib.svgir_unpack_planes.restype = C.c_int
+N.lib.svgir_unpack_planes.argtypes = [C.c_int32]
+N.lib.svgir_unpack_forward.restype = C.c_int
+N.lib.svgir_unpack_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+N.lib.svgir_unpack_backward.restype = C.c_int
+N.lib.svgir_unpack_backward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9
+N.lib.svgir_depth2normal.restype = C.c_int
+N.lib.svgir_depth2normal.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p]
 
-def rgb_to_srgb(img, clip=True):
-    """utils/graphics_utils.py:198-221 (torch branch)."""
-    out = torch.where(img > 0.0031308, torch.pow(torch.clamp(img, min=0.0031308), 1.0 / 2.4) * 1.055 - 0.055, 12.92 * img)
-    return out.clamp(0.0, 1.0) if clip else out
+TRAIN_PLANES = ("pbr", "normal", "base_color", "roughness", "diffuse", "local_lights", "visibility")
+EVAL_PLANES = ("pbr", "normal", "base_color", "roughness", "direct", "indirect", "lights", "local_lights", "visibility")
+
+
+class _Unpack(torch.autograd.Function):
+    """svgir_unpack_forward / svgir_unpack_backward (csrc/epilogue.hip): one pass over the rasterizer's planes."""
+
+    @staticmethod
+    def forward(ctx, opacity, feature, vfeature, bg, training):
+        dev = opacity.device
+        if dev.type != "cuda":
+            raise RuntimeError("unpack: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
+        op, fe, vf, bgc = (N.f32c(t, dev) for t in (opacity, feature, vfeature, bg))
+        H, W = op.shape[-2], op.shape[-1]
+        S, VC = (4, 13) if training else (7, 16)
+        if fe.shape[0] != S or vf.shape[0] != VC:
+            raise RuntimeError(f"unpack: expected {S} feature / {VC} vfeature planes, got {fe.shape[0]} / {vf.shape[0]}")
+        out = torch.empty((N.lib.svgir_unpack_planes(int(training)), H, W), dtype=torch.float32, device=dev)
+        N.check(N.lib.svgir_unpack_forward(W, H, int(training), bgc.data_ptr(), op.data_ptr(), fe.data_ptr(), vf.data_ptr(),
+                                           out.data_ptr(), N.stream_ptr(dev)), "unpack_forward")
+        ctx.save_for_backward(op, fe, vf, bgc)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        op, fe, vf, bgc = ctx.saved_tensors
+        dev = op.device
+        H, W = op.shape[-2], op.shape[-1]
+        g = N.f32c(g_out, dev)
+        d_op, d_fe, d_vf = torch.empty_like(op), torch.empty_like(fe), torch.empty_like(vf)
+        N.check(N.lib.svgir_unpack_backward(W, H, int(ctx.training), bgc.data_ptr(), op.data_ptr(), fe.data_ptr(), vf.data_ptr(),
+                                            g.data_ptr(), d_op.data_ptr(), d_fe.data_ptr(), d_vf.data_ptr(), N.stream_ptr(dev)),
+                "unpack_backward")
+        return d_op, d_fe, d_vf, None, None
+
+
+def depth2normal(depth, mask, fovx, fovy, prcppoint=(0.5, 0.5)):
+    """utils/image_utils.py:61-125 as one HIP kernel: depth, mask [1,H,W] -> pseudo normal [3,H,W] (no gradient)."""
+    dev = depth.device
+    d, m = N.f32c(depth.detach(), dev), N.f32c(mask.to(torch.float32), dev)
+    H, W = d.shape[-2], d.shape[-1]
+    out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    N.check(N.lib.svgir_depth2normal(W, H, d.data_ptr(), m.data_ptr(), float(fovx), float(fovy), float(prcppoint[0]),
+                                     float(prcppoint[1]), out.data_ptr(), N.stream_ptr(dev)), "depth2normal")
+    return out
 
 
 def unpack(rendered, bg_color, is_training):
     """svgss.py:188-246.  `rendered` = the rasterizer's 9-tuple; returns the result dict of the reference."""
     (num_rendered, image, normal, opacity, depth, feature, vfeature, weights, radii) = rendered
-    feature = feature / opacity.clamp_min(1e-5)
-    vfeature = vfeature / opacity.clamp_min(1e-5)
-    bg = bg_color[:, None, None]
-
-    def over_bg(r):
-        return r * opacity + (1 - opacity) * bg
-
-    res = {}
-    if is_training:
-        vis, local = feature.split([1, 3], dim=0)
-        res.update(local_lights=over_bg(rgb_to_srgb(local)), visibility=over_bg(vis))
-        pbr, base, shading_normal, rough, diffuse = vfeature.split([3, 3, 3, 1, 3], dim=0)
-        res.update(base_color=over_bg(rgb_to_srgb(base)), diffuse=over_bg(rgb_to_srgb(diffuse)), roughness=over_bg(rough))
-    else:
-        light, local, vis = feature.split([3, 3, 1], dim=0)
-        res.update(lights=over_bg(rgb_to_srgb(light)), local_lights=over_bg(rgb_to_srgb(local)), visibility=over_bg(vis))
-        pbr, base, shading_normal, rough, direct, indirect = vfeature.split([3, 3, 3, 1, 3, 3], dim=0)
-        res.update(base_color=over_bg(rgb_to_srgb(base)), direct=rgb_to_srgb(direct), indirect=rgb_to_srgb(indirect),
-                   roughness=over_bg(rough))
-    res.update(render=image, depth=depth, pbr=rgb_to_srgb(over_bg(pbr)), normal=shading_normal, opacity=opacity,
-               visibility_filter=radii > 0, radii=radii, num_rendered=num_rendered, weights=weights)
+    planes = _Unpack.apply(opacity, feature, vfeature, bg_color, bool(is_training))
+    res = {k: planes[3 * i:3 * i + 3] for i, k in enumerate(TRAIN_PLANES if is_training else EVAL_PLANES)}
+    res.update(render=image, depth=depth, opacity=opacity, visibility_filter=radii > 0, radii=radii,
+               num_rendered=num_rendered, weights=weights)
     return res
 
 

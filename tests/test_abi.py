@@ -14,7 +14,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 def test_library_exports_every_symbol_of_the_header(built):
     from gaussian_renderer import _native
     hdr = open(os.path.join(ROOT, "include", "svgir_raster.h")).read()
-    declared = set(re.findall(r"\b(svgir_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(svgir_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"svgir_alloc_fn"}
     assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
     lib = C.CDLL(_native.LIB_PATH)

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc
+from oracle import epilogue_oracle as eo
 from oracle import shading_oracle as so
 from svgir_harness import render_view, runner, scenes, shade_inputs
 
@@ -48,11 +49,46 @@ def test_svgss_view_end_to_end(built, is_training):
     t = lambda k: torch.from_numpy(np.asarray(im[k], dtype=np.float64))  # noqa: E731
     rendered = (R, t("color"), t("normal"), t("opacity"), t("depth"), t("feature"), t("vfeature"),
                 torch.from_numpy(np.asarray(im["weights"], dtype=np.float64)), torch.from_numpy(im["radii"]))
-    exp = render_view.unpack(rendered, torch.from_numpy(sc["bg"]).double(), is_training)
+    exp = eo.unpack_svgss_torch(t("opacity"), t("feature"), t("vfeature"), torch.from_numpy(sc["bg"]).double(), is_training)
+    exp.update(render=t("color"), depth=t("depth"), opacity=t("opacity"))
     assert res["num_rendered"] == R
-    assert torch.equal(res["radii"].cpu(), exp["radii"])
+    assert np.array_equal(res["radii"].cpu().numpy(), im["radii"])
     keys = ["render", "depth", "opacity", "pbr", "normal", "base_color", "roughness", "local_lights", "visibility"]
     keys += ["diffuse"] if is_training else ["lights", "direct", "indirect"]
     for k in keys:
         assert res[k].shape == exp[k].shape, k
         _cmp(k, res[k], exp[k].numpy())
+
+
+@pytest.mark.parametrize("tag", ["train", "eval"])
+def test_epilogue_kernels_match_reference_render_view(built, tag):
+    """the fused unpack kernel and depth2normal against what the reference's own render_view produced
+    from the same rasterizer buffers (tests/golden/render_view.npz), and the unpack backward against torch.autograd of the
+    pinned restatement."""
+    import os
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_view.npz"))
+    training = tag == "train"
+    ras = {k: torch.from_numpy(g[f"{tag}_raster_{k}"]).to(dev) for k in ("image", "normal", "opacity", "depth", "feature", "vfeature", "weights", "radii")}
+    tup = (1234, ras["image"], ras["normal"], ras["opacity"], ras["depth"], ras["feature"], ras["vfeature"], ras["weights"], ras["radii"])
+    bg = torch.from_numpy(g["bg"]).to(dev)
+    got = render_view.unpack(tup, bg, training)
+    keys = ["pbr", "normal", "base_color", "roughness", "local_lights", "visibility"] + (["diffuse"] if training else ["lights", "direct", "indirect"])
+    for k in keys + ["render", "depth", "opacity"]:
+        np.testing.assert_allclose(got[k].cpu().numpy(), np.broadcast_to(g[f"{tag}_res_{k}"], got[k].shape), rtol=2e-5, atol=2e-6, err_msg=k)
+    assert np.array_equal(got["visibility_filter"].cpu().numpy(), g[f"{tag}_res_visibility_filter"])
+    fovx, fovy = g["cam_fov"]
+    pn = render_view.depth2normal(ras["depth"], torch.from_numpy(g["image_mask"]).to(dev), fovx, fovy, g["cam_prcppoint"])
+    np.testing.assert_allclose(pn.cpu().numpy(), g[f"{tag}_res_pseudo_normal"], rtol=0, atol=3e-5)
+    # backward: random upstream gradients on every result plane
+    gen = torch.Generator().manual_seed(5)
+    lv = {k: ras[k].clone().requires_grad_(True) for k in ("opacity", "feature", "vfeature")}
+    res = render_view.unpack((1234, ras["image"], ras["normal"], lv["opacity"], ras["depth"], lv["feature"], lv["vfeature"],
+                              ras["weights"], ras["radii"]), bg, training)
+    wts = {k: torch.randn(res[k].shape, generator=gen) for k in keys}
+    sum((res[k] * wts[k].to(dev)).sum() for k in keys).backward()
+    ld = {k: ras[k].double().cpu().requires_grad_(True) for k in ("opacity", "feature", "vfeature")}
+    ref = eo.unpack_svgss_torch(ld["opacity"], ld["feature"], ld["vfeature"], bg.double().cpu(), training)
+    sum((ref[k] * wts[k].double()).sum() for k in keys).backward()
+    for k in ("opacity", "feature", "vfeature"):
+        _cmp("d_" + k, lv[k].grad, ld[k].grad.numpy(), tol=2e-4, flip_frac=2e-3)
