@@ -356,9 +356,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         launch_order_desc(I.sub_total, 4 * T, I.sub_order, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
-        if (launch_render_fwd(ra, svgss, s) < 0)
-            return fail(SVGIR_ERR_INVALID, "no forward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ra.VS,
-                        svgss ? "svgss" : "rgss");
+        if (launch_render_fwd(ra, svgss, s) < 0) launch_render_fwd_generic(ra, svgss, s);   // run-time-width kernels
         if (int rc = check("render")) return rc;
         if (timed) tm.mark("render");
         return 0;
@@ -463,20 +461,21 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     if (!scratch || scratch_bytes < need)
         return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes() = %zu",
                     scratch ? scratch_bytes : (size_t)0, need);
-    const bool rows = ba.VS > 0;
+    const bool generic = !render_specialised(p->S, ba.VS, svgss);   // run-time-width kernels: atomics on the dL_d* tensors
+    const bool rows = ba.VS > 0 && !generic;
     const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
-    ba.grad_rows = (float*)scratch;
+    ba.grad_rows = generic ? nullptr : (float*)scratch;
     ba.row_flags = nullptr;
-    if (rows) {
+    if (generic) {
+    } else if (rows) {
         ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
         if (R > 0) HIP_OK(hipMemsetAsync(ba.row_flags, 0, (size_t)4 * cap, s));
     } else {
         HIP_OK(hipMemsetAsync(ba.grad_rows, 0, (size_t)P * rg.RS * 4, s));
     }
     if (R > 0) {
-        if (launch_render_bwd(ba, svgss, s) < 0)
-            return fail(SVGIR_ERR_INVALID, "no backward composite kernel instantiated for S=%d VS=%d (%s)", p->S, ba.VS,
-                        svgss ? "svgss" : "rgss");
+        if (generic) launch_render_bwd_generic(ba, svgss, s);
+        else (void)launch_render_bwd(ba, svgss, s);
     }
     tm.mark("render_bwd");
     if (R > 0 && rows) {
@@ -498,7 +497,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ga.cfg = cfg; ga.svgss = svgss;
     ga.dL_dmean2D = g->dL_dmeans2D; ga.dL_dconic = g->dL_dconic; ga.dL_dcolor = g->dL_dcolors; ga.dL_dnormal = g->dL_dnormal;
     ga.dL_ddepth = g->dL_ddepth;
-    ga.packed = rows ? nullptr : ba.grad_rows; ga.S = p->S;
+    ga.packed = (rows || generic) ? nullptr : ba.grad_rows; ga.S = p->S;
     ga.dL_dopacity = g->dL_dopacity; ga.dL_dfeature = g->dL_dfeatures;
     ga.dL_dmean3D = g->dL_dmeans3D; ga.dL_dcov3D = g->dL_dcov3D; ga.dL_dsh = g->dL_dsh; ga.dL_dscale = g->dL_dscales;
     ga.dL_drot = g->dL_drotations; ga.dL_dviewmat = g->dL_dviewmat; ga.dL_dprojmat = g->dL_dprojmat; ga.dL_dcampos = g->dL_dcampos;

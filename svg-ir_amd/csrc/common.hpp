@@ -298,8 +298,12 @@ void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
-int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 if (S,VS) unsupported
-int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 if (S,VS) unsupported
+int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 (nothing launched) if (S,VS) has no specialised kernel
+int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 (nothing launched) if (S,VS) has no specialised kernel
+bool render_specialised(int S, int VS, bool svgss);
+// run-time-width composite kernels for every other (S, VS) the reference accepts (render_generic.hip)
+void launch_render_fwd_generic(const RenderArgs& a, bool svgss, hipStream_t s);
+void launch_render_bwd_generic(const RenderBwdArgs& a, bool svgss, hipStream_t s);
 void launch_grad_reduce(const GradReduceArgs& a, hipStream_t s);
 void launch_geom_bwd(const GeomBwdArgs& a, hipStream_t s);
 void launch_image_ops(int W, int H, const float* view, float focal_x, float focal_y, float cx, float cy,

@@ -378,6 +378,15 @@ int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s) {
     return -1;
 }
 
+bool render_specialised(int S, int VS, bool svgss) {
+    const int VC = VS / 4;
+#define CASE(SV, VCV, SG) if (S == SV && VC == VCV && svgss == SG) return true;
+    CASE(0, 0, true) CASE(4, 13, true) CASE(7, 16, true) CASE(3, 2, true) CASE(1, 1, true) CASE(5, 0, true)
+    CASE(0, 0, false) CASE(5, 0, false) CASE(3, 0, false) CASE(1, 0, false)
+#undef CASE
+    return false;
+}
+
 #if defined(SVGIR_DEV)
 // development builds only: copies the per-wave records of kernel slot 0 (forward) / 1 (backward) and resets the slot
 extern "C" int svgir_dev_trace_read(int slot, unsigned long long* out, int cap_records) {

@@ -203,37 +203,3 @@ def last_timings(with_counts=False):
     if with_counts:
         return [(names[i].decode(), float(ms[i]), int(cnt[i])) for i in range(n)]
     return [(names[i].decode(), float(ms[i])) for i in range(n)]
-
-
-def plan_channel_passes(S, VC, natives):
-    """Channel widths without a specialised kernel are rendered in several passes over channel groups, each padded
-    with zero channels to a specialised (S', VC') width.  The composite is linear in the feature channels and so is
-    its backward in the upstream gradients, hence the passes simply add up under autograd.
-    Returns [(s0, s1, v0, v1, S', VC'), ...] covering features [0,S) and vfeature channels [0,VC)."""
-    natives = sorted(natives, key=lambda w: (w[0] + 4 * w[1], w))
-    for sp, vp in natives:                         # one pass, smallest specialised width that holds everything
-        if sp >= S and vp >= VC:
-            return [(0, S, 0, VC, sp, vp)]
-    smax = max(w[0] for w in natives)
-    vmax = max(w[1] for w in natives)
-    wide = [w for w in natives if (w[0] == smax or smax == 0) and (VC == 0 or w[1] == vmax)]
-    sp, vp = max(wide, key=lambda w: (w[0], w[1])) if wide else max(natives, key=lambda w: (w[0] + 4 * w[1]))
-    if (S and sp == 0) or (VC and vp == 0):
-        raise RuntimeError(f"no specialised kernel can hold S={S}, VS={4 * VC}")
-    n = max(-(-S // sp) if sp else 0, -(-VC // vp) if vp else 0, 1)
-    plan = []
-    for i in range(n):
-        s0, s1 = min(S, i * sp), min(S, (i + 1) * sp)
-        v0, v1 = min(VC, i * vp), min(VC, (i + 1) * vp)
-        plan.append((s0, s1, v0, v1, sp, vp))
-    return plan
-
-
-def pad_cols(t, n, width, rows, device):
-    """t[:, :n] zero-padded to `width` columns ([rows, width]); differentiable."""
-    if width == 0:
-        return torch.empty((rows, 0), dtype=torch.float32, device=device)
-    if n == width:
-        return t
-    z = torch.zeros((rows, width - n), dtype=torch.float32, device=device)
-    return z if n == 0 else torch.cat([t, z], dim=1)

@@ -157,26 +157,10 @@ def rasterize_gaussians(
         cov3Ds_precomp,
         raster_settings,
 ):
-    S = features.size(1) if features.dim() == 2 else 0
-    if (S, 0) in NATIVE_WIDTHS:
-        return _RasterizeGaussians.apply(
-            means3D, means2D, features, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-            raster_settings)
-    # widths without a specialised kernel: several passes over zero-padded channel groups (N.plan_channel_passes)
-    P, dev = means3D.size(0), means3D.device
-    first, f_out = None, []
-    for (s0, s1, _v0, _v1, sp, _vp) in N.plan_channel_passes(S, 0, NATIVE_WIDTHS):
-        f = N.pad_cols(features[:, s0:s1], s1 - s0, sp, P, dev)
-        out = _RasterizeGaussians.apply(means3D, means2D, f, sh, colors_precomp, opacities, scales, rotations,
-                                        cov3Ds_precomp, raster_settings)
-        if first is None:
-            first = out
-        f_out.append(out[6][:s1 - s0])
-    return first[:6] + (torch.cat(f_out, dim=0),) + first[7:]
-
-
-# (S, 0) widths with a specialised composite kernel (csrc/render_fwd.hip, render_bwd.hip)
-NATIVE_WIDTHS = {(0, 0), (1, 0), (3, 0), (5, 0)}
+    # (every channel width the reference accepts runs through the C ABI: widths without a specialised composite kernel
+    #  use the run-time-width kernels of csrc/render_generic.hip)
+    return _RasterizeGaussians.apply(
+        means3D, means2D, features, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
 
 
 class _RasterizeGaussians(torch.autograd.Function):

@@ -165,32 +165,11 @@ def rasterize_gaussians(
 ):
     # Parameter names are mislabelled in the reference too (Q13); the positional pass-through is what matters.
     # (positionally: sh <- features, features <- vfeatures, vfeatures <- shs; see GaussianRasterizer.forward)
-    feats, vfeats = sh, features
-    S = feats.size(1) if feats.dim() == 2 else 0
-    VS = vfeats.size(1) if vfeats.dim() == 2 else 0
-    if (S, VS // 4) in NATIVE_WIDTHS or VS % 4 != 0:
-        return _RasterizeGaussians.apply(
-            means3D, means2D, sh, features, vfeatures, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-            viewmatrix, projmatrix, campos, raster_settings)
-    # widths without a specialised kernel: several passes over zero-padded channel groups (N.plan_channel_passes)
-    P, dev = means3D.size(0), means3D.device
-    first, f_out, v_out = None, [], []
-    for (s0, s1, v0, v1, sp, vp) in N.plan_channel_passes(S, VS // 4, NATIVE_WIDTHS):
-        f = N.pad_cols(feats[:, s0:s1] if S else feats, s1 - s0, sp, P, dev)
-        v = N.pad_cols(vfeats[:, 4 * v0:4 * v1] if VS else vfeats, 4 * (v1 - v0), 4 * vp, P, dev)
-        out = _RasterizeGaussians.apply(means3D, means2D, f, v, vfeatures, colors_precomp, opacities, scales,
-                                        rotations, cov3Ds_precomp, viewmatrix, projmatrix, campos, raster_settings)
-        if first is None:
-            first = out
-        f_out.append(out[5][:s1 - s0])
-        v_out.append(out[6][:v1 - v0])
-    num_rendered, color, normal, opacity, depth, _, _, weights, radii = first
-    return (num_rendered, color, normal, opacity, depth, torch.cat(f_out, dim=0), torch.cat(v_out, dim=0), weights,
-            radii)
-
-
-# (S, VS/4) pairs with a specialised composite kernel (csrc/render_fwd.hip, render_bwd.hip)
-NATIVE_WIDTHS = {(0, 0), (1, 1), (3, 2), (5, 0), (4, 13), (7, 16)}
+    # (every channel width the reference accepts runs through the C ABI: widths without a specialised composite kernel
+    #  use the run-time-width kernels of csrc/render_generic.hip)
+    return _RasterizeGaussians.apply(
+        means3D, means2D, sh, features, vfeatures, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+        viewmatrix, projmatrix, campos, raster_settings)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
