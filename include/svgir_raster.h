@@ -269,6 +269,21 @@ int svgir_unpack_forward(int32_t W, int32_t H, int32_t training, const float* bg
 int svgir_unpack_backward(int32_t W, int32_t H, int32_t training, const float* bg, const float* opacity, const float* feature,
                           const float* vfeature, const float* dL_dout, float* dL_dopacity, float* dL_dfeature,
                           float* dL_dvfeature, void* stream);
+/* Stage 1 (rgss) counterparts (gaussian_renderer/render.py:83-91, 107-114).
+ * pack: features [P,5] = [geometric normal (world) 3, view depth d, d^2], d = (xyz1 @ viewmatrix).z; the backward maps
+ *       dL/d(features) to dL/d(means3D) and dL/d(normals).
+ * unpack: x_c = feature_c / max(opacity, 1e-5) * (num_contrib > 0) for the 5 feature planes; out [6,H,W] = [x_0 .. x_4,
+ *       depth_var = x_4 - depth^2]; the backward maps dL/d(out) to dL/d(opacity, depth, feature). */
+int svgir_pack_rgss_forward(int32_t P, const float* means3D, const float* normals, const float* viewmatrix, float* features,
+                            void* stream);
+int svgir_pack_rgss_backward(int32_t P, const float* means3D, const float* viewmatrix, const float* dL_dfeatures,
+                             float* dL_dmeans3D, float* dL_dnormals, void* stream);
+int svgir_unpack_rgss_forward(int32_t W, int32_t H, const int32_t* num_contrib, const float* opacity, const float* depth,
+                              const float* feature, float* out, void* stream);
+int svgir_unpack_rgss_backward(int32_t W, int32_t H, const int32_t* num_contrib, const float* opacity, const float* depth,
+                               const float* feature, const float* dL_dout, float* dL_dopacity, float* dL_ddepth,
+                               float* dL_dfeature, void* stream);
+
 /* depth2normal (utils/image_utils.py:61-125): depth, mask [1,H,W] -> normal [3,H,W]; fovx / fovy in radians, prcp = the
  * camera's principal point as a fraction of the image (Camera.prcppoint). */
 int svgir_depth2normal(int32_t W, int32_t H, const float* depth, const float* mask, float fovx, float fovy, float prcp_x,

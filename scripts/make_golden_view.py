@@ -177,6 +177,76 @@ def render_view_fixtures():
     print("wrote render_view.npz", len(out), "arrays")
 
 
+class RecordingRgssRasterizer(torch.nn.Module):
+    """Stands in for gaussian_renderer.rgss_rasterization.GaussianRasterizer inside the reference's stage-1 render_view."""
+    log = []
+    outputs = None
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, features=None):
+        RecordingRgssRasterizer.log.append(dict(settings=self.raster_settings, features=features.detach().clone()))
+        o = RecordingRgssRasterizer.outputs
+        return (o["num_rendered"], o["num_contrib"], o["image"], o["normal"], o["opacity"], o["depth"], o["feature"],
+                o["pseudo_normal"], o["surface_xyz"], o["weights"], o["radii"])
+
+
+def rgss_view_fixtures():
+    """gaussian_renderer/render.py:16-135 (stage 1) with a recording stub rasterizer: pins the rgss feature packing
+    ([geo normal, view depth, depth^2], :83-91) and the image-space tail (:107-114)."""
+    import importlib
+    importlib.import_module("gaussian_renderer.render")
+    ref_render = sys.modules["gaussian_renderer.render"]   # (the package also exports a function called `render`)
+    from scene.cameras import Camera
+    ref_render.GaussianRasterizer = RecordingRgssRasterizer
+    out = {}
+    n, H, W = 193, 36, 52
+    g = torch.Generator().manual_seed(777)
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    unif = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    pc = types.SimpleNamespace(
+        get_xyz=0.6 * rnd(n, 3), get_opacity=unif(n, 1), get_scaling=0.02 + 0.05 * unif(n, 3),
+        get_rotation=torch.nn.functional.normalize(rnd(n, 4), dim=-1), get_shs=0.3 * rnd(n, 16, 3),
+        active_sh_degree=3, max_sh_degree=3, get_geo_normal=torch.nn.functional.normalize(rnd(n, 3), dim=-1))
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, compute_SHs_python=False)
+    A = rnd(3, 3).double().numpy()
+    Q, _ = np.linalg.qr(A)
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    T = np.array([-0.2, 0.1, 3.0])
+    fovx, fovy = 0.8, 0.6
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    with cpu_reference():
+        cam = Camera(colmap_id=0, R=Q, T=T, FoVx=fovx, FoVy=fovy, fx=None, fy=None, cx=None, cy=None, image=None,
+                     image_name="x", uid=0, data_device="cpu", height=H, width=W)
+        cam.image_mask = (unif(1, H, W) > 0.1).float()
+        RecordingRgssRasterizer.outputs = dict(
+            num_rendered=999, num_contrib=(unif(H, W) * 3).int(), image=unif(3, H, W), normal=rnd(3, H, W), opacity=unif(1, H, W),
+            depth=2.0 + unif(1, H, W), feature=rnd(5, H, W), pseudo_normal=rnd(3, H, W), surface_xyz=rnd(3, H, W),
+            weights=unif(n, 1), radii=(unif(n) * 9).int())
+        res = ref_render.render_view(cam, pc, pipe, bg, 1.0, None, computer_pseudo_normal=False)
+        rec = RecordingRgssRasterizer.log[-1]
+        out["features"] = np32(rec["features"])
+        st = rec["settings"]
+        out["settings_fields"] = np.array(type(st)._fields)
+        out["settings_viewmatrix"] = np32(st.viewmatrix)
+        out["settings_scalars"] = np.array([st.image_height, st.image_width, st.tanfovx, st.tanfovy, st.cx, st.cy], dtype=np.float64)
+        for k, v in RecordingRgssRasterizer.outputs.items():
+            if torch.is_tensor(v):
+                out["raster_" + k] = np32(v)
+        for k in ("depth_var", "pseudo_normal", "normal", "depth", "opacity", "render"):
+            out["res_" + k] = np32(res[k])
+        out["pc_xyz"], out["pc_geo_normal"] = np32(pc.get_xyz), np32(pc.get_geo_normal)
+        out["image_mask"] = np32(cam.image_mask)
+        out["cam_fov"] = np.array([fovx, fovy])
+        out["cam_prcppoint"] = np32(cam.prcppoint)
+    np.savez_compressed(os.path.join(OUT, "render_view_rgss.npz"), **out)
+    print("wrote render_view_rgss.npz", len(out), "arrays")
+
+
 def light_fixtures():
     from scene.direct_light_map import DirectLightMap
     from scene.envmap import EnvLight
@@ -239,3 +309,4 @@ if __name__ == "__main__":
     incident_dir_fixtures()
     light_fixtures()
     render_view_fixtures()
+    rgss_view_fixtures()

@@ -152,6 +152,60 @@ __global__ void __launch_bounds__(BLOCK) depth2normal_kernel(const float* __rest
     for (int j = 0; j < 3; j++) normal[(size_t)j * N + i] = n[j] / len * mc;
 }
 
+// ---- stage 1 (rgss) feature packing and image-space tail (gaussian_renderer/render.py:83-91, 107-114) ----------
+// pack: features[P,5] = [geometric normal (world), view depth d, d^2], d = (xyz1 @ viewmatrix).z
+__global__ void __launch_bounds__(BLOCK) pack_rgss_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ normals,
+                                                          const float* __restrict__ V, float* __restrict__ features,
+                                                          const float* __restrict__ g_features, float* __restrict__ d_means3D,
+                                                          float* __restrict__ d_normals) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    const float d = x * V[2] + y * V[6] + z * V[10] + V[14];
+    if (features) {
+        float* f = features + (size_t)i * 5;
+        f[0] = normals[3 * i]; f[1] = normals[3 * i + 1]; f[2] = normals[3 * i + 2]; f[3] = d; f[4] = d * d;
+    }
+    if (g_features) {
+        const float* g = g_features + (size_t)i * 5;
+        const float gd = g[3] + 2.f * d * g[4];
+        d_normals[3 * i] = g[0]; d_normals[3 * i + 1] = g[1]; d_normals[3 * i + 2] = g[2];
+        d_means3D[3 * i] = gd * V[2]; d_means3D[3 * i + 1] = gd * V[6]; d_means3D[3 * i + 2] = gd * V[10];
+    }
+}
+
+// unpack: x_c = feature_c / max(opacity, 1e-5) * (num_contrib > 0); out = [x_0..x_4 | depth_var = x_4 - depth^2]
+template <bool BWD>
+__global__ void __launch_bounds__(BLOCK) unpack_rgss_kernel(int N, const int32_t* __restrict__ num_contrib,
+                                                            const float* __restrict__ opacity, const float* __restrict__ depth,
+                                                            const float* __restrict__ feature, float* __restrict__ out,
+                                                            const float* __restrict__ g_out, float* __restrict__ d_opacity,
+                                                            float* __restrict__ d_depth, float* __restrict__ d_feature) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const float o = opacity[i];
+    const float m = num_contrib[i] > 0 ? 1.f : 0.f;
+    const float inv = m / fmaxf(o, 1e-5f);
+    const float dinv = o > 1e-5f ? -inv / o : 0.f;
+    const float dep = depth[i];
+    if (!BWD) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) out[(size_t)c * N + i] = feature[(size_t)c * N + i] * inv;
+        out[(size_t)5 * N + i] = feature[(size_t)4 * N + i] * inv - dep * dep;
+    } else {
+        float d_o = 0.f;
+        const float gv = g_out[(size_t)5 * N + i];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const float g = g_out[(size_t)c * N + i] + (c == 4 ? gv : 0.f);
+            d_feature[(size_t)c * N + i] = g * inv;
+            d_o += g * feature[(size_t)c * N + i] * dinv;
+        }
+        d_opacity[i] = d_o;
+        d_depth[i] = -2.f * dep * gv;
+    }
+}
+
 }  // namespace
 
 }  // namespace svgir
@@ -190,6 +244,44 @@ int svgir_unpack_backward(int32_t W, int32_t H, int32_t training, const float* b
     if (training) hipLaunchKernelGGL((unpack_kernel<true, true>), dim3((unsigned)((N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL((unpack_kernel<true, false>), dim3((unsigned)((N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
     stage_mark(tm, "unpack_bwd");
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_pack_rgss_forward(int32_t P, const float* means3D, const float* normals, const float* viewmatrix, float* features,
+                            void* stream) {
+    if (P < 0 || (P > 0 && (!means3D || !normals || !viewmatrix || !features))) return SVGIR_ERR_INVALID;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(pack_rgss_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, P, means3D, normals,
+                       viewmatrix, features, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_pack_rgss_backward(int32_t P, const float* means3D, const float* viewmatrix, const float* dL_dfeatures,
+                             float* dL_dmeans3D, float* dL_dnormals, void* stream) {
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !dL_dfeatures || !dL_dmeans3D || !dL_dnormals))) return SVGIR_ERR_INVALID;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(pack_rgss_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, P, means3D,
+                       (const float*)nullptr, viewmatrix, (float*)nullptr, dL_dfeatures, dL_dmeans3D, dL_dnormals);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_unpack_rgss_forward(int32_t W, int32_t H, const int32_t* num_contrib, const float* opacity, const float* depth,
+                              const float* feature, float* out, void* stream) {
+    if (W <= 0 || H <= 0 || !num_contrib || !opacity || !depth || !feature || !out) return SVGIR_ERR_INVALID;
+    const int N = W * H;
+    hipLaunchKernelGGL(unpack_rgss_kernel<false>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, N, num_contrib,
+                       opacity, depth, feature, out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_unpack_rgss_backward(int32_t W, int32_t H, const int32_t* num_contrib, const float* opacity, const float* depth,
+                               const float* feature, const float* dL_dout, float* dL_dopacity, float* dL_ddepth,
+                               float* dL_dfeature, void* stream) {
+    if (W <= 0 || H <= 0 || !num_contrib || !opacity || !depth || !feature || !dL_dout || !dL_dopacity || !dL_ddepth || !dL_dfeature)
+        return SVGIR_ERR_INVALID;
+    const int N = W * H;
+    hipLaunchKernelGGL(unpack_rgss_kernel<true>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, N, num_contrib,
+                       opacity, depth, feature, (float*)nullptr, dL_dout, dL_dopacity, dL_ddepth, dL_dfeature);
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 

@@ -26,6 +26,13 @@ N.lib.svgir_depth2normal.restype = C.c_int
 N.lib.svgir_depth2normal.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p]
 
+for _n, _k in (("svgir_pack_rgss_forward", 5), ("svgir_pack_rgss_backward", 6)):
+    getattr(N.lib, _n).restype = C.c_int
+    getattr(N.lib, _n).argtypes = [C.c_int32] + [C.c_void_p] * _k
+for _n, _k in (("svgir_unpack_rgss_forward", 6), ("svgir_unpack_rgss_backward", 9)):
+    getattr(N.lib, _n).restype = C.c_int
+    getattr(N.lib, _n).argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * _k
+
 TRAIN_PLANES = ("pbr", "normal", "base_color", "roughness", "diffuse", "local_lights", "visibility")
 EVAL_PLANES = ("pbr", "normal", "base_color", "roughness", "direct", "indirect", "lights", "local_lights", "visibility")
 
@@ -61,6 +68,72 @@ class _Unpack(torch.autograd.Function):
                                             g.data_ptr(), d_op.data_ptr(), d_fe.data_ptr(), d_vf.data_ptr(), N.stream_ptr(dev)),
                 "unpack_backward")
         return d_op, d_fe, d_vf, None, None
+
+
+class _PackRgss(torch.autograd.Function):
+    """render.py:83-91: features = [geo normal, view depth, depth^2] (svgir_pack_rgss_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, means3D, normals, viewmatrix):
+        dev = means3D.device
+        m3, nr, vm = (N.f32c(t, dev) for t in (means3D, normals, viewmatrix))
+        out = torch.empty((m3.shape[0], 5), dtype=torch.float32, device=dev)
+        N.check(N.lib.svgir_pack_rgss_forward(m3.shape[0], N.ptr(m3), N.ptr(nr), vm.data_ptr(), N.ptr(out), N.stream_ptr(dev)), "pack_rgss")
+        ctx.save_for_backward(m3, vm)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m3, vm = ctx.saved_tensors
+        dev = m3.device
+        g = N.f32c(g, dev)
+        d_m, d_n = torch.empty_like(m3), torch.empty_like(m3)
+        N.check(N.lib.svgir_pack_rgss_backward(m3.shape[0], N.ptr(m3), vm.data_ptr(), N.ptr(g), N.ptr(d_m), N.ptr(d_n), N.stream_ptr(dev)),
+                "pack_rgss_backward")
+        return d_m, d_n, None
+
+
+class _UnpackRgss(torch.autograd.Function):
+    """render.py:107-114 (svgir_unpack_rgss_forward / _backward): [normal3, depth, depth2, depth_var] planes."""
+
+    @staticmethod
+    def forward(ctx, num_contrib, opacity, depth, feature):
+        dev = opacity.device
+        nc = num_contrib.to(torch.int32).contiguous()
+        op, de, fe = (N.f32c(t, dev) for t in (opacity, depth, feature))
+        H, W = op.shape[-2], op.shape[-1]
+        if fe.shape[0] != 5:
+            raise RuntimeError("unpack_rgss: expected the 5 stage-1 feature planes [normal 3, depth, depth^2]")
+        out = torch.empty((6, H, W), dtype=torch.float32, device=dev)
+        N.check(N.lib.svgir_unpack_rgss_forward(W, H, nc.data_ptr(), op.data_ptr(), de.data_ptr(), fe.data_ptr(), out.data_ptr(),
+                                                N.stream_ptr(dev)), "unpack_rgss")
+        ctx.save_for_backward(nc, op, de, fe)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nc, op, de, fe = ctx.saved_tensors
+        dev = op.device
+        H, W = op.shape[-2], op.shape[-1]
+        g = N.f32c(g, dev)
+        d_op, d_de, d_fe = torch.empty_like(op), torch.empty_like(de), torch.empty_like(fe)
+        N.check(N.lib.svgir_unpack_rgss_backward(W, H, nc.data_ptr(), op.data_ptr(), de.data_ptr(), fe.data_ptr(), g.data_ptr(),
+                                                 d_op.data_ptr(), d_de.data_ptr(), d_fe.data_ptr(), N.stream_ptr(dev)), "unpack_rgss_backward")
+        return None, d_op, d_de, d_fe
+
+
+def pack_rgss(means3D, geo_normals, viewmatrix):
+    return _PackRgss.apply(means3D, geo_normals, viewmatrix)
+
+
+def unpack_rgss(rendered):
+    """render.py:107-135.  `rendered` = the rgss rasterizer's 11-tuple; returns the reference's result dict entries that are
+    derived in image space."""
+    (num_rendered, num_contrib, image, normal, opacity, depth, feature, pseudo_normal, surface_xyz, weights, radii) = rendered
+    planes = _UnpackRgss.apply(num_contrib, opacity, depth, feature)
+    return dict(render=image, opacity=opacity, depth=depth, depth_var=planes[5:6], normal=normal, feature_normal=planes[0:3],
+                feature_depth=planes[3:4], surface_xyz=surface_xyz, visibility_filter=radii > 0, radii=radii,
+                num_rendered=num_rendered, num_contrib=num_contrib, weights=weights)
 
 
 def depth2normal(depth, mask, fovx, fovy, prcppoint=(0.5, 0.5)):

@@ -92,3 +92,39 @@ def test_epilogue_kernels_match_reference_render_view(built, tag):
     sum((ref[k] * wts[k].double()).sum() for k in keys).backward()
     for k in ("opacity", "feature", "vfeature"):
         _cmp("d_" + k, lv[k].grad, ld[k].grad.numpy(), tol=2e-4, flip_frac=2e-3)
+
+
+def test_rgss_packing_and_unpacking_match_reference_render_view(built):
+    """Stage 1 (gaussian_renderer/render.py): the features the reference hands to its rasterizer and the image-space tail,
+    recorded from the reference's own render_view (tests/golden/render_view_rgss.npz); backward vs torch.autograd."""
+    import os
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_view_rgss.npz"))
+    t = lambda k: torch.from_numpy(g[k]).to(dev)  # noqa: E731
+    xyz, nrm, vm = t("pc_xyz").requires_grad_(True), t("pc_geo_normal").requires_grad_(True), t("settings_viewmatrix")
+    f = render_view.pack_rgss(xyz, nrm, vm)
+    np.testing.assert_allclose(f.detach().cpu().numpy(), g["features"], rtol=2e-6, atol=2e-6)
+    w = torch.randn(f.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    (f * w).sum().backward()
+    x64, n64 = xyz.detach().double().cpu().requires_grad_(True), nrm.detach().double().cpu().requires_grad_(True)
+    d = (torch.cat([x64, torch.ones_like(x64[:, :1])], -1) @ vm.double().cpu())[:, 2:3]
+    (torch.cat([n64, d, d * d], -1) * w.double().cpu()).sum().backward()
+    _cmp("d_means3D", xyz.grad, x64.grad.numpy(), tol=1e-5, flip_frac=0)
+    _cmp("d_normals", nrm.grad, n64.grad.numpy(), tol=1e-6, flip_frac=0)
+    ras = {k: t("raster_" + k) for k in ("num_contrib", "image", "normal", "opacity", "depth", "feature", "pseudo_normal", "surface_xyz", "weights", "radii")}
+    lv = {k: ras[k].clone().requires_grad_(True) for k in ("opacity", "depth", "feature")}
+    res = render_view.unpack_rgss((999, ras["num_contrib"], ras["image"], ras["normal"], lv["opacity"], lv["depth"], lv["feature"],
+                                   ras["pseudo_normal"], ras["surface_xyz"], ras["weights"], ras["radii"]))
+    np.testing.assert_allclose(res["depth_var"].detach().cpu().numpy(), g["res_depth_var"], rtol=2e-5, atol=2e-5)
+    wv = torch.randn(res["depth_var"].shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    wn = torch.randn(res["feature_normal"].shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    ((res["depth_var"] * wv).sum() + (res["feature_normal"] * wn).sum()).backward()
+    ld = {k: ras[k].double().cpu().requires_grad_(True) for k in ("opacity", "depth", "feature")}
+    mask = (ras["num_contrib"] > 0).double().cpu()
+    xf = ld["feature"] / ld["opacity"].clamp_min(1e-5) * mask
+    ((((xf[4:5] - ld["depth"].square()) * wv.double().cpu()).sum()) + (xf[0:3] * wn.double().cpu()).sum()).backward()
+    for k in ("opacity", "depth", "feature"):
+        _cmp("d_" + k, lv[k].grad, ld[k].grad.numpy(), tol=2e-5, flip_frac=1e-4)
+    fovx, fovy = g["cam_fov"]
+    pn = render_view.depth2normal(ras["depth"], t("image_mask"), fovx, fovy, g["cam_prcppoint"])
+    np.testing.assert_allclose(pn.cpu().numpy(), g["res_pseudo_normal"], rtol=0, atol=3e-5)
