@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 4
+#define SVGIR_ABI_VERSION 5
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -78,7 +78,8 @@ typedef struct svgir_params {
     int32_t debug;                  /* synchronise + check after every kernel (reference CHECK_CUDA) */
 } svgir_params;
 
-/* Outputs of forward.  Every buffer is written completely (no need to pre-zero) except where noted. */
+/* Outputs of forward.  Every buffer is written completely: the caller need not clear any of them (the reference's glue
+ * hands zero-filled tensors to its kernels, rasterize_points.cu:76-88; here the kernels that run anyway write the zeros). */
 typedef struct svgir_outputs {
     float* out_color;         /* [3,H,W] */
     float* out_normal;        /* [3,H,W] */
@@ -86,16 +87,18 @@ typedef struct svgir_outputs {
     float* out_opacity;       /* [1,H,W] */
     float* out_feature;       /* [S,H,W] */
     float* out_vfeature;      /* [VS/4,H,W]  svgss */
-    float* out_pseudo_normal; /* [3,H,W]     rgss; must be zero-filled by the caller (pixels with a
-                                 degenerate stencil are left untouched, forward.cu:620-622) */
-    float* out_surface_xyz;   /* [3,H,W]     rgss */
-    float* out_weights;       /* [P]   must be zero-filled by the caller (accumulated atomically) */
+    float* out_pseudo_normal; /* [3,H,W]     rgss; zero without computer_pseudo_normal and at pixels with a
+                                 degenerate stencil (forward.cu:620-622) */
+    float* out_surface_xyz;   /* [3,H,W]     rgss; zero without computer_pseudo_normal */
+    float* out_weights;       /* [P] */
     int32_t* radii;           /* [P] */
 } svgir_outputs;
 
 /* Upstream gradients and gradient outputs of backward (Rasterizer::backward, svgss rasterizer_impl.cu:386-432,
- * rgss :411-449).  All dL_d* outputs must be zero-filled by the caller (as the reference's glue does,
- * rasterize_points.cu:195-211). */
+ * rgss :411-449).  Every element of every dL_d* output is written by svgir_backward (zeros for culled Gaussians, unused
+ * components and inactive SH coefficients): the caller need not clear them.  (The reference's glue zero-fills them,
+ * rasterize_points.cu:195-211, and its kernels accumulate; a full clear of ~21 floats per Gaussian is a launch the
+ * backward does not need.) */
 typedef struct svgir_grads {
     const float* dL_dout_color;    /* [3,H,W] */
     const float* dL_dout_normal;   /* [3,H,W] */
@@ -116,7 +119,8 @@ typedef struct svgir_grads {
     float* dL_dsh;        /* [P,M,3] */
     float* dL_dscales;    /* [P,3] */
     float* dL_drotations; /* [P,4] */
-    float* dL_dviewmat;   /* [16] svgss (only written when config[3] > 0) */
+    float* dL_dviewmat;   /* [16] svgss (zero unless config[3] > 0); the three camera gradients are cleared with one
+                             memset when they are laid out back to back (viewmat, projmat, campos) */
     float* dL_dprojmat;   /* [16] svgss */
     float* dL_dcampos;    /* [3]  svgss */
 } svgir_grads;

@@ -265,6 +265,8 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         HIP_OK(hipMemsetAsync(o->out_opacity, 0, N * 4, s));
         if (p->S) HIP_OK(hipMemsetAsync(o->out_feature, 0, (size_t)p->S * N * 4, s));
         if (svgss && p->VS) HIP_OK(hipMemsetAsync(o->out_vfeature, 0, (size_t)(p->VS / 4) * N * 4, s));
+        if (!svgss && o->out_pseudo_normal) HIP_OK(hipMemsetAsync(o->out_pseudo_normal, 0, 3 * N * 4, s));
+        if (!svgss && o->out_surface_xyz) HIP_OK(hipMemsetAsync(o->out_surface_xyz, 0, 3 * N * 4, s));
         return 0;
     }
     const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
@@ -297,6 +299,8 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     pa.focal_x = focal_x; pa.focal_y = focal_y; pa.cfg = cfg;
     pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
     pa.radii = o->radii;
+    pa.out_weights = o->out_weights;
+    pa.zero_words = radix_gtot(G.radix_tbl, P); pa.n_zero_words = (int)radix_gtot_words(P);
     pa.prefilter_violation = nullptr;
     if (p->prefiltered) {   // the violation flag sits next to the instance counter and is read back with it
         HIP_OK(hipMemsetAsync(G.counters, 0, 16, s));
@@ -332,7 +336,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     auto run_binning_and_render = [&](char* bblob, int cap, bool timed) -> int {
         const BinLayout B = bin_layout(bblob, cap, T, nstate);
         launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
-                    I.counters, s);
+                    I.counters, B.radix_tbl, s);
         if (int rc = check("emit")) return rc;
         if (timed) tm.mark("emit");
         launch_radix_sort(B.key, B.val, cap, G.counters, plan.bits, plan.bits_per_pass, B.radix_tbl, s);
@@ -352,6 +356,10 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
         ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
         ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
+        // rgss without computer_pseudo_normal: the two stencil outputs are all zero (rasterize_points.cu:85-86)
+        const bool clear_stencil = !svgss && !p->computer_pseudo_normal;
+        ra.zero_a = clear_stencil ? o->out_pseudo_normal : nullptr;
+        ra.zero_b = clear_stencil ? o->out_surface_xyz : nullptr;
         launch_cull(ra, s);
         launch_order_desc(I.sub_total, 4 * T, I.sub_order, s);
         if (int rc = check("cull")) return rc;
@@ -467,6 +475,16 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.grad_rows = generic ? nullptr : (float*)scratch;
     ba.row_flags = nullptr;
     if (generic) {
+        // atomics straight into the caller's tensors: clear them first (the specialised paths overwrite instead)
+        const size_t Pz = (size_t)P * 4;
+        HIP_OK(hipMemsetAsync(g->dL_dmeans2D, 0, 3 * Pz, s));
+        HIP_OK(hipMemsetAsync(g->dL_dconic, 0, 4 * Pz, s));
+        HIP_OK(hipMemsetAsync(g->dL_dopacity, 0, Pz, s));
+        HIP_OK(hipMemsetAsync(g->dL_dcolors, 0, 3 * Pz, s));
+        HIP_OK(hipMemsetAsync(g->dL_dnormal, 0, 3 * Pz, s));
+        HIP_OK(hipMemsetAsync(g->dL_ddepth, 0, Pz, s));
+        if (p->S) HIP_OK(hipMemsetAsync(g->dL_dfeatures, 0, (size_t)p->S * Pz, s));
+        if (ba.VS) HIP_OK(hipMemsetAsync(g->dL_dvfeatures, 0, (size_t)ba.VS * Pz, s));
     } else if (rows) {
         ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
         if (R > 0) HIP_OK(hipMemsetAsync(ba.row_flags, 0, (size_t)4 * cap, s));
@@ -478,7 +496,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         else (void)launch_render_bwd(ba, svgss, s);
     }
     tm.mark("render_bwd");
-    if (R > 0 && rows) {
+    if (rows) {   // (also with R == 0: it is the writer of the composite gradients)
         GradReduceArgs ra;
         ra.P = P; ra.S = p->S; ra.VS = ba.VS; ra.radii = radii; ra.tiles = G.tiles; ra.rec = G.rec;
         ra.grad_rows = ba.grad_rows; ra.row_flags = ba.row_flags;
@@ -502,6 +520,15 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ga.dL_dmean3D = g->dL_dmeans3D; ga.dL_dcov3D = g->dL_dcov3D; ga.dL_dsh = g->dL_dsh; ga.dL_dscale = g->dL_dscales;
     ga.dL_drot = g->dL_drotations; ga.dL_dviewmat = g->dL_dviewmat; ga.dL_dprojmat = g->dL_dprojmat; ga.dL_dcampos = g->dL_dcampos;
     if (ga.scales && !ga.rotations) return fail(SVGIR_ERR_INVALID, "rotations missing");
+    if (svgss && g->dL_dviewmat && g->dL_dprojmat && g->dL_dcampos) {   // accumulated with atomics (config[3] > 0), else zero
+        if (g->dL_dprojmat == g->dL_dviewmat + 16 && g->dL_dcampos == g->dL_dviewmat + 32) {
+            HIP_OK(hipMemsetAsync(g->dL_dviewmat, 0, 35 * 4, s));
+        } else {
+            HIP_OK(hipMemsetAsync(g->dL_dviewmat, 0, 16 * 4, s));
+            HIP_OK(hipMemsetAsync(g->dL_dprojmat, 0, 16 * 4, s));
+            HIP_OK(hipMemsetAsync(g->dL_dcampos, 0, 3 * 4, s));
+        }
+    }
     launch_geom_bwd(ga, s);
     tm.mark("geom_bwd");
     hipError_t e = p->debug ? hipStreamSynchronize(s) : hipSuccess;

@@ -215,10 +215,12 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
                                                      const int32_t* __restrict__ radii, int gx, int gy,
                                                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
                                                      uint32_t cap, uint32_t* __restrict__ ranges, int n_ranges,
-                                                     uint32_t* __restrict__ seg_count) {
+                                                     uint32_t* __restrict__ seg_count, uint32_t* __restrict__ gtot,
+                                                     int n_gtot) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    // piggy-backed initialisation of two small tables used by later stages (saves two memset launches)
+    // piggy-backed initialisation of three small tables used by later stages (saves three memset launches)
     for (int j = i; j < n_ranges; j += gridDim.x * BLOCK) ranges[j] = 0u;
+    for (int j = i; j < n_gtot; j += gridDim.x * BLOCK) gtot[j] = 0u;
     if (i == 0) seg_count[0] = 0u;
     if (i >= P) return;
     const uint32_t g = order[i];
@@ -330,7 +332,6 @@ static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int 
     const int nb = (n + per - 1) / per;
     const int ng = (nb + GS - 1) / GS;
     const int passes = (total_bits + bits_per_pass - 1) / bits_per_pass;
-    (void)hipMemsetAsync(gtot, 0, (size_t)passes * ng * 256 * 4, s);
     for (int p = 0; p < passes; p++) {
         const int lo = p * bits_per_pass, nbits = std::min(bits_per_pass, total_bits - lo);
         uint32_t* gt = gtot + (size_t)p * ng * 256;
@@ -343,12 +344,12 @@ static void radix_sort_impl(uint32_t* const key[2], uint32_t* const val[2], int 
 
 // Stable LSD radix sort of (u32 key, u32 value) pairs on bits [0, total_bits) in passes of bits_per_pass (<= 8);
 // the result lands in slot (passes & 1) of the ping/pong buffers.  `n` sizes the launch and the scratch
-// (`table`: radix_table_words(n) counters); if `n_dev` is not null the element count is min(n, *n_dev), read on the
+// (`table`: radix_table_words(n) counters, its radix_gtot() part zeroed by the caller); if `n_dev` is not null the element count is min(n, *n_dev), read on the
 // device (the count need not be known on the host at launch time).
 void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, int total_bits,
                        int bits_per_pass, uint32_t* table, hipStream_t s) {
     if (n <= 0) return;
-    uint32_t* gtot = table + (size_t)256 * sort_blocks(n);  // [passes <= 4][groups][256] group digit totals
+    uint32_t* gtot = radix_gtot(table, n);  // [passes <= 4][groups][256] group digit totals, zero on entry
     if (n <= (1 << 20)) radix_sort_impl<4>(key, val, n, n_dev, total_bits, bits_per_pass, table, gtot, s);
     else radix_sort_impl<16>(key, val, n, n_dev, total_bits, bits_per_pass, table, gtot, s);
 }
@@ -363,9 +364,10 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
 
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
-                 uint32_t* seg_count, hipStream_t s) {
+                 uint32_t* seg_count, uint32_t* sort_table, hipStream_t s) {
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,
-                       radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy, seg_count);
+                       radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy, seg_count,
+                       radix_gtot(sort_table, cap), (int)radix_gtot_words(cap));
 }
 
 // `ranges` must already be zero (launch_emit clears it)

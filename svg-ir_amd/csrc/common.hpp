@@ -42,7 +42,11 @@ constexpr int SORT_BLOCK_ELEMS = BLOCK * SORT_ITEMS;  // 4096
 // upper bound of the number of radix blocks for n keys (1024 keys per block for small inputs)
 inline int sort_blocks(int n) { return n <= 0 ? 1 : (n + 1023) / 1024; }
 // radix scratch: [sort_blocks][256] block histograms + [4 passes][sort_blocks/32 + 1][256] group totals
-inline size_t radix_table_words(int n) { return (size_t)256 * sort_blocks(n) + (size_t)4 * 256 * (sort_blocks(n) / 32 + 1); }
+inline size_t radix_gtot_words(int n) { return (size_t)4 * 256 * (sort_blocks(n) / 32 + 1); }
+inline size_t radix_table_words(int n) { return (size_t)256 * sort_blocks(n) + radix_gtot_words(n); }
+// group totals of a sort over (up to) n elements; they must be ZERO when launch_radix_sort runs (the stage in front of each
+// sort clears them in passing: preprocess for the depth sort, emit for the tile sort)
+inline uint32_t* radix_gtot(uint32_t* table, int n) { return table + (size_t)256 * sort_blocks(n); }
 constexpr int SCAN_BLOCK_ELEMS = 2048;
 inline int scan_blocks(int n) { return n <= 0 ? 1 : (n + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS; }
 
@@ -224,6 +228,8 @@ struct PreArgs {
     float scale_modifier, tanx, tany, focal_x, focal_y;
     CfgRef cfg;
     float* rec; float* cov3D; uint32_t* clamped; uint32_t* tiles; uint32_t* key; uint32_t* idx; int32_t* radii;
+    float* out_weights;              // [P] zeroed here (accumulated with atomics by the composite)
+    uint32_t* zero_words; int n_zero_words;   // small table cleared in passing (the depth sort's group totals)
     uint32_t* prefilter_violation;   // non-null <=> `prefiltered`: set to 1 when a frustum / back-face cull fires (auxiliary.h:163-167)
 };
 
@@ -237,6 +243,7 @@ struct RenderArgs {
     uint32_t* sub_ndump; uint32_t* seg_list; uint32_t* seg_count; float* seg_state;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
+    float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
 };
 
 struct RenderBwdArgs {
@@ -289,10 +296,11 @@ void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, co
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
                          uint32_t* total_out, hipStream_t s);
-// also clears ranges[2*gx*gy] and the live-segment counter
+// also clears ranges[2*gx*gy], the live-segment counter and the group totals of the tile sort's table (`sort_table`,
+// sized for `cap` elements)
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
-                 uint32_t* seg_count, hipStream_t s);
+                 uint32_t* seg_count, uint32_t* sort_table, hipStream_t s);
 void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
 // order[] = item ids sorted by descending counts[] (longest-processing-time-first dispatch of the composite waves)
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s);

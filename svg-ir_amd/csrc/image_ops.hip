@@ -45,9 +45,12 @@ __global__ void __launch_bounds__(BLOCK) pseudo_normal_kernel(int W, int H, cons
     }
     float n[3] = {ga[1] * gb[2] - ga[2] * gb[1], -ga[0] * gb[2] + ga[2] * gb[0], ga[0] * gb[1] - ga[1] * gb[0]};
     const float nn = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-    if (nn <= 0.00000f) return;
-    n[0] = -n[0] / nn; n[1] = -n[1] / nn; n[2] = -n[2] / nn;
     const size_t id = (size_t)W * y + x;
+    if (nn <= 0.00000f) {   // degenerate stencil: the reference leaves its zero-initialised output (forward.cu:620-622)
+        nrm[id] = 0.f; nrm[N + id] = 0.f; nrm[2 * N + id] = 0.f;
+        return;
+    }
+    n[0] = -n[0] / nn; n[1] = -n[1] / nn; n[2] = -n[2] / nn;
     nrm[id] = V[0] * n[0] + V[1] * n[1] + V[2] * n[2];
     nrm[N + id] = V[4] * n[0] + V[5] * n[1] + V[6] * n[2];
     nrm[2 * N + id] = V[8] * n[0] + V[9] * n[1] + V[10] * n[2];

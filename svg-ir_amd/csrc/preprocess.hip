@@ -119,8 +119,10 @@ __device__ __forceinline__ uint32_t sh_to_rgb(const PreArgs& a, int idx, const f
 template <bool SVGSS>
 __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    for (int j = idx; j < a.n_zero_words; j += gridDim.x * BLOCK) a.zero_words[j] = 0u;
     if (idx >= a.P) return;
     const bool surface = cfg_flag(a.cfg, 0), pix_depth = cfg_flag(a.cfg, 2);
+    if (a.out_weights) a.out_weights[idx] = 0.f;
     // defaults for a culled Gaussian
     a.radii[idx] = 0;
     a.tiles[idx] = 0;

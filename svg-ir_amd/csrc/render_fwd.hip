@@ -48,6 +48,14 @@ __global__ void __launch_bounds__(BLOCK) cull_kernel(const RenderArgs a) {
     const int len = (int)(r1 - r0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tx = tile % a.gx, ty = tile / a.gx;
+    if (a.zero_a || a.zero_b) {   // planes this call leaves at zero: every thread clears its pixel of the tile
+        const int px = tx * TILE + (t & 15), py = ty * TILE + (t >> 4);
+        if (px < a.W && py < a.H) {
+            const size_t N_ = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
+            if (a.zero_a) { a.zero_a[pid] = 0.f; a.zero_a[N_ + pid] = 0.f; a.zero_a[2 * N_ + pid] = 0.f; }
+            if (a.zero_b) { a.zero_b[pid] = 0.f; a.zero_b[N_ + pid] = 0.f; a.zero_b[2 * N_ + pid] = 0.f; }
+        }
+    }
     if (len == 0) {
         // Empty tile: nothing will ever be blended here.  The 256 threads write the background result of the whole
         // 16x16 tile (64-byte rows) and the four composite waves of the tile exit at once (render_fwd_kernel).

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
 
 RGSS, SVGSS = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -172,9 +172,20 @@ class BlobAllocator:
         return out
 
 
-def zeros_like_blob(device, shapes):
-    """Zero-initialised fp32 tensors of `shapes` carved out of ONE allocation (a single fill kernel instead of one
-    per gradient tensor); every view starts on a 256-byte boundary."""
+POISON = os.environ.get("SVGIR_POISON", "") not in ("", "0")   # tests: NaN-fill every buffer the library must overwrite
+
+
+def out_tensor(shape, dtype, device):
+    """An output buffer the library writes completely (ABI 5: nothing needs clearing by the caller)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if POISON and t.numel():
+        t.fill_(float("nan") if dtype.is_floating_point else -7)
+    return t
+
+
+def grad_blob(device, shapes, zero=False):
+    """fp32 gradient tensors of `shapes` carved out of ONE allocation; every view starts on a 256-byte boundary.  Not
+    cleared (unless `zero`: the P = 0 case, where nothing runs): svgir_backward writes every element."""
     sizes = [1] * len(shapes)
     for i, sh in enumerate(shapes):
         for d in sh:
@@ -183,7 +194,7 @@ def zeros_like_blob(device, shapes):
     for n in sizes:
         offs.append(tot)
         tot += (n + 63) // 64 * 64
-    blob = torch.zeros(tot, dtype=torch.float32, device=device)
+    blob = torch.zeros(tot, dtype=torch.float32, device=device) if zero else out_tensor((tot,), torch.float32, device)
     return [blob[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 

@@ -43,15 +43,16 @@ class _CBinding:
         if P == 0:  # nothing is launched: the reference returns its zero-initialised outputs (rasterize_points.cu:100)
             torch_empty = torch.zeros
         else:
-            torch_empty = torch.empty  # every pixel is written by the composite kernel
+            def torch_empty(shape, **kw):  # every element is written by the library
+                return N.out_tensor(shape, kw["dtype"], kw["device"])
         out_color = torch_empty((3, H, W), **f32)
         out_normal = torch_empty((3, H, W), **f32)
         out_depth = torch_empty((1, H, W), **f32)
         out_opac = torch_empty((1, H, W), **f32)
         out_feature = torch_empty((S, H, W), **f32)
         out_vfeature = torch_empty((VS // 4, H, W), **f32)
-        out_weights = torch.zeros((P, 1), **f32)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        out_weights = torch_empty((P, 1), **f32)
+        radii = torch_empty((P,), dtype=torch.int32, device=dev)
         blobs = N.BlobAllocator(dev)
         rendered = 0
         if P != 0:
@@ -96,8 +97,8 @@ class _CBinding:
         M = sh.size(1) if sh.numel() != 0 else 0
         (dL_dmeans3D, dL_dmeans2D, dL_dfeatures, dL_dvfeatures, dL_dcolors, dL_dnormal, dL_ddepth, dL_dconic,
          dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos) = \
-            N.zeros_like_blob(dev, [(P, 3), (P, 3), (P, S), (P, VS), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6),
-                                    (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)])
+            N.grad_blob(dev, [(P, 3), (P, 3), (P, S), (P, VS), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6),
+                                    (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)], zero=(P == 0))
         if P != 0:
             keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, vfeatures, scales, rotations,
                                               cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint, patchbbox,

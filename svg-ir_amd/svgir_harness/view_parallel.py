@@ -71,10 +71,10 @@ class MetricsGatherer:
         if self.pending[i] is not None:          # the gather issued two steps ago used this slot
             self.pending[i].wait()
             self.pending[i] = None
-        self.src[i].copy_(vec.reshape(-1))
-        if self.world == 1:
-            self.bufs[i].copy_(self.src[i])
+        if self.world == 1:       # nothing to exchange: the table is the vector itself
+            self.bufs[i] = vec.reshape(-1)
         else:
+            self.src[i].copy_(vec.reshape(-1))
             self.pending[i] = dist.all_gather_into_tensor(self.bufs[i], self.src[i], async_op=True)
         self.last = i
         self.step += 1
@@ -93,6 +93,16 @@ class MetricsGatherer:
             if self.pending[i] is not None:
                 self.pending[i].wait()
                 self.pending[i] = None
+
+
+def gather_rows(vec):
+    """[world, k] table of every rank's 1-D `vec` (blocking; one all_gather)."""
+    vec = vec.reshape(-1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return vec[None, :].clone()
+    out = torch.empty(dist.get_world_size() * vec.numel(), dtype=vec.dtype, device=vec.device)
+    dist.all_gather_into_tensor(out, vec.contiguous())
+    return out.reshape(dist.get_world_size(), vec.numel())
 
 
 def barrier():
