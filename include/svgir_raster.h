@@ -95,10 +95,11 @@ typedef struct svgir_outputs {
 } svgir_outputs;
 
 /* Upstream gradients and gradient outputs of backward (Rasterizer::backward, svgss rasterizer_impl.cu:386-432,
- * rgss :411-449).  Every element of every dL_d* output is written by svgir_backward (zeros for culled Gaussians, unused
- * components and inactive SH coefficients): the caller need not clear them.  (The reference's glue zero-fills them,
- * rasterize_points.cu:195-211, and its kernels accumulate; a full clear of ~21 floats per Gaussian is a launch the
- * backward does not need.) */
+ * rgss :411-449).  The caller need not clear the dL_d* outputs (the reference's glue zero-fills them,
+ * rasterize_points.cu:195-211): svgir_backward clears them itself, on an internal side stream while the composite
+ * backward -- which accumulates in the scratch, not in these tensors -- runs on the caller's stream, and joins the two
+ * before the per-Gaussian kernels write the gradients of the visible Gaussians.  A caller that lays all outputs out in
+ * one allocation passes it as clear_base / clear_bytes: one memset instead of one per tensor. */
 typedef struct svgir_grads {
     const float* dL_dout_color;    /* [3,H,W] */
     const float* dL_dout_normal;   /* [3,H,W] */
@@ -119,10 +120,11 @@ typedef struct svgir_grads {
     float* dL_dsh;        /* [P,M,3] */
     float* dL_dscales;    /* [P,3] */
     float* dL_drotations; /* [P,4] */
-    float* dL_dviewmat;   /* [16] svgss (zero unless config[3] > 0); the three camera gradients are cleared with one
-                             memset when they are laid out back to back (viewmat, projmat, campos) */
+    float* dL_dviewmat;   /* [16] svgss (zero unless config[3] > 0) */
     float* dL_dprojmat;   /* [16] svgss */
     float* dL_dcampos;    /* [3]  svgss */
+    void* clear_base;     /* optional: a region that contains every dL_d* output above and nothing the library must */
+    size_t clear_bytes;   /*           preserve (NULL / 0: the outputs are cleared one by one) */
 } svgir_grads;
 
 int svgir_abi_version(void);

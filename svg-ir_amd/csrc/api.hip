@@ -75,6 +75,25 @@ uint32_t* pinned_slot() {
     });
     return g_pinned ? g_pinned + 2 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
 }   // instance count of the previous forward: sizes the speculative binning blob
+// Side stream of the backward: the gradient tensors are cleared there while the composite backward (which only writes the
+// scratch) runs on the caller's stream.  One per device, created on first use; fork / join through events.
+struct SideStream { hipStream_t s = nullptr; bool ok = false; };
+std::mutex g_side_mu;
+SideStream g_side[16];
+hipStream_t side_stream() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream& ss = g_side[dev];
+    if (!ss.ok) {
+        // lowest priority: the clear only has to be done by the time the composite backward ends
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+        ss.ok = true;
+    }
+    return ss.s;
+}
 std::mutex g_times_mu;
 struct Pending { hipEvent_t a, b; const char* name; };
 std::vector<Pending> g_pending;
@@ -471,20 +490,49 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
                     scratch ? scratch_bytes : (size_t)0, need);
     const bool generic = !render_specialised(p->S, ba.VS, svgss);   // run-time-width kernels: atomics on the dL_d* tensors
     const bool rows = ba.VS > 0 && !generic;
+    // The dL_d* outputs start from zero (the kernels write the visible Gaussians only).  The specialised composite
+    // backward does not touch them (it accumulates in the scratch), so the clear runs on a side stream next to it and
+    // is joined before the per-Gaussian kernels; the run-time-width composite adds into them, so there the clear comes first.
+    hipEvent_t ev_cleared = nullptr;
+    {
+        hipStream_t cs = generic ? s : side_stream();
+        if (!cs) cs = s;
+        hipEvent_t ev_fork = nullptr;
+        if (cs != s) {   // the tensors may have been used on `s` before (stream-ordered allocators): order the clear after that
+            HIP_OK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(ev_fork, s));
+            HIP_OK(hipStreamWaitEvent(cs, ev_fork, 0));
+            (void)hipEventDestroy(ev_fork);
+        }
+        const size_t Pz = (size_t)P * 4;
+        if (g->clear_base && g->clear_bytes) {
+            HIP_OK(hipMemsetAsync(g->clear_base, 0, g->clear_bytes, cs));
+        } else {
+            struct { float* p; size_t n; } t[] = {
+                {g->dL_dmeans2D, 3 * Pz}, {g->dL_dconic, 4 * Pz}, {g->dL_dopacity, Pz}, {g->dL_dcolors, 3 * Pz},
+                {g->dL_dfeatures, (size_t)p->S * Pz}, {g->dL_dvfeatures, (size_t)ba.VS * Pz}, {g->dL_dnormal, 3 * Pz},
+                {g->dL_ddepth, Pz}, {g->dL_dmeans3D, 3 * Pz}, {g->dL_dcov3D, 6 * Pz}, {g->dL_dsh, (size_t)p->M * 3 * Pz},
+                {g->dL_dscales, 3 * Pz}, {g->dL_drotations, 4 * Pz}, {svgss ? g->dL_dviewmat : nullptr, 64},
+                {svgss ? g->dL_dprojmat : nullptr, 64}, {svgss ? g->dL_dcampos : nullptr, 12}};
+            for (auto& e : t)
+                if (e.p && e.n) HIP_OK(hipMemsetAsync(e.p, 0, e.n, cs));
+        }
+        if (cs != s) {
+            HIP_OK(hipEventCreateWithFlags(&ev_cleared, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(ev_cleared, cs));
+        }
+    }
+    auto join_clear = [&]() {
+        if (ev_cleared) {
+            (void)hipStreamWaitEvent(s, ev_cleared, 0);
+            (void)hipEventDestroy(ev_cleared);
+            ev_cleared = nullptr;
+        }
+    };
     const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
     ba.grad_rows = generic ? nullptr : (float*)scratch;
     ba.row_flags = nullptr;
     if (generic) {
-        // atomics straight into the caller's tensors: clear them first (the specialised paths overwrite instead)
-        const size_t Pz = (size_t)P * 4;
-        HIP_OK(hipMemsetAsync(g->dL_dmeans2D, 0, 3 * Pz, s));
-        HIP_OK(hipMemsetAsync(g->dL_dconic, 0, 4 * Pz, s));
-        HIP_OK(hipMemsetAsync(g->dL_dopacity, 0, Pz, s));
-        HIP_OK(hipMemsetAsync(g->dL_dcolors, 0, 3 * Pz, s));
-        HIP_OK(hipMemsetAsync(g->dL_dnormal, 0, 3 * Pz, s));
-        HIP_OK(hipMemsetAsync(g->dL_ddepth, 0, Pz, s));
-        if (p->S) HIP_OK(hipMemsetAsync(g->dL_dfeatures, 0, (size_t)p->S * Pz, s));
-        if (ba.VS) HIP_OK(hipMemsetAsync(g->dL_dvfeatures, 0, (size_t)ba.VS * Pz, s));
     } else if (rows) {
         ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
         if (R > 0) HIP_OK(hipMemsetAsync(ba.row_flags, 0, (size_t)4 * cap, s));
@@ -496,7 +544,8 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         else (void)launch_render_bwd(ba, svgss, s);
     }
     tm.mark("render_bwd");
-    if (rows) {   // (also with R == 0: it is the writer of the composite gradients)
+    join_clear();
+    if (R > 0 && rows) {
         GradReduceArgs ra;
         ra.P = P; ra.S = p->S; ra.VS = ba.VS; ra.radii = radii; ra.tiles = G.tiles; ra.rec = G.rec;
         ra.grad_rows = ba.grad_rows; ra.row_flags = ba.row_flags;
@@ -520,15 +569,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ga.dL_dmean3D = g->dL_dmeans3D; ga.dL_dcov3D = g->dL_dcov3D; ga.dL_dsh = g->dL_dsh; ga.dL_dscale = g->dL_dscales;
     ga.dL_drot = g->dL_drotations; ga.dL_dviewmat = g->dL_dviewmat; ga.dL_dprojmat = g->dL_dprojmat; ga.dL_dcampos = g->dL_dcampos;
     if (ga.scales && !ga.rotations) return fail(SVGIR_ERR_INVALID, "rotations missing");
-    if (svgss && g->dL_dviewmat && g->dL_dprojmat && g->dL_dcampos) {   // accumulated with atomics (config[3] > 0), else zero
-        if (g->dL_dprojmat == g->dL_dviewmat + 16 && g->dL_dcampos == g->dL_dviewmat + 32) {
-            HIP_OK(hipMemsetAsync(g->dL_dviewmat, 0, 35 * 4, s));
-        } else {
-            HIP_OK(hipMemsetAsync(g->dL_dviewmat, 0, 16 * 4, s));
-            HIP_OK(hipMemsetAsync(g->dL_dprojmat, 0, 16 * 4, s));
-            HIP_OK(hipMemsetAsync(g->dL_dcampos, 0, 3 * 4, s));
-        }
-    }
+
     launch_geom_bwd(ga, s);
     tm.mark("geom_bwd");
     hipError_t e = p->debug ? hipStreamSynchronize(s) : hipSuccess;

@@ -44,10 +44,7 @@ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 
 __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
-    // Every element of every gradient tensor is written by the backward (the caller need not clear them): a Gaussian that
-    // was culled gets zeros.
-    const bool visible = a.radii[idx] > 0;
+    if (idx >= a.P || !(a.radii[idx] > 0)) return;
     if (a.packed) {
         // rgss: the backward composite accumulated this Gaussian's gradients in one packed row (common.hpp GradRowGeom:
         // colour3, normal3, depth, feature S | pad | mean2D.xy, conic.xyz, opacity); unpack it into the caller's tensors
@@ -60,25 +57,6 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         a.dL_dmean2D[3 * idx] = row[P4]; a.dL_dmean2D[3 * idx + 1] = row[P4 + 1];
         a.dL_dconic[4 * idx] = row[P4 + 2]; a.dL_dconic[4 * idx + 1] = row[P4 + 3]; a.dL_dconic[4 * idx + 3] = row[P4 + 4];
         a.dL_dopacity[idx] = row[P4 + 5];
-        a.dL_dmean2D[3 * idx + 2] = 0.f; a.dL_dconic[4 * idx + 2] = 0.f;
-    }
-    if (!visible) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * idx + i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * idx + i] = 0.f;
-        if (a.dL_dsh) {
-            float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
-            if (a.M == 16 && (((size_t)a.dL_dsh) & 15) == 0) {
-#pragma unroll
-                for (int i = 0; i < 12; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                for (int i = 0; i < 3 * a.M; i++) dsh[i] = 0.f;
-            }
-        }
-        if (a.dL_dscale) { a.dL_dscale[3 * idx] = 0.f; a.dL_dscale[3 * idx + 1] = 0.f; a.dL_dscale[3 * idx + 2] = 0.f; }
-        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
     }
     const bool surface = cfg_flag(a.cfg, 0);
     const bool lrn_cam = a.svgss && a.cfg.len >= 0 && cfg_flag(a.cfg, 3);
@@ -264,7 +242,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         }
 #undef SET
 #undef SH
-        // dL_dsh[k][c] = cf[k] * g[c]; coefficients above the active degree are zero
+        // dL_dsh[k][c] = cf[k] * g[c]; coefficients above the active degree are left untouched (the caller zero-fills)
         if (vec && a.D == 3) {
             float o[48];
 #pragma unroll
@@ -277,7 +255,6 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
             for (int k = 0; k < 16; k++) {
                 if (k < nk) { dsh[3 * k] = cf[k] * g[0]; dsh[3 * k + 1] = cf[k] * g[1]; dsh[3 * k + 2] = cf[k] * g[2]; }
             }
-            for (int i = 3 * nk; i < 3 * a.M; i++) dsh[i] = 0.f;
         }
         const float ddir[3] = {ddx[0] * g[0] + ddx[1] * g[1] + ddx[2] * g[2], ddy[0] * g[0] + ddy[1] * g[1] + ddy[2] * g[2],
                                ddz[0] * g[0] + ddz[1] * g[1] + ddz[2] * g[2]};
@@ -290,8 +267,6 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
             for (int i = 0; i < 3; i++) if (dm[i] != 0.f) atomic_add_f32(&a.dL_dcampos[i], -dm[i]);
 #pragma unroll
         for (int i = 0; i < 3; i++) dmean[i] += dm[i];
-    } else if (a.dL_dsh) {   // precomputed colours: no SH gradient
-        for (int i = 0; i < 3 * a.M; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * idx + i] = dmean[i];
@@ -347,9 +322,6 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         dq.w = 2 * r * (DR(0, 1) - DR(1, 0)) + 2 * x * (DR(2, 0) + DR(0, 2)) + 2 * y * (DR(1, 2) + DR(2, 1)) - 4 * z * (DR(1, 1) + DR(0, 0));
 #undef DR
         reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
-    } else {   // precomputed covariance: no scale / rotation gradient
-        if (a.dL_dscale) { a.dL_dscale[3 * idx] = 0.f; a.dL_dscale[3 * idx + 1] = 0.f; a.dL_dscale[3 * idx + 2] = 0.f; }
-        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 

@@ -23,12 +23,14 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
     const int32_t radius = a.radii[g];
     const uint32_t ntiles = a.tiles[g];
     const size_t base = (size_t)4 * __builtin_bit_cast(uint32_t, a.rec[(size_t)g * REC + R_IBASE]);
-    // (a culled Gaussian has no rows: its outputs are written as zeros -- the backward writes every gradient element)
-    const uint32_t nslots = radius > 0 ? 4u * ntiles : 0u;
+    if (!(radius > 0) || ntiles == 0) return;
+    const uint32_t nslots = 4u * ntiles;
     float acc0 = 0.f, acc1 = 0.f;
+    bool any = false;
     for (uint32_t s0 = 0; s0 < nslots; s0 += 64) {
         const uint32_t s = s0 + (uint32_t)lane;
         unsigned long long m = __ballot(s < nslots && a.row_flags[base + s] != 0);
+        any = any || m != 0ull;
         // up to four valid rows per step: all their loads are issued before the first add (one memory latency per
         // four rows instead of one per row); the adds keep slot order, so the result is reproducible
         while (m) {
@@ -50,7 +52,8 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
                 if (b[k] >= 0) { acc0 += v0[k]; acc1 += v1[k]; }
         }
     }
-    // scatter the summed row to the output tensors (this is their only writer)
+    if (!any) return;   // outputs stay at the caller's zeros
+    // scatter the summed row to the output tensors (the caller zero-fills them; this is the only writer)
     auto put = [&](int e, float v) {
         if (e < 3) a.dL_dcolor[(size_t)g * 3 + e] = v;
         else if (e < 6) a.dL_dnormal[(size_t)g * 3 + (e - 3)] = v;
@@ -58,14 +61,8 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
         else if (e < rg.NC0) a.dL_dfeature[(size_t)g * a.S + (e - 7)] = v;
         else if (e < rg.P4) {}
         else if (e < rg.GEO) a.dL_dvfeature[(size_t)g * a.VS + (e - rg.P4)] = v;
-        else if (e < rg.GEO + 2) {
-            a.dL_dmean2D[(size_t)g * 3 + (e - rg.GEO)] = v;
-            if (e == rg.GEO + 1) a.dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
-        } else if (e < rg.GEO + 5) {
-            const int j = e - rg.GEO - 2;
-            a.dL_dconic[(size_t)g * 4 + (j == 2 ? 3 : j)] = v;
-            if (j == 2) a.dL_dconic[(size_t)g * 4 + 2] = 0.f;
-        }
+        else if (e < rg.GEO + 2) a.dL_dmean2D[(size_t)g * 3 + (e - rg.GEO)] = v;
+        else if (e < rg.GEO + 5) { const int j = e - rg.GEO - 2; a.dL_dconic[(size_t)g * 4 + (j == 2 ? 3 : j)] = v; }
         else if (e < rg.GEO + 6) a.dL_dopacity[g] = v;
     };
     if (lane < rg.RS) put(lane, acc0);

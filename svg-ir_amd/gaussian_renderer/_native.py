@@ -45,7 +45,7 @@ class Grads(C.Structure):
         "dL_dout_color", "dL_dout_normal", "dL_dout_depth", "dL_dout_opacity", "dL_dout_feature", "dL_dout_vfeature",
         "dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dfeatures", "dL_dvfeatures", "dL_dnormal",
         "dL_ddepth", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dviewmat",
-        "dL_dprojmat", "dL_dcampos")]
+        "dL_dprojmat", "dL_dcampos", "clear_base")] + [("clear_bytes", C.c_size_t)]
 
 
 def _load():
@@ -184,8 +184,9 @@ def out_tensor(shape, dtype, device):
 
 
 def grad_blob(device, shapes, zero=False):
-    """fp32 gradient tensors of `shapes` carved out of ONE allocation; every view starts on a 256-byte boundary.  Not
-    cleared (unless `zero`: the P = 0 case, where nothing runs): svgir_backward writes every element."""
+    """fp32 gradient tensors of `shapes` carved out of ONE allocation; every view starts on a 256-byte boundary.  Returns
+    (views, blob).  Not cleared (unless `zero`: the P = 0 case, where nothing runs): svgir_backward clears the blob itself
+    (Grads.clear_base / clear_bytes) next to its first kernel."""
     sizes = [1] * len(shapes)
     for i, sh in enumerate(shapes):
         for d in sh:
@@ -195,7 +196,7 @@ def grad_blob(device, shapes, zero=False):
         offs.append(tot)
         tot += (n + 63) // 64 * 64
     blob = torch.zeros(tot, dtype=torch.float32, device=device) if zero else out_tensor((tot,), torch.float32, device)
-    return [blob[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+    return [blob[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)], blob
 
 
 def stream_ptr(device):

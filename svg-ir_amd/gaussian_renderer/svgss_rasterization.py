@@ -96,7 +96,7 @@ class _CBinding:
         H, W = dL_dout_color.size(1), dL_dout_color.size(2)
         M = sh.size(1) if sh.numel() != 0 else 0
         (dL_dmeans3D, dL_dmeans2D, dL_dfeatures, dL_dvfeatures, dL_dcolors, dL_dnormal, dL_ddepth, dL_dconic,
-         dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos) = \
+         dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos), gblob = \
             N.grad_blob(dev, [(P, 3), (P, 3), (P, S), (P, VS), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6),
                                     (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)], zero=(P == 0))
         if P != 0:
@@ -123,6 +123,7 @@ class _CBinding:
             g.dL_dnormal, g.dL_ddepth, g.dL_dmeans3D = dL_dnormal.data_ptr(), dL_ddepth.data_ptr(), dL_dmeans3D.data_ptr()
             g.dL_dcov3D, g.dL_dsh, g.dL_dscales = dL_dcov3D.data_ptr(), N.ptr(dL_dsh), dL_dscales.data_ptr()
             g.dL_drotations = dL_drotations.data_ptr()
+            g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
             g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
             rad = radii.contiguous()
             # scratch for the gradient accumulation (rows per (instance, sub-tile), summed per Gaussian)
