@@ -34,6 +34,7 @@
 
 #include "common.hpp"
 #include "stage.hpp"
+#include "pairstage.hpp"
 #include "dev_trace.hpp"
 
 namespace svgir {
@@ -120,12 +121,16 @@ __global__ void __launch_bounds__(BLOCK) cull_kernel(const RenderArgs a) {
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(StageGeom<S, VC>::WPE, StageGeom<S, VC>::WPE)))
 render_fwd_kernel(const RenderArgs a) {
-    using SG = StageGeom<S, VC>;
-    constexpr int KB = SG::KB, CH = SG::CH;
+    using PG = PairGeom<S, VC>;
+    constexpr int CH = PG::CH, PF = PG::PF;
+    constexpr int KB = StageGeom<S, VC>::KB, NP = KB / 2;   // candidates / staged pairs per branch-free group
+    static_assert(KB == 4 && CH % KB == 0, "a group = the 4 K-rows of one MFMA");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sD = reinterpret_cast<float*>(smem);                              // [CH][NF] staged candidates
-    uint2* sQ = reinterpret_cast<uint2*>(smem + (size_t)CH * SG::NF * 4);    // [2][CH] {gid, slot}: this batch / next batch
-    float* sW = reinterpret_cast<float*>(smem + (size_t)CH * SG::NF * 4 + (size_t)SG::QN * 8);   // [2][CH] blend-weight sums
+    float* sD = reinterpret_cast<float*>(smem);                  // [CH / 2][PF] staged pairs (pairstage.hpp)
+    uint2* sQ = reinterpret_cast<uint2*>(smem + PG::off_q);      // [2][CH] {gid, slot}: this batch / next batch
+    float* sW = reinterpret_cast<float*>(smem + PG::off_w);      // [2][CH] blend-weight sums
+    float* sP = reinterpret_cast<float*>(smem + PG::off_p);      // [PROWS][PS] blend-weight panel (MFMA A operand) / transposition tile
+    constexpr int PS = PG::PS;
 
     if ((int)blockIdx.x >= 4 * a.gx * a.gy) return;
     const uint32_t sid = a.sub_order[blockIdx.x];
@@ -136,24 +141,62 @@ render_fwd_kernel(const RenderArgs a) {
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
+    const f32x2 pxx = {pxf, pxf}, pyy = {pyf, pyf};
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int len = (int)(r1 - r0);
     if (len == 0) return;   // empty tile: the cull kernel has written its background pixels
     DEV_TRACE_DECL();
     const int total = (int)a.sub_total[sid];
+    // The kernel ends when its longest candidate list has been walked (the walk is sequential per pixel), and waves are
+    // dispatched longest-first: blockIdx.x is the wave's rank.  The SIMD's instruction arbiter serves the longer list first.
+#ifndef FWD_PRIO
+#define FWD_PRIO 1
+#endif
+    if (FWD_PRIO) {
+        if (blockIdx.x < 1024u) __builtin_amdgcn_s_setprio(3);
+        else if (blockIdx.x < 2048u) __builtin_amdgcn_s_setprio(2);
+        else if (blockIdx.x < 3072u) __builtin_amdgcn_s_setprio(1);
+    }
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
     const bool sp = surface && cfg_flag(a.cfg, 2);
     const uint2* __restrict__ list = a.sub_list + (size_t)4 * r0 + (size_t)sub * len;
 
     bool done = !inside;
     float T = 1.0f, D = 0.f;
-    float C[3] = {0.f, 0.f, 0.f}, N[3] = {0.f, 0.f, 0.f};
-    float F[S > 0 ? S : 1];
-    float VF[VC > 0 ? VC : 1];
+    // Channel and vfeature accumulators live on the matrix pipe: acc[mt] / vacc[mt] are the D tiles of
+    // v_mfma_f32_16x16x4_f32 for the pixels 16 mt .. 16 mt + 15 (lane l, register r: pixel 16 mt + 4 (l >> 4) + r,
+    // channel l & 15).  Channels: r g b nx ny nz F0..F(S-1).
+    f32x4 acc[4], vacc[4];
 #pragma unroll
-    for (int i = 0; i < (S > 0 ? S : 1); i++) F[i] = 0.f;
+    for (int i = 0; i < 4; i++) { acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; vacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int kq = lane >> 4, nq = lane & 15;
+    // lane = pixel view of the accumulators (through the LDS tile): chv[c], vfv[c]
+    float chv[PG::NCH], vfv[VC > 0 ? VC : 1];
+    auto gather_acc = [&]() {
+        wave_lds_sync();
 #pragma unroll
-    for (int i = 0; i < (VC > 0 ? VC : 1); i++) VF[i] = 0.f;
+        for (int mt = 0; mt < 4; mt++) {
+            float* d = sP + nq * PS + 16 * mt + 4 * kq;
+            d[0] = acc[mt].x; d[1] = acc[mt].y; d[2] = acc[mt].z; d[3] = acc[mt].w;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int c = 0; c < PG::NCH; c++) chv[c] = sP[c * PS + lane];
+        if (VC > 0) {
+            wave_lds_sync();
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                float* d = sP + nq * PS + 16 * mt + 4 * kq;
+                d[0] = vacc[mt].x; d[1] = vacc[mt].y; d[2] = vacc[mt].z; d[3] = vacc[mt].w;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < VC; c++) vfv[c] = sP[c * PS + lane];
+        }
+        wave_lds_sync();
+    };
+    auto chan = [&](int c) -> float { return chv[c]; };
+    auto vchan = [&](int c) -> float { return vfv[c]; };
     uint32_t last_contributor = 0;
 
     // segment-boundary state dumps (see common.hpp SEG)
@@ -161,20 +204,23 @@ render_fwd_kernel(const RenderArgs a) {
     const uint32_t dump_base = seg_state_base(r0, (uint32_t)len, tile, sub);
     uint32_t ndump = 0;
     auto dump_state = [&](uint32_t j) {
+        gather_acc();
         float* d = a.seg_state + ((size_t)(dump_base + j) * NST) * 64 + lane;
-        d[0] = T; d[64] = C[0]; d[128] = C[1]; d[192] = C[2];
-        d[256] = N[0]; d[320] = N[1]; d[384] = N[2]; d[448] = D;
+        d[0] = T; d[64] = chan(0); d[128] = chan(1); d[192] = chan(2);
+        // (the normal channels are blended unconditionally; without `surface` they do not exist for the consumers)
+        d[256] = surface ? chan(3) : 0.f; d[320] = surface ? chan(4) : 0.f; d[384] = surface ? chan(5) : 0.f; d[448] = D;
 #pragma unroll
-        for (int ch = 0; ch < S; ch++) d[(8 + ch) * 64] = F[ch];
+        for (int ch = 0; ch < S; ch++) d[(8 + ch) * 64] = chan(6 + ch);
 #pragma unroll
-        for (int ch = 0; ch < VC; ch++) d[(8 + S + ch) * 64] = VF[ch];
+        for (int ch = 0; ch < VC; ch++) d[(8 + S + ch) * 64] = vchan(ch);
     };
 
     uint32_t head = 0;   // candidates consumed so far (wave-uniform)
     if (total > 0) {
         // The staging buffer starts as zeros: slots beyond a batch's size then always hold finite values (zeros or an
-        // older candidate), so the blend loop needs no per-candidate bounds branches -- such slots get weight 0.
-        for (int i = lane; i < CH * SG::NF / 4; i += 64) reinterpret_cast<float4*>(sD)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // older candidate), so the blend loop needs no per-candidate bounds branches -- such slots get weight 0.  The
+        // padding channels of the blocks are never written and stay zero.
+        for (int i = lane; i < (CH / 2) * PF / 4; i += 64) reinterpret_cast<float4*>(sD)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         // software pipeline: {gid, slot} entries are fetched two batches ahead, records one batch ahead
         auto load_entries = [&](int b) -> uint2 {
             const int i = b * CH + lane;
@@ -184,8 +230,10 @@ render_fwd_kernel(const RenderArgs a) {
         if (lane < CH) sQ[lane] = load_entries(0);
         uint2 e_next = load_entries(1);
         wave_lds_sync();
-        StageRegs<S, VC, CH> sr;
-        stage_load<S, VC, CH>(sr, min(CH, total), [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
+        PairMap<S, VC> pmap;
+        pmap.init(lane);
+        PairRegs<S, VC> sr;
+        pair_stage_load<S, VC>(sr, pmap, min(CH, total), [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
         bool wave_done = __all(done);
         int nflush = 0;   // candidates of the previous batch whose out_weights sums are still parked in LDS
         // out_weights of a batch: one atomic instruction, lane = candidate.  It is issued one batch late, BEFORE the next
@@ -202,7 +250,7 @@ render_fwd_kernel(const RenderArgs a) {
             const uint2* q_cur = sQ + (b & 1) * CH;
             float* w_cur = sW + (b & 1) * CH;
             wave_lds_sync();   // previous batch fully consumed
-            stage_store<S, VC, CH>(sr, sD, m, lane);
+            pair_stage_store<S, VC>(sr, pmap, sD, m, lane);
             flush_weights(b - 1);
             wave_lds_sync();   // ... before its {gid, slot} entries are overwritten
             if (lane < CH) sQ[((b + 1) & 1) * CH + lane] = e_next;
@@ -210,29 +258,33 @@ render_fwd_kernel(const RenderArgs a) {
             wave_lds_sync();
             if (b + 1 < nb) {
                 const uint2* q_nxt = sQ + ((b + 1) & 1) * CH;
-                stage_load<S, VC, CH>(sr, min(CH, total - (b + 1) * CH), [&](int s) { return q_nxt[s].x; }, lane, a.rec,
-                                      a.features, a.vfeatures);
+                pair_stage_load<S, VC>(sr, pmap, min(CH, total - (b + 1) * CH), [&](int s) { return q_nxt[s].x; }, lane, a.rec,
+                                       a.features, a.vfeatures);
             }
             DEV_TRACE_MARK(1);   // staging
             int nproc = m;   // candidates of this batch whose weight sums are valid
             for (int c0 = 0; c0 < m; c0 += KB) {
-                // ---- (1) KB independent alphas, lock-step ----
-                float4 A[KB], B[KB];
+                // ---- (1) the alphas of KB candidates: NP pairs, packed (element-wise the reference's operations) ----
+                f32x2 dx[NP], dy[NP];
+                f32x4 Gd[NP], Ge[NP];   // (depth, DA) pairs; (DB, 1/umax) pairs
+                float pw[KB], al[KB];
                 uint32_t slot[KB];
 #pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    const float4* q = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF);
-                    A[k] = q[0];   // x, y, conic.x, conic.y
-                    B[k] = q[1];   // conic.z, opacity, depth, DA
-                    slot[k] = q_cur[c0 + k].y;
+                for (int p = 0; p < NP; p++) {
+                    const f32x4* P = reinterpret_cast<const f32x4*>(sD + ((c0 >> 1) + p) * PF);
+                    const f32x4 G0 = P[0], G1 = P[1], G2 = P[2];   // (x, y), (conic.x, conic.z), (conic.y, opacity) of both
+                    Gd[p] = P[3]; Ge[p] = P[4];
+                    dx[p] = G0.xy - pxx; dy[p] = G0.zw - pyy;
+                    const f32x2 pw2 = pair_power2(G1.xy, G2.xy, G1.zw, dx[p], dy[p]);
+                    f32x2 a2;
+                    {
+#pragma clang fp contract(off)
+                        a2 = G2.zw * exp_nonpos2(pw2);
+                    }
+                    pw[2 * p] = pw2.x; pw[2 * p + 1] = pw2.y;
+                    al[2 * p] = fminf(0.99f, a2.x); al[2 * p + 1] = fminf(0.99f, a2.y);
+                    slot[2 * p] = q_cur[c0 + 2 * p].y; slot[2 * p + 1] = q_cur[c0 + 2 * p + 1].y;
                 }
-                float dx[KB], dy[KB], pw[KB], al[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) { dx[k] = A[k].x - pxf; dy[k] = A[k].y - pyf; }
-#pragma unroll
-                for (int k = 0; k < KB; k++) pw[k] = pair_power(A[k].z, A[k].w, B[k].x, dx[k], dy[k]);
-#pragma unroll
-                for (int k = 0; k < KB; k++) al[k] = fminf(0.99f, B[k].y * exp_nonpos(pw[k]));
                 bool pre[KB];
 #pragma unroll
                 for (int k = 0; k < KB; k++) pre[k] = (c0 + k < m) && pw[k] <= 0.0f && al[k] >= (1.0f / 255.0f);
@@ -249,62 +301,60 @@ render_fwd_kernel(const RenderArgs a) {
                     T = pass ? test_T : T;
                     last_contributor = pass ? slot[k] + 1u : last_contributor;
                 }
-                // ---- (3) independent accumulations (weight 0 for everything that did not pass) ----
-                float4 E[KB], Nn[KB];
+                // ---- (3) accumulations (weight 0 for everything that did not pass) ----
+                f32x2 wq[NP][4];   // svgss: bilinear corner weights x blend weight, per pair
 #pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    const float4* q = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF);
-                    E[k] = q[3];    // DB, r, g, b
-                    Nn[k] = q[4];   // nx, ny, nz, 1/umax
-                }
-                float w0[KB], w1[KB], w2[KB], w3[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    float dep = B[k].z;
-                    w0[k] = w1[k] = w2[k] = w3[k] = 0.f;
+                for (int p = 0; p < NP; p++) {
+                    f32x2 dep = Gd[p].xy;
+                    const f32x2 w2 = {w[2 * p], w[2 * p + 1]};
                     if (sp) {
-                        dep -= dx[k] * B[k].w + dy[k] * E[k].x;   // depth differencing (common.hpp R_DA / R_DB)
+                        dep -= dx[p] * Gd[p].zw + dy[p] * Ge[p].xy;   // depth differencing (common.hpp R_DA / R_DB)
                         if (SVGSS && VC > 0) {
-                            const float4* q = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF);
-                            const float4 J = q[2];   // J0..J3
-                            const float iv = q[5].x;
-                            const float du = dx[k] * J.x + dy[k] * J.y;
-                            const float dv = dx[k] * J.z + dy[k] * J.w;
-                            float u = du * Nn[k].w * 0.5f + 0.5f, v = dv * iv * 0.5f + 0.5f;
-                            u = fminf(0.999f, fmaxf(0.001f, u));
-                            v = fminf(0.999f, fmaxf(0.001f, v));
+                            const f32x4* P = reinterpret_cast<const f32x4*>(sD + ((c0 >> 1) + p) * PF);
+                            const f32x4 G5 = P[5], G6 = P[6], G7 = P[7];   // (1/vmax, .), (J0, J1), (J2, J3)
+                            const f32x2 du = dx[p] * G6.xy + dy[p] * G6.zw;
+                            const f32x2 dv = dx[p] * G7.xy + dy[p] * G7.zw;
+                            const f32x2 half = {0.5f, 0.5f}, one = {1.f, 1.f};
+                            f32x2 u = du * Ge[p].zw * half + half, v = dv * G5.xy * half + half;
+                            u.x = __builtin_amdgcn_fmed3f(u.x, 0.001f, 0.999f); u.y = __builtin_amdgcn_fmed3f(u.y, 0.001f, 0.999f);
+                            v.x = __builtin_amdgcn_fmed3f(v.x, 0.001f, 0.999f); v.y = __builtin_amdgcn_fmed3f(v.y, 0.001f, 0.999f);
                             // pre-multiplied by the blend weight
-                            w0[k] = (1.f - u) * (1.f - v) * w[k]; w1[k] = u * (1.f - v) * w[k];
-                            w2[k] = (1.f - u) * v * w[k]; w3[k] = u * v * w[k];
+                            wq[p][0] = (one - u) * (one - v) * w2; wq[p][1] = u * (one - v) * w2;
+                            wq[p][2] = (one - u) * v * w2; wq[p][3] = u * v * w2;
                         }
                     }
-                    D += dep * w[k];
+                    D += dep.x * w[2 * p];
+                    D += dep.y * w[2 * p + 1];
                 }
+                // colour / normal / feature / vfeature sums on the matrix pipe: panel rows (lane = pixel) -> A operands
 #pragma unroll
-                for (int k = 0; k < KB; k++) { C[0] += E[k].y * w[k]; C[1] += E[k].z * w[k]; C[2] += E[k].w * w[k]; }
-                if (surface) {
-#pragma unroll
-                    for (int k = 0; k < KB; k++) { N[0] += Nn[k].x * w[k]; N[1] += Nn[k].y * w[k]; N[2] += Nn[k].z * w[k]; }
-                }
-                if (S > 0) {
-#pragma unroll
-                    for (int k = 0; k < KB; k++) {
-                        const float* f = sD + (c0 + k) * SG::NF + SG::F_OFF;
-#pragma unroll
-                        for (int ch = 0; ch < S; ch++) F[ch] += f[ch] * w[k];
-                    }
-                }
+                for (int k = 0; k < KB; k++) sP[k * PS + lane] = w[k];
                 if (VC > 0) {
 #pragma unroll
-                    for (int k = 0; k < KB; k++) {
-                        const float4* vf = reinterpret_cast<const float4*>(sD + (c0 + k) * SG::NF + SG::V_OFF);
+                    for (int k = 0; k < KB; k++)
 #pragma unroll
-                        for (int ch = 0; ch < VC; ch++) {
-                            const float4 c4 = vf[ch];
-                            VF[ch] += c4.x * w0[k] + c4.y * w1[k] + c4.z * w2[k] + c4.w * w3[k];
+                        for (int j = 0; j < 4; j++) {
+                            const float wj = (k & 1) ? wq[k >> 1][j].y : wq[k >> 1][j].x;
+                            sP[(4 + k * 4 + j) * PS + lane] = sp ? wj : 0.f;
                         }
+                }
+                wave_lds_sync();
+                {   // channels: K = the 4 candidates of the group; B[k][n] = channel n of candidate k
+                    const float bch = sD[((c0 >> 1) + (kq >> 1)) * PF + PG::CH_OFF + (kq & 1) * PG::CHP + nq];
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[kq * PS + 16 * mt + nq], bch, acc[mt], 0, 0, 0);
+                }
+                if (VC > 0) {   // vfeatures: one MFMA set per candidate, K = its 4 corners; B[k][n] = corner k of channel n
+#pragma unroll
+                    for (int k = 0; k < KB; k++) {
+                        const float bv = sD[((c0 + k) >> 1) * PF + PG::V_OFF + (k & 1) * PG::VB + kq * PG::VCP + nq];
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++)
+                            vacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[(4 + k * 4 + kq) * PS + 16 * mt + nq], bv, vacc[mt], 0, 0, 0);
                     }
                 }
+                wave_lds_sync();   // panel consumed before the next group overwrites it
                 // ---- (4) out_weights: KB interleaved wave reductions, parked in LDS ----
                 float ws[KB];
 #pragma unroll
@@ -331,6 +381,7 @@ render_fwd_kernel(const RenderArgs a) {
     if (lane == 0 && nseg != 0) seg_at = atomicAdd(a.seg_count, nseg);
     if (lane == 0) { a.sub_count[sid] = head; a.sub_ndump[sid] = ndump; }
     if (head != 0 && ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
+    else gather_acc();
 
     if (inside) {
         const size_t N_ = (size_t)a.W * a.H;
@@ -338,16 +389,16 @@ render_fwd_kernel(const RenderArgs a) {
         T = fminf((float)(1 - 0.000001), T);
         a.final_T[pid] = T;
         a.n_contrib[pid] = (int32_t)last_contributor;
-        a.out_color[pid] = C[0] + T * a.bg[0];
-        a.out_color[N_ + pid] = C[1] + T * a.bg[1];
-        a.out_color[2 * N_ + pid] = C[2] + T * a.bg[2];
+        a.out_color[pid] = chan(0) + T * a.bg[0];
+        a.out_color[N_ + pid] = chan(1) + T * a.bg[1];
+        a.out_color[2 * N_ + pid] = chan(2) + T * a.bg[2];
 #pragma unroll
-        for (int ch = 0; ch < S; ch++) a.out_feature[ch * N_ + pid] = F[ch];
+        for (int ch = 0; ch < S; ch++) a.out_feature[ch * N_ + pid] = chan(6 + ch);
 #pragma unroll
-        for (int ch = 0; ch < VC; ch++) a.out_vfeature[ch * N_ + pid] = VF[ch];
-        a.out_normal[pid] = surface ? N[0] : 0.f;
-        a.out_normal[N_ + pid] = surface ? N[1] : 0.f;
-        a.out_normal[2 * N_ + pid] = surface ? N[2] : 0.f;
+        for (int ch = 0; ch < VC; ch++) a.out_vfeature[ch * N_ + pid] = vchan(ch);
+        a.out_normal[pid] = surface ? chan(3) : 0.f;
+        a.out_normal[N_ + pid] = surface ? chan(4) : 0.f;
+        a.out_normal[2 * N_ + pid] = surface ? chan(5) : 0.f;
         a.out_depth[pid] = normalize_depth ? D / (1.f - T) : D + T * 10.f;
         a.out_opacity[pid] = 1.f - T;
         a.final_D[pid] = D;
@@ -364,9 +415,9 @@ render_fwd_kernel(const RenderArgs a) {
 #endif
 template <int S, int VC, bool SVGSS>
 void launch(const RenderArgs& a, hipStream_t s) {
-    using SG = StageGeom<S, VC>;
+    using PG = PairGeom<S, VC>;
     hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(4 * a.gx * a.gy), dim3(64),
-                       std::max(SG::lds_bytes(), (size_t)FWD_LDS_MIN), s, a);
+                       std::max(PG::lds_bytes(), (size_t)FWD_LDS_MIN), s, a);
 }
 
 }  // namespace

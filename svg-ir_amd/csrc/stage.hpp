@@ -25,7 +25,7 @@ struct StageGeom {
     static constexpr int CH = NF <= 48 ? 64 : 32;    // candidates staged per batch (<= ~13 KB of LDS per wave)
     static constexpr int QN = 2 * CH;                // {gid, slot} entries of the current and the next staging batch
 #ifndef FWD_KB_V
-#define FWD_KB_V 2
+#define FWD_KB_V 4
 #endif
 #ifndef FWD_KB_P
 #define FWD_KB_P 4
