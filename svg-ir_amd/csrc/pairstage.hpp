@@ -27,7 +27,7 @@ namespace svgir {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int S, int VC>
+template <int S, int VC, int CHN = (VC > 0 ? 16 : 64)>
 struct PairGeom {
     static constexpr bool SV = VC > 0;
     static constexpr int GEOF = SV ? 18 : 10;              // geometry fields per candidate
@@ -39,7 +39,7 @@ struct PairGeom {
     static constexpr int NVP = VCP / 2;                    // vfeature accumulator pairs
     static constexpr int PF = 2 * GEOF + 2 * CHP + 2 * VB; // floats per staged pair
     static constexpr int CH_OFF = 2 * GEOF, V_OFF = 2 * GEOF + 2 * CHP;
-    static constexpr int CH = SV ? 16 : 64;                // candidates staged per batch
+    static constexpr int CH = CHN;                         // candidates staged per batch (forward: 16 / 64)
     static constexpr int QN = 2 * CH;
     // gather geometry: record pieces (16 bytes) per candidate and the lane -> (candidate, piece) split
     static constexpr int RSLOT = SV ? 8 : 4;               // lanes per candidate in a record load (svgss: 6 of 8 used)
@@ -97,7 +97,7 @@ __device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x) {
 // A negative offset = the value is not staged.
 template <int S, int VC>
 __device__ __forceinline__ void rec_piece_dest(int piece, int j, int& off, int& odd_step) {
-    using PG = PairGeom<S, VC>;
+    using PG = PairGeom<S, VC>;   // (offsets do not depend on the batch size)
     constexpr int G = 0, C = 1, X = 2;   // geometry field / channel / dropped
     // source float 4*piece + j of the record (common.hpp RecField) -> {kind, index}
     constexpr int kind[24] = {G, G, G, G,  G, G, G, G,  G, G, G, G,  G, C, C, C,  C, C, C, G,  G, G, G, X};
@@ -111,9 +111,9 @@ __device__ __forceinline__ void rec_piece_dest(int piece, int j, int& off, int& 
     else { off = -1; odd_step = 0; }
 }
 
-template <int S, int VC>
+template <int S, int VC, int CHN = (VC > 0 ? 16 : 64)>
 struct PairRegs {
-    using PG = PairGeom<S, VC>;
+    using PG = PairGeom<S, VC, CHN>;
     f32x4 r[PG::KR];
     f32x4 v[PG::KVF > 0 ? PG::KVF : 1];
     float f[PG::KF > 0 ? PG::KF : 1];
@@ -121,9 +121,9 @@ struct PairRegs {
 
 // Per-lane constants of the scatter: byte addresses (relative to the staging buffer) of the four destinations of the
 // lane's record piece for its candidate of load 0 (load u adds u * RCPL / 2 pairs), and of its vfeature channel.
-template <int S, int VC>
+template <int S, int VC, int CHN = (VC > 0 ? 16 : 64)>
 struct PairMap {
-    using PG = PairGeom<S, VC>;
+    using PG = PairGeom<S, VC, CHN>;
     int rpiece;       // record piece this lane fetches (0..5), -1: idle lane
     int rdst[4];      // float offsets, -1: dropped
     int vch;          // vfeature channel this lane fetches, -1: idle
@@ -144,11 +144,11 @@ struct PairMap {
     }
 };
 
-template <int S, int VC, typename GidOf>
-__device__ __forceinline__ void pair_stage_load(PairRegs<S, VC>& r, const PairMap<S, VC>& mp, int m, GidOf gid_of, int lane,
+template <int S, int VC, int CHN, typename GidOf>
+__device__ __forceinline__ void pair_stage_load(PairRegs<S, VC, CHN>& r, const PairMap<S, VC, CHN>& mp, int m, GidOf gid_of, int lane,
                                                 const float* __restrict__ rec, const float* __restrict__ feat,
                                                 const float* __restrict__ vfeat) {
-    using PG = PairGeom<S, VC>;
+    using PG = PairGeom<S, VC, CHN>;
     const f32x4* rec4 = reinterpret_cast<const f32x4*>(rec);
     const f32x4* vf4 = reinterpret_cast<const f32x4*>(vfeat);
     const int rc = lane / PG::RSLOT, rp = mp.rpiece < 0 ? 0 : mp.rpiece;
@@ -176,10 +176,10 @@ __device__ __forceinline__ void pair_stage_load(PairRegs<S, VC>& r, const PairMa
     }
 }
 
-template <int S, int VC>
-__device__ __forceinline__ void pair_stage_store(const PairRegs<S, VC>& r, const PairMap<S, VC>& mp, float* __restrict__ sD, int m,
-                                                 int lane) {
-    using PG = PairGeom<S, VC>;
+template <int S, int VC, int CHN>
+__device__ __forceinline__ void pair_stage_store(const PairRegs<S, VC, CHN>& r, const PairMap<S, VC, CHN>& mp, float* __restrict__ sD,
+                                                 int m, int lane) {
+    using PG = PairGeom<S, VC, CHN>;
     const int rc = lane / PG::RSLOT;
 #pragma unroll
     for (int u = 0; u < PG::KR; u++) {

@@ -257,6 +257,32 @@ render_bwd_kernel(const RenderBwdArgs a) {
 
         for (int c0 = 0; c0 < m; c0 += SB) {
             uint32_t live = 0;  // bit cs set: candidate c0+cs has at least one blending pixel (wave-uniform)
+            if (VC > 0 && sp) {
+                // h[pixel][(candidate, corner)] = sum_ch vfeature[candidate][ch][corner] * gVF[pixel][ch] for the SB = 4
+                // candidates of this block on the matrix pipe: M = pixels (4 tiles of 16), K = channels (4 steps of 4),
+                // N = (candidate, corner).  A = the gVF columns of sG, B = the staged vfeature floats (lane: channel
+                // 4 ks + (l >> 4), candidate (l & 15) >> 2, corner l & 3).  The D tiles (lane l, register r: pixel
+                // 16 mt + 4 (l >> 4) + r, column l & 15) go to the weight panel's rows (candidate, corner) -- the rows phase A
+                // later overwrites with the blend weights of the same (candidate, corner) -- and are read back lane = pixel.
+                f32x4 hacc[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) hacc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* vb = sD + (c0 + (colB >> 2)) * SG::NF + SG::V_OFF + (colB & 3);
+#pragma unroll
+                for (int ks = 0; ks < (VC + 3) / 4; ks++) {
+                    const int ch = 4 * ks + grpB;
+                    const float bv = ch < VC ? vb[4 * ch] : 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) {
+                        const float av = ch < VC ? sG[(16 * mt + colB) * GROW + NC0 + ch] : 0.f;
+                        hacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, hacc[mt], 0, 0, 0);
+                    }
+                }
+                wave_lds_sync();   // (the previous block's phase B has read its panel)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) *reinterpret_cast<f32x4*>(sP + colB * PS + 16 * mt + 4 * grpB) = hacc[mt];
+                wave_lds_sync();
+            }
             // ---------------- phase A: lane = pixel, KB candidates per branch-free group, lock-step ----------------
 #pragma unroll 1
             for (int cs0 = 0; cs0 < SB && c0 + cs0 < m; cs0 += KB) {
@@ -323,15 +349,12 @@ render_bwd_kernel(const RenderBwdArgs a) {
                 if (VC > 0) {
 #pragma unroll
                     for (int k = 0; k < KB; k++) {
-                        // sum_ch (c4[ch] . cw) gVF[ch] = cw . (sum_ch c4[ch] gVF[ch])
-                        const float4* vf = reinterpret_cast<const float4*>(sD + (cb + k) * SG::NF + SG::V_OFF);
-                        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
-#pragma unroll
-                        for (int ch = 0; ch < VC; ch++) {
-                            const float4 c4 = vf[ch];
-                            h0 += c4.x * gVF[ch]; h1 += c4.y * gVF[ch]; h2 += c4.z * gVF[ch]; h3 += c4.w * gVF[ch];
+                        // sum_ch (c4[ch] . cw) gVF[ch] = cw . (sum_ch c4[ch] gVF[ch]) = cw . h (h: the block's MFMA above)
+                        if (sp) {
+                            const float* hp = sP + ((cs0 + k) * 4) * PS + lane;
+                            const float h0 = hp[0], h1 = hp[PS], h2 = hp[2 * PS], h3 = hp[3 * PS];
+                            sd[k] += (h0 * cw0[k] + h1 * cw1[k]) + (h2 * cw2[k] + h3 * cw3[k]);
                         }
-                        sd[k] += (h0 * cw0[k] + h1 * cw1[k]) + (h2 * cw2[k] + h3 * cw3[k]);
                     }
                 }
                 // (2) the sequential part: T <- T / (1 - alpha) and the scalar replay recurrence (backward.cu:700-850)

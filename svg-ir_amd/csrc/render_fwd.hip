@@ -233,7 +233,7 @@ render_fwd_kernel(const RenderArgs a) {
         PairMap<S, VC> pmap;
         pmap.init(lane);
         PairRegs<S, VC> sr;
-        pair_stage_load<S, VC>(sr, pmap, min(CH, total), [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
+        pair_stage_load<S, VC, CH>(sr, pmap, min(CH, total), [&](int s) { return sQ[s].x; }, lane, a.rec, a.features, a.vfeatures);
         bool wave_done = __all(done);
         int nflush = 0;   // candidates of the previous batch whose out_weights sums are still parked in LDS
         // out_weights of a batch: one atomic instruction, lane = candidate.  It is issued one batch late, BEFORE the next
@@ -250,7 +250,7 @@ render_fwd_kernel(const RenderArgs a) {
             const uint2* q_cur = sQ + (b & 1) * CH;
             float* w_cur = sW + (b & 1) * CH;
             wave_lds_sync();   // previous batch fully consumed
-            pair_stage_store<S, VC>(sr, pmap, sD, m, lane);
+            pair_stage_store<S, VC, CH>(sr, pmap, sD, m, lane);
             flush_weights(b - 1);
             wave_lds_sync();   // ... before its {gid, slot} entries are overwritten
             if (lane < CH) sQ[((b + 1) & 1) * CH + lane] = e_next;
@@ -258,7 +258,7 @@ render_fwd_kernel(const RenderArgs a) {
             wave_lds_sync();
             if (b + 1 < nb) {
                 const uint2* q_nxt = sQ + ((b + 1) & 1) * CH;
-                pair_stage_load<S, VC>(sr, pmap, min(CH, total - (b + 1) * CH), [&](int s) { return q_nxt[s].x; }, lane, a.rec,
+                pair_stage_load<S, VC, CH>(sr, pmap, min(CH, total - (b + 1) * CH), [&](int s) { return q_nxt[s].x; }, lane, a.rec,
                                        a.features, a.vfeatures);
             }
             DEV_TRACE_MARK(1);   // staging
