@@ -172,6 +172,7 @@ class BlobAllocator:
         return out
 
 
+CLEAR_HINT = True   # pass the gradient blob as svgir_grads.clear_base (tests switch it off to cover the per-tensor clears)
 POISON = os.environ.get("SVGIR_POISON", "") not in ("", "0")   # tests: NaN-fill every buffer the library must overwrite
 
 

@@ -122,7 +122,8 @@ class _CBinding:
             g.dL_dnormal, g.dL_ddepth, g.dL_dmeans3D = dL_dnormal.data_ptr(), dL_ddepth.data_ptr(), dL_dmeans3D.data_ptr()
             g.dL_dcov3D, g.dL_dsh, g.dL_dscales = dL_dcov3D.data_ptr(), N.ptr(dL_dsh), dL_dscales.data_ptr()
             g.dL_drotations = dL_drotations.data_ptr()
-            g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
+            if N.CLEAR_HINT:
+                g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
             rad = radii.contiguous()
             # scratch: one packed gradient row per Gaussian (include/svgir_raster.h)
             nscr = N.lib.svgir_backward_scratch_bytes(N.RGSS, P, binningBuffer.numel(), W, H, S, 0)

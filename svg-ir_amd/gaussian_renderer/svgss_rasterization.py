@@ -123,7 +123,8 @@ class _CBinding:
             g.dL_dnormal, g.dL_ddepth, g.dL_dmeans3D = dL_dnormal.data_ptr(), dL_ddepth.data_ptr(), dL_dmeans3D.data_ptr()
             g.dL_dcov3D, g.dL_dsh, g.dL_dscales = dL_dcov3D.data_ptr(), N.ptr(dL_dsh), dL_dscales.data_ptr()
             g.dL_drotations = dL_drotations.data_ptr()
-            g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
+            if N.CLEAR_HINT:
+                g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
             g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
             rad = radii.contiguous()
             # scratch for the gradient accumulation (rows per (instance, sub-tile), summed per Gaussian)

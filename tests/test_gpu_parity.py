@@ -376,3 +376,23 @@ def test_prefiltered_flag_reports_culled_points(built):
     res = GaussianRasterizer(st)(**kw2)
     assert res[0] == out_all["num_rendered"]
     assert torch.equal(res[1], out_all["color"])
+
+
+@pytest.mark.parametrize("variant,S,VS", [("rgss", 5, 0), ("svgss", 3, 8)])
+def test_outputs_need_no_clearing_by_the_caller(built, variant, S, VS, monkeypatch):
+    """ABI 5: the library writes / clears every output itself.  The suite runs with SVGIR_POISON=1 (conftest.py: the
+    bindings NaN-fill every output and gradient buffer before the call); here additionally WITHOUT the clear_base hint, so
+    that svgir_backward clears the gradient tensors one by one on its side stream -- and twice in a row, so that the second
+    call runs while buffers of the first are being recycled by the allocator."""
+    from gaussian_renderer import _native
+    assert _native.POISON, "tests are expected to run with poisoned output buffers"
+    monkeypatch.setattr(_native, "CLEAR_HINT", False)
+    sc = scenes.surface_scene(P=5000, W=160, H=112, seed=93, sh_degree=2, variant=variant, S=S, VS=VS, scale_lo=0.01, scale_hi=0.07)
+    grads = scenes.upstream_grads(sc, variant, seed=5)
+    for _ in range(2):
+        out, leaves, o, R = _run_both(sc, variant, grads)
+        _check_forward(out, o, R, variant)
+        _check_backward(leaves, o, variant)
+    for k, v in out.items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            assert torch.isfinite(v).all(), k
