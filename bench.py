@@ -241,8 +241,10 @@ def timed(wl, args, world, dev, dry=None):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             R, color, gm = step()
-            gatherer.submit(metrics(R, color, gm))
-        gatherer.results()   # inside the timed region: the last collective has completed
+            if world > 1:   # (one rank: nothing to gather -- the checksums of the last step are taken after the region)
+                gatherer.submit(metrics(R, color, gm))
+        if world > 1:
+            gatherer.results()   # inside the timed region: the last collective has completed
         vp.barrier()
         sync()
         regions.append(time.perf_counter() - t0)
@@ -253,6 +255,8 @@ def timed(wl, args, world, dev, dry=None):
     el = torch.tensor(regions, dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    if gatherer.results() is None:   # (no warm-up steps on one rank)
+        gatherer.submit(metrics(R, color, gm))
     table = gatherer.results().clone()
     table[:, 1:] = vp.gather_rows(checksums(R, color, gm))[:, 1:]
     return el.cpu().numpy(), int(R), stage, table.cpu().numpy()

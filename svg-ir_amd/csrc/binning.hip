@@ -259,31 +259,36 @@ __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t
     if (i == R - 1) ranges[2 * cur + 1] = (uint32_t)R;
 }
 
-// One-block counting sort of n work items by descending size (1024 size buckets): order[] = item ids, largest first.
+// One-block counting sort of n work items by descending size: order[] = item ids, largest first.  1024 size buckets, one
+// per count below 1023 (exact order there; everything longer shares the first bucket -- those waves start first anyway).
 __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __restrict__ counts, int n,
                                                           uint32_t* __restrict__ order) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t maxlen_s;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     hist[t] = 0;
-    if (t == 0) maxlen_s = 0;
     __syncthreads();
-    uint32_t mx = 0;
-    for (int i = t; i < n; i += 1024) mx = max(mx, counts[i]);
-    atomicMax(&maxlen_s, mx);
-    __syncthreads();
-    const uint32_t maxlen = maxlen_s + 1;
     // Items of size 0 (most of an image is usually empty) all land in the last bucket: they are counted with one
     // atomic per wave instead of one per item, and placed in index order at the very end.
-    for (int i0 = 0; i0 < n; i0 += 1024) {
+    constexpr int KEEP = 12;   // counts cached in registers between the two passes (n <= 12288 = an 880 x 880 image)
+    uint32_t cache[KEEP];
+#pragma unroll
+    for (int q = 0; q < KEEP; q++) {
+        const int i = q * 1024 + t;
+        cache[q] = i < n ? counts[i] : 1u;
+    }
+    auto count_of = [&](int q, int i) -> uint32_t { return i < n ? counts[i] : 1u; };
+    for (int i0 = 0, q = 0; i0 < n; i0 += 1024, q++) {
         const int i = i0 + t;
-        const uint32_t len = i < n ? counts[i] : 1u;
-        const unsigned long long zero = __ballot(i < n && len == 0u);
-        if (i < n && len != 0u) {
-            const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
-            atomicAdd(&hist[b], 1u);
+        uint32_t len = 1u;
+        if (q < KEEP) {
+#pragma unroll
+            for (int qq = 0; qq < KEEP; qq++) len = qq == q ? cache[qq] : len;
+        } else {
+            len = count_of(q, i);
         }
+        const unsigned long long zero = __ballot(i < n && len == 0u);
+        if (i < n && len != 0u) atomicAdd(&hist[1023u - min(1023u, len)], 1u);
         if (lane == 0 && zero) atomicAdd(&hist[1023], (uint32_t)__popcll(zero));
     }
     __syncthreads();
@@ -303,15 +308,18 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
     hist[t] = woff + incl - v;  // becomes the bucket cursor
     __syncthreads();
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int i0 = 0; i0 < n; i0 += 1024) {
+    for (int i0 = 0, q = 0; i0 < n; i0 += 1024, q++) {
         const int i = i0 + t;
-        const uint32_t len = i < n ? counts[i] : 1u;
+        uint32_t len = 1u;
+        if (q < KEEP) {
+#pragma unroll
+            for (int qq = 0; qq < KEEP; qq++) len = qq == q ? cache[qq] : len;
+        } else {
+            len = count_of(q, i);
+        }
         const bool z = i < n && len == 0u;
         const unsigned long long zero = __ballot(z);
-        if (i < n && len != 0u) {
-            const uint32_t b = 1023u - min(1023u, (uint32_t)(((unsigned long long)len * 1024ull) / maxlen));
-            order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
-        }
+        if (i < n && len != 0u) order[atomicAdd(&hist[1023u - min(1023u, len)], 1u)] = (uint32_t)i;
         uint32_t zbase = 0;
         if (lane == 0 && zero) zbase = atomicAdd(&hist[1023], (uint32_t)__popcll(zero));
         zbase = (uint32_t)__shfl((int)zbase, 0);

@@ -163,9 +163,17 @@ render_fwd_kernel(const RenderArgs a) {
 
     bool done = !inside;
     float T = 1.0f, D = 0.f;
-    // Channel and vfeature accumulators live on the matrix pipe: acc[mt] / vacc[mt] are the D tiles of
-    // v_mfma_f32_16x16x4_f32 for the pixels 16 mt .. 16 mt + 15 (lane l, register r: pixel 16 mt + 4 (l >> 4) + r,
-    // channel l & 15).  Channels: r g b nx ny nz F0..F(S-1).
+    // Channel accumulators (r g b nx ny nz F0..F(S-1)) and vfeature accumulators.
+    //  * with vfeatures (svgss widths) they live on the matrix pipe: acc[mt] / vacc[mt] are the D tiles of
+    //    v_mfma_f32_16x16x4_f32 for the pixels 16 mt .. 16 mt + 15 (lane l, register r: pixel 16 mt + 4 (l >> 4) + r,
+    //    channel l & 15): the 4 + 52..64 products per (pixel, candidate) would otherwise be 13-16 broadcast ds_read_b128 and
+    //    as many VALU instructions per candidate -- the forward at those widths was bound by exactly that;
+    //  * without (rgss: 11 channels) packed FMAs on channel pairs (C0,C1) (C2,N0) ... are cheaper than the panel round trip.
+    constexpr bool MF = VC > 0;
+    constexpr int NPAIR = (PG::NCH + 1) / 2;
+    f32x2 accp[NPAIR];
+#pragma unroll
+    for (int i = 0; i < NPAIR; i++) accp[i] = (f32x2){0.f, 0.f};
     f32x4 acc[4], vacc[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; vacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -173,6 +181,11 @@ render_fwd_kernel(const RenderArgs a) {
     // lane = pixel view of the accumulators (through the LDS tile): chv[c], vfv[c]
     float chv[PG::NCH], vfv[VC > 0 ? VC : 1];
     auto gather_acc = [&]() {
+        if (!MF) {
+#pragma unroll
+            for (int c = 0; c < PG::NCH; c++) chv[c] = (c & 1) ? accp[c >> 1].y : accp[c >> 1].x;
+            return;
+        }
         wave_lds_sync();
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
@@ -326,35 +339,49 @@ render_fwd_kernel(const RenderArgs a) {
                     D += dep.x * w[2 * p];
                     D += dep.y * w[2 * p + 1];
                 }
-                // colour / normal / feature / vfeature sums on the matrix pipe: panel rows (lane = pixel) -> A operands
-#pragma unroll
-                for (int k = 0; k < KB; k++) sP[k * PS + lane] = w[k];
-                if (VC > 0) {
-#pragma unroll
-                    for (int k = 0; k < KB; k++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const float wj = (k & 1) ? wq[k >> 1][j].y : wq[k >> 1][j].x;
-                            sP[(4 + k * 4 + j) * PS + lane] = sp ? wj : 0.f;
-                        }
-                }
-                wave_lds_sync();
-                {   // channels: K = the 4 candidates of the group; B[k][n] = channel n of candidate k
-                    const float bch = sD[((c0 >> 1) + (kq >> 1)) * PF + PG::CH_OFF + (kq & 1) * PG::CHP + nq];
-#pragma unroll
-                    for (int mt = 0; mt < 4; mt++)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[kq * PS + 16 * mt + nq], bch, acc[mt], 0, 0, 0);
-                }
-                if (VC > 0) {   // vfeatures: one MFMA set per candidate, K = its 4 corners; B[k][n] = corner k of channel n
+                if (!MF) {
 #pragma unroll
                     for (int k = 0; k < KB; k++) {
-                        const float bv = sD[((c0 + k) >> 1) * PF + PG::V_OFF + (k & 1) * PG::VB + kq * PG::VCP + nq];
+                        const f32x4* Cb = reinterpret_cast<const f32x4*>(sD + ((c0 + k) >> 1) * PF + PG::CH_OFF + (k & 1) * PG::CHP);
+                        const f32x2 ww = {w[k], w[k]};
 #pragma unroll
-                        for (int mt = 0; mt < 4; mt++)
-                            vacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[(4 + k * 4 + kq) * PS + 16 * mt + nq], bv, vacc[mt], 0, 0, 0);
+                        for (int q = 0; q < (PG::NCH + 3) / 4; q++) {
+                            const f32x4 c4 = Cb[q];
+                            accp[2 * q] = __builtin_elementwise_fma(c4.xy, ww, accp[2 * q]);
+                            if (2 * q + 1 < NPAIR) accp[2 * q + 1] = __builtin_elementwise_fma(c4.zw, ww, accp[2 * q + 1]);
+                        }
                     }
+                } else {
+                    // colour / normal / feature / vfeature sums on the matrix pipe: panel rows (lane = pixel) -> A operands
+    #pragma unroll
+                    for (int k = 0; k < KB; k++) sP[k * PS + lane] = w[k];
+                    if (VC > 0) {
+    #pragma unroll
+                        for (int k = 0; k < KB; k++)
+    #pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const float wj = (k & 1) ? wq[k >> 1][j].y : wq[k >> 1][j].x;
+                                sP[(4 + k * 4 + j) * PS + lane] = sp ? wj : 0.f;
+                            }
+                    }
+                    wave_lds_sync();
+                    {   // channels: K = the 4 candidates of the group; B[k][n] = channel n of candidate k
+                        const float bch = sD[((c0 >> 1) + (kq >> 1)) * PF + PG::CH_OFF + (kq & 1) * PG::CHP + nq];
+    #pragma unroll
+                        for (int mt = 0; mt < 4; mt++)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[kq * PS + 16 * mt + nq], bch, acc[mt], 0, 0, 0);
+                    }
+                    if (VC > 0) {   // vfeatures: one MFMA set per candidate, K = its 4 corners; B[k][n] = corner k of channel n
+    #pragma unroll
+                        for (int k = 0; k < KB; k++) {
+                            const float bv = sD[((c0 + k) >> 1) * PF + PG::V_OFF + (k & 1) * PG::VB + kq * PG::VCP + nq];
+    #pragma unroll
+                            for (int mt = 0; mt < 4; mt++)
+                                vacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sP[(4 + k * 4 + kq) * PS + 16 * mt + nq], bv, vacc[mt], 0, 0, 0);
+                        }
+                    }
+                    wave_lds_sync();   // panel consumed before the next group overwrites it
                 }
-                wave_lds_sync();   // panel consumed before the next group overwrites it
                 // ---- (4) out_weights: KB interleaved wave reductions, parked in LDS ----
                 float ws[KB];
 #pragma unroll
