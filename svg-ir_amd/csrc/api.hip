@@ -539,6 +539,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     } else {
         HIP_OK(hipMemsetAsync(ba.grad_rows, 0, (size_t)P * rg.RS * 4, s));
     }
+    tm.mark("bwd_clear");   // scratch / validity clears and the side-stream fork: the composite's own mark brackets the kernel only
     if (R > 0) {
         if (generic) launch_render_bwd_generic(ba, svgss, s);
         else (void)launch_render_bwd(ba, svgss, s);
