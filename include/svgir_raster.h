@@ -295,6 +295,20 @@ int svgir_unpack_rgss_backward(int32_t W, int32_t H, const int32_t* num_contrib,
 int svgir_depth2normal(int32_t W, int32_t H, const float* depth, const float* mask, float fovx, float fovy, float prcp_x,
                        float prcp_y, float* normal, void* stream);
 
+/* Image losses behind render_view: L1 and SSIM with the reference's 11 x 11 Gaussian window
+ * (`F.l1_loss(image, gt)` and `ssim(image, gt)`, gaussian_renderer/svgss.py:281-289, render.py:150-151;
+ * utils/loss_utils.py:21-64), img1 / img2 = [C,H,W] planes.
+ *   forward : writes 2 floats per 16x16 tile and channel -- the tile's sums of the SSIM map and of |img1 - img2| -- into
+ *             `partial` [svgir_l1_ssim_partials(C,H,W)][2] (their totals / (C H W) are the two means; summing them is left to
+ *             the caller: a few thousand floats), and, if `dmaps` [3,C,H,W] is not NULL, what the backward needs;
+ *   backward: dL_dimg1 [C,H,W] = g_ssim_mean * d(mean SSIM)/d(img1) + g_l1_mean * d(mean |img1 - img2|)/d(img1), written
+ *             completely.  img2 (the ground truth) gets no gradient. */
+size_t svgir_l1_ssim_partials(int32_t C, int32_t H, int32_t W);
+int svgir_l1_ssim_forward(const float* img1, const float* img2, int32_t C, int32_t H, int32_t W, float* partial, float* dmaps,
+                          void* stream);
+int svgir_l1_ssim_backward(const float* img1, const float* img2, const float* dmaps, int32_t C, int32_t H, int32_t W,
+                           float g_ssim_mean, float g_l1_mean, float* dL_dimg1, void* stream);
+
 /* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
  * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,
  * the AVERAGE duration in milliseconds and the number of samples since profiling was (re-)enabled.

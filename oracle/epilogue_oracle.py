@@ -9,7 +9,8 @@ Restates, in plain per-element math,
     F.interpolate(mode='bilinear', align_corners=False));
   * the image-space epilogue of `render_view` (gaussian_renderer/svgss.py:187-262): division by the rendered opacity,
     channel split, sRGB (`rgb_to_srgb`, utils/graphics_utils.py:198-215), compositing over the background;
-  * `depth2normal` (utils/image_utils.py:61-125).
+  * `depth2normal` (utils/image_utils.py:61-125);
+  * `ssim` + `F.l1_loss` as called on the rendered image (utils/loss_utils.py:21-64; svgss.py:281-289, render.py:150-151).
 Parity: PINNED -- tests/golden/{incident_dirs,lights,render_view}.npz hold inputs and outputs produced by running the
 reference's own functions (and its whole `render_view` with a recording stub rasterizer) in the authoring container
 (scripts/make_golden_view.py); tests/test_view_fixtures.py checks every function here against them.
@@ -173,3 +174,29 @@ def unpack_svgss_torch(opacity, feature, vfeature, bg, training):
                    direct=srgb(direct), indirect=srgb(indirect), roughness=over(rough))
     res.update(pbr=srgb(over(pbr)), normal=normal.expand(3, -1, -1))
     return res
+
+
+# ---- f2: image losses --------------------------------------------------------------------------------------------
+def ssim_window():
+    """utils/loss_utils.py:21-23 `gaussian(11, 1.5)`: fp32 values, divided by their fp32 sum."""
+    g = np.array([math.exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)], dtype=np.float32)
+    return (g / g.sum(dtype=np.float32)).astype(np.float64)
+
+
+def l1_ssim_torch(img1, img2):
+    """(mean |img1 - img2|, mean SSIM map) in differentiable torch fp64 -- utils/loss_utils.py:44-61 with the 2-D window
+    written out (outer product of the 1-D one), zero padding, one depthwise convolution per windowed moment."""
+    import torch
+    a, b = img1.to(torch.float64), img2.to(torch.float64)
+    C = a.shape[0]
+    g = torch.from_numpy(ssim_window()).to(a.device)
+    w = (g[:, None] * g[None, :])[None, None].expand(C, 1, 11, 11)
+
+    def blur(x):
+        return torch.nn.functional.conv2d(x[None], w, padding=5, groups=C)[0]
+
+    mu1, mu2 = blur(a), blur(b)
+    s1, s2, s12 = blur(a * a) - mu1 * mu1, blur(b * b) - mu2 * mu2, blur(a * b) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    smap = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))
+    return (a - b).abs().mean(), smap.mean()

@@ -1,5 +1,5 @@
 """Reference-run fixtures for the callers either side of the rasterizer (tests/golden/render_view.npz, lights.npz,
-incident_dirs.npz).  Runs only in the authoring container: imports the REFERENCE's own Python from /root/reference
+incident_dirs.npz, render_view_rgss.npz, losses.npz).  Runs only in the authoring container: imports the REFERENCE's own Python from /root/reference
 and executes it on CPU; the committed fixtures are data (inputs + the reference's outputs), no reference source.
 
 What is executed, unmodified, from the reference:
@@ -304,9 +304,36 @@ def incident_dir_fixtures():
     print("wrote incident_dirs.npz", len(out), "arrays")
 
 
+def loss_fixtures():
+    """utils/loss_utils.py `ssim` and F.l1_loss exactly as gaussian_renderer/svgss.py:281-282 calls them on [3,H,W] images,
+    with the autograd gradients w.r.t. the rendered image."""
+    from utils.loss_utils import ssim
+    import torch.nn.functional as F
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    for tag, (H, W) in (("a", (45, 70)), ("b", (64, 64)), ("c", (17, 23))):
+        gt = torch.rand(3, H, W, generator=g)
+        gt[:, : H // 3] = 0.25                                        # a flat region (sigma ~ 0)
+        img = (gt + 0.15 * torch.randn(3, H, W, generator=g)).clamp(0, 1).requires_grad_(True)
+        with cpu_reference():
+            s = ssim(img, gt)
+            l1 = F.l1_loss(img, gt)
+            gs, = torch.autograd.grad(s, img, retain_graph=True)
+            gl, = torch.autograd.grad(l1, img)
+        out[f"{tag}_img"], out[f"{tag}_gt"] = np32(img.detach()), np32(gt)
+        out[f"{tag}_ssim"], out[f"{tag}_l1"] = np32(s.detach()), np32(l1.detach())
+        out[f"{tag}_dssim"], out[f"{tag}_dl1"] = np32(gs), np32(gl)
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+    print("wrote losses.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     setup_reference()
+    if "--losses-only" in sys.argv:
+        loss_fixtures()
+        sys.exit(0)
     incident_dir_fixtures()
     light_fixtures()
     render_view_fixtures()
     rgss_view_fixtures()
+    loss_fixtures()

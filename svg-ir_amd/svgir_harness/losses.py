@@ -1,0 +1,58 @@
+"""L1 and SSIM of a rendered image against the ground truth, fused (csrc/loss.hip): the reference's
+`F.l1_loss(image, gt)` + `ssim(image, gt)` (gaussian_renderer/svgss.py:281-289, render.py:150-151;
+utils/loss_utils.py:21-64), one kernel forward, one backward."""
+import ctypes as C
+
+import torch
+
+from gaussian_renderer import _native as N
+
+N.lib.svgir_l1_ssim_partials.restype = C.c_size_t
+N.lib.svgir_l1_ssim_partials.argtypes = [C.c_int32] * 3
+N.lib.svgir_l1_ssim_forward.restype = C.c_int
+N.lib.svgir_l1_ssim_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+N.lib.svgir_l1_ssim_backward.restype = C.c_int
+N.lib.svgir_l1_ssim_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                         C.c_void_p, C.c_void_p]
+
+
+class _L1Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt):
+        dev = img.device
+        if dev.type != "cuda":
+            raise RuntimeError("l1_ssim: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
+        a, b = N.f32c(img, dev), N.f32c(gt, dev)
+        Cc, H, W = a.shape[-3], a.shape[-2], a.shape[-1]
+        nblk = N.lib.svgir_l1_ssim_partials(Cc, H, W)
+        partial = torch.empty((nblk, 2), dtype=torch.float32, device=dev)
+        need = img.requires_grad
+        dmaps = torch.empty((3, Cc, H, W), dtype=torch.float32, device=dev) if need else None
+        N.check(N.lib.svgir_l1_ssim_forward(a.data_ptr(), b.data_ptr(), Cc, H, W, partial.data_ptr(), N.ptr(dmaps),
+                                            N.stream_ptr(dev)), "l1_ssim forward")
+        sums = partial.to(torch.float64).sum(dim=0) / float(Cc * H * W)
+        ctx.save_for_backward(a, b, dmaps)
+        return sums[1].to(torch.float32), sums[0].to(torch.float32)   # (l1, ssim)
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        a, b, dmaps = ctx.saved_tensors
+        Cc, H, W = a.shape[-3], a.shape[-2], a.shape[-1]
+        out = torch.empty_like(a)
+        gl = 0.0 if g_l1 is None else float(g_l1)
+        gs = 0.0 if g_ssim is None else float(g_ssim)
+        N.check(N.lib.svgir_l1_ssim_backward(a.data_ptr(), b.data_ptr(), dmaps.data_ptr(), Cc, H, W, gs, gl, out.data_ptr(),
+                                             N.stream_ptr(a.device)), "l1_ssim backward")
+        return out, None
+
+
+def l1_ssim(image, gt):
+    """(F.l1_loss(image, gt), ssim(image, gt)) of the reference, [C,H,W] images; differentiable in `image`."""
+    return _L1Ssim.apply(image, gt)
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """Drop-in for utils/loss_utils.py:33 (window 11, size_average=True -- the only form the reference calls)."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("only the reference's call form ssim(img1, img2) is implemented")
+    return l1_ssim(img1, img2)[1]

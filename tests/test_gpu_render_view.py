@@ -1,5 +1,7 @@
 """End-to-end svgss view on the GPU (shading -> packing -> rasterizer -> unpacking, svgir_harness/render_view.py)
 against the same chain assembled from the two CPU oracles in fp64.  Tolerances as in test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,7 @@ from oracle import shading_oracle as so
 from svgir_harness import render_view, runner, scenes, shade_inputs
 
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _cmp(name, a, b, tol=2e-4, flip_frac=5e-4):
@@ -128,3 +131,50 @@ def test_rgss_packing_and_unpacking_match_reference_render_view(built):
     fovx, fovy = g["cam_fov"]
     pn = render_view.depth2normal(ras["depth"], t("image_mask"), fovx, fovy, g["cam_prcppoint"])
     np.testing.assert_allclose(pn.cpu().numpy(), g["res_pseudo_normal"], rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_l1_ssim_kernels_match_reference_losses(built, tag):
+    """csrc/loss.hip against the reference's `ssim` / `F.l1_loss` (fixture: scripts/make_golden_view.py::loss_fixtures) and
+    against the fp64 oracle: values and the gradient w.r.t. the rendered image, for L1 alone, SSIM alone and the training
+    loss's combination (1 - lambda) L1 + lambda (1 - SSIM), lambda = 0.2."""
+    from svgir_harness import losses
+    fx = np.load(os.path.join(GOLD, "losses.npz"))
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(fx[f"{tag}_img"]).to(dev).requires_grad_(True)
+    gt = torch.from_numpy(fx[f"{tag}_gt"]).to(dev)
+    l1, s = losses.l1_ssim(img, gt)
+    assert abs(float(s) - float(fx[f"{tag}_ssim"])) < 1e-5 and abs(float(l1) - float(fx[f"{tag}_l1"])) < 1e-6
+    gs, = torch.autograd.grad(s, img, retain_graph=True)
+    gl, = torch.autograd.grad(l1, img, retain_graph=True)
+    i64 = torch.from_numpy(fx[f"{tag}_img"]).to(torch.float64).requires_grad_(True)
+    o_l1, o_s = eo.l1_ssim_torch(i64, torch.from_numpy(fx[f"{tag}_gt"]))
+    os_, = torch.autograd.grad(o_s, i64, retain_graph=True)
+    ol_, = torch.autograd.grad(o_l1, i64, retain_graph=True)
+    assert abs(float(s) - float(o_s)) < 1e-5 and abs(float(l1) - float(o_l1)) < 1e-6
+    for got, ref in ((gs, os_), (gl, ol_)):
+        ref = ref.numpy()
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert np.abs(gs.cpu().numpy() - fx[f"{tag}_dssim"]).max() <= 3e-4 * np.abs(fx[f"{tag}_dssim"]).max()   # fp32 autograd of the reference
+    lam = 0.2
+    loss = (1 - lam) * l1 + lam * (1 - s)
+    g, = torch.autograd.grad(loss, img)
+    ref = ((1 - lam) * ol_ - lam * os_).numpy()
+    assert np.abs(g.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert float(losses.ssim(img.detach(), gt)) == float(s)
+
+
+def test_l1_ssim_full_size_properties(built):
+    """800 x 800: SSIM of an image with itself is 1 with zero gradient; SSIM and L1 are symmetric in their arguments' values."""
+    from svgir_harness import losses
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(3, 800, 800, generator=g).to(dev).requires_grad_(True)
+    b = torch.rand(3, 800, 800, generator=g).to(dev)
+    l1, s = losses.l1_ssim(a, a.detach().clone())
+    assert abs(float(s) - 1.0) < 1e-6 and float(l1) == 0.0
+    gs, = torch.autograd.grad(s, a)
+    assert float(gs.abs().max()) < 1e-7
+    l1_ab, s_ab = losses.l1_ssim(a, b)
+    l1_ba, s_ba = losses.l1_ssim(b, a.detach())
+    assert abs(float(s_ab) - float(s_ba)) < 1e-6 and abs(float(l1_ab) - float(l1_ba)) < 1e-7

@@ -108,3 +108,22 @@ def test_incident_direction_generation_matches_reference():
     np.testing.assert_allclose(d, g["sample_eval_24"], rtol=0, atol=3e-6)
     d, _ = eo.fibonacci_dirs(g["normals"], 24, offsets=g["sample_train_24_offsets"])
     np.testing.assert_allclose(d, g["sample_train_24"], rtol=0, atol=3e-6)
+
+
+def test_l1_ssim_oracle_matches_the_reference_losses():
+    """oracle/epilogue_oracle.py::l1_ssim_torch against `ssim` / `F.l1_loss` of the reference run in the authoring container
+    (scripts/make_golden_view.py::loss_fixtures), values and autograd gradients."""
+    import torch
+    from oracle import epilogue_oracle as eo
+    fx = np.load(os.path.join(GOLD, "losses.npz"))
+    for tag in ("a", "b", "c"):
+        img = torch.from_numpy(fx[f"{tag}_img"]).to(torch.float64).requires_grad_(True)
+        gt = torch.from_numpy(fx[f"{tag}_gt"]).to(torch.float64)
+        l1, s = eo.l1_ssim_torch(img, gt)
+        gs, = torch.autograd.grad(s, img, retain_graph=True)
+        gl, = torch.autograd.grad(l1, img)
+        assert abs(float(s) - float(fx[f"{tag}_ssim"])) < 2e-6, tag
+        assert abs(float(l1) - float(fx[f"{tag}_l1"])) < 1e-6, tag
+        ref = fx[f"{tag}_dssim"].astype(np.float64)
+        assert np.abs(gs.numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), tag    # (the reference's gradient is fp32 autograd)
+        assert np.abs(gl.numpy() - fx[f"{tag}_dl1"]).max() <= 1e-9, tag
