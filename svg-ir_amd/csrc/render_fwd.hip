@@ -42,14 +42,18 @@ namespace svgir {
 namespace {
 
 // ---- cull: tile list -> four compact sub-tile lists -----------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) cull_kernel(const RenderArgs a) {
-    __shared__ uint32_t wcnt[4][4];   // [wave][sub-tile] survivors of the current round
+#ifndef CULL_THREADS
+#define CULL_THREADS 256
+#endif
+constexpr int CT = CULL_THREADS, CNW = CT / 64;   // threads / waves of a cull workgroup (a tile's list is walked CT entries per round)
+__global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
+    __shared__ uint32_t wcnt[CNW][4];   // [wave][sub-tile] survivors of the current round
     const int tile = blockIdx.x;
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int len = (int)(r1 - r0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    if (a.zero_a || a.zero_b) {   // planes this call leaves at zero: every thread clears its pixel of the tile
+    if (t < 256 && (a.zero_a || a.zero_b)) {   // planes this call leaves at zero: one thread per pixel of the tile
         const int px = tx * TILE + (t & 15), py = ty * TILE + (t >> 4);
         if (px < a.W && py < a.H) {
             const size_t N_ = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
@@ -62,7 +66,7 @@ __global__ void __launch_bounds__(BLOCK) cull_kernel(const RenderArgs a) {
         // 16x16 tile (64-byte rows) and the four composite waves of the tile exit at once (render_fwd_kernel).
         if (t < 4) { a.sub_total[4 * tile + t] = 0u; a.sub_count[4 * tile + t] = 0u; a.sub_ndump[4 * tile + t] = 0u; }
         const int px = tx * TILE + (t & 15), py = ty * TILE + (t >> 4);
-        if (px < a.W && py < a.H) {
+        if (t < 256 && px < a.W && py < a.H) {
             const size_t N_ = (size_t)a.W * a.H;
             const size_t pid = (size_t)a.W * py + px;
             const float T = (float)(1 - 0.000001);   // forward.cu:671
@@ -81,7 +85,7 @@ __global__ void __launch_bounds__(BLOCK) cull_kernel(const RenderArgs a) {
     uint2* __restrict__ out = a.sub_list + (size_t)4 * r0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t run[4] = {0u, 0u, 0u, 0u};   // survivors so far per sub-tile (uniform)
-    for (int base = 0; base < len; base += BLOCK) {
+    for (int base = 0; base < len; base += CT) {
         const int i = base + t;
         bool m[4] = {false, false, false, false};
         uint32_t gid = 0;
@@ -108,13 +112,13 @@ __global__ void __launch_bounds__(BLOCK) cull_kernel(const RenderArgs a) {
         for (int w = 0; w < 4; w++) {
             uint32_t before = 0, all = 0;
 #pragma unroll
-            for (int v = 0; v < 4; v++) { const uint32_t c = wcnt[v][w]; all += c; before += v < wave ? c : 0u; }
+            for (int v = 0; v < CNW; v++) { const uint32_t c = wcnt[v][w]; all += c; before += v < wave ? c : 0u; }
             if (m[w]) out[(size_t)w * len + run[w] + before + (uint32_t)__popcll(mask[w] & lt_mask)] = e;
             run[w] += all;
         }
         __syncthreads();   // counts consumed before the next round overwrites them
     }
-    if (t < 4) a.sub_total[4 * tile + t] = run[t];
+    if (t < 4) a.sub_total[4 * tile + t] = t == 0 ? run[0] : t == 1 ? run[1] : t == 2 ? run[2] : run[3];
 }
 
 // ---- blend --------------------------------------------------------------------------------------------------
@@ -450,7 +454,7 @@ void launch(const RenderArgs& a, hipStream_t s) {
 }  // namespace
 
 void launch_cull(const RenderArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(cull_kernel, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(cull_kernel, dim3(a.gx * a.gy), dim3(CT), 0, s, a);
 }
 
 // Channel-count specialisations: the widths the reference's callers use (render.py:91 S=5; svgss.py:148-166
