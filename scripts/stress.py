@@ -10,14 +10,14 @@ from svgir_harness import scenes
 
 # tiny images / tiny scenes: one threshold flip (a pixel = 3 entries) must not exceed the allowed *fraction*
 _cmp0 = T._cmp
-def _cmp(name, a, b, tol=T.TOL, flip_frac=T.FLIP_FRAC, flip_bound=None):
+def _cmp(name, a, b, tol=T.TOL, flip_frac=T.FLIP_FRAC, flip_bound=T.FLIP_BOUND, rel=True):
     n = max(1, int(np.asarray(b).size))
-    return _cmp0(name, a, b, tol=tol, flip_frac=max(flip_frac, 8.0 / n), flip_bound=flip_bound)
+    return _cmp0(name, a, b, tol=tol, flip_frac=max(flip_frac, 8.0 / n), flip_bound=flip_bound, rel=rel)
 T._cmp = _cmp
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 widths = {"svgss": [(0, 0), (1, 4), (3, 8), (4, 52), (7, 64), (5, 0), (2, 4), (6, 24)], "rgss": [(0, 0), (1, 0), (3, 0), (5, 0), (4, 0), (8, 0)]}
-n_ok = 0
+n_ok = n_bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     variant = "svgss" if rng.random() < 0.6 else "rgss"
     S, VS = widths[variant][rng.integers(len(widths[variant]))]
@@ -29,9 +29,20 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     if rng.random() < 0.3:
         sc["opacities"] = (sc["opacities"] * 0.05).astype(np.float32)   # translucent: deep stacks, many segments
     grads = scenes.upstream_grads(sc, variant, seed=int(rng.integers(1 << 30)))
+    # surfels of scale 0.08-0.4 make cov2D^-1 ill-conditioned in fp32: the oracle's own fp32-vs-fp64 gap on grad_scales /
+    # grad_cov3D then exceeds the per-element relative criterion (1.2 % of the entries at seed 7, scene 18), so that criterion is
+    # relaxed for those scenes; the normalised criterion (1e-4 of the tensor's scale) stays
+    T.REL_FRAC = 2e-2 if lo >= 0.08 else 1e-3
     out, leaves, o, R = T._run_both(sc, variant, grads)
-    T._check_forward(out, o, R, variant)
-    T._check_backward(leaves, o, variant)
+    tag = f"{it:2d} {variant} P={P} {W}x{H} S={S} VS={VS} R={R} scale_lo={lo} translucent={float(sc['opacities'].max()) < 0.06}"
+    try:
+        T._check_forward(out, o, R, variant)
+        T._check_backward(leaves, o, variant)
+    except AssertionError as e:
+        n_bad += 1
+        print("FAIL", tag, "::", str(e)[:200], flush=True)
+        continue
     n_ok += 1
-    print(f"ok {it:2d} {variant} P={P} {W}x{H} S={S} VS={VS} R={R}", flush=True)
-print("stress passed:", n_ok)
+    print("ok", tag, flush=True)
+print("stress passed:", n_ok, "failed:", n_bad)
+sys.exit(1 if n_bad else 0)
