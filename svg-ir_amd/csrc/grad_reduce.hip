@@ -15,6 +15,11 @@ namespace svgir {
 
 namespace {
 
+#ifndef GRAD_REDUCE_RB
+#define GRAD_REDUCE_RB 8
+#endif
+constexpr int RB = GRAD_REDUCE_RB;   // gradient rows in flight per wave
+
 __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs a, const GradRowGeom rg) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -31,24 +36,25 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
         const uint32_t s = s0 + (uint32_t)lane;
         unsigned long long m = __ballot(s < nslots && a.row_flags[base + s] != 0);
         any = any || m != 0ull;
-        // up to four valid rows per step: all their loads are issued before the first add (one memory latency per
-        // four rows instead of one per row); the adds keep slot order, so the result is reproducible
+        // up to RB valid rows per step: all their loads are issued before the first add (one memory latency per RB rows
+        // instead of one per row -- most Gaussians have fewer than RB valid rows, i.e. one round trip); the adds keep slot
+        // order, so the result is reproducible
         while (m) {
-            int b[4];
+            int b[RB];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < RB; k++) {
                 b[k] = m ? __builtin_ctzll(m) : -1;
                 m &= m - 1;   // (0 & anything stays 0)
             }
-            float v0[4], v1[4];
+            float v0[RB], v1[RB];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < RB; k++) {
                 const float* row = a.grad_rows + (base + s0 + (uint32_t)(b[k] >= 0 ? b[k] : b[0])) * (size_t)rg.RS;
                 v0[k] = lane < rg.RS ? row[lane] : 0.f;
                 v1[k] = lane + 64 < rg.RS ? row[lane + 64] : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < RB; k++)
                 if (b[k] >= 0) { acc0 += v0[k]; acc1 += v1[k]; }
         }
     }
