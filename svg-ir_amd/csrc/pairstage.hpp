@@ -1,24 +1,22 @@
-// svg-ir_amd/csrc/pairstage.hpp -- pair-interleaved LDS staging for the composite kernels (packed fp32 math).
+// svg-ir_amd/csrc/pairstage.hpp -- pair-interleaved LDS staging of the forward composite (packed fp32 math, MFMA operands).
 //
-// The composite kernels are bound by VALU issue (one wave64 fp32 instruction = 4 cycles; ~50 per (wave, candidate) in the
-// forward).  gfx950 executes v_pk_{add,mul,fma}_f32 -- two fp32 lanes per VGPR pair -- at the same rate, so the
-// per-candidate arithmetic is done on PAIRS:
-//   * everything that is computed per candidate and not summed over candidates (pixel offsets, the conic form, exp, alpha,
-//     depth differencing, bilinear corner weights; in the backward also the dot products with the upstream gradients and
-//     the geometric gradients) runs on two consecutive candidates at once: element-wise the same operations in the same
-//     order, i.e. bit-identical results;
-//   * the per-pixel accumulators (colour, normal, features, vfeatures), whose sums run over the candidates in list order,
-//     are paired over CHANNELS instead: (C0,C1) += (r,g) * (w,w), ... -- again the same operation order per channel.
-// The operands of a packed instruction are aligned VGPR pairs, so the staged data has to arrive that way: a staged PAIR of
-// candidates (c0 = even slot, c1 = odd slot of the batch) is laid out as
+// gfx950 executes v_pk_{add,mul,fma}_f32 -- two fp32 lanes per aligned VGPR pair -- at the rate of the scalar forms, so
+// everything the forward computes per candidate and does not sum over candidates (pixel offsets, the conic form, the exp
+// argument reduction, alpha, depth differencing, the bilinear corner weights) runs on TWO consecutive candidates at once:
+// element-wise the same operations in the same order, i.e. bit-identical results.  The per-pixel sums over the candidates
+// (colour, normal, features, vfeatures) are a contraction [pixels x candidates] . [candidates x channels]: at svgss widths
+// they run on the matrix pipe (render_fwd.hip), at rgss widths as packed FMAs on channel pairs (C0,C1) += (r,g) * (w,w).
+// Packed operands are aligned register pairs and MFMA B operands are 16-float rows, so the staged data is laid out for
+// its consumers: a staged PAIR of candidates (c0 = even slot, c1 = odd slot of the batch) is
 //   [0, 2 GEOF)          geometry, interleaved: field g of candidate c at 2 g + c   (a ds_read_b128 yields two fields of both)
-//   [2 GEOF + c CHP, ..) channel block of candidate c: r g b nx ny nz F0..F(S-1), zero padded to a multiple of 4
-//   [.. + c VB, ..)      vfeatures of candidate c, corner-major: plane j (corner j) holds channel ch at j VCP + ch
+//   [2 GEOF + 16 c, ..)  channel block of candidate c: r g b nx ny nz F0..F(S-1), zero padded to 16 (one MFMA B row)
+//   [.. + 64 c, ..)      vfeatures of candidate c, corner-major: plane j (corner j) holds channel ch at 16 j + ch
 // Geometry fields: 0 x, 1 y, 2 conic.x, 3 conic.z, 4 conic.y, 5 opacity, 6 depth, 7 DA, 8 DB, 9 1/umax,
 //                  [svgss:] 10 1/vmax, 11 first instance (bits), 12..15 J0..J3, 16 tile rect (bits), 17 pad.
 // The gather itself is unchanged in spirit (stage.hpp): 16-byte loads of the 96-byte record and the vfeatures, one batch
 // ahead of their use; here every lane always fetches the same piece of "its" candidate slot, so the four LDS destinations of
-// its float4 are loop-invariant per-lane constants (the scatter costs four ds_write_b32 per load and no address math).
+// its float4 are loop-invariant per-lane constants (the scatter costs four ds_write_b32 per load and no address math); at
+// rgss widths only the four record pieces the forward reads are fetched (64 of the 96 bytes).
 #pragma once
 #include "common.hpp"
 #include "stage.hpp"

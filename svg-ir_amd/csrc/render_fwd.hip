@@ -12,13 +12,12 @@
 //     order (ballot + popcount in the wave, per-wave counts through LDS across the waves) into one list per sub-tile
 //     {Gaussian id, slot in the tile list}; forward and backward composite both consume these lists.
 //   render_fwd_kernel: one wave64 per 8x8 sub-tile (one wave per workgroup, no barriers), sub-tiles dispatched by
-//     descending candidate count.  Candidates are staged CH at a time into LDS (record + features + vfeatures, 16-byte
-//     loads, all in flight together and issued one batch AHEAD: the gathers of batch b+1 fly while batch b is blended)
-//     and consumed KB at a time with wave-uniform broadcast reads.  A group of KB candidates is blended without
-//     branches and written in lock-step (the same operation for all KB candidates, then the next one), so the wave's
-//     instruction stream carries KB independent dependency chains: the alphas are independent, only the
-//     transmittance chain (T <- T (1 - alpha), the 1e-4 cut-off) is sequential, and the accumulations are independent
-//     FMAs again;
+//     descending candidate count.  Candidates are staged CH at a time into LDS in the pair-interleaved layout of
+//     pairstage.hpp (16-byte gathers, all in flight together and issued one batch AHEAD) and consumed four at a time:
+//     the alphas of a group are packed fp32 instructions on two candidates each, only the transmittance chain
+//     (T <- T (1 - alpha), the 1e-4 cut-off) is scalar and sequential, and the colour / normal / feature / vfeature sums
+//     are MFMAs (svgss widths: blend weights -> LDS panel -> A operands, staged channel rows -> B operands) or packed
+//     FMAs on channel pairs (rgss widths);
 //   * channel counts are template parameters so every accumulator lives in a VGPR (the reference keeps >640 floats
 //     per thread in scratch, forward.cu:483-493);
 //   * the per-(pixel,splat) out_weights atomic of the reference (forward.cu:653) becomes one DPP wave reduction per
