@@ -309,6 +309,36 @@ int svgir_l1_ssim_forward(const float* img1, const float* img2, int32_t C, int32
 int svgir_l1_ssim_backward(const float* img1, const float* img2, const float* dmaps, int32_t C, int32_t H, int32_t W,
                            float g_ssim_mean, float g_l1_mean, float* dL_dimg1, void* stream);
 
+/* The consumers of the rasterizer's gradients: Adam over the per-Gaussian parameter block, the
+ * densification statistics, and the row compaction behind pruning (scene/gaussian_model.py:737-773, 1020-1062, 1270-1276).
+ *
+ * svgir_adam_step: one launch for up to SVGIR_ADAM_MAX_TENSORS parameter tensors -- torch.optim.Adam's update (amsgrad
+ *   off, no weight decay) with a learning rate and a step count per tensor (`step` = the count AFTER this update, >= 1;
+ *   bias corrections in double precision on the host, like torch).  Tensors with n = 0 are skipped.
+ * svgir_densify_stats: GaussianModel.add_densification_stats -- weights_accum += weights (if given);
+ *   for rows with update_filter: xyz_gradient_accum += |viewspace_grad[:, :2]|, denom += 1.  grad_stride = floats per row
+ *   of viewspace_grad (3 in the reference).
+ * svgir_mask_scan: order-preserving list `kept` [<= P] of the rows with keep != 0 and their number (count_dev[0], device
+ *   memory); `work` = svgir_mask_scan_work_words(P) uint32 of scratch.
+ * svgir_gather_rows: dst[t][r] = src[t][kept[r]] for r < min(rows_max, *count_dev), for up to SVGIR_ADAM_MAX_TENSORS
+ *   tensors with rows of row_bytes (multiple of 4) in one launch: the `tensor[mask]` of _prune_optimizer for every
+ *   parameter, both Adam moments and the bookkeeping arrays at once. */
+#define SVGIR_ADAM_MAX_TENSORS 32
+typedef struct svgir_adam_tensor {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n;        /* elements */
+    double lr;
+    int32_t step;
+} svgir_adam_tensor;
+typedef struct svgir_row_tensor { const void* src; void* dst; int32_t row_bytes; } svgir_row_tensor;
+int svgir_adam_step(const svgir_adam_tensor* tensors, int32_t count, double beta1, double beta2, double eps, void* stream);
+int svgir_densify_stats(int32_t P, const float* viewspace_grad, int32_t grad_stride, const uint8_t* update_filter,
+                        const float* weights, float* weights_accum, float* xyz_gradient_accum, float* denom, void* stream);
+size_t svgir_mask_scan_work_words(int32_t P);
+int svgir_mask_scan(int32_t P, const uint8_t* keep, uint32_t* kept, uint32_t* work, uint32_t* count_dev, void* stream);
+int svgir_gather_rows(const svgir_row_tensor* tensors, int32_t count, const uint32_t* kept, const uint32_t* count_dev,
+                      int32_t rows_max, void* stream);
+
 /* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
  * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,
  * the AVERAGE duration in milliseconds and the number of samples since profiling was (re-)enabled.

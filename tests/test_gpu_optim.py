@@ -1,0 +1,113 @@
+"""csrc/optim.hip: the fused Adam step, the densification statistics and the fused row compaction, against
+PyTorch's own implementations of what the reference calls (torch.optim.Adam with the reference's settings, boolean-mask
+indexing, torch.norm) evaluated in fp64 on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _groups(dev, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    # the reference's parameter block (scene/gaussian_model.py:745-768): names, shapes per Gaussian, learning rates
+    spec = [("xyz", (3,), 1.6e-4), ("normal", (3,), 1e-3), ("rotation", (4,), 1e-3), ("scaling", (3,), 5e-3), ("opacity", (1,), 5e-2),
+            ("f_dc", (1, 3), 2.5e-3), ("f_rest", (15, 3), 2.5e-3 / 20), ("base_color", (4, 3), 1e-2), ("roughness", (4, 1), 1e-2),
+            ("incidents_dc", (1, 3), 2e-3), ("incidents_rest", (15, 3), 1e-4), ("visibility_dc", (1, 1), 2.5e-3),
+            ("visibility_rest", (15, 1), 1.25e-4)]
+    P = 3001
+    return [{"params": [torch.nn.Parameter(torch.randn((P,) + shp, generator=g).to(device=dev, dtype=dtype))], "lr": lr, "name": n}
+            for n, shp, lr in spec], g, P
+
+
+def test_fused_adam_matches_torch_adam(built):
+    from svgir_harness.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    mine, g1, P = _groups(dev, torch.float32, 5)
+    ref, g2, _ = _groups("cpu", torch.float64, 5)
+    opt = FusedAdam(mine, lr=1e-4, eps=1e-15)
+    oref = torch.optim.Adam(ref, lr=1e-4, eps=1e-15)
+    gen = torch.Generator().manual_seed(9)
+    for it in range(25):
+        for gm, gr in zip(opt.param_groups, oref.param_groups):
+            grad = torch.randn(gr["params"][0].shape, generator=gen, dtype=torch.float64) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=gen)))
+            if it % 7 == 3 and gm["name"] == "normal":
+                gm["params"][0].grad = None; gr["params"][0].grad = None   # a group without a gradient is skipped, its step count stays
+                continue
+            gm["params"][0].grad = grad.to(device=dev, dtype=torch.float32)
+            gr["params"][0].grad = grad.to(torch.float32).to(torch.float64)
+        if it == 10:   # learning-rate schedule on the position group (update_learning_rate)
+            opt.param_groups[0]["lr"] = oref.param_groups[0]["lr"] = 8e-5
+        opt.step(); oref.step()
+    for gm, gr in zip(opt.param_groups, oref.param_groups):
+        p, q = gm["params"][0], gr["params"][0]
+        st, sr = opt.state[p], oref.state[q]
+        assert float(st["step"]) == float(sr["step"]), gm["name"]
+        for a, b, what in ((p, q, "param"), (st["exp_avg"], sr["exp_avg"], "exp_avg"), (st["exp_avg_sq"], sr["exp_avg_sq"], "exp_avg_sq")):
+            a = a.detach().double().cpu().numpy(); b = b.detach().numpy()
+            # fp32 state against the fp64 evaluation of the same recurrence (25 steps of rounding; the gradients span eight
+            # decades with random signs, so small moments carry the cancellation error of large ones: the criterion is
+            # normalised by the tensor's scale, plus a loose element-wise one)
+            scale = np.abs(b).max()
+            assert np.abs(a - b).max() <= 3e-6 * scale, (gm["name"], what, np.abs(a - b).max() / scale)
+            err = np.abs(a - b) / (np.abs(b) + 1e-6 * scale)
+            assert np.quantile(err, 0.99) < 1e-4, (gm["name"], what, np.quantile(err, 0.99))
+
+
+def test_fused_adam_state_layout_survives_the_reference_prune(built):
+    """The reference swaps parameters and indexes the moments inside the optimizer (scene/gaussian_model.py:1020-1036); the
+    same statements run on FusedAdam, and prune_rows gives what they give."""
+    from svgir_harness.optim import FusedAdam, prune_rows
+    dev = torch.device("cuda:0")
+    groups, g, P = _groups(dev, torch.float32, 6)
+    opt = FusedAdam(groups, lr=1e-4, eps=1e-15)
+    for grp in opt.param_groups:
+        grp["params"][0].grad = torch.randn_like(grp["params"][0])
+    opt.step()
+    mask = (torch.rand(P, generator=g) > 0.37).to(dev)
+    flat, names = [], []
+    for grp in opt.param_groups:
+        p = grp["params"][0]
+        flat += [p.detach(), opt.state[p]["exp_avg"], opt.state[p]["exp_avg_sq"]]
+        names += [grp["name"]] * 3
+    book = [torch.rand(P, 1, device=dev), torch.randint(0, 9, (P,), device=dev, dtype=torch.int32)]
+    pruned = prune_rows(flat + book, mask)
+    for t, q in zip(flat + book, pruned):
+        assert torch.equal(t[mask], q)
+    # the reference's own statements
+    for group in opt.param_groups:
+        stored_state = opt.state.get(group["params"][0], None)
+        assert stored_state is not None
+        stored_state["exp_avg"] = stored_state["exp_avg"][mask]
+        stored_state["exp_avg_sq"] = stored_state["exp_avg_sq"][mask]
+        del opt.state[group["params"][0]]
+        group["params"][0] = torch.nn.Parameter((group["params"][0][mask].requires_grad_(True)))
+        opt.state[group["params"][0]] = stored_state
+    for grp in opt.param_groups:
+        grp["params"][0].grad = torch.randn_like(grp["params"][0])
+    opt.step()
+    assert all(float(opt.state[grp["params"][0]]["step"]) == 2.0 for grp in opt.param_groups)
+    # edge cases: nothing kept / everything kept / empty input
+    none = prune_rows([flat[0]], torch.zeros(P, dtype=torch.bool, device=dev))
+    assert none[0].shape == (0, 3)
+    allk = prune_rows([flat[0]], torch.ones(P, dtype=torch.bool, device=dev))
+    assert torch.equal(allk[0], flat[0])
+    assert prune_rows([torch.empty(0, 3, device=dev)], torch.empty(0, dtype=torch.bool, device=dev))[0].shape == (0, 3)
+
+
+def test_densification_stats(built):
+    from svgir_harness.optim import add_densification_stats
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    P = 70001
+    vg = torch.randn(P, 3, generator=g).to(dev)
+    flt = (torch.rand(P, generator=g) > 0.5).to(dev)
+    w = torch.rand(P, 1, generator=g).to(dev)
+    acc = [torch.rand(P, 1, generator=g).to(dev) for _ in range(3)]
+    ref = [a.clone() for a in acc]
+    ref[0] += w
+    ref[1][flt] += torch.norm(vg[flt, :2], dim=-1, keepdim=True)
+    ref[2][flt] += 1
+    add_densification_stats(vg, flt, w, acc[0], acc[1], acc[2])
+    for a, b in zip(acc, ref):
+        assert torch.allclose(a, b, rtol=2e-7, atol=0)
