@@ -52,12 +52,16 @@ def algorithmic_bytes(P, R, W, H, S, VS, svgss):
     return dict(G=G, fwd=fwd, bwd=bwd)
 
 
+# sources of the kernels whose HBM traffic is recorded in profiles/traffic_*.json (the composite and shading kernels)
+TRAFFIC_SOURCES = ("common.hpp", "stage.hpp", "pairstage.hpp", "dev_trace.hpp", "render_fwd.hip", "render_bwd.hip", "grad_reduce.hip",
+                   "shade.hip")
+
+
 def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "svg-ir_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in TRAFFIC_SOURCES:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

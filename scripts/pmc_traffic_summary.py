@@ -7,13 +7,11 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 
-def kernel_source_hash():   # (same as bench.py: the measurement is only valid for the kernel sources it was taken with)
-    h = hashlib.sha256()
-    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svg-ir_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+def kernel_source_hash():   # bench.py's: the measurement is only valid for the kernel sources it was taken with
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    return bench.kernel_source_hash()
 
 
 def load(d):
