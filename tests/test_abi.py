@@ -45,6 +45,10 @@ def test_struct_layouts_match_header_field_order(built):
     assert fields("svgir_grads") == [f[0] for f in _native.Grads._fields_]
     from gaussian_renderer import shading
     assert fields("svgir_shade_params") == [f[0] for f in shading.ShadeParams._fields_]
+    from svgir_harness import optim
+    assert fields("svgir_adam_tensor") == [f[0] for f in optim._AdamTensor._fields_]
+    assert fields("svgir_row_tensor") == [f[0] for f in optim._RowTensor._fields_]
+    assert re.search(r"#define SVGIR_ADAM_MAX_TENSORS (\d+)", hdr).group(1) == str(optim.MAX_TENSORS)
 
 
 def test_blob_sizes_and_error_reporting(built):
