@@ -65,6 +65,16 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def library_hash():
+    """sha256 of the libsvgir_raster.so this process would load (a stale prebuilt library then cannot pass for the
+    sources' measurement)."""
+    lib = os.environ.get("SVGIR_RASTER_LIB") or os.path.join(ROOT, "svg-ir_amd", "libsvgir_raster.so")
+    try:
+        return hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,13 +94,36 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """Number of GPUs a child process will see, WITHOUT loading the HIP runtime in this (parent) process: KFD topology
+    nodes with SIMDs, narrowed by the *_VISIBLE_DEVICES lists.  None when the topology is not readable (the children
+    then check their own device and exit 2)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
-    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (nothing here has touched the GPU)."""
-    import torch
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes.  Nothing in this process touches the
+    GPU or the HIP runtime (no torch import): the children are plain child processes, never an exec of a GPU process."""
     n = args.gpus
     if not args.dry_run:
-        have = torch.cuda.device_count()   # (does not initialise the GPU)
-        if have < n:
+        have = visible_gpu_count()
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible", file=sys.stderr)
             return 2
     with socket.socket() as s:
@@ -307,14 +340,14 @@ def roofline_of(wl, R, stage, workload):
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("kernel_source_hash") == kernel_source_hash():
+        if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("library_hash") == library_hash():
             tr = 0
             for kname, kv in tj.get("kernels", {}).items():
                 if kname.startswith("render_bwd_kernel") or kname.startswith("grad_reduce_kernel"):
                     tr += kv["read_bytes"] + kv["write_bytes"]
             out["traffic"] = tr or None
         else:
-            out["traffic_note"] = "profiles/traffic_%s.json was measured with different kernel sources" % workload
+            out["traffic_note"] = "profiles/traffic_%s.json was measured with different kernel sources / another library build" % workload
     return out
 
 
@@ -413,6 +446,11 @@ def main():
     torch.cuda.set_device(dev)
     wl = Workload(name, dev, rank, world, args)
     regions, R, stage, table = timed(wl, args, world, dev)
+    # which physical GPU every rank ran on (a rank that silently fell back to another device would show up here)
+    pr = torch.cuda.get_device_properties(dev)
+    ids = vp.gather_rows(torch.tensor([float(torch.cuda.current_device()), float(getattr(pr, "pci_domain_id", -1)),
+                                       float(getattr(pr, "pci_bus_id", -1)), float(getattr(pr, "pci_device_id", -1))],
+                                      dtype=torch.float64, device=dev)).cpu().numpy()
     res = None
     if rank == 0:
         med = float(np.median(regions))
@@ -427,7 +465,9 @@ def main():
                                    f"S={wl.S}, VS={wl.VS}, {'fwd+bwd' if wl.train else 'fwd'}, one view per step per GPU "
                                    f"(BASELINE.json configs[1] = cfg2 at N=1; configs[3] = cfg4, view r on rank r, at N>1)",
                        "num_rendered": int(R), "views_per_step": world, "parallelism": f"view-parallel x{world}",
-                       "per_rank_num_rendered": [int(r[2]) for r in table]},
+                       "per_rank_num_rendered": [int(r[2]) for r in table],
+                       "per_rank_device": [{"rank": i, "ordinal": int(r[0]), "pci": "%04x:%02x:%02x" % (int(r[1]) & 0xffff, int(r[2]) & 0xff, int(r[3]) & 0xff)}
+                                           for i, r in enumerate(ids)]},
             "roofline": roofline_of(wl, R, stage, name),
             "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
         }

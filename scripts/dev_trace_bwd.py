@@ -18,15 +18,16 @@ sc = scenes.make(wl)
 sct = runner.to_torch(sc, dev)
 grads = scenes.upstream_grads(sc, variant)
 lib = _native.lib
-lib.svgir_dev_trace_read_bwd.restype = C.c_int
-lib.svgir_dev_trace_read_bwd.argtypes = [C.c_void_p, C.c_int]
+reader = lib.svgir_dev_trace_read_bwd_plain if variant == "rgss" and hasattr(lib, "svgir_dev_trace_read_bwd_plain") else lib.svgir_dev_trace_read_bwd
+reader.restype = C.c_int
+reader.argtypes = [C.c_void_p, C.c_int]
 CAP = 1 << 17
 buf = np.zeros((CAP, 8), dtype=np.uint64)
 for it in range(3):
     out, leaves = runner.render(sct, variant, requires_grad=True)
     runner.backward(out, grads, variant)
     torch.cuda.synchronize()
-    n = lib.svgir_dev_trace_read_bwd(buf.ctypes.data, CAP)
+    n = reader(buf.ctypes.data, CAP)
 rec = buf[:n].astype(np.int64)
 dur, r0, r1 = rec[:, 0], rec[:, 1], rec[:, 2]
 items, cands = rec[:, 3] >> 32, rec[:, 3] & 0xffffffff
@@ -38,7 +39,7 @@ print("start delay (us): p50 %.1f p90 %.1f max %.1f" % tuple(np.quantile((r0 - t
 print("end time (us): p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.quantile((r1 - t_begin) / 100.0, [0.5, 0.9, 0.99, 1.0])))
 print("wave duration (us): p50 %.1f p90 %.1f max %.1f ; items per wave max %d" % (*np.quantile((r1 - r0) / 100.0, [0.5, 0.9, 1.0]), items.max()))
 tot = dur.sum()
-print("cycle shares: setup %.2f stage %.2f phaseA %.2f phaseB(+loop) %.2f" % (setup.sum() / tot, stage.sum() / tot, phA.sum() / tot, phB.sum() / tot))
+print("cycle shares: setup %.2f stage/epilogue %.2f phaseA %.2f phaseB(+loop) %.2f" % (setup.sum() / tot, stage.sum() / tot, phA.sum() / tot, phB.sum() / tot))
 print("cycles per candidate: total %.0f phaseA %.0f phaseB %.0f stage %.0f ; setup cycles per segment %.0f" % (
     tot / cands.sum(), phA.sum() / cands.sum(), phB.sum() / cands.sum(), stage.sum() / cands.sum(), setup.sum() / items.sum()))
 mid = (t_begin + t_end) // 2

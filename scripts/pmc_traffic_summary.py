@@ -7,10 +7,11 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 
-def kernel_source_hash():   # bench.py's: the measurement is only valid for the kernel sources it was taken with
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, root)
-    import bench
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench   # its hashes: the measurement is only valid for the kernel sources AND the library build it was taken with
+
+
+def kernel_source_hash():
     return bench.kernel_source_hash()
 
 
@@ -23,7 +24,7 @@ def load(d):
 
 
 rd, wr = load(sys.argv[1]), load(sys.argv[2])
-out = {"workload": sys.argv[3], "kernel_source_hash": kernel_source_hash(), "method": __doc__.split("usage")[0].strip(), "kernels": {}}
+out = {"workload": sys.argv[3], "kernel_source_hash": kernel_source_hash(), "library_hash": bench.library_hash(), "method": __doc__.split("usage")[0].strip(), "kernels": {}}
 for k in rd:
     if not any(p in k for p in ("render_", "cull_kernel", "shade_fwd", "shade_bwd", "grad_reduce")):
         continue

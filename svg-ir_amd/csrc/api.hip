@@ -190,6 +190,7 @@ int validate(const svgir_params* p, bool fwd) {
     if (!p) return fail(SVGIR_ERR_INVALID, "params is NULL");
     if (p->variant != SVGIR_RGSS && p->variant != SVGIR_SVGSS) return fail(SVGIR_ERR_INVALID, "unknown variant %d", p->variant);
     if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(SVGIR_ERR_INVALID, "bad sizes P=%d W=%d H=%d", p->P, p->W, p->H);
+    if (p->P > 40000000) return fail(SVGIR_ERR_INVALID, "P=%d exceeds the supported 40 000 000 Gaussians (32-bit byte offsets into the splat records)", p->P);
     {   // packing limits of the state blobs: tile rectangle x0 | y0 << 10 | width << 20 (common.hpp R_RECT) and
         // (sub-tile id << SEG_K_BITS) | segment (seg_list)
         const long long gx = (p->W + TILE - 1) / TILE, gy = (p->H + TILE - 1) / TILE;
@@ -371,7 +372,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         ra.bg = p->background;
         ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_total = I.sub_total; ra.sub_order = I.sub_order;
         ra.sub_count = I.sub_count;
-        ra.sub_ndump = I.sub_ndump; ra.seg_list = B.seg_list; ra.seg_count = I.counters; ra.seg_state = B.seg_state;
+        ra.sub_ndump = I.sub_ndump; ra.seg_list = B.seg_list; ra.seg_desc = B.seg_desc; ra.seg_count = I.counters; ra.seg_block = I.seg_block; ra.seg_state = B.seg_state;
         ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
         ra.out_color = o->out_color; ra.out_normal = o->out_normal; ra.out_depth = o->out_depth; ra.out_opacity = o->out_opacity;
         ra.out_feature = o->out_feature; ra.out_vfeature = o->out_vfeature; ra.out_weights = o->out_weights;
@@ -386,6 +387,9 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         if (launch_render_fwd(ra, svgss, s) < 0) launch_render_fwd_generic(ra, svgss, s);   // run-time-width kernels
         if (int rc = check("render")) return rc;
         if (timed) tm.mark("render");
+        launch_seg_build(ra, s);
+        if (int rc = check("segment list")) return rc;
+        if (timed) tm.mark("seg_build");
         return 0;
     };
 
@@ -473,7 +477,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.ranges = I.ranges; ba.point_list = B.val[fin]; ba.rec = G.rec; ba.features = p->features; ba.vfeatures = p->vfeatures;
     ba.bg = p->background;
     ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count;
-    ba.sub_ndump = I.sub_ndump; ba.seg_list = B.seg_list; ba.seg_count = I.counters; ba.seg_state = B.seg_state;
+    ba.sub_ndump = I.sub_ndump; ba.seg_list = B.seg_list; ba.seg_desc = B.seg_desc; ba.seg_count = I.counters; ba.seg_state = B.seg_state;
     ba.seg_cap = (int)B.seg_cap;
     ba.backward_geometry = p->backward_geometry;
     ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;

@@ -89,6 +89,7 @@ struct ImageLayout {
     float* final_D;      // [N]
     int32_t* n_contrib;  // [N]
     uint32_t* ranges;    // [2*T]
+    uint32_t* seg_block; // [seg_blocks(T)] live backward segments per block of 256 tiles (summed by the forward; directly behind ranges)
     uint32_t* sub_total; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the cull kernel)
     uint32_t* sub_order; // [4*T] sub-tiles sorted by descending candidate count (heaviest work is dispatched first)
     uint32_t* sub_count; // [4*T] #candidates the forward composite consumed before every pixel was done (<= sub_total)
@@ -107,7 +108,8 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.final_D = (float*)take(N * 4);
     im.ncontrib_off = off;
     im.n_contrib = (int32_t*)take(N * 4);
-    im.ranges = (uint32_t*)take(T * 8);
+    im.ranges = (uint32_t*)take((T * 2 + (T + 255) / 256) * 4);
+    im.seg_block = im.ranges ? im.ranges + T * 2 : nullptr;
     im.sub_total = (uint32_t*)take(T * 4 * 4);
     im.sub_order = (uint32_t*)take(T * 4 * 4);
     im.sub_count = (uint32_t*)take(T * 4 * 4);
@@ -137,8 +139,10 @@ inline size_t grad_scratch_bytes(int cap, int S, int VS) {   // rows + one valid
 // candidate and once at the end; a backward segment starts its back-to-front replay from the state at its far end
 // (transmittance there, and "everything behind" = (final - prefix) / T) instead of from the end of the list.
 // State slot of sub-tile i = 4*tile+w, segment k:  (4*r0 + w*len) / SEG + i + k   (disjoint by construction).
-// The live segments are appended by the forward to a compact list (seg_list, seg_count) that the backward's
-// persistent waves walk.
+// After the forward composite a one-workgroup scan (seg_build_kernel) lists the live segments in TILE ORDER -- seg_list
+// (compact ids) and seg_desc (everything a backward wave needs to start: SegDesc) -- and the backward's waves walk that
+// list in eight contiguous chunks, one per XCD (seg_item_of): neighbouring sub-tiles share splat records, gradient planes
+// and dumped states, which then stay in ONE 4 MiB L2.
 constexpr int SEG = 64;
 #if defined(__HIPCC__)
 __host__ __device__
@@ -148,6 +152,15 @@ inline uint32_t seg_state_base(uint32_t r0, uint32_t len, int tile, int sub) {
 }
 inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
 constexpr int SEG_K_BITS = 14;   // seg_list entry = (sub-tile id << SEG_K_BITS) | k
+struct SegDesc { uint32_t sm, r0, len, count, ndump, pad0, pad1, pad2; };   // 32 B: seg_list entry, tile range start / length, sub_count, sub_ndump
+// Work item w (workgroups are dealt to the XCDs round-robin: w & 7 = XCD) -> position in the tile-ordered list of n segments:
+// XCD c walks the contiguous chunk [c L, (c + 1) L), L = ceil(n / 8).  Returns n (invalid) past the end.
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t seg_item_of(uint32_t w, uint32_t n) {
+    const uint32_t L = (n + 7u) >> 3, item = (w & 7u) * L + (w >> 3);
+    return ((w >> 3) < L && item < n) ? item : n;
+}
+#endif
 
 // The binning blob is laid out for an instance CAPACITY (a multiple of 4096 >= R): the forward may size it from a
 // guess before the host knows R, and the backward recovers the capacity from the blob's byte size.
@@ -162,7 +175,8 @@ struct BinLayout {
     uint32_t* radix_tbl;
     uint2* sub_list;   // [4*R] compact per-sub-tile candidate lists {Gaussian id, slot in the tile list}; sub-tile w
                        // of a tile with range [r0,r1) owns entries [4*r0 + w*(r1-r0), 4*r0 + (w+1)*(r1-r0))
-    uint32_t* seg_list; // [seg_capacity] live backward segments, compact (appended by the forward)
+    uint32_t* seg_list; // [seg_capacity] live backward segments in tile order (seg_build_kernel)
+    SegDesc* seg_desc;  // [seg_capacity] their descriptors
     float* seg_state;  // [seg_capacity][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
     size_t seg_cap;
     size_t bytes;
@@ -181,6 +195,7 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     b.sub_list = (uint2*)take(r * 4 * 8);
     b.seg_cap = seg_capacity(R, T);
     b.seg_list = (uint32_t*)take(b.seg_cap * 4);
+    b.seg_desc = (SegDesc*)take(b.seg_cap * sizeof(SegDesc));
     b.seg_state = (float*)take(b.seg_cap * (size_t)nstate * 64 * 4);
     b.bytes = off;
     return b;
@@ -240,7 +255,7 @@ struct RenderArgs {
     const float* bg;
     CfgRef cfg;
     uint2* sub_list; uint32_t* sub_total; uint32_t* sub_order; uint32_t* sub_count;
-    uint32_t* sub_ndump; uint32_t* seg_list; uint32_t* seg_count; float* seg_state;
+    uint32_t* sub_ndump; uint32_t* seg_list; SegDesc* seg_desc; uint32_t* seg_count; uint32_t* seg_block; float* seg_state;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
@@ -253,7 +268,7 @@ struct RenderBwdArgs {
     const float* bg;
     CfgRef cfg; int backward_geometry;
     const uint2* sub_list; const uint32_t* sub_count;
-    const uint32_t* sub_ndump; const uint32_t* seg_list; const uint32_t* seg_count; const float* seg_state; int seg_cap;
+    const uint32_t* sub_ndump; const uint32_t* seg_list; const SegDesc* seg_desc; const uint32_t* seg_count; const float* seg_state; int seg_cap;
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
@@ -296,7 +311,7 @@ void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, co
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
                          uint32_t* total_out, hipStream_t s);
-// also clears ranges[2*gx*gy], the live-segment counter and the group totals of the tile sort's table (`sort_table`,
+// also clears ranges[2*gx*gy] + the per-tile-block segment counts behind it, the live-segment counter and the group totals of the tile sort's table (`sort_table`,
 // sized for `cap` elements)
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
@@ -306,8 +321,11 @@ void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
+// tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump
+void launch_seg_build(const RenderArgs& a, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 (nothing launched) if (S,VS) has no specialised kernel
 int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 (nothing launched) if (S,VS) has no specialised kernel
+int launch_render_bwd_plain(const RenderBwdArgs& a, bool svgss, hipStream_t s);   // VS = 0 widths (render_bwd_plain.hip); <0 if not specialised
 bool render_specialised(int S, int VS, bool svgss);
 // run-time-width composite kernels for every other (S, VS) the reference accepts (render_generic.hip)
 void launch_render_fwd_generic(const RenderArgs& a, bool svgss, hipStream_t s);

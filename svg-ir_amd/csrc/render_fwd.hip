@@ -404,12 +404,13 @@ render_fwd_kernel(const RenderArgs a) {
         wave_lds_sync();
         flush_weights(b - 1);
     }
-    // live segments (those that hold at least one consumed candidate) are appended to the compact list the backward's
-    // waves walk; the list position comes from a returning atomic whose latency is covered by the output stores below
-    const uint32_t nseg = head != 0 ? min((head + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u) : 0u;
-    uint32_t seg_at = 0;
-    if (lane == 0 && nseg != 0) seg_at = atomicAdd(a.seg_count, nseg);
-    if (lane == 0) { a.sub_count[sid] = head; a.sub_ndump[sid] = ndump; }
+    // the live segments -- those that hold at least one consumed candidate -- are listed in tile order by seg_build_kernel
+    // from these counts; the per-block totals it needs are summed here (fire-and-forget atomics, 4 T / 1024 counters)
+    if (lane == 0) {
+        a.sub_count[sid] = head; a.sub_ndump[sid] = ndump;
+        const uint32_t nseg = head != 0 ? min((head + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u) : 0u;
+        if (nseg != 0) atomicAdd(a.seg_block + (tile >> 8), nseg);
+    }
     if (head != 0 && ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
     else gather_acc();
 
@@ -433,10 +434,64 @@ render_fwd_kernel(const RenderArgs a) {
         a.out_opacity[pid] = 1.f - T;
         a.final_D[pid] = D;
     }
-    seg_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_at);
-    for (uint32_t k = lane; k < nseg; k += 64) a.seg_list[seg_at + k] = (sid << SEG_K_BITS) | k;
     DEV_TRACE_MARK(3);   // dumps + epilogue
     DEV_TRACE_END(0, (unsigned)total, head, blockIdx.x);
+}
+
+// ---- live backward segments in tile order ---------------------------------------------------------------------
+// One thread per tile (its four sub-tiles), 256 tiles per workgroup.  A sub-tile that consumed `count` candidates and dumped
+// `ndump` states has min(ceil(count / SEG), ndump + 1) live segments; the forward has already summed them per workgroup
+// (seg_block), so every workgroup derives its own base, scans its 256 tiles and writes ids + descriptors.  Deterministic
+// (an atomic append would list them in completion order) and ordered by tile for the backward's XCD-local walk.
+__global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int T) {
+    __shared__ uint32_t wsum[4], red[2][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x * 256 + t;
+    // base of this workgroup and the grand total from the per-workgroup sums
+    uint32_t before = 0, total = 0;
+    for (int j = t; j < (int)gridDim.x; j += 256) {
+        const uint32_t v = a.seg_block[j];
+        total += v;
+        before += j < (int)blockIdx.x ? v : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { before += (uint32_t)__shfl_xor((int)before, d); total += (uint32_t)__shfl_xor((int)total, d); }
+    if (lane == 0) { red[0][wave] = before; red[1][wave] = total; }
+    uint32_t nseg[4] = {0u, 0u, 0u, 0u}, head[4] = {0u, 0u, 0u, 0u}, nd[4] = {0u, 0u, 0u, 0u}, r0 = 0, r1 = 0;
+    if (tile < T) {
+        const uint4 c4 = reinterpret_cast<const uint4*>(a.sub_count)[tile], d4 = reinterpret_cast<const uint4*>(a.sub_ndump)[tile];
+        const uint2 rr = reinterpret_cast<const uint2*>(a.ranges)[tile];
+        r0 = rr.x; r1 = rr.y;
+        head[0] = c4.x; head[1] = c4.y; head[2] = c4.z; head[3] = c4.w;
+        nd[0] = d4.x; nd[1] = d4.y; nd[2] = d4.z; nd[3] = d4.w;
+#pragma unroll
+        for (int w = 0; w < 4; w++) nseg[w] = head[w] != 0 ? min((head[w] + (uint32_t)SEG - 1u) / (uint32_t)SEG, nd[w] + 1u) : 0u;
+    }
+    const uint32_t mine = (nseg[0] + nseg[1]) + (nseg[2] + nseg[3]);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t at = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) + incl - mine;
+#pragma unroll
+    for (int v = 0; v < 4; v++) at += v < wave ? wsum[v] : 0u;
+    if (blockIdx.x == 0 && t == 0) a.seg_count[0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (mine == 0) return;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        for (uint32_t k = 0; k < nseg[w]; k++) {
+            const uint32_t sm = ((uint32_t)(4 * tile + w) << SEG_K_BITS) | k;
+            a.seg_list[at] = sm;
+            uint4* d = reinterpret_cast<uint4*>(a.seg_desc + at);
+            d[0] = make_uint4(sm, r0, r1 - r0, head[w]);
+            d[1] = make_uint4(nd[w], 0u, 0u, 0u);
+            at++;
+        }
+    }
 }
 
 // The LDS request doubles as a residency control for experiments (build_variant.sh -DFWD_LDS_MIN=...).
@@ -451,6 +506,11 @@ void launch(const RenderArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+void launch_seg_build(const RenderArgs& a, hipStream_t s) {
+    const int T = a.gx * a.gy;
+    hipLaunchKernelGGL(seg_build_kernel, dim3((T + 255) / 256), dim3(256), 0, s, a, T);
+}
 
 void launch_cull(const RenderArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(cull_kernel, dim3(a.gx * a.gy), dim3(CT), 0, s, a);
