@@ -374,7 +374,7 @@ void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
                  uint32_t* seg_count, uint32_t* sort_table, hipStream_t s) {
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,
-                       radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy + (gx * gy + 255) / 256, seg_count,
+                       radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy + (gx * gy + 255) / 256 * SEG_BLOCK_STRIDE, seg_count,
                        radix_gtot(sort_table, cap), (int)radix_gtot_words(cap));
 }
 

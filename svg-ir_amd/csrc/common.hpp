@@ -84,12 +84,15 @@ inline GeomLayout geom_layout(char* base, int P) {
     return g;
 }
 
+constexpr int SEG_CLASSES = 5, SEG_BLOCK_STRIDE = 8;   // backward-segment length classes (see SEG); per-256-tile-block counters padded to 8
+
 struct ImageLayout {
     float* final_T;      // [N]
     float* final_D;      // [N]
     int32_t* n_contrib;  // [N]
     uint32_t* ranges;    // [2*T]
-    uint32_t* seg_block; // [seg_blocks(T)] live backward segments per block of 256 tiles (summed by the forward; directly behind ranges)
+    uint32_t* seg_block; // [ceil(T / 256)][SEG_BLOCK_STRIDE] live backward segments per block of 256 tiles and length class (summed by the
+                         // forward; directly behind ranges)
     uint32_t* sub_total; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the cull kernel)
     uint32_t* sub_order; // [4*T] sub-tiles sorted by descending candidate count (heaviest work is dispatched first)
     uint32_t* sub_count; // [4*T] #candidates the forward composite consumed before every pixel was done (<= sub_total)
@@ -108,7 +111,7 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.final_D = (float*)take(N * 4);
     im.ncontrib_off = off;
     im.n_contrib = (int32_t*)take(N * 4);
-    im.ranges = (uint32_t*)take((T * 2 + (T + 255) / 256) * 4);
+    im.ranges = (uint32_t*)take((T * 2 + (T + 255) / 256 * SEG_BLOCK_STRIDE) * 4);
     im.seg_block = im.ranges ? im.ranges + T * 2 : nullptr;
     im.sub_total = (uint32_t*)take(T * 4 * 4);
     im.sub_order = (uint32_t*)take(T * 4 * 4);
@@ -139,10 +142,13 @@ inline size_t grad_scratch_bytes(int cap, int S, int VS) {   // rows + one valid
 // candidate and once at the end; a backward segment starts its back-to-front replay from the state at its far end
 // (transmittance there, and "everything behind" = (final - prefix) / T) instead of from the end of the list.
 // State slot of sub-tile i = 4*tile+w, segment k:  (4*r0 + w*len) / SEG + i + k   (disjoint by construction).
-// After the forward composite a one-workgroup scan (seg_build_kernel) lists the live segments in TILE ORDER -- seg_list
-// (compact ids) and seg_desc (everything a backward wave needs to start: SegDesc) -- and the backward's waves walk that
-// list in eight contiguous chunks, one per XCD (seg_item_of): neighbouring sub-tiles share splat records, gradient planes
-// and dumped states, which then stay in ONE 4 MiB L2.
+// After the forward composite seg_build_kernel lists the live segments -- seg_list (compact ids) and seg_desc (everything a
+// backward wave needs to start: SegDesc) -- LONGEST FIRST: class 0 = full segments (SEG candidates), classes 1..4 = the
+// partial last segments of the sub-tiles by length quarter; tile order inside a class.  The backward's waves take the list
+// round-robin, so the last, partly filled round consists of the shortest items (a kernel lasts ceil(items / resident waves)
+// rounds: with ~2.1 rounds of equal items a third of the time was the tail).  Work ids map to list positions in blocks of
+// SEG_XCD_BLOCK consecutive items per XCD (seg_item_of): neighbouring sub-tiles share splat records, gradient planes and
+// dumped states, which then stay in ONE 4 MiB L2.
 constexpr int SEG = 64;
 #if defined(__HIPCC__)
 __host__ __device__
@@ -153,14 +159,26 @@ inline uint32_t seg_state_base(uint32_t r0, uint32_t len, int tile, int sub) {
 inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
 constexpr int SEG_K_BITS = 14;   // seg_list entry = (sub-tile id << SEG_K_BITS) | k
 struct SegDesc { uint32_t sm, r0, len, count, ndump, pad0, pad1, pad2; };   // 32 B: seg_list entry, tile range start / length, sub_count, sub_ndump
-// Work item w (workgroups are dealt to the XCDs round-robin: w & 7 = XCD) -> position in the tile-ordered list of n segments:
-// XCD c walks the contiguous chunk [c L, (c + 1) L), L = ceil(n / 8).  Returns n (invalid) past the end.
 #if defined(__HIPCC__)
-__device__ __forceinline__ uint32_t seg_item_of(uint32_t w, uint32_t n) {
-    const uint32_t L = (n + 7u) >> 3, item = (w & 7u) * L + (w >> 3);
-    return ((w >> 3) < L && item < n) ? item : n;
-}
+__host__ __device__
 #endif
+inline int seg_class(uint32_t nent) { return nent >= (uint32_t)SEG ? 0 : 4 - (int)(nent * 4u / (uint32_t)SEG); }   // 64 | 48-63 | 32-47 | 16-31 | 1-15
+// Work id w (workgroups are dealt to the XCDs round-robin: w & 7 = XCD) -> list position: XCD c takes the blocks c, c + 8,
+// c + 16, ... of SEG_XCD_BLOCK consecutive items.  Independent of the item count (a wave can fetch its descriptor and the
+// count with two independent loads); ids >= 8 * ceil(n / 8 / B) * B ... are simply past the end (position >= n).
+constexpr uint32_t SEG_XCD_BLOCK = 32;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t seg_item_of(uint32_t w) {
+    const uint32_t c = w & 7u, q = w >> 3;
+    return ((q / SEG_XCD_BLOCK) * 8u + c) * SEG_XCD_BLOCK + (q % SEG_XCD_BLOCK);
+}
+// number of work ids that cover n items
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t seg_work_ids(uint32_t n) { return (n + 8u * SEG_XCD_BLOCK - 1u) / (8u * SEG_XCD_BLOCK) * (8u * SEG_XCD_BLOCK); }
 
 // The binning blob is laid out for an instance CAPACITY (a multiple of 4096 >= R): the forward may size it from a
 // guess before the host knows R, and the backward recovers the capacity from the blob's byte size.
@@ -175,8 +193,8 @@ struct BinLayout {
     uint32_t* radix_tbl;
     uint2* sub_list;   // [4*R] compact per-sub-tile candidate lists {Gaussian id, slot in the tile list}; sub-tile w
                        // of a tile with range [r0,r1) owns entries [4*r0 + w*(r1-r0), 4*r0 + (w+1)*(r1-r0))
-    uint32_t* seg_list; // [seg_capacity] live backward segments in tile order (seg_build_kernel)
-    SegDesc* seg_desc;  // [seg_capacity] their descriptors
+    uint32_t* seg_list; // [seg_capacity] live backward segments, longest first (seg_build_kernel)
+    SegDesc* seg_desc;  // [seg_capacity + 256] their descriptors (same order)
     float* seg_state;  // [seg_capacity][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
     size_t seg_cap;
     size_t bytes;
@@ -195,7 +213,7 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     b.sub_list = (uint2*)take(r * 4 * 8);
     b.seg_cap = seg_capacity(R, T);
     b.seg_list = (uint32_t*)take(b.seg_cap * 4);
-    b.seg_desc = (SegDesc*)take(b.seg_cap * sizeof(SegDesc));
+    b.seg_desc = (SegDesc*)take((b.seg_cap + 8 * SEG_XCD_BLOCK) * sizeof(SegDesc));
     b.seg_state = (float*)take(b.seg_cap * (size_t)nstate * 64 * 4);
     b.bytes = off;
     return b;

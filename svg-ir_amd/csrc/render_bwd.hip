@@ -139,11 +139,12 @@ render_bwd_kernel(const RenderBwdArgs a) {
     // the waves stride over the compact list of live depth segments (common.hpp SEG) the forward appended;
     // entry = (sub-tile id << SEG_K_BITS) | k
     const uint32_t nlive = min(a.seg_count[0], (uint32_t)a.seg_cap);
-    if (blockIdx.x >= 8u * ((nlive + 7u) >> 3)) return;
+    const uint32_t nwork = seg_work_ids(nlive);
+    if (blockIdx.x >= nwork) return;
     DEV_TRACE_DECL();
     [[maybe_unused]] unsigned dev_items = 0, dev_cands = 0;
-    for (uint32_t wi = blockIdx.x; wi < 8u * ((nlive + 7u) >> 3); wi += gridDim.x) {
-    const uint32_t item = seg_item_of(wi, nlive);   // XCD-local walk of the tile-ordered list (common.hpp)
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint32_t item = seg_item_of(wi);   // longest-first list, dealt to the XCDs in blocks of consecutive items (common.hpp)
     if (item >= nlive) continue;
     DEV_TRACE_MARK(3);
     wave_lds_sync();   // the previous segment's LDS traffic is complete before its buffers are reused

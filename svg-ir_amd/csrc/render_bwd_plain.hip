@@ -31,8 +31,11 @@ namespace {
 typedef const __attribute__((address_space(4))) float cfloat;      // constant address space: uniform loads become s_load
 typedef const __attribute__((address_space(4))) uint32_t cuint;
 
+#ifndef BWDP_GRID_MULT
+#define BWDP_GRID_MULT 4   // workgroups launched per resident wave slot
+#endif
 #ifndef BWDP_WPE
-#define BWDP_WPE 6
+#define BWDP_WPE 4
 #endif
 
 template <int S>
@@ -72,17 +75,15 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int colB = lane & 15, grpB = lane >> 4;
 
-    // B operand of the moment contraction, lane l: Mom[pixel 16 (l >> 4) + kk][column l & 15] = mx(kk & 7)^ex my(kk >> 3)^ey,
-    // (mx, my) = pixel position inside the 8x8 sub-tile minus 3.5, (ex, ey) by column: 1, px, py, px^2, px py, py^2
-    float momx[8], momy[2];
+    // B operand of the moment contraction, lane l: Mom[pixel 16 (l >> 4) + kk][column l & 15] = X(mx(kk & 7)) Y(my(kk >> 3)),
+    // (mx, my) = pixel position inside the 8x8 sub-tile minus 3.5, columns 1, px, py, px^2, px py, py^2 (others 0):
+    // X(m) = cx0 + m (cx1 + m cx2) with one-hot (cx0, cx1, cx2) by column -- evaluated between the MFMAs, where the wave
+    // waits for the matrix pipe anyway -- and Y for the lane's two pixel rows in momy[2]
+    float cx0, cx1, cx2, momy[2];
     {
         const int ex = colB == 1 || colB == 4 ? 1 : colB == 3 ? 2 : 0;
         const int ey = colB == 2 || colB == 4 ? 1 : colB == 5 ? 2 : 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float mx = (float)i - 3.5f;
-            momx[i] = colB >= 6 ? 0.f : ex == 0 ? 1.f : ex == 1 ? mx : mx * mx;
-        }
+        cx0 = (colB < 6 && ex == 0) ? 1.f : 0.f; cx1 = ex == 1 ? 1.f : 0.f; cx2 = ex == 2 ? 1.f : 0.f;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const float my = (float)(2 * grpB + h) - 3.5f;
@@ -90,19 +91,27 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         }
     }
 
+    typedef const __attribute__((address_space(4))) uint32_t cu32;
+    // the segment count and this wave's first descriptor are independent loads (the list position of a work id does not
+    // depend on the count: common.hpp seg_item_of)
+    cu32* dsc0 = (cu32*)(uintptr_t)(a.seg_desc + min(seg_item_of(blockIdx.x), (uint32_t)a.seg_cap));
+    uint32_t d_sm = dsc0[0], d_r0 = dsc0[1], d_len = dsc0[2], d_count = dsc0[3], d_ndump = dsc0[4];
     const uint32_t nlive = min(a.seg_count[0], (uint32_t)a.seg_cap);
-    if (blockIdx.x >= 8u * ((nlive + 7u) >> 3)) return;
+    const uint32_t nwork = seg_work_ids(nlive);
+    if (blockIdx.x >= nwork) return;
     DEV_TRACE_DECL();
     [[maybe_unused]] unsigned dev_items = 0, dev_cands = 0;
-    typedef const __attribute__((address_space(4))) uint32_t cu32;
-    for (uint32_t w = blockIdx.x; w < 8u * ((nlive + 7u) >> 3); w += gridDim.x) {
-    const uint32_t item = seg_item_of(w, nlive);   // XCD-local walk of the tile-ordered list (common.hpp)
+    for (uint32_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+    // longest-first list, dealt to the XCDs in blocks of consecutive items
+    const uint32_t item = seg_item_of(w);
     if (item >= nlive) continue;
+    if (w != blockIdx.x) {
+        cu32* dsc = (cu32*)(uintptr_t)(a.seg_desc + item);
+        d_sm = dsc[0]; d_r0 = dsc[1]; d_len = dsc[2]; d_count = dsc[3]; d_ndump = dsc[4];
+    }
     wave_lds_sync();   // the previous segment's LDS traffic is complete before its buffers are reused
-    // the segment's descriptor: one scalar load, then every other load of the set-up is independent of the rest
-    cu32* dsc = (cu32*)(uintptr_t)(a.seg_desc + item);
-    const uint32_t sm = dsc[0], r0 = dsc[1], tlen = dsc[2];
-    const int count = (int)dsc[3], ndump = (int)dsc[4];
+    const uint32_t sm = d_sm, r0 = d_r0, tlen = d_len;
+    const int count = (int)d_count, ndump = (int)d_ndump;
     const int sid = (int)(sm >> SEG_K_BITS), kseg = (int)(sm & ((1u << SEG_K_BITS) - 1u));
     const int tile = sid >> 2, sub = sid & 3;
     const int seg_lo = kseg * SEG, seg_hi = min(count, seg_lo + SEG);
@@ -115,6 +124,47 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     const float cxs = (float)(tx * TILE + (sub & 1) * 8) + 3.5f, cys = (float)(ty * TILE + (sub >> 1) * 8) + 3.5f;   // sub-tile centre
     const uint2* __restrict__ sub_in = a.sub_list + (size_t)4 * r0 + (size_t)sub * tlen;
     const size_t pid = inside ? (size_t)a.W * py + px : 0;
+    const int nent = seg_hi - seg_lo;
+    cuint* list_c = (cuint*)(uintptr_t)(sub_in + (seg_hi - 1));   // entry i of the walk = {list_c[-2 i], list_c[-2 i + 1]}
+
+    // per-candidate attributes (wave-uniform -> SGPRs): list entries are fetched two candidates ahead, records one ahead
+    struct Cand { float X, Y, cxx, cxy, cyy, op, dep, DA, DB, cr, cg, cb, nx, ny, nz, f[SS]; uint32_t slot; };
+    struct Entry { uint32_t gid, slot; };
+    typedef const __attribute__((address_space(4))) char cchar;
+    cchar* rec_b = (cchar*)(uintptr_t)a.rec;
+    cchar* feat_b = (cchar*)(uintptr_t)a.features;
+    auto fetch_entry = [&](int i) -> Entry {
+        const int ci = min(i, nent - 1);   // (uniform) clamped: slots beyond the list replay a real record with weight 0
+        Entry e;
+        e.gid = list_c[-2 * ci];
+        const uint32_t sl = list_c[-2 * ci + 1];
+        e.slot = i < nent ? sl : 0xffffffffu;   // (slot 2^32-1: never blends)
+        return e;
+    };
+    auto fetch_rec = [&](const Entry& e) -> Cand {
+        // 32-bit byte offsets: P * 96 B < 4 GiB (api.hip validate)
+        cfloat* r = (cfloat*)(rec_b + (uint32_t)(e.gid * (uint32_t)(REC * 4)));
+        Cand c;
+        c.X = r[R_X]; c.Y = r[R_Y]; c.cxx = r[R_CX]; c.cxy = r[R_CY]; c.cyy = r[R_CZ]; c.op = r[R_OP]; c.dep = r[R_DEPTH]; c.DA = r[R_DA];
+        c.DB = r[R_DB]; c.cr = r[R_R]; c.cg = r[R_G]; c.cb = r[R_B]; c.nx = r[R_NX]; c.ny = r[R_NY]; c.nz = r[R_NZ];
+        cfloat* f = (cfloat*)(feat_b + (uint32_t)(e.gid * (uint32_t)(S * 4)));
+        if (S >= 4) {   // (scalar loads only need dword alignment: one x4 + singles instead of S singles)
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f32x4u f4 = *reinterpret_cast<const __attribute__((address_space(4))) f32x4u*>(f);
+            c.f[0] = f4.x; c.f[1 % SS] = f4.y; c.f[2 % SS] = f4.z; c.f[3 % SS] = f4.w;
+#pragma unroll
+            for (int ch = 4; ch < S; ch++) c.f[ch] = f[ch];
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < SS; ch++) c.f[ch] = ch < S ? f[ch] : 0.f;
+        }
+        c.slot = e.slot;
+        return c;
+    };
+    // speculative: the replay usually starts at entry 0 -- its record is fetched while the per-pixel loads are in flight
+    const Cand spec_cur = fetch_rec(fetch_entry(0));
+    const Entry spec_en1 = fetch_entry(1);
+    asm volatile("" :: "s"(spec_cur.X), "s"(spec_en1.gid));   // (keeps the scalar loads here instead of at their first use)
 
     const float T_final = inside ? a.final_T[pid] : 0.f;
     const float D_final = (inside && normalize_depth) ? a.final_D[pid] : 0.f;
@@ -187,7 +237,6 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
 
     // The segment's list entries, deepest first (the replay walks back to front): LDS copy for the per-lane consumers
     // (atomics of phase B); the per-candidate math reads them with scalar loads.
-    const int nent = seg_hi - seg_lo;
     int nskip = 0;   // entries that lie behind every pixel of this wave (a prefix: slots descend)
     {
         uint2 e = make_uint2(0u, 0u);
@@ -195,42 +244,6 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         sQ[lane] = e;
         nskip = __popcll(__ballot(lane < nent && e.y >= wmax));
     }
-    cuint* list_c = (cuint*)(uintptr_t)(sub_in + (seg_hi - 1));   // entry i of the walk = {list_c[-2 i], list_c[-2 i + 1]}
-
-    // per-candidate attributes (wave-uniform -> SGPRs): list entries are fetched two candidates ahead, records one ahead
-    struct Cand { float X, Y, cxx, cxy, cyy, op, dep, DA, DB, cr, cg, cb, nx, ny, nz, f[SS]; uint32_t slot; };
-    struct Entry { uint32_t gid, slot; };
-    typedef const __attribute__((address_space(4))) char cchar;
-    cchar* rec_b = (cchar*)(uintptr_t)a.rec;
-    cchar* feat_b = (cchar*)(uintptr_t)a.features;
-    auto fetch_entry = [&](int i) -> Entry {
-        const int ci = min(i, nent - 1);   // (uniform) clamped: slots beyond the list replay a real record with weight 0
-        Entry e;
-        e.gid = list_c[-2 * ci];
-        const uint32_t sl = list_c[-2 * ci + 1];
-        e.slot = i < nent ? sl : 0xffffffffu;   // (slot 2^32-1: never blends)
-        return e;
-    };
-    auto fetch_rec = [&](const Entry& e) -> Cand {
-        // 32-bit byte offsets: P * 96 B < 4 GiB (api.hip validate)
-        cfloat* r = (cfloat*)(rec_b + (uint32_t)(e.gid * (uint32_t)(REC * 4)));
-        Cand c;
-        c.X = r[R_X]; c.Y = r[R_Y]; c.cxx = r[R_CX]; c.cxy = r[R_CY]; c.cyy = r[R_CZ]; c.op = r[R_OP]; c.dep = r[R_DEPTH]; c.DA = r[R_DA];
-        c.DB = r[R_DB]; c.cr = r[R_R]; c.cg = r[R_G]; c.cb = r[R_B]; c.nx = r[R_NX]; c.ny = r[R_NY]; c.nz = r[R_NZ];
-        cfloat* f = (cfloat*)(feat_b + (uint32_t)(e.gid * (uint32_t)(S * 4)));
-        if (S >= 4) {   // (scalar loads only need dword alignment: one x4 + singles instead of S singles)
-            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            const f32x4u f4 = *reinterpret_cast<const __attribute__((address_space(4))) f32x4u*>(f);
-            c.f[0] = f4.x; c.f[1 % SS] = f4.y; c.f[2 % SS] = f4.z; c.f[3 % SS] = f4.w;
-#pragma unroll
-            for (int ch = 4; ch < S; ch++) c.f[ch] = f[ch];
-        } else {
-#pragma unroll
-            for (int ch = 0; ch < SS; ch++) c.f[ch] = ch < S ? f[ch] : 0.f;
-        }
-        c.slot = e.slot;
-        return c;
-    };
     // flags folded into the per-pixel factors: the replay itself is branch-free
     const float gNe0 = surface ? gN[0] : 0.f, gNe1 = surface ? gN[1] : 0.f, gNe2 = surface ? gN[2] : 0.f;
     float gFe[SS];
@@ -240,13 +253,19 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     const float gOT = gO_kbg * T_final;
 
     const int cstart = (nskip / SB) * SB;
-    Cand cur = fetch_rec(fetch_entry(cstart));
-    Entry en1 = fetch_entry(cstart + 1);
+    Cand cur = spec_cur;
+    Entry en1 = spec_en1;
+    if (cstart != 0) {   // (uniform) the deepest entries lie behind every pixel of the wave: start further in
+        cur = fetch_rec(fetch_entry(cstart));
+        en1 = fetch_entry(cstart + 1);
+    }
     // Per-candidate constants of a block for its geometric epilogue (lane = (chunk, candidate)): copied global -> LDS by the
     // DMA path (no VGPRs, nothing waits) one block ahead -- issued here for the first block, then at the end of every block
     auto prefetch_consts = [&](int cb) {
-        if (lane < 3 * SB) {
-            const int cq = lane & 7, chunk = lane >> 3;
+        int lC = lane;
+        asm volatile("" : "+v"(lC));
+        if (lC < 3 * SB) {
+            const int cq = lC & 7, chunk = lC >> 3;
             const uint32_t gq = sQ[min(cb + cq, SEG - 1)].x;
             const float* src = a.rec + (uint32_t)(gq * (uint32_t)REC + (uint32_t)(chunk == 2 ? 12 : 4 * chunk));
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(smem + PG::off_c), 16, 0, 0);
@@ -297,6 +316,9 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
             hu = pre ? q5g : 0.f;                  // u: its pixel sum is the Q5 term (0 unless per-pixel depth is on)
             live |= (__builtin_amdgcn_ballot_w64(pre) != 0ull ? 1u : 0u) << k;
             cur = nxt;
+#ifdef BWDP_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         sP[(SB - 1) * PS + lane] = hw; sP[(2 * SB - 1) * PS + lane] = hv; sP[(3 * SB - 1) * PS + lane] = hu;
         DEV_TRACE_MARK(2);   // phase A
@@ -304,15 +326,23 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         wave_lds_sync();          // panel rows visible
         // ---------------- phase B: panel x [G | Mom] on the matrix pipe ----------------
         // D layout: lane l, register r -> row 4 (l >> 4) + r, column l & 15
+        // (lane-derived addresses are re-derived here every block: hoisted out of the loop they would hold ~20 VGPRs across phase A)
+        int lB = lane;
+        asm volatile("" : "+v"(lB));
+        const int colB = lB & 15, grpB = lB >> 4;
         f32x4 accM = {0.f, 0.f, 0.f, 0.f};
         {   // rows (v | u) x Mom: lanes 0..31, columns 0..5 = the six pixel moments of v; lanes 32..63, column 0 = sum of u
             const float4* ap = reinterpret_cast<const float4*>(sP + (SB + colB) * PS + 16 * grpB);
             const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
             const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w,
                                   a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+            float c0l = cx0;
+            asm volatile("" : "+v"(c0l));   // (opaque: the 16 operand values are not hoisted out of the block loop into 16 VGPRs)
 #pragma unroll
-            for (int kk = 0; kk < 16; kk++)
-                accM = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], momx[kk & 7] * momy[kk >> 3], accM, 0, 0, 0);
+            for (int kk = 0; kk < 16; kk++) {
+                const float mx = (float)(kk & 7) - 3.5f;
+                accM = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], (c0l + mx * (cx1 + mx * cx2)) * momy[kk >> 3], accM, 0, 0, 0);
+            }
         }
         if (grpB < 2) {
             if (colB < 6) {
@@ -337,7 +367,7 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         DEV_TRACE_MARK(3);   // phase B (MFMA)
         // lane = (value j = lane >> 3, candidate c = lane & 7): the six geometric gradients from the moments
         {
-            const int cq = lane & 7, jq = lane >> 3;
+            const int cq = lB & 7, jq = lB >> 3;
             if (jq < 6 && ((live >> cq) & 1u)) {
                 const float4 m03 = *reinterpret_cast<const float4*>(sM + cq * 8);
                 const float4 m47 = *reinterpret_cast<const float4*>(sM + cq * 8 + 4);
@@ -378,7 +408,7 @@ template <int S, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
     using PG = PlainGeom<S>;
     // one wave per live segment up to a few waves per resident slot; waves beyond the (device-side) count exit at once
-    const int grid = std::max(8, std::min(a.seg_cap, 4 * 256 * 4 * BWDP_WPE) & ~7);   // a multiple of 8: work id & 7 = XCD in every round
+    const int grid = std::max(8, std::min(a.seg_cap, BWDP_GRID_MULT * 256 * 4 * BWDP_WPE) & ~7);   // a multiple of 8: work id & 7 = XCD in every round
     hipLaunchKernelGGL((render_bwd_plain_kernel<S, SVGSS>), dim3(grid), dim3(64), PG::lds_bytes, s, a);
 }
 

@@ -409,7 +409,12 @@ render_fwd_kernel(const RenderArgs a) {
     if (lane == 0) {
         a.sub_count[sid] = head; a.sub_ndump[sid] = ndump;
         const uint32_t nseg = head != 0 ? min((head + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u) : 0u;
-        if (nseg != 0) atomicAdd(a.seg_block + (tile >> 8), nseg);
+        if (nseg != 0) {   // nseg - 1 full segments + the last one, by its length class
+            uint32_t* cnt = a.seg_block + (tile >> 8) * SEG_BLOCK_STRIDE;
+            const int lc = seg_class(head - (nseg - 1u) * (uint32_t)SEG);
+            if (nseg > 1u || lc == 0) atomicAdd(cnt, nseg - (lc == 0 ? 0u : 1u));
+            if (lc != 0) atomicAdd(cnt + lc, 1u);
+        }
     }
     if (head != 0 && ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
     else gather_acc();
@@ -438,26 +443,36 @@ render_fwd_kernel(const RenderArgs a) {
     DEV_TRACE_END(0, (unsigned)total, head, blockIdx.x);
 }
 
-// ---- live backward segments in tile order ---------------------------------------------------------------------
+// ---- live backward segments, longest first (common.hpp SEG) ------------------------------------------------------
 // One thread per tile (its four sub-tiles), 256 tiles per workgroup.  A sub-tile that consumed `count` candidates and dumped
-// `ndump` states has min(ceil(count / SEG), ndump + 1) live segments; the forward has already summed them per workgroup
-// (seg_block), so every workgroup derives its own base, scans its 256 tiles and writes ids + descriptors.  Deterministic
-// (an atomic append would list them in completion order) and ordered by tile for the backward's XCD-local walk.
+// `ndump` states has min(ceil(count / SEG), ndump + 1) live segments: all full but possibly the last.  The forward has
+// already summed them per workgroup and length class (seg_block), so every workgroup derives its own bases, scans its 256
+// tiles and writes ids + descriptors: class-major, tile order inside a class.  Deterministic.
 __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int T) {
-    __shared__ uint32_t wsum[4], red[2][4];
+    __shared__ uint32_t red_b[SEG_CLASSES][4], red_t[SEG_CLASSES][4], wfull[4];
+    __shared__ unsigned long long wpart[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tile = blockIdx.x * 256 + t;
-    // base of this workgroup and the grand total from the per-workgroup sums
-    uint32_t before = 0, total = 0;
+    // per class: segments in the workgroups before this one, and in all of them
+    uint32_t bef[SEG_CLASSES], tot[SEG_CLASSES];
+#pragma unroll
+    for (int c = 0; c < SEG_CLASSES; c++) bef[c] = tot[c] = 0u;
     for (int j = t; j < (int)gridDim.x; j += 256) {
-        const uint32_t v = a.seg_block[j];
-        total += v;
-        before += j < (int)blockIdx.x ? v : 0u;
+#pragma unroll
+        for (int c = 0; c < SEG_CLASSES; c++) {
+            const uint32_t v = a.seg_block[j * SEG_BLOCK_STRIDE + c];
+            tot[c] += v;
+            bef[c] += j < (int)blockIdx.x ? v : 0u;
+        }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { before += (uint32_t)__shfl_xor((int)before, d); total += (uint32_t)__shfl_xor((int)total, d); }
-    if (lane == 0) { red[0][wave] = before; red[1][wave] = total; }
+    for (int c = 0; c < SEG_CLASSES; c++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { bef[c] += (uint32_t)__shfl_xor((int)bef[c], d); tot[c] += (uint32_t)__shfl_xor((int)tot[c], d); }
+        if (lane == 0) { red_b[c][wave] = bef[c]; red_t[c][wave] = tot[c]; }
+    }
     uint32_t nseg[4] = {0u, 0u, 0u, 0u}, head[4] = {0u, 0u, 0u, 0u}, nd[4] = {0u, 0u, 0u, 0u}, r0 = 0, r1 = 0;
+    int lcls[4] = {0, 0, 0, 0};
     if (tile < T) {
         const uint4 c4 = reinterpret_cast<const uint4*>(a.sub_count)[tile], d4 = reinterpret_cast<const uint4*>(a.sub_ndump)[tile];
         const uint2 rr = reinterpret_cast<const uint2*>(a.ranges)[tile];
@@ -465,31 +480,57 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
         head[0] = c4.x; head[1] = c4.y; head[2] = c4.z; head[3] = c4.w;
         nd[0] = d4.x; nd[1] = d4.y; nd[2] = d4.z; nd[3] = d4.w;
 #pragma unroll
-        for (int w = 0; w < 4; w++) nseg[w] = head[w] != 0 ? min((head[w] + (uint32_t)SEG - 1u) / (uint32_t)SEG, nd[w] + 1u) : 0u;
+        for (int w = 0; w < 4; w++) {
+            nseg[w] = head[w] != 0 ? min((head[w] + (uint32_t)SEG - 1u) / (uint32_t)SEG, nd[w] + 1u) : 0u;
+            lcls[w] = nseg[w] != 0 ? seg_class(head[w] - (nseg[w] - 1u) * (uint32_t)SEG) : 0;
+        }
     }
-    const uint32_t mine = (nseg[0] + nseg[1]) + (nseg[2] + nseg[3]);
-    uint32_t incl = mine;
+    // this thread's segments: full ones (class 0) and, packed 16 bits per class, its partial last segments (classes 1..4)
+    uint32_t nfull = 0;
+    unsigned long long npart = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (nseg[w] == 0) continue;
+        nfull += nseg[w] - (lcls[w] == 0 ? 0u : 1u);
+        if (lcls[w] != 0) npart += 1ull << (16 * (lcls[w] - 1));
+    }
+    uint32_t ifull = nfull;
+    unsigned long long ipart = npart;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += o;
+        const uint32_t of = (uint32_t)__shfl_up((int)ifull, d);
+        const unsigned long long op = (unsigned long long)__shfl_up((long long)ipart, d);
+        if (lane >= d) { ifull += of; ipart += op; }
     }
-    if (lane == 63) wsum[wave] = incl;
+    if (lane == 63) { wfull[wave] = ifull; wpart[wave] = ipart; }
     __syncthreads();
-    uint32_t at = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) + incl - mine;
+    uint32_t base[SEG_CLASSES], n_all = 0;
 #pragma unroll
-    for (int v = 0; v < 4; v++) at += v < wave ? wsum[v] : 0u;
-    if (blockIdx.x == 0 && t == 0) a.seg_count[0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    if (mine == 0) return;
+    for (int c = 0; c < SEG_CLASSES; c++) {
+        base[c] = n_all + (red_b[c][0] + red_b[c][1]) + (red_b[c][2] + red_b[c][3]);   // classes before + workgroups before
+        n_all += (red_t[c][0] + red_t[c][1]) + (red_t[c][2] + red_t[c][3]);
+    }
+    uint32_t xfull = ifull - nfull;
+    unsigned long long xpart = ipart - npart;
+#pragma unroll
+    for (int v = 0; v < 4; v++) { xfull += v < wave ? wfull[v] : 0u; xpart += v < wave ? wpart[v] : 0ull; }
+    if (blockIdx.x == 0 && t == 0) a.seg_count[0] = n_all;
+    if (nfull == 0 && npart == 0ull) return;
+    uint32_t at[SEG_CLASSES];
+    at[0] = base[0] + xfull;
+#pragma unroll
+    for (int c = 1; c < SEG_CLASSES; c++) at[c] = base[c] + (uint32_t)((xpart >> (16 * (c - 1))) & 0xffffull);
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         for (uint32_t k = 0; k < nseg[w]; k++) {
+            const int c = (k + 1u == nseg[w]) ? lcls[w] : 0;
+            uint32_t pos;
+            if (c == 0) pos = at[0]++; else if (c == 1) pos = at[1]++; else if (c == 2) pos = at[2]++; else if (c == 3) pos = at[3]++; else pos = at[4]++;
             const uint32_t sm = ((uint32_t)(4 * tile + w) << SEG_K_BITS) | k;
-            a.seg_list[at] = sm;
-            uint4* d = reinterpret_cast<uint4*>(a.seg_desc + at);
+            a.seg_list[pos] = sm;
+            uint4* d = reinterpret_cast<uint4*>(a.seg_desc + pos);
             d[0] = make_uint4(sm, r0, r1 - r0, head[w]);
             d[1] = make_uint4(nd[w], 0u, 0u, 0u);
-            at++;
         }
     }
 }

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64) render_fwd_generic_kernel(const RenderArgs
     // no depth segments: the backward replays the whole list from the end (one list entry per sub-tile)
     if (lane == 0) {
         a.sub_count[sid] = (uint32_t)i; a.sub_ndump[sid] = 0u;
-        if (i != 0) atomicAdd(a.seg_block + (sid >> 10), 1u);   // one live segment (common.hpp seg_build)
+        if (i != 0) atomicAdd(a.seg_block + (sid >> 10) * SEG_BLOCK_STRIDE + seg_class((uint32_t)i), 1u);   // one live segment (render_fwd.hip seg_build_kernel)
     }
     if (inside) {
         const size_t N_ = (size_t)a.W * a.H;
