@@ -59,24 +59,27 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
                                                               int n_cap, const uint32_t* __restrict__ n_dev, int bit_lo, int nbits,
                                                               const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ gtot, int ngroups) {
-    __shared__ uint32_t running[256];     // global output cursor per digit for this block
-    __shared__ uint32_t wave_cnt[4][256];  // per-wave digit counts of the current chunk
+    __shared__ uint32_t wcnt[4][256];   // per-wave digit counters, later the waves' output cursors
     __shared__ uint32_t wtot[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t mask = (1u << nbits) - 1;
     const int n = n_dev ? (int)min((uint32_t)n_cap, n_dev[0]) : n_cap;
-    const int base = blockIdx.x * (BLOCK * ITEMS);
+    // wave w owns the w-th quarter of the block's keys (consecutive keys: round-major, lane-minor = key order)
+    const int base = blockIdx.x * (BLOCK * ITEMS) + wave * (64 * ITEMS);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // all loads of the block up front
-    uint32_t ks[ITEMS], vs[ITEMS];
+    uint32_t ks[ITEMS], vs[ITEMS], rk[ITEMS];
 #pragma unroll
     for (int c = 0; c < ITEMS; c++) {
-        const int e = base + c * BLOCK + t;
+        const int e = base + c * 64 + lane;
         ks[c] = e < n ? kin[e] : 0u;
         vs[c] = e < n ? vin[e] : 0u;
     }
+#pragma unroll
+    for (int w = 0; w < 4; w++) wcnt[w][t] = 0;
     // Output cursor of digit t for this block:
     //   sum_{d < t} total[d]  +  sum_{groups before mine} gtot[g][t]  +  sum_{blocks before me in my group} table[b][t]
+    uint32_t cursor;
     {
         const int g = blockIdx.x / GS;
         uint32_t tot = 0, pre = 0;
@@ -95,42 +98,42 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
             if (lane >= d) incl += o;
         }
         if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
+        __syncthreads();   // (also: the wave counters are zero)
         uint32_t woff = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) woff += w < wave ? wtot[w] : 0u;
-        running[t] = woff + incl - tot + pre;
+        cursor = woff + incl - tot + pre;
     }
+    // rank of every key among the keys of its WAVE with the same digit: wave-level digit matching (ballots) against a
+    // wave-private digit counter in LDS -- no workgroup barrier inside the ranking
 #pragma unroll
     for (int c = 0; c < ITEMS; c++) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) wave_cnt[w][t] = 0;
-        __syncthreads();
-        const int e = base + c * BLOCK + t;
-        const bool valid = e < n;
-        const uint32_t k = ks[c], v = vs[c];
-        const uint32_t d = (k >> bit_lo) & mask;
-        // lanes of this wave holding the same digit
+        const bool valid = base + c * 64 + lane < n;
+        const uint32_t d = (ks[c] >> bit_lo) & mask;
         unsigned long long same = __ballot(valid);
         for (int b = 0; b < nbits; b++) {
             const unsigned long long m = __ballot((d >> b) & 1u);
             same &= ((d >> b) & 1u) ? m : ~m;
         }
-        const uint32_t rank_in_wave = __popcll(same & lt_mask);
-        if (valid && rank_in_wave == 0) wave_cnt[wave][d] = __popcll(same);
+        const uint32_t in_round = (uint32_t)__popcll(same & lt_mask);
+        const uint32_t prior = wcnt[wave][d];   // (the DS operations of a wave execute in order: every lane reads before the leader writes)
+        rk[c] = prior + in_round;
+        if (valid && in_round == 0) wcnt[wave][d] = prior + (uint32_t)__popcll(same);
+    }
+    __syncthreads();
+    {   // digit t: the waves' cursors = block cursor + counts of the waves in front
+        const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t];
         __syncthreads();
-        uint32_t pos = 0;
-        if (valid) {
-            pos = running[d] + rank_in_wave;
-            for (int w = 0; w < wave; w++) pos += wave_cnt[w][d];
+        wcnt[0][t] = cursor; wcnt[1][t] = cursor + c0; wcnt[2][t] = cursor + c0 + c1; wcnt[3][t] = cursor + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ITEMS; c++) {
+        if (base + c * 64 + lane < n) {
+            const uint32_t pos = wcnt[wave][(ks[c] >> bit_lo) & mask] + rk[c];
+            kout[pos] = ks[c];
+            vout[pos] = vs[c];
         }
-        __syncthreads();
-        if (t <= (int)mask) running[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
-        if (valid) {
-            kout[pos] = k;
-            vout[pos] = v;
-        }
-        __syncthreads();
     }
 }
 
