@@ -339,6 +339,27 @@ int svgir_mask_scan(int32_t P, const uint8_t* keep, uint32_t* kept, uint32_t* wo
 int svgir_gather_rows(const svgir_row_tensor* tensors, int32_t count, const uint32_t* kept, const uint32_t* count_dev,
                       int32_t rows_max, void* stream);
 
+/* The producer of the visibility the shading kernels stream: a linear BVH over the surfels and the
+ * visibility tracer of submodules/bvh (`RayTracer`, __init__.py:28-71; `create_bvh` src/bvh.cu:8-28 + src/construct.cu:151-265;
+ * `trace_bvh_opacity` src/bvh.cu:86-115 + src/trace.cu:186-262).
+ *   svgir_bvh_bytes : size of the opaque BVH blob for P surfels.
+ *   svgir_bvh_build : leaf boxes from the eight corners mean +- 3 (s_a a +- s_b b +- s_c c) (a, b, c = columns of the
+ *       rotation of the normalised quaternion), Morton sort, hierarchy, bottom-up refit.  means3D [P,3], scales [P,3],
+ *       rotations [P,4] (r,x,y,z; need not be normalised).
+ *   svgir_bvh_trace_visibility : per ray, origin rays_o + t_offset * rays_d (the reference's caller passes 0.05), the
+ *       product of (1 - opacity exp(power)) over the surfels whose leaf box the ray enters, with opacity >= 1/255, facing
+ *       the ray (normal . d <= 0), t >= 0.01 and power <= 0, where t = (m^T C d) / (d^T C d) and
+ *       power = -1/2 (mean - x(t))^T C (mean - x(t)); visibility = 0 (and contribute = 0) as soon as the product drops
+ *       below 0.9, else the product and the number of contributing surfels.  means3D [P,3], cov_inv [P,6] (symmetric,
+ *       xx xy xz yy yz zz), opacity [P], normals [P,3] may differ from the arrays the BVH was built from (they do in the
+ *       reference: build from scaling/rotation, trace with the inverse covariance); rays_o / rays_d [num_rays,3];
+ *       contribute [num_rays] int32, visibility [num_rays]. */
+size_t svgir_bvh_bytes(int32_t P);
+int svgir_bvh_build(int32_t P, const float* means3D, const float* scales, const float* rotations, char* bvh, void* stream);
+int svgir_bvh_trace_visibility(int32_t P, char* bvh, int64_t num_rays, const float* rays_o, const float* rays_d, float t_offset,
+                               const float* means3D, const float* cov_inv, const float* opacity, const float* normals,
+                               int32_t* contribute, float* visibility, void* stream);
+
 /* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
  * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,
  * the AVERAGE duration in milliseconds and the number of samples since profiling was (re-)enabled.

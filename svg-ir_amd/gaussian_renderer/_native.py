@@ -95,7 +95,8 @@ EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_
            "svgir_unpack_forward", "svgir_unpack_backward", "svgir_depth2normal", "svgir_pack_rgss_forward",
            "svgir_pack_rgss_backward", "svgir_unpack_rgss_forward", "svgir_unpack_rgss_backward", "svgir_l1_ssim_partials",
            "svgir_l1_ssim_forward", "svgir_l1_ssim_backward", "svgir_adam_step", "svgir_densify_stats",
-           "svgir_mask_scan_work_words", "svgir_mask_scan", "svgir_gather_rows")
+           "svgir_mask_scan_work_words", "svgir_mask_scan", "svgir_gather_rows", "svgir_bvh_bytes", "svgir_bvh_build",
+           "svgir_bvh_trace_visibility")
 
 
 def last_error():
