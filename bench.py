@@ -102,7 +102,7 @@ def visible_gpu_count():
     n = 0
     nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
     if not nodes:
-        return None
+        return 0    # no KFD topology: no AMD GPU driver in this container
     for f in nodes:
         try:
             props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)

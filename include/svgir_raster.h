@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 5
+#define SVGIR_ABI_VERSION 6
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -324,11 +324,19 @@ int svgir_l1_ssim_backward(const float* img1, const float* img2, const float* dm
  *   tensors with rows of row_bytes (multiple of 4) in one launch: the `tensor[mask]` of _prune_optimizer for every
  *   parameter, both Adam moments and the bookkeeping arrays at once. */
 #define SVGIR_ADAM_MAX_TENSORS 32
+/* svgir_adam_tensor.flags -- GaussianModel.step() (scene/gaussian_model.py:775-813) folded into the Adam pass:
+ *   SVGIR_ADAM_SCRUB_NAN : replace_nangrad_to_zero -- NaN gradient entries are replaced by `nan_value` (0 or 1e-6 by group)
+ *                          before the update, and in the gradient tensor itself;
+ *   SVGIR_ADAM_ZERO_GRAD : optimizer.zero_grad() -- the gradient tensor is left zero-filled. */
+#define SVGIR_ADAM_SCRUB_NAN 1
+#define SVGIR_ADAM_ZERO_GRAD 2
 typedef struct svgir_adam_tensor {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
     int64_t n;        /* elements */
     double lr;
     int32_t step;
+    int32_t flags;    /* SVGIR_ADAM_* (the gradient is written when a flag is set) */
+    float nan_value;
 } svgir_adam_tensor;
 typedef struct svgir_row_tensor { const void* src; void* dst; int32_t row_bytes; } svgir_row_tensor;
 int svgir_adam_step(const svgir_adam_tensor* tensors, int32_t count, double beta1, double beta2, double eps, void* stream);
@@ -359,6 +367,28 @@ int svgir_bvh_build(int32_t P, const float* means3D, const float* scales, const 
 int svgir_bvh_trace_visibility(int32_t P, char* bvh, int64_t num_rays, const float* rays_o, const float* rays_d, float t_offset,
                                const float* means3D, const float* cov_inv, const float* opacity, const float* normals,
                                int32_t* contribute, float* visibility, void* stream);
+
+/* Densification (scene/gaussian_model.py:1064-1248).
+ * svgir_densify_masks : the selection of densify_and_clone / densify_and_split from the statistics densify_and_prune
+ *   derives (grads = xyz_gradient_accum / denom and normal_gradient_accum / denom, NaN -> 0): selected when
+ *   |grads| >= grad_threshold or |grads_normal| >= normal_threshold; clone_mask = selected and max(exp(scaling_raw)) <=
+ *   size_limit (= percent_dense * scene_extent), split_mask = selected and > size_limit.  normal_gradient_accum may be NULL.
+ * svgir_append_rows : cat_tensors_to_optimizer / densification_postfix for up to SVGIR_ADAM_MAX_TENSORS per-row tensors in
+ *   one launch: dst = cat(src[0:rows_old], repeat(src[list[0:n]], repeat)), n = min(n_sel_max, *count_dev) (list / count_dev
+ *   as produced by svgir_mask_scan); SVGIR_APPEND_ZERO_NEW leaves the new rows zero (the Adam moments of the new points).
+ *   dst holds rows_old + n_sel_max * repeat rows of row_bytes (multiple of 4).
+ * svgir_split_transform : densify_and_split's new points, in place on the n_new appended copies of the selected rows:
+ *   xyz <- R(rotation) (z * exp(scaling)) + xyz, scaling <- log(exp(scaling) / (0.8 N)) with the last axis at -1e10;
+ *   z [n_new,3] = the standard-normal draws (torch.normal(mean = 0, std = stds) = stds * z). */
+#define SVGIR_APPEND_ZERO_NEW 1
+typedef struct svgir_append_tensor { const void* src; void* dst; int32_t row_bytes; int32_t flags; } svgir_append_tensor;
+int svgir_densify_masks(int32_t P, const float* xyz_gradient_accum, const float* normal_gradient_accum, const float* denom,
+                        const float* scaling_raw, float grad_threshold, float normal_threshold, float size_limit,
+                        uint8_t* clone_mask, uint8_t* split_mask, void* stream);
+int svgir_append_rows(const svgir_append_tensor* tensors, int32_t count, int64_t rows_old, const uint32_t* list,
+                      const uint32_t* count_dev, int64_t n_sel_max, int32_t repeat, void* stream);
+int svgir_split_transform(int64_t n_new, int32_t N, const float* z, float* xyz_new, float* scaling_new, const float* rotation_new,
+                          void* stream);
 
 /* Per-stage GPU timing.  While enabled, forward/backward record HIP events on the launch stream at every stage
  * boundary (no extra synchronisation); svgir_last_timings() waits for the recorded events and returns, per stage,

@@ -25,6 +25,8 @@ struct AdamTable {
     long long n[ADAM_MAX];
     int first_chunk[ADAM_MAX + 1];
     float neg_step_size[ADAM_MAX], bc2_sqrt[ADAM_MAX];
+    float nan_value[ADAM_MAX]; int flags[ADAM_MAX];   // SVGIR_ADAM_SCRUB_NAN / SVGIR_ADAM_ZERO_GRAD
+    float* gw[ADAM_MAX];                              // writable alias of g when a flag needs it
     int count;
 };
 
@@ -34,15 +36,23 @@ __global__ void __launch_bounds__(BLOCK) adam_kernel(const AdamTable t, float w1
     while (k + 1 < t.count && (int)blockIdx.x >= t.first_chunk[k + 1]) k++;   // (<= 32 steps, scalar)
     const long long base = (long long)((int)blockIdx.x - t.first_chunk[k]) * ADAM_CHUNK;
     float* __restrict__ p = t.p[k];
-    const float* __restrict__ g = t.g[k];
+    const float* g = t.g[k];   // (may alias gw)
     float* __restrict__ m = t.m[k];
     float* __restrict__ v = t.v[k];
     const long long n = t.n[k];
     const float nss = t.neg_step_size[k], bs = t.bc2_sqrt[k];
+    const int flags = t.flags[k];
+    const float nanv = t.nan_value[k];
+    float* gw = t.gw[k];
     for (int j = threadIdx.x; j < ADAM_CHUNK; j += BLOCK) {
         const long long i = base + j;
         if (i >= n) break;
-        const float gi = g[i];
+        float gi = g[i];
+        // GaussianModel.step(): replace_nangrad_to_zero (NaN gradient entries -> the group's replacement value, in place),
+        // optimizer.step(), optimizer.zero_grad() -- folded into the one pass over the gradient
+        if ((flags & SVGIR_ADAM_SCRUB_NAN) && gi != gi) gi = nanv;
+        if (flags & SVGIR_ADAM_ZERO_GRAD) gw[i] = 0.f;
+        else if (flags & SVGIR_ADAM_SCRUB_NAN) gw[i] = gi;
         float mi = m[i], vi = v[i];
         mi = mi + w1 * (gi - mi);              // exp_avg.lerp_(grad, 1 - beta1)
         vi = vi * b2;                          // exp_avg_sq.mul_(beta2)
@@ -142,11 +152,129 @@ __global__ void __launch_bounds__(BLOCK) gather_rows_kernel(const GatherTable t,
     t.dst[k][row * words + j] = t.src[k][(size_t)kept[row] * words + j];
 }
 
+// ---- densification: selection masks, fused append, split transform (scene/gaussian_model.py:1136-1248) ---------------------
+__global__ void __launch_bounds__(BLOCK) densify_masks_kernel(int P, const float* __restrict__ grad_accum, const float* __restrict__ normal_accum,
+                                                              const float* __restrict__ denom, const float* __restrict__ scaling_raw,
+                                                              float grad_threshold, float normal_threshold, float size_limit,
+                                                              uint8_t* __restrict__ clone_mask, uint8_t* __restrict__ split_mask) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P) return;
+    // densify_and_prune: grads = accum / denom, NaN -> 0; norm over the last (size-1) axis = |.|
+    float g = grad_accum[i] / denom[i], gn = normal_accum ? normal_accum[i] / denom[i] : 0.f;
+    g = g != g ? 0.f : fabsf(g);
+    gn = gn != gn ? 0.f : fabsf(gn);
+    const bool sel = g >= grad_threshold || gn >= normal_threshold;
+    // get_scaling = exp(_scaling); max over the three axes
+    const float s = fmaxf(fmaxf(expf(scaling_raw[3 * i]), expf(scaling_raw[3 * i + 1])), expf(scaling_raw[3 * i + 2]));
+    clone_mask[i] = sel && s <= size_limit;
+    split_mask[i] = sel && s > size_limit;
+}
+
+struct AppendTable {
+    const uint32_t* src[ADAM_MAX]; uint32_t* dst[ADAM_MAX];
+    int words[ADAM_MAX]; int flags[ADAM_MAX];
+    long long first_word[ADAM_MAX + 1];
+    int count;
+};
+// dst = cat(src[0 : rows_old], repeat(src[list], repeat))  (new rows zero for SVGIR_APPEND_ZERO_NEW: the Adam moments of
+// cat_tensors_to_optimizer); one launch for every parameter, both moments and the bookkeeping arrays
+__global__ void __launch_bounds__(BLOCK) append_rows_kernel(const AppendTable t, const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ count_dev, long long rows_old, long long n_sel_max,
+                                                            int repeat) {
+    const long long n_sel = min((long long)count_dev[0], n_sel_max);
+    const long long w = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    int k = 0;
+    while (k + 1 < t.count && w >= t.first_word[k + 1]) k++;
+    if (w >= t.first_word[t.count]) return;
+    const long long r = w - t.first_word[k];
+    const int words = t.words[k];
+    const long long row = r / words;
+    const int j = (int)(r - row * words);
+    if (row < rows_old) { t.dst[k][r] = t.src[k][r]; return; }
+    const long long q = row - rows_old;
+    if (q >= n_sel * repeat) return;
+    t.dst[k][r] = (t.flags[k] & SVGIR_APPEND_ZERO_NEW) ? 0u : t.src[k][(size_t)list[q % n_sel] * words + j];
+}
+
+// densify_and_split on the freshly appended copies (rows [rows_old, rows_old + n_new)): xyz <- R(q) (z * exp(s)) + xyz,
+// scaling <- log(exp(s) / (0.8 N)) with the last axis at -1e10 (scene/gaussian_model.py:1152-1161); z = standard normal
+// draws supplied by the caller ([n_new, 3], torch.normal(mean = 0, std = stds) = stds * z)
+__global__ void __launch_bounds__(BLOCK) split_transform_kernel(long long n_new, int N, const float* __restrict__ z,
+                                                                float* __restrict__ xyz, float* __restrict__ scaling,
+                                                                const float* __restrict__ rotation) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_new) return;
+    const float s0 = expf(scaling[3 * i]), s1 = expf(scaling[3 * i + 1]), s2 = expf(scaling[3 * i + 2]);
+    const float v[3] = {z[3 * i] * s0, z[3 * i + 1] * s1, z[3 * i + 2] * s2};
+    float q0 = rotation[4 * i], q1 = rotation[4 * i + 1], q2 = rotation[4 * i + 2], q3 = rotation[4 * i + 3];
+    const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);   // build_rotation (utils/general_utils.py:82-103)
+    q0 /= nrm; q1 /= nrm; q2 /= nrm; q3 /= nrm;
+    const float r = q0, x = q1, y = q2, w = q3;
+    const float R[3][3] = {{1 - 2 * (y * y + w * w), 2 * (x * y - r * w), 2 * (x * w + r * y)},
+                           {2 * (x * y + r * w), 1 - 2 * (x * x + w * w), 2 * (y * w - r * x)},
+                           {2 * (x * w - r * y), 2 * (y * w + r * x), 1 - 2 * (x * x + y * y)}};
+#pragma unroll
+    for (int c = 0; c < 3; c++) xyz[3 * i + c] = ((R[c][0] * v[0] + R[c][1] * v[1]) + R[c][2] * v[2]) + xyz[3 * i + c];
+    const float k = 0.8f * (float)N;
+    scaling[3 * i] = logf(s0 / k); scaling[3 * i + 1] = logf(s1 / k); scaling[3 * i + 2] = -1e10f;
+}
+
 }  // namespace
 
 }  // namespace svgir
 
 extern "C" {
+
+int svgir_densify_masks(int32_t P, const float* xyz_gradient_accum, const float* normal_gradient_accum, const float* denom,
+                        const float* scaling_raw, float grad_threshold, float normal_threshold, float size_limit,
+                        uint8_t* clone_mask, uint8_t* split_mask, void* stream) {
+    using namespace svgir;
+    if (P < 0 || (P > 0 && (!xyz_gradient_accum || !denom || !scaling_raw || !clone_mask || !split_mask))) return SVGIR_ERR_INVALID;
+    if (P == 0) return SVGIR_OK;
+    hipLaunchKernelGGL(densify_masks_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, P, xyz_gradient_accum,
+                       normal_gradient_accum, denom, scaling_raw, grad_threshold, normal_threshold, size_limit, clone_mask, split_mask);
+    return hipGetLastError() == hipSuccess ? SVGIR_OK : SVGIR_ERR_HIP;
+}
+
+int svgir_append_rows(const svgir_append_tensor* tensors, int32_t count, int64_t rows_old, const uint32_t* list,
+                      const uint32_t* count_dev, int64_t n_sel_max, int32_t repeat, void* stream) {
+    using namespace svgir;
+    if (count < 0 || count > ADAM_MAX || rows_old < 0 || n_sel_max < 0 || repeat < 1 || (count > 0 && !tensors) ||
+        (n_sel_max > 0 && (!list || !count_dev)))
+        return SVGIR_ERR_INVALID;
+    if (count == 0) return SVGIR_OK;
+    AppendTable t;
+    t.count = 0;
+    long long words = 0;
+    const long long rows_new = rows_old + n_sel_max * repeat;
+    for (int i = 0; i < count; i++) {
+        const svgir_append_tensor& a = tensors[i];
+        if (a.row_bytes == 0) continue;
+        if (!a.dst || (!a.src && rows_old > 0) || a.row_bytes % 4 != 0) return SVGIR_ERR_INVALID;
+        const int k = t.count++;
+        t.src[k] = (const uint32_t*)a.src; t.dst[k] = (uint32_t*)a.dst; t.words[k] = a.row_bytes / 4; t.flags[k] = a.flags;
+        t.first_word[k] = words;
+        words += rows_new * t.words[k];
+    }
+    if (t.count == 0 || words == 0) return SVGIR_OK;
+    t.first_word[t.count] = words;
+    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, t, list,
+                       count_dev, (long long)rows_old, (long long)n_sel_max, repeat);
+    return hipGetLastError() == hipSuccess ? SVGIR_OK : SVGIR_ERR_HIP;
+}
+
+int svgir_split_transform(int64_t n_new, int32_t N, const float* z, float* xyz_new, float* scaling_new, const float* rotation_new,
+                          void* stream) {
+    using namespace svgir;
+    if (n_new < 0 || N < 1 || (n_new > 0 && (!z || !xyz_new || !scaling_new || !rotation_new))) return SVGIR_ERR_INVALID;
+    if (n_new == 0) return SVGIR_OK;
+    hipLaunchKernelGGL(split_transform_kernel, dim3((unsigned)((n_new + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (long long)n_new, N, z, xyz_new, scaling_new, rotation_new);
+    return hipGetLastError() == hipSuccess ? SVGIR_OK : SVGIR_ERR_HIP;
+}
+
 
 int svgir_adam_step(const svgir_adam_tensor* tensors, int32_t count, double beta1, double beta2, double eps, void* stream) {
     using namespace svgir;
@@ -160,6 +288,7 @@ int svgir_adam_step(const svgir_adam_tensor* tensors, int32_t count, double beta
         if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq || a.step < 1) return SVGIR_ERR_INVALID;
         const int k = t.count++;
         t.p[k] = a.param; t.g[k] = a.grad; t.m[k] = a.exp_avg; t.v[k] = a.exp_avg_sq; t.n[k] = a.n;
+        t.flags[k] = a.flags; t.nan_value[k] = a.nan_value; t.gw[k] = const_cast<float*>(a.grad);
         t.first_chunk[k] = chunks;
         chunks += (int)((a.n + ADAM_CHUNK - 1) / ADAM_CHUNK);
         // torch/optim/adam.py _single_tensor_adam: python-float (double) bias corrections

@@ -111,3 +111,85 @@ def test_densification_stats(built):
     add_densification_stats(vg, flt, w, acc[0], acc[1], acc[2])
     for a, b in zip(acc, ref):
         assert torch.allclose(a, b, rtol=2e-7, atol=0)
+
+
+# ---- GaussianModel.step() and densify_and_prune against the reference's own methods (tests/golden/densify.npz) ----
+_SPEC = [("xyz", 1.6e-4), ("normal", 1e-3), ("rotation", 1e-3), ("scaling", 5e-3), ("opacity", 5e-2), ("f_dc", 2.5e-3),
+         ("f_rest", 1.25e-4), ("base_color", 1e-2), ("roughness", 1e-2), ("incidents_dc", 2e-3), ("incidents_rest", 1e-4),
+         ("visibility_dc", 2.5e-3), ("visibility_rest", 1.25e-4)]
+
+
+def _densify_state(gold):
+    from svgir_harness.optim import DensifyState, FusedAdam
+    dev = torch.device("cuda:0")
+    params = {n: torch.nn.Parameter(torch.from_numpy(gold["init_" + n]).to(dev)) for n, _ in _SPEC}
+    opt = FusedAdam([{"params": [params[n]], "lr": lr, "name": n} for n, lr in _SPEC], lr=1e-4, eps=1e-15)
+    return DensifyState(params, opt, percent_dense=0.01, use_pbr=True), dev
+
+
+def _same(a, b, what, tol=2e-6):
+    a = a.detach().double().cpu().numpy(); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.size == 0:
+        return
+    finite = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), finite), what
+    scale = max(np.abs(b[finite]).max(), 1e-30) if finite.any() else 1.0
+    err = np.abs(a[finite] - b[finite]).max() if finite.any() else 0.0
+    assert err <= tol * scale, (what, err / scale)
+
+
+def test_step_and_densify_and_prune_match_the_reference_methods(built):
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "densify.npz"))
+    st, dev = _densify_state(gold)
+    # ---- GaussianModel.step(): NaN-gradient scrub + Adam + zero_grad, one launch ----
+    for it in range(3):
+        for n, _ in _SPEC:
+            g = gold[f"grad{it}_{n}"]
+            st.params[n].grad = torch.from_numpy(g).to(dev) if g.size else None
+        st.step()
+        for n, _ in _SPEC:   # zero_grad: the gradients are left zero (the reference sets them to None)
+            assert st.params[n].grad is None or float(st.params[n].grad.abs().max()) == 0.0
+    for n, _ in _SPEC:
+        p = st.params[n]
+        s = st.optimizer.state[p]
+        _same(p, gold["step_" + n], "step " + n)
+        _same(s["exp_avg"], gold["step_m_" + n], "step m " + n)
+        _same(s["exp_avg_sq"], gold["step_v_" + n], "step v " + n, tol=4e-6)
+    # ---- densify_and_prune ----
+    for k in ("weights_accum", "xyz_gradient_accum", "normal_gradient_accum", "denom", "max_radii2D"):
+        setattr(st, k, torch.from_numpy(gold["stat_" + k]).to(dev))
+    max_grad, min_opacity, extent, max_screen, max_grad_normal = [float(x) for x in gold["densify_args"]]
+    st.densify_and_prune(max_grad, min_opacity, extent, max_screen, max_grad_normal, z=torch.from_numpy(gold["split_z"]).to(dev))
+    for n, _ in _SPEC:
+        p = st.params[n]
+        s = st.optimizer.state[p]
+        assert p.requires_grad and isinstance(p, torch.nn.Parameter)
+        _same(p, gold["dens_" + n], "densify " + n, tol=3e-6)
+        _same(s["exp_avg"], gold["dens_m_" + n], "densify m " + n)
+        _same(s["exp_avg_sq"], gold["dens_v_" + n], "densify v " + n, tol=4e-6)
+    for k in ("weights_accum", "xyz_gradient_accum", "normal_gradient_accum", "denom", "max_radii2D"):
+        _same(getattr(st, k), gold["dens_" + k], "densify " + k)
+    # the optimizer keeps stepping on the new block
+    for n, _ in _SPEC:
+        st.params[n].grad = torch.ones_like(st.params[n]) * 1e-3
+    st.step()
+    P_new = gold["dens_xyz"].shape[0]
+    assert all(st.params[n].shape[0] == P_new and st.optimizer.state[st.params[n]]["exp_avg"].shape[0] == P_new for n, _ in _SPEC)
+    assert torch.isfinite(st.params["xyz"]).all()   # (groups outside replace_nangrad_to_zero keep their NaNs, as in the reference)
+
+
+def test_append_rows_and_masks_edge_cases(built):
+    from svgir_harness import optim as O
+    dev = torch.device("cuda:0")
+    a = torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3)
+    b = torch.arange(4, dtype=torch.int32, device=dev)
+    lst, cnt, n = O._scan(torch.tensor([True, False, True, False], device=dev))
+    o = O.append_rows([a, b, a], lst, cnt, n, repeat=2, zero_new={2})
+    assert torch.equal(o[0], torch.cat([a, a[[0, 2]], a[[0, 2]]]))
+    assert torch.equal(o[1], torch.cat([b, b[[0, 2]], b[[0, 2]]]))
+    assert torch.equal(o[2], torch.cat([a, torch.zeros(4, 3, device=dev)]))
+    lst, cnt, n = O._scan(torch.zeros(4, dtype=torch.bool, device=dev))       # nothing selected
+    o = O.append_rows([a], lst, cnt, n)
+    assert n == 0 and torch.equal(o[0], a)
