@@ -294,6 +294,11 @@ int svgir_unpack_rgss_backward(int32_t W, int32_t H, const int32_t* num_contrib,
  * camera's principal point as a fraction of the image (Camera.prcppoint). */
 int svgir_depth2normal(int32_t W, int32_t H, const float* depth, const float* mask, float fovx, float fovy, float prcp_x,
                        float prcp_y, float* normal, void* stream);
+/* adjoint of svgir_depth2normal w.r.t. the depth plane (the reference's depth2normal is differentiable and the stage-1 loss
+ * `cos_loss(rendered_normal, d2n)` uses it without detaching, gaussian_renderer/render.py:158-160): dL_ddepth [1,H,W] is
+ * written completely; the mask gets no gradient. */
+int svgir_depth2normal_backward(int32_t W, int32_t H, const float* depth, const float* mask, const float* dL_dnormal, float fovx,
+                                float fovy, float prcp_x, float prcp_y, float* dL_ddepth, void* stream);
 
 /* Image losses behind render_view: L1 and SSIM with the reference's 11 x 11 Gaussian window
  * (`F.l1_loss(image, gt)` and `ssim(image, gt)`, gaussian_renderer/svgss.py:281-289, render.py:150-151;

@@ -152,6 +152,88 @@ __global__ void __launch_bounds__(BLOCK) depth2normal_kernel(const float* __rest
     for (int j = 0; j < 3; j++) normal[(size_t)j * N + i] = n[j] / len * mc;
 }
 
+// adjoint of depth2normal: every pixel recomputes its five camera points and scatters d(loss)/d(depth) of its own normal to
+// the (clamped) depths it read -- the depth-normal consistency loss differentiates through the pseudo normal
+// (gaussian_renderer/render.py:158-160).  dL_ddepth must be zero on entry.
+__global__ void __launch_bounds__(BLOCK) depth2normal_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ mask,
+                                                                 const float* __restrict__ g_normal, int W, int H, float k00, float k11,
+                                                                 float ppx, float ppy, float* __restrict__ dL_ddepth) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = i % W, y = i / W;
+    float ray[5][3], m[5];
+    int at[5];
+    float p[5][3];
+    const int ox[5] = {0, 0, -1, 0, 1}, oy[5] = {0, -1, 0, 1, 0};   // centre, up, left, bottom, right
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int xx = min(max(x + ox[q], 0), W - 1), yy = min(max(y + oy[q], 0), H - 1);
+        at[q] = yy * W + xx;
+        const float d = depth[at[q]];
+        m[q] = mask[at[q]] != 0.f ? 1.f : 0.f;
+        ray[q][0] = ((float)xx - ppx) / k00; ray[q][1] = ((float)yy - ppy) / k11; ray[q][2] = 1.f;
+        p[q][0] = ((float)xx - ppx) * d / k00; p[q][1] = ((float)yy - ppy) * d / k11; p[q][2] = d;
+    }
+    float c[3], e[5][3];   // e[1..4] = u, l, b, r
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        c[j] = p[0][j] * m[0];
+#pragma unroll
+        for (int q = 1; q < 5; q++) e[q][j] = (p[q][j] - c[j]) * m[q];
+    }
+    auto cross = [](const float* a, const float* b_, float* o) {
+        o[0] = a[1] * b_[2] - a[2] * b_[1]; o[1] = a[2] * b_[0] - a[0] * b_[2]; o[2] = a[0] * b_[1] - a[1] * b_[0];
+    };
+    const float *u = e[1], *l = e[2], *b = e[3], *r = e[4];
+    float n1[3], n2[3], n3[3], n4[3], n[3];
+    cross(u, l, n1); cross(r, u, n2); cross(b, r, n3); cross(l, b, n4);
+#pragma unroll
+    for (int j = 0; j < 3; j++) n[j] = n1[j] + n2[j] + n3[j] + n4[j];
+    const size_t N = (size_t)W * H;
+    // normal = n / max(|n|, 1e-12) * mask_c
+    float g[3] = {g_normal[i] * m[0], g_normal[N + i] * m[0], g_normal[2 * N + i] * m[0]};
+    const float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    float gn[3];
+    if (len > 1e-12f) {
+        const float dot = (n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) / (len * len);
+#pragma unroll
+        for (int j = 0; j < 3; j++) gn[j] = (g[j] - n[j] * dot) / len;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) gn[j] = g[j] / 1e-12f;
+    }
+    // n = u x l + r x u + b x r + l x b;  for a x b: d/da = b x g, d/db = g x a
+    float t1[3], t2[3], ge[5][3];
+    cross(l, gn, t1); cross(gn, r, t2);
+#pragma unroll
+    for (int j = 0; j < 3; j++) ge[1][j] = t1[j] + t2[j];   // u
+    cross(gn, u, t1); cross(b, gn, t2);
+#pragma unroll
+    for (int j = 0; j < 3; j++) ge[2][j] = t1[j] + t2[j];   // l
+    cross(r, gn, t1); cross(gn, l, t2);
+#pragma unroll
+    for (int j = 0; j < 3; j++) ge[3][j] = t1[j] + t2[j];   // b
+    cross(u, gn, t1); cross(gn, b, t2);
+#pragma unroll
+    for (int j = 0; j < 3; j++) ge[4][j] = t1[j] + t2[j];   // r
+    float gc[3] = {0.f, 0.f, 0.f};
+    float gd[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 1; q < 5; q++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float gp = ge[q][j] * m[q];       // e = (p_q - c) m_q
+            gd[q] += gp * ray[q][j];
+            gc[j] -= gp;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) gd[0] += gc[j] * m[0] * ray[0][j];   // c = p_c m_c
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+        if (gd[q] != 0.f) atomic_add_f32(&dL_ddepth[at[q]], gd[q]);
+}
+
 // ---- stage 1 (rgss) feature packing and image-space tail (gaussian_renderer/render.py:83-91, 107-114) ----------
 // pack: features[P,5] = [geometric normal (world), view depth d, d^2], d = (xyz1 @ viewmatrix).z
 __global__ void __launch_bounds__(BLOCK) pack_rgss_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ normals,
@@ -294,6 +376,17 @@ int svgir_depth2normal(int32_t W, int32_t H, const float* depth, const float* ma
     hipLaunchKernelGGL(depth2normal_kernel, dim3((W * H + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, depth, mask, W, H, k00, k11,
                        prcp_x * (float)W, prcp_y * (float)H, normal);
     stage_mark(tm, "depth2normal");
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_depth2normal_backward(int32_t W, int32_t H, const float* depth, const float* mask, const float* dL_dnormal, float fovx,
+                                float fovy, float prcp_x, float prcp_y, float* dL_ddepth, void* stream) {
+    if (W <= 0 || H <= 0 || !depth || !mask || !dL_dnormal || !dL_ddepth) return SVGIR_ERR_INVALID;
+    const float k00 = (float)H / (2.f * tanf(fovy * 0.5f)), k11 = (float)W / (2.f * tanf(fovx * 0.5f));
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dL_ddepth, 0, (size_t)W * H * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
+    hipLaunchKernelGGL(depth2normal_bwd_kernel, dim3((W * H + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, depth, mask, dL_dnormal, W, H, k00,
+                       k11, prcp_x * (float)W, prcp_y * (float)H, dL_ddepth);
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 

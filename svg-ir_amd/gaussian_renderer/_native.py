@@ -92,7 +92,7 @@ EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_
            "svgir_image_ncontrib_offset", "svgir_image_ranges_offset", "svgir_binning_point_list_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
            "svgir_backward_scratch_bytes", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
            "svgir_shade_backward", "svgir_incident_dirs", "svgir_resample_bilinear", "svgir_unpack_planes",
-           "svgir_unpack_forward", "svgir_unpack_backward", "svgir_depth2normal", "svgir_pack_rgss_forward",
+           "svgir_unpack_forward", "svgir_unpack_backward", "svgir_depth2normal", "svgir_depth2normal_backward", "svgir_pack_rgss_forward",
            "svgir_pack_rgss_backward", "svgir_unpack_rgss_forward", "svgir_unpack_rgss_backward", "svgir_l1_ssim_partials",
            "svgir_l1_ssim_forward", "svgir_l1_ssim_backward", "svgir_adam_step", "svgir_densify_stats",
            "svgir_mask_scan_work_words", "svgir_mask_scan", "svgir_gather_rows", "svgir_densify_masks", "svgir_append_rows",

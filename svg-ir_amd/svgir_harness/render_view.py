@@ -136,15 +136,45 @@ def unpack_rgss(rendered):
                 num_rendered=num_rendered, num_contrib=num_contrib, weights=weights)
 
 
+N.lib.svgir_depth2normal_backward.restype = C.c_int
+N.lib.svgir_depth2normal_backward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                             C.c_float, C.c_void_p, C.c_void_p]
+
+
+class _Depth2Normal(torch.autograd.Function):
+    """svgir_depth2normal / svgir_depth2normal_backward: differentiable w.r.t. the depth like the reference's function (the
+    stage-1 loss uses the pseudo normal without detaching, gaussian_renderer/render.py:158-160)."""
+
+    @staticmethod
+    def forward(ctx, depth, mask, fovx, fovy, px, py):
+        dev = depth.device
+        d, m = N.f32c(depth.detach(), dev), N.f32c(mask.to(torch.float32), dev)
+        H, W = d.shape[-2], d.shape[-1]
+        out = N.out_tensor((3, H, W), torch.float32, dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib.svgir_depth2normal(W, H, d.data_ptr(), m.data_ptr(), fovx, fovy, px, py, out.data_ptr(), N.stream_ptr(dev)),
+                    "depth2normal")
+        ctx.save_for_backward(d, m)
+        ctx.cam = (fovx, fovy, px, py, tuple(depth.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d, m = ctx.saved_tensors
+        fovx, fovy, px, py, shape = ctx.cam
+        dev = d.device
+        H, W = d.shape[-2], d.shape[-1]
+        gd = N.out_tensor((H, W), torch.float32, dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib.svgir_depth2normal_backward(W, H, d.data_ptr(), m.data_ptr(), N.f32c(g, dev).data_ptr(), fovx, fovy, px, py,
+                                                      gd.data_ptr(), N.stream_ptr(dev)), "depth2normal_backward")
+        return gd.reshape(shape), None, None, None, None, None
+
+
 def depth2normal(depth, mask, fovx, fovy, prcppoint=(0.5, 0.5)):
-    """utils/image_utils.py:61-125 as one HIP kernel: depth, mask [1,H,W] -> pseudo normal [3,H,W] (no gradient)."""
-    dev = depth.device
-    d, m = N.f32c(depth.detach(), dev), N.f32c(mask.to(torch.float32), dev)
-    H, W = d.shape[-2], d.shape[-1]
-    out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    N.check(N.lib.svgir_depth2normal(W, H, d.data_ptr(), m.data_ptr(), float(fovx), float(fovy), float(prcppoint[0]),
-                                     float(prcppoint[1]), out.data_ptr(), N.stream_ptr(dev)), "depth2normal")
-    return out
+    """utils/image_utils.py:61-125 as one HIP kernel per direction: depth, mask [1,H,W] -> pseudo normal [3,H,W],
+    differentiable w.r.t. `depth` (pass `depth.detach()` where the reference detaches, svgss.py:345)."""
+    return _Depth2Normal.apply(depth, mask, float(fovx), float(fovy), float(prcppoint[0]), float(prcppoint[1]))
 
 
 def unpack(rendered, bg_color, is_training):

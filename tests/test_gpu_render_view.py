@@ -178,3 +178,28 @@ def test_l1_ssim_full_size_properties(built):
     l1_ab, s_ab = losses.l1_ssim(a, b)
     l1_ba, s_ba = losses.l1_ssim(b, a.detach())
     assert abs(float(s_ab) - float(s_ba)) < 1e-6 and abs(float(l1_ab) - float(l1_ba)) < 1e-7
+
+
+def test_depth2normal_is_differentiable_like_the_reference(built):
+    """utils/image_utils.py:61-125 with autograd (tests/golden/depth2normal_grad.npz, scripts/make_golden_d2n.py): the stage-1
+    loss differentiates through the pseudo normal (gaussian_renderer/render.py:158-160)."""
+    from svgir_harness import render_view
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "depth2normal_grad.npz"))
+    dev = torch.device("cuda:0")
+    depth = torch.from_numpy(g["depth"]).to(dev).requires_grad_(True)
+    n = render_view.depth2normal(depth, torch.from_numpy(g["mask"]).to(dev), float(g["fovx"]), float(g["fovy"]), g["prcppoint"])
+    ref_n = g["normal"]
+    assert np.abs(n.detach().cpu().numpy() - ref_n).max() < 2e-5
+    (n * torch.from_numpy(g["upstream"]).to(dev)).sum().backward()
+    got, ref = depth.grad.cpu().numpy(), g["depth_grad"]
+    assert got.shape == ref.shape
+    # Pixels whose summed cross product is EXACTLY zero (an image-border pixel next to a masked one: two of its four
+    # differences vanish) go through normalize's 1 / eps = 1e12 branch; analytically their contributions cancel, numerically
+    # both the reference (fp32 autograd) and the kernel leave 1e12 x rounding noise there.  They and the pixels they touch are
+    # excluded; everything else is compared.
+    degenerate = (np.abs(ref_n).sum(0) == 0) & g["mask"][0]
+    touched = degenerate.copy()
+    touched[1:] |= degenerate[:-1]; touched[:-1] |= degenerate[1:]; touched[:, 1:] |= degenerate[:, :-1]; touched[:, :-1] |= degenerate[:, 1:]
+    ok = ~touched[None]
+    assert ok.mean() > 0.85
+    assert np.abs(got - ref)[ok].max() <= 2e-4 * np.abs(ref[ok]).max(), np.abs(got - ref)[ok].max() / np.abs(ref[ok]).max()
