@@ -304,15 +304,17 @@ int svgir_depth2normal_backward(int32_t W, int32_t H, const float* depth, const 
  * (`F.l1_loss(image, gt)` and `ssim(image, gt)`, gaussian_renderer/svgss.py:281-289, render.py:150-151;
  * utils/loss_utils.py:21-64), img1 / img2 = [C,H,W] planes.
  *   forward : writes 2 floats per 16x16 tile and channel -- the tile's sums of the SSIM map and of |img1 - img2| -- into
- *             `partial` [svgir_l1_ssim_partials(C,H,W)][2] (their totals / (C H W) are the two means; summing them is left to
- *             the caller: a few thousand floats), and, if `dmaps` [3,C,H,W] is not NULL, what the backward needs;
+ *             `partial` [svgir_l1_ssim_partials(C,H,W)][2], if `dmaps` [3,C,H,W] is not NULL what the backward needs, and if
+ *             `means2` is not NULL the two means {mean SSIM, mean |img1 - img2|} (device floats: fixed-order double sum of
+ *             the partials by a second small kernel);
  *   backward: dL_dimg1 [C,H,W] = g_ssim_mean * d(mean SSIM)/d(img1) + g_l1_mean * d(mean |img1 - img2|)/d(img1), written
- *             completely.  img2 (the ground truth) gets no gradient. */
+ *             completely; if `g_dev` is not NULL the two host scalars are multiplied by g_dev[0] / g_dev[1] read on the
+ *             device (upstream gradients that never visit the host).  img2 (the ground truth) gets no gradient. */
 size_t svgir_l1_ssim_partials(int32_t C, int32_t H, int32_t W);
 int svgir_l1_ssim_forward(const float* img1, const float* img2, int32_t C, int32_t H, int32_t W, float* partial, float* dmaps,
-                          void* stream);
+                          float* means2, void* stream);
 int svgir_l1_ssim_backward(const float* img1, const float* img2, const float* dmaps, int32_t C, int32_t H, int32_t W,
-                           float g_ssim_mean, float g_l1_mean, float* dL_dimg1, void* stream);
+                           float g_ssim_mean, float g_l1_mean, const float* g_dev, float* dL_dimg1, void* stream);
 
 /* The consumers of the rasterizer's gradients: Adam over the per-Gaussian parameter block, the
  * densification statistics, and the row compaction behind pruning (scene/gaussian_model.py:737-773, 1020-1062, 1270-1276).

@@ -80,9 +80,13 @@ uint32_t* pinned_slot() {
 struct SideStream { hipStream_t s = nullptr; bool ok = false; };
 std::mutex g_side_mu;
 SideStream g_side[16];
-hipStream_t side_stream() {
+hipStream_t side_stream(hipStream_t of) {
+    // the device that owns the caller's stream (the current device need not be it); the null stream belongs to the current one
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    hipDevice_t sd;
+    if (of != nullptr && hipStreamGetDevice(of, &sd) == hipSuccess) dev = (int)sd;
+    else if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev < 0 || dev >= 16) return nullptr;
     std::lock_guard<std::mutex> lk(g_side_mu);
     SideStream& ss = g_side[dev];
     if (!ss.ok) {
@@ -442,6 +446,8 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
 
 size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_bytes, int32_t W, int32_t H, int32_t S,
                                     int32_t VS) {
+    if (!render_specialised(S, variant == SVGIR_SVGSS ? VS : 0, variant == SVGIR_SVGSS))
+        return 256;   // run-time-width kernels accumulate straight into the dL_d* tensors: no scratch (a token size, never touched)
     if (variant != SVGIR_SVGSS || VS == 0)   // one packed gradient row per Gaussian
         return align_up((size_t)(P > 0 ? P : 1) * grad_row_geom(S, 0).RS * 4);
     const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
@@ -488,18 +494,27 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     // Composite gradients go through the scratch: svgss (VS > 0) -> one row per (instance, sub-tile) pair, summed per
     // Gaussian by grad_reduce (no atomics, deterministic); otherwise one packed row per Gaussian accumulated with float
     // atomics and unpacked by geom_bwd.
+    const bool generic = !render_specialised(p->S, ba.VS, svgss);   // run-time-width kernels: atomics on the dL_d* tensors
     const size_t need = svgir_backward_scratch_bytes(p->variant, P, binning_bytes, W, H, p->S, ba.VS);
-    if (!scratch || scratch_bytes < need)
+    if (!generic && (!scratch || scratch_bytes < need))
         return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes() = %zu",
                     scratch ? scratch_bytes : (size_t)0, need);
-    const bool generic = !render_specialised(p->S, ba.VS, svgss);   // run-time-width kernels: atomics on the dL_d* tensors
     const bool rows = ba.VS > 0 && !generic;
     // The dL_d* outputs start from zero (the kernels write the visible Gaussians only).  The specialised composite
     // backward does not touch them (it accumulates in the scratch), so the clear runs on a side stream next to it and
     // is joined before the per-Gaussian kernels; the run-time-width composite adds into them, so there the clear comes first.
-    hipEvent_t ev_cleared = nullptr;
+    // (scope guard: every exit path -- including the error returns below -- joins the side-stream clear with the caller's
+    // stream and releases the event)
+    struct ClearJoin {
+        hipStream_t s; hipEvent_t ev = nullptr;
+        void join() {
+            if (ev) { (void)hipStreamWaitEvent(s, ev, 0); (void)hipEventDestroy(ev); ev = nullptr; }
+        }
+        ~ClearJoin() { join(); }
+    } cleared{s};
+    hipEvent_t& ev_cleared = cleared.ev;
     {
-        hipStream_t cs = generic ? s : side_stream();
+        hipStream_t cs = generic ? s : side_stream(s);
         if (!cs) cs = s;
         hipEvent_t ev_fork = nullptr;
         if (cs != s) {   // the tensors may have been used on `s` before (stream-ordered allocators): order the clear after that
@@ -526,13 +541,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
             HIP_OK(hipEventRecord(ev_cleared, cs));
         }
     }
-    auto join_clear = [&]() {
-        if (ev_cleared) {
-            (void)hipStreamWaitEvent(s, ev_cleared, 0);
-            (void)hipEventDestroy(ev_cleared);
-            ev_cleared = nullptr;
-        }
-    };
+    auto join_clear = [&]() { cleared.join(); };
     const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
     ba.grad_rows = generic ? nullptr : (float*)scratch;
     ba.row_flags = nullptr;

@@ -99,7 +99,9 @@ __global__ void __launch_bounds__(LT * LT) ssim_fwd_kernel(const float* __restri
 
 __global__ void __launch_bounds__(LT * LT) ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                            const float* __restrict__ dmaps, int H, int W, SsimWindow win,
-                                                           float g_ssim, float g_l1, float* __restrict__ dL_dimg1) {
+                                                           float g_ssim, float g_l1, const float* __restrict__ g_dev,
+                                                           float* __restrict__ dL_dimg1) {
+    if (g_dev) { g_ssim *= g_dev[0]; g_l1 *= g_dev[1]; }   // upstream scalars still on the device (no host read-back)
     __shared__ float sM[3][LW][LW + 1];
     __shared__ float sH[3][LW][LT + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, t = threadIdx.x;
@@ -135,6 +137,21 @@ __global__ void __launch_bounds__(LT * LT) ssim_bwd_kernel(const float* __restri
     dL_dimg1[o] = g_ssim * (c0 + 2.f * u * c1 + v * c2) + g_l1 * sgn;
 }
 
+// the two means from the per-tile partial sums: one workgroup, fixed order, double accumulation
+__global__ void __launch_bounds__(256) ssim_reduce_kernel(const float* __restrict__ partial, int nblk, double inv, float* __restrict__ out2) {
+    __shared__ double red[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * inv);
+        out2[1] = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * inv);
+    }
+}
+
 }  // namespace
 
 }  // namespace svgir
@@ -146,21 +163,24 @@ size_t svgir_l1_ssim_partials(int32_t C, int32_t H, int32_t W) {
 }
 
 int svgir_l1_ssim_forward(const float* img1, const float* img2, int32_t C, int32_t H, int32_t W, float* partial, float* dmaps,
-                          void* stream) {
+                          float* means2, void* stream) {
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !partial) return SVGIR_ERR_INVALID;
     const dim3 grid((W + svgir::LT - 1) / svgir::LT, (H + svgir::LT - 1) / svgir::LT, C);
     hipLaunchKernelGGL(svgir::ssim_fwd_kernel, grid, dim3(svgir::LT * svgir::LT), 0, (hipStream_t)stream, img1, img2, H, W,
                        svgir::ssim_window(), partial, dmaps);
+    if (means2)
+        hipLaunchKernelGGL(svgir::ssim_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, (int)(grid.x * grid.y * grid.z),
+                           1.0 / ((double)C * (double)H * (double)W), means2);
     return hipGetLastError() == hipSuccess ? SVGIR_OK : SVGIR_ERR_HIP;
 }
 
 int svgir_l1_ssim_backward(const float* img1, const float* img2, const float* dmaps, int32_t C, int32_t H, int32_t W,
-                           float g_ssim_mean, float g_l1_mean, float* dL_dimg1, void* stream) {
+                           float g_ssim_mean, float g_l1_mean, const float* g_dev, float* dL_dimg1, void* stream) {
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dmaps || !dL_dimg1) return SVGIR_ERR_INVALID;
     const float inv = 1.f / ((float)C * (float)H * (float)W);   // both losses are means over all C H W elements
     const dim3 grid((W + svgir::LT - 1) / svgir::LT, (H + svgir::LT - 1) / svgir::LT, C);
     hipLaunchKernelGGL(svgir::ssim_bwd_kernel, grid, dim3(svgir::LT * svgir::LT), 0, (hipStream_t)stream, img1, img2, dmaps, H, W,
-                       svgir::ssim_window(), g_ssim_mean * inv, g_l1_mean * inv, dL_dimg1);
+                       svgir::ssim_window(), g_ssim_mean * inv, g_l1_mean * inv, g_dev, dL_dimg1);
     return hipGetLastError() == hipSuccess ? SVGIR_OK : SVGIR_ERR_HIP;
 }
 

@@ -11,6 +11,8 @@
 // Arithmetic of the Adam step = torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False), single-tensor form:
 //   m <- m + (1 - b1) (g - m);  v <- v b2 + (1 - b2) g g;  p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // with the bias corrections evaluated on the host in double precision like torch does.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace svgir {
@@ -139,17 +141,15 @@ struct GatherTable {
 };
 __global__ void __launch_bounds__(BLOCK) gather_rows_kernel(const GatherTable t, const uint32_t* __restrict__ kept,
                                                             const uint32_t* __restrict__ count_dev, long long rows_max) {
+    // grid.y = tensor (no per-thread table search); a thread copies one 4-byte word of one row
     const uint32_t rows = min((uint32_t)rows_max, count_dev[0]);
-    const long long w = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    int k = 0;
-    while (k + 1 < t.count && w >= t.first_word[k + 1]) k++;
-    if (w >= t.first_word[t.count]) return;
-    const long long r = w - t.first_word[k];
+    const int k = blockIdx.y;
     const int words = t.words[k];
+    const long long r = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= (long long)rows * words) return;
     const long long row = r / words;
     const int j = (int)(r - row * words);
-    if (row >= (long long)rows) return;
-    t.dst[k][row * words + j] = t.src[k][(size_t)kept[row] * words + j];
+    t.dst[k][r] = t.src[k][(size_t)kept[row] * words + j];
 }
 
 // ---- densification: selection masks, fused append, split transform (scene/gaussian_model.py:1136-1248) ---------------------
@@ -182,13 +182,11 @@ struct AppendTable {
 __global__ void __launch_bounds__(BLOCK) append_rows_kernel(const AppendTable t, const uint32_t* __restrict__ list,
                                                             const uint32_t* __restrict__ count_dev, long long rows_old, long long n_sel_max,
                                                             int repeat) {
-    const long long n_sel = min((long long)count_dev[0], n_sel_max);
-    const long long w = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    int k = 0;
-    while (k + 1 < t.count && w >= t.first_word[k + 1]) k++;
-    if (w >= t.first_word[t.count]) return;
-    const long long r = w - t.first_word[k];
+    const long long n_sel = n_sel_max > 0 ? min((long long)count_dev[0], n_sel_max) : 0;
+    const int k = blockIdx.y;   // grid.y = tensor
     const int words = t.words[k];
+    const long long r = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= (rows_old + n_sel_max * repeat) * words) return;
     const long long row = r / words;
     const int j = (int)(r - row * words);
     if (row < rows_old) { t.dst[k][r] = t.src[k][r]; return; }
@@ -260,8 +258,10 @@ int svgir_append_rows(const svgir_append_tensor* tensors, int32_t count, int64_t
     }
     if (t.count == 0 || words == 0) return SVGIR_OK;
     t.first_word[t.count] = words;
-    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, t, list,
-                       count_dev, (long long)rows_old, (long long)n_sel_max, repeat);
+    int wmax = 0;
+    for (int k = 0; k < t.count; k++) wmax = std::max(wmax, t.words[k]);
+    hipLaunchKernelGGL(append_rows_kernel, dim3((unsigned)((rows_new * wmax + BLOCK - 1) / BLOCK), (unsigned)t.count), dim3(BLOCK), 0,
+                       (hipStream_t)stream, t, list, count_dev, (long long)rows_old, (long long)n_sel_max, repeat);
     return hipGetLastError() == hipSuccess ? SVGIR_OK : SVGIR_ERR_HIP;
 }
 
@@ -348,8 +348,10 @@ int svgir_gather_rows(const svgir_row_tensor* tensors, int32_t count, const uint
     }
     if (t.count == 0) return SVGIR_OK;
     t.first_word[t.count] = words;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, t, kept,
-                       count_dev, (long long)rows_max);
+    int wmax = 0;
+    for (int k = 0; k < t.count; k++) wmax = std::max(wmax, t.words[k]);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((long long)rows_max * wmax + BLOCK - 1) / BLOCK), (unsigned)t.count), dim3(BLOCK),
+                       0, (hipStream_t)stream, t, kept, count_dev, (long long)rows_max);
     return hipGetLastError() == hipSuccess ? SVGIR_OK : SVGIR_ERR_HIP;
 }
 

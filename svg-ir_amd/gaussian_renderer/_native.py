@@ -110,6 +110,13 @@ def check(rc, what):
     return rc
 
 
+def guarded(dev, what, fn, *args):
+    """Calls a C-ABI entry point with `dev` as the current device (the library creates its side stream / events on the device
+    that owns the stream; tensors on a non-current device must not end up with helpers on another GPU)."""
+    with torch.cuda.device(dev):
+        return check(fn(*args), what)
+
+
 def ptr(t):
     """Device pointer of a contiguous float/int tensor, or None for empty/absent tensors (the reference passes
     `torch.Tensor([])` whose data pointer is null, rasterize_points.cu:111-119)."""

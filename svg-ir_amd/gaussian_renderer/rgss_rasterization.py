@@ -77,8 +77,8 @@ class _CBinding:
             o.out_feature = N.ptr(out_feature)
             o.out_pseudo_normal, o.out_surface_xyz = out_pseudo_normal.data_ptr(), out_surface_xyz.data_ptr()
             o.out_weights, o.radii = out_weights.data_ptr(), radii.data_ptr()
-            rendered = N.check(N.lib.svgir_forward(p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
-                                                   blobs.fn("image"), None, N.stream_ptr(dev)), "forward")
+            rendered = N.guarded(dev, "forward", N.lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
+                                                   blobs.fn("image"), None, N.stream_ptr(dev))
             img = blobs.get("image")
             off = N.lib.svgir_image_ncontrib_offset(W, H)
             n_contrib = img[off:off + 4 * H * W].view(torch.int32).view(H, W)  # view into the blob (Q10)
@@ -128,9 +128,9 @@ class _CBinding:
             # scratch: one packed gradient row per Gaussian (include/svgir_raster.h)
             nscr = N.lib.svgir_backward_scratch_bytes(N.RGSS, P, binningBuffer.numel(), W, H, S, 0)
             scratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
-            N.check(N.lib.svgir_backward(p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+            N.guarded(dev, "backward", N.lib.svgir_backward, p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
                                          binningBuffer.numel(), imageBuffer.data_ptr(), scratch.data_ptr(), nscr,
-                                         N.stream_ptr(dev)), "backward")
+                                         N.stream_ptr(dev))
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dcov3D, dL_dsh, dL_dscales,
                 dL_drotations)
 
@@ -140,8 +140,8 @@ class _CBinding:
         present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
         if P != 0:
             m3, vm, pm = (N.f32c(t, means3D.device) for t in (means3D, viewmatrix, projmatrix))
-            N.check(N.lib.svgir_mark_visible(N.RGSS, P, m3.data_ptr(), vm.data_ptr(), pm.data_ptr(),
-                                             present.data_ptr(), N.stream_ptr(means3D.device)), "mark_visible")
+            N.guarded(means3D.device, "mark_visible", N.lib.svgir_mark_visible, N.RGSS, P, m3.data_ptr(), vm.data_ptr(), pm.data_ptr(),
+                                             present.data_ptr(), N.stream_ptr(means3D.device))
         return present
 
 

@@ -77,8 +77,8 @@ class _CBinding:
                                                                      out_depth.data_ptr(), out_opac.data_ptr())
             o.out_feature, o.out_vfeature = N.ptr(out_feature), N.ptr(out_vfeature)
             o.out_weights, o.radii = out_weights.data_ptr(), radii.data_ptr()
-            rendered = N.check(N.lib.svgir_forward(p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
-                                                   blobs.fn("image"), None, N.stream_ptr(dev)), "forward")
+            rendered = N.guarded(dev, "forward", N.lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
+                                                   blobs.fn("image"), None, N.stream_ptr(dev))
         # note: C++ order is (..., depth, opac, ...) -- the Python wrapper re-orders (svgss_rasterization.py:175,183)
         return (rendered, out_color, out_normal, out_depth, out_opac, out_feature, out_vfeature, out_weights, radii,
                 *blobs.take("geom", "binning", "image"))
@@ -130,9 +130,9 @@ class _CBinding:
             # scratch for the gradient accumulation (rows per (instance, sub-tile), summed per Gaussian)
             nscr = N.lib.svgir_backward_scratch_bytes(N.SVGSS, P, binningBuffer.numel(), W, H, S, VS)
             scratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
-            N.check(N.lib.svgir_backward(p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+            N.guarded(dev, "backward", N.lib.svgir_backward, p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
                                          binningBuffer.numel(), imageBuffer.data_ptr(), scratch.data_ptr(), nscr,
-                                         N.stream_ptr(dev)), "backward")
+                                         N.stream_ptr(dev))
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dvfeatures, dL_dcov3D, dL_dsh,
                 dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos)
 
@@ -142,8 +142,8 @@ class _CBinding:
         present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
         if P != 0:
             m3, vm, pm = (N.f32c(t, means3D.device) for t in (means3D, viewmatrix, projmatrix))
-            N.check(N.lib.svgir_mark_visible(N.SVGSS, P, m3.data_ptr(), vm.data_ptr(), pm.data_ptr(),
-                                             present.data_ptr(), N.stream_ptr(means3D.device)), "mark_visible")
+            N.guarded(means3D.device, "mark_visible", N.lib.svgir_mark_visible, N.SVGSS, P, m3.data_ptr(), vm.data_ptr(), pm.data_ptr(),
+                                             present.data_ptr(), N.stream_ptr(means3D.device))
         return present
 
 

@@ -10,10 +10,10 @@ from gaussian_renderer import _native as N
 N.lib.svgir_l1_ssim_partials.restype = C.c_size_t
 N.lib.svgir_l1_ssim_partials.argtypes = [C.c_int32] * 3
 N.lib.svgir_l1_ssim_forward.restype = C.c_int
-N.lib.svgir_l1_ssim_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+N.lib.svgir_l1_ssim_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 N.lib.svgir_l1_ssim_backward.restype = C.c_int
 N.lib.svgir_l1_ssim_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                         C.c_void_p, C.c_void_p]
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
 
 
 class _L1Ssim(torch.autograd.Function):
@@ -28,21 +28,22 @@ class _L1Ssim(torch.autograd.Function):
         partial = torch.empty((nblk, 2), dtype=torch.float32, device=dev)
         need = img.requires_grad
         dmaps = torch.empty((3, Cc, H, W), dtype=torch.float32, device=dev) if need else None
-        N.check(N.lib.svgir_l1_ssim_forward(a.data_ptr(), b.data_ptr(), Cc, H, W, partial.data_ptr(), N.ptr(dmaps),
+        means = torch.empty(2, dtype=torch.float32, device=dev)   # {mean SSIM, mean L1}: reduced on the device
+        N.check(N.lib.svgir_l1_ssim_forward(a.data_ptr(), b.data_ptr(), Cc, H, W, partial.data_ptr(), N.ptr(dmaps), means.data_ptr(),
                                             N.stream_ptr(dev)), "l1_ssim forward")
-        sums = partial.to(torch.float64).sum(dim=0) / float(Cc * H * W)
         ctx.save_for_backward(a, b, dmaps)
-        return sums[1].to(torch.float32), sums[0].to(torch.float32)   # (l1, ssim)
+        return means[1], means[0]   # (l1, ssim)
 
     @staticmethod
     def backward(ctx, g_l1, g_ssim):
         a, b, dmaps = ctx.saved_tensors
         Cc, H, W = a.shape[-3], a.shape[-2], a.shape[-1]
         out = torch.empty_like(a)
-        gl = 0.0 if g_l1 is None else float(g_l1)
-        gs = 0.0 if g_ssim is None else float(g_ssim)
-        N.check(N.lib.svgir_l1_ssim_backward(a.data_ptr(), b.data_ptr(), dmaps.data_ptr(), Cc, H, W, gs, gl, out.data_ptr(),
-                                             N.stream_ptr(a.device)), "l1_ssim backward")
+        # the upstream scalars stay on the device: a 2-float buffer {g_ssim, g_l1} the kernel reads (no blocking read-back)
+        zero = torch.zeros((), dtype=torch.float32, device=a.device)
+        gdev = torch.stack([zero if g_ssim is None else g_ssim.to(torch.float32), zero if g_l1 is None else g_l1.to(torch.float32)])
+        N.check(N.lib.svgir_l1_ssim_backward(a.data_ptr(), b.data_ptr(), dmaps.data_ptr(), Cc, H, W, 1.0, 1.0, gdev.data_ptr(),
+                                             out.data_ptr(), N.stream_ptr(a.device)), "l1_ssim backward")
         return out, None
 
 
