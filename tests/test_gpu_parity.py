@@ -18,8 +18,10 @@ from svgir_harness import runner, scenes
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4          # normalised tolerance (north_star)
-FLIP_FRAC = 2e-5    # share of forward entries that may exceed it (threshold flips), each bounded by FLIP_BOUND * max|ref|
-GRAD_FLIP_FRAC = 3e-4
+# Budgets ~10x what profiles/parity_r03.json measures on cfg1-cfg5 (0 threshold flips anywhere, worst normalised error 5.2e-5,
+# worst share beyond REL_TOL 1.6e-4): a regression that introduces real flips fails.
+FLIP_FRAC = 5e-6    # share of forward entries that may exceed TOL (threshold flips), each bounded by FLIP_BOUND * max|ref|
+GRAD_FLIP_FRAC = 2e-5
 FLIP_BOUND = 0.05
 REL_TOL = 5e-3      # element-wise relative tolerance on entries > 1e-3 max|ref| ...
 REL_FRAC = 1e-3     # ... for all but this share (differences of nearly cancelling sums)
@@ -217,9 +219,16 @@ def test_rgss_pseudo_normal_ncontrib_view_and_backward_geometry(built):
     out, leaves, o, R = _run_both(sc, "rgss", grads)
     im = _check_forward(out, o, R, "rgss")
     _cmp("surface_xyz", out["surface_xyz"], im["surface_xyz"])
-    # the stencil normal amplifies per-pixel depth flips: compare where the neighbourhood agrees
-    pn, pr = out["pseudo_normal"].cpu().numpy(), im["pseudo_normal"]
-    assert (np.abs(pn - pr).max(0) < 1e-3).mean() > 0.995
+    # the stencil normal divides differences of neighbouring depths by their (possibly tiny) norm: it is compared on every pixel
+    # whose 3x3 neighbourhood of depth AND opacity agrees with the oracle's to 1e-6 -- there ALL normals must agree to 1e-4 --
+    # and those pixels must be nearly all of the image
+    pn, pr = out["pseudo_normal"].detach().cpu().numpy(), im["pseudo_normal"]
+    dd = np.maximum(np.abs(out["depth"].detach().cpu().numpy() - im["depth"])[0], np.abs(out["opacity"].detach().cpu().numpy() - im["opacity"])[0])
+    pad = np.pad(dd, 1, mode="edge")
+    nb = np.max([pad[1 + dy:1 + dy + dd.shape[0], 1 + dx:1 + dx + dd.shape[1]] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0)
+    agree = nb <= 1e-6
+    assert agree.mean() > 0.98, agree.mean()
+    assert np.abs(pn - pr).max(0)[agree].max() < 1e-4, np.abs(pn - pr).max(0)[agree].max()
     assert out["n_contrib"].dtype == torch.int32 and tuple(out["n_contrib"].shape) == (120, 160)
     _check_backward(leaves, o, "rgss")
 

@@ -329,3 +329,51 @@ def test_envlight_resample_matches_reference(built):
     # lookups: a single white surfel whose `global light` mean is the env lookup itself is awkward; use the oracle path
     got = so.env_lookup(env.double().cpu(), torch.from_numpy(g["dirs"]).double(), softplus=False, scale=1.0)
     np.testing.assert_allclose(got.numpy(), g["el_light"], rtol=2e-5, atol=2e-6)
+
+
+def test_shading_cfg5_scale_in_chunks(built):
+    """BASELINE configs[4]'s other half: the shading kernels at P = 2 000 000 surfels, Ns = 384 incident directions (66 % of
+    the cfg5 step), in 4 chunks of 500 000 surfels like the reference's evaluation chunk loop (svgss.py:121-136), incident
+    directions generated in the kernels (Fibonacci lattice, f1).  A random subset of 20 000 surfels (5 000 per chunk) is
+    recomputed by the fp64 oracle on the CPU from the oracle's own lattice (oracle/epilogue_oracle.py) and compared:
+    pbr / direct / indirect / diffuse_light / specular and the packed evaluation features."""
+    from gaussian_renderer import shading
+    from oracle import epilogue_oracle as eo
+    dev = torch.device("cuda:0")
+    P, Ns, chunk, per = 2_000_000, 384, 500_000, 5_000
+    g = torch.Generator(device=dev).manual_seed(17)
+    env = 3.0 * torch.rand(1, 32, 64, 3, generator=g, device=dev)
+    view = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))[0]
+    vm = torch.eye(4, dtype=torch.float64)
+    vm[:3, :3] = view
+    vmf = vm.float().to(dev)
+    worst = {}
+    for c in range(P // chunk):
+        rnd = lambda *s: torch.randn(*s, generator=g, device=dev)  # noqa: E731
+        geo = torch.nn.functional.normalize(rnd(chunk, 3), dim=-1)
+        base = torch.sigmoid(rnd(chunk, 12)) * 0.77 + 0.03
+        rough = torch.sigmoid(rnd(chunk, 4)) * 0.69 + 0.3            # (>= 0.3: the fp32-well-conditioned range, see the module docstring)
+        normals = torch.nn.functional.normalize(geo[:, None] + 0.1 * rnd(chunk, 4, 3), dim=-1)
+        viewdirs = torch.nn.functional.normalize(geo + 0.5 * rnd(chunk, 3), dim=-1)
+        vis = (torch.rand(chunk, Ns, 1, generator=g, device=dev) > 0.3).float()
+        radiance = (0.2 * rnd(chunk, Ns, 3)).abs_()
+        lat, _ = shading.sample_incident_rays(geo, False, Ns, materialize=False)
+        with torch.no_grad():
+            pbr, ex = shading.rendering_equation4(base, rough, normals, viewdirs, radiance, _Light(env), visibility_precompute=vis,
+                                                  incident_dirs_precompute=lat, incident_areas_precompute=None)
+            f, vf, _ = shading.shade_and_pack(base, rough, normals, viewdirs, radiance, _Light(env), vis, lat, None, vmf, False)
+        torch.cuda.synchronize()
+        assert pbr.shape == (chunk, 12) and f.shape == (chunk, 7) and vf.shape == (chunk, 64)
+        pick = torch.randperm(chunk, generator=torch.Generator().manual_seed(c))[:per].to(dev)
+        cpu = lambda t: t[pick].double().cpu()  # noqa: E731
+        dn, an = eo.fibonacci_dirs(geo[pick].float().cpu().numpy(), Ns)
+        dirs, areas = torch.from_numpy(dn), torch.from_numpy(an)
+        ref = so.shade(cpu(base), cpu(rough), cpu(normals), cpu(viewdirs), cpu(radiance), cpu(vis), dirs, areas, env.double().cpu())
+        fr, vr = so.pack(ref, cpu(base), cpu(rough), cpu(normals), view, False)
+        _close(f"chunk{c} pbr", pbr[pick], ref["pbr"])
+        for k in ("diffuse_light", "specular", "direct", "indirect"):
+            _close(f"chunk{c} {k}", ex[k][pick], ref[k])
+        _close(f"chunk{c} features", f[pick], fr)
+        _close(f"chunk{c} vfeatures", vf[pick], vr)
+        del radiance, vis, pbr, ex, f, vf
+        torch.cuda.empty_cache()
