@@ -51,49 +51,42 @@ template <int S, int VC>
 struct BwdGeom {
     using SG = StageGeom<S, VC>;
 #ifndef BWD_KB_V
-#define BWD_KB_V 2
+#define BWD_KB_V 1
 #endif
-#ifndef BWD_KB_P
-#define BWD_KB_P 4
+    static_assert(VC > 0, "widths without vfeatures are handled by render_bwd_plain.hip");
+    // One candidate per replay group: a wave issues one instruction per ~8 cycles whether or not instructions depend on each
+    // other (scripts/probes/valu_rate_probe.hip), so lock-step groups buy no speed and cost registers and LDS.
+    static constexpr int KB = BWD_KB_V;                  // candidates replayed per branch-free group
+#ifndef BWD_CHB_V
+#define BWD_CHB_V 8
 #endif
-    static constexpr int KB = (VC > 0) ? BWD_KB_V : BWD_KB_P;   // candidates replayed per branch-free group
-    static constexpr int CHB = 16;                       // candidates staged per batch
-    static constexpr int SB = (VC > 0) ? 4 : 8;          // candidates per phase-B contraction (<= 16 panel rows)
+    static constexpr int CHB = BWD_CHB_V;                // candidates staged per batch
+    static constexpr int SB = 4;                         // candidates per phase-B contraction (16 panel rows = 4 x 4 corners)
     static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S  (<= 16)
-    static constexpr int NG = NC0 + VC;                  // columns of G
-    static constexpr int GROW = NG + 1;                  // odd or even, padded so that lanes hit different banks
+    static constexpr int GPROW = NC0 + 1;                // row stride of the transposition tile of the NC0 "plain" columns
+    static constexpr int GV = VC + 1;                    // row stride of the vfeature columns of G kept in LDS
     static constexpr int PS = 68;                        // panel row stride (floats): 16-byte aligned, bank-staggered rows
-    // Geometric gradients (mean2D.xy, conic.xyz, opacity).  MOM (rgss widths): all six are linear in the six pixel
-    // moments  M = sum_pixels v [1, px, py, px^2, px py, py^2]  of ONE per-(pixel, candidate) scalar v = G dL_dalpha (px, py
-    // relative to the sub-tile centre), so v gets a second panel row per candidate and the moments are a second MFMA
-    // contraction against a constant matrix: no geometric panel, no per-group LDS round trip, 7.3 KB of LDS per wave.
-    // Otherwise (svgss widths): the six values per pixel go to a panel [candidate][6][64] and are summed lane-parallel.
-    static constexpr bool MOM = (VC == 0);
-    static constexpr int GEO_ROWS = MOM ? 0 : KB * 6;    // geometric panel rows of one group
+    static constexpr int GEO_ROWS = KB * 6;              // geometric panel rows of one group
     static constexpr int LPR = KB >= 4 ? 2 : (KB == 2 ? 4 : 8);   // lanes that share one geometric row
 #ifndef BWD_WPE_V
-#define BWD_WPE_V 2
+#define BWD_WPE_V 3
 #endif
-#ifndef BWD_WPE_P
-#define BWD_WPE_P 3
-#endif
-    // waves per SIMD the register budget is held to
-    static constexpr int WPE = (VC > 0) ? BWD_WPE_V : BWD_WPE_P;
+    // waves per SIMD the register budget is held to (LDS: 12.8 KB per wave at the training widths -> 12 waves per CU)
+    static constexpr int WPE = BWD_WPE_V;
     static constexpr size_t off_q = (size_t)CHB * SG::NF * 4;
     static constexpr size_t off_p = off_q + (size_t)SEG * 8;          // the whole segment's {gid, slot} entries
-    static constexpr int PROWS = 16;                                  // weight panel rows: (candidate, corner) | MOM: 8 w rows + 8 v rows
+    static constexpr int PROWS = 16;                                  // weight panel rows: (candidate, corner)
     static constexpr size_t off_pg = off_p + (size_t)PROWS * PS * 4;
-    static constexpr size_t geo_bytes = MOM ? (size_t)(SB * 8 + SB) * 4 : (size_t)GEO_ROWS * PS * 4;   // MOM: moments [SB][8] + Q5 sums [SB]
-    static constexpr size_t g_bytes = (size_t)64 * GROW * 4;
-    // G (the MFMA B operand): svgss keeps it in LDS for the whole segment (two column groups, 32 VGPRs otherwise);
-    // rgss transposes it once through LDS (aliasing the weight panel) into 16 VGPRs -- its LDS budget decides
-    // how many waves a CU holds.
-    static constexpr bool G_IN_REGS = (VC == 0);
-    static constexpr size_t off_g = G_IN_REGS ? off_p : off_pg + geo_bytes;
-    static constexpr size_t lds_bytes = G_IN_REGS ? off_pg + geo_bytes : off_g + g_bytes;
+    static constexpr size_t geo_bytes = (size_t)GEO_ROWS * PS * 4;
+    static constexpr size_t g_bytes = (size_t)64 * GV * 4;
+    // G (the MFMA B operand): its NC0 plain columns are transposed once per segment through LDS (a tile that aliases the
+    // weight panel) into 16 VGPRs; the VC vfeature columns stay in LDS for the whole segment (they are also the A operand of
+    // the h contraction).  A wave's LDS footprint decides how many waves a CU holds: see WPE.
+    static constexpr size_t off_g = off_pg + geo_bytes;
+    static constexpr size_t lds_bytes = off_g + g_bytes;
     static_assert(NC0 <= 16 && VC <= 16, "one 16-wide MFMA column tile per channel group");
     static_assert(SB % KB == 0 && CHB % SB == 0 && GEO_ROWS * LPR <= 64, "batch nesting");
-    static_assert(!G_IN_REGS || g_bytes <= (size_t)PROWS * PS * 4, "the G transposition tile aliases the weight panel");
+    static_assert((size_t)64 * GPROW * 4 <= (size_t)PROWS * PS * 4, "the transposition tile aliases the weight panel");
 };
 
 template <int S, int VC, bool SVGSS>
@@ -102,16 +95,15 @@ render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int VS = VC * 4;
     using SG = StageGeom<S, VC>;
     using BG = BwdGeom<S, VC>;
-    constexpr int SB = BG::SB, KB = BG::KB, NC0 = BG::NC0, GROW = BG::GROW, CHB = BG::CHB, PS = BG::PS, LPR = BG::LPR;
-    constexpr bool MOM = BG::MOM;
+    constexpr int SB = BG::SB, KB = BG::KB, NC0 = BG::NC0, GV = BG::GV, GPROW = BG::GPROW, CHB = BG::CHB, PS = BG::PS, LPR = BG::LPR;
     constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
     constexpr int P4 = (NC0 + 3) / 4 * 4, GEO = P4 + VS, RS = (GEO + 6 + 3) / 4 * 4;   // common.hpp GradRowGeom
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sD = reinterpret_cast<float*>(smem);                    // [CHB][NF] staged candidates
     uint2* sQ = reinterpret_cast<uint2*>(smem + BG::off_q);        // [SEG] {gid, slot} of the segment, deepest first
     float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [16][PS] blend-weight panel (MFMA A operand)
-    float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [KB*6][PS] geometric gradients per pixel | MOM: moments [SB][8], Q5 sums [SB]
-    float* sG = reinterpret_cast<float*>(smem + BG::off_g);        // [64][GROW] upstream gradients of the sub-tile (MFMA B operand)
+    float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [KB*6][PS] geometric gradients per pixel
+    float* sG = reinterpret_cast<float*>(smem + BG::off_g);        // [64][GV] upstream vfeature gradients of the sub-tile (MFMA operands)
 
     const int lane = threadIdx.x;
     const bool surface = cfg_flag(a.cfg, 0), normalize_depth = cfg_flag(a.cfg, 1);
@@ -120,16 +112,6 @@ render_bwd_kernel(const RenderBwdArgs a) {
     const size_t N_ = (size_t)a.W * a.H;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int colB = lane & 15, grpB = lane >> 4;
-    // MOM: B operand of the moment contraction, lane l: Mom[pixel = 16 (l >> 4) + kk][column = l & 15], columns
-    // [1, px, py, px^2, px py, py^2] with (px, py) = pixel position inside the 8x8 sub-tile minus 3.5 (exact in fp32)
-    float Mp[MOM ? 16 : 1];
-    if (MOM) {
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            const float mx = (float)(kk & 7) - 3.5f, my = (float)(2 * grpB + (kk >> 3)) - 3.5f;
-            Mp[kk] = colB == 0 ? 1.f : colB == 1 ? mx : colB == 2 ? my : colB == 3 ? mx * mx : colB == 4 ? mx * my : colB == 5 ? my * my : 0.f;
-        }
-    }
 
     // The staging buffer and the weight panel start as zeros: slots beyond a batch's size then always hold finite values
     // (zeros or an older candidate), so the replay needs no per-candidate bounds branches -- such slots get weight 0.
@@ -160,7 +142,6 @@ render_bwd_kernel(const RenderBwdArgs a) {
     const int py = ty * TILE + (sub >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float cxs = (float)(tx * TILE + (sub & 1) * 8) + 3.5f, cys = (float)(ty * TILE + (sub >> 1) * 8) + 3.5f;   // sub-tile centre
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const uint2* __restrict__ sub_in = a.sub_list + (size_t)4 * r0 + (size_t)sub * (r1 - r0);
     const size_t pid = inside ? (size_t)a.W * py + px : 0;
@@ -191,26 +172,27 @@ render_bwd_kernel(const RenderBwdArgs a) {
     if (wmax == 0) continue;
 
     // G matrix of this sub-tile: row = pixel (lane), columns = [colour3 | normal3 x10 (Q4) | depth | feature S | vfeature VC].
-    // Phase B needs it as the MFMA B operand (lane l: G[pixel = 16*(l>>4) + kk][channel = l&15], kk = 0..15): svgss reads
-    // it from LDS right before the MFMAs, rgss keeps the 16 values in registers (BwdGeom::G_IN_REGS).
+    // Phase B needs it as the MFMA B operand (lane l: G[pixel = 16*(l>>4) + kk][channel = l&15], kk = 0..15): the NC0 plain
+    // columns are transposed once through LDS (a tile that aliases the weight panel) into 16 registers, the vfeature columns
+    // stay in LDS (sG, row stride GV).
+    float Bp[16];
     {
-        float* g = sG + lane * GROW;
+        float* g = sP + lane * GPROW;
         g[0] = gC[0]; g[1] = gC[1]; g[2] = gC[2];
         g[3] = surface ? gN[0] * 10.f : 0.f; g[4] = surface ? gN[1] * 10.f : 0.f; g[5] = surface ? gN[2] * 10.f : 0.f;
         g[6] = gDn;
 #pragma unroll
         for (int i = 0; i < S; i++) g[7 + i] = gF[i];
+        float* gv = sG + lane * GV;
 #pragma unroll
-        for (int i = 0; i < VC; i++) g[NC0 + i] = gVF[i];
-    }
-
-    float Bp[16];
-    if (BG::G_IN_REGS) {
+        for (int i = 0; i < VC; i++) gv[i] = gVF[i];
         wave_lds_sync();
-        const float* gB = sG + (16 * grpB) * GROW + (colB < NC0 ? colB : 0);
+        const float* gB = sP + (16 * grpB) * GPROW + (colB < NC0 ? colB : 0);
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) Bp[kk] = colB < NC0 ? gB[kk * GROW] : 0.f;
-        wave_lds_sync();   // sG aliases the weight panel
+        for (int kk = 0; kk < 16; kk++) Bp[kk] = colB < NC0 ? gB[kk * GPROW] : 0.f;
+        wave_lds_sync();
+        // the weight panel starts as zeros again (slots beyond a batch's size must hold finite values)
+        for (int i = lane; i < BG::PROWS * PS / 4; i += 64) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // Replay state.  The reference keeps, per channel, the blend of everything behind the current splat (accum_rec)
@@ -296,7 +278,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
                     const float bv = ch < VC ? vb[4 * ch] : 0.f;
 #pragma unroll
                     for (int mt = 0; mt < 4; mt++) {
-                        const float av = ch < VC ? sG[(16 * mt + colB) * GROW + NC0 + ch] : 0.f;
+                        const float av = ch < VC ? sG[(16 * mt + colB) * GV + ch] : 0.f;
                         hacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, hacc[mt], 0, 0, 0);
                     }
                 }
@@ -397,7 +379,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
                     dLa[k] = pass ? dL_dalpha : 0.f;
                     vw[k] = pass ? al[k] * Tn : 0.f;
                 }
-                // (3) independent again: weight panel rows and the geometric gradients per pixel
+                // (3) independent again: weight panel rows and the six geometric gradients per pixel
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
                     if (VC > 0) {   // rows (candidate, corner); the four corner weights sum to the blend weight
@@ -408,26 +390,6 @@ render_bwd_kernel(const RenderBwdArgs a) {
                         sP[(cs0 + k) * PS + lane] = vw[k];
                     }
                 }
-                uint32_t glive = 0;
-#pragma unroll
-                for (int k = 0; k < KB; k++) glive |= (__ballot(pre[k]) != 0ull ? 1u : 0u) << k;
-                live |= glive << cs0;
-                if (MOM) {
-                    // v = G dL_dalpha (0 where the pixel does not blend): row SB + candidate of the panel.  dL_ddist = v (-0.5 opacity)
-                    // and everything else of the six geometric gradients is per-candidate (phase B).  The un-weighted Q5 term needs
-                    // sum_pixels [pixel blends] (-gD): a DPP wave reduction per candidate, parked in LDS by lane 63.
-#pragma unroll
-                    for (int k = 0; k < KB; k++) sP[(SB + cs0 + k) * PS + lane] = pre[k] ? Gs[k] * dLa[k] : 0.f;
-                    if (sp) {
-                        float qs[KB];
-#pragma unroll
-                        for (int k = 0; k < KB; k++) qs[k] = wave_scan_last(pre[k] ? q5g : 0.f);
-                        if (lane == 63) {
-#pragma unroll
-                            for (int k = 0; k < KB; k++) sPg[SB * 8 + cs0 + k] = qs[k];
-                        }
-                    }
-                } else {
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
                     const float dL_ddist = dLa[k] * (B[k].y * -0.5f) * Gs[k];
@@ -442,6 +404,10 @@ render_bwd_kernel(const RenderBwdArgs a) {
                     pg[0] = pre[k] ? ge0 : 0.f; pg[PS] = pre[k] ? ge1 : 0.f; pg[2 * PS] = pre[k] ? ge2 : 0.f;
                     pg[3 * PS] = pre[k] ? ge3 : 0.f; pg[4 * PS] = pre[k] ? ge4 : 0.f; pg[5 * PS] = pre[k] ? ge5 : 0.f;
                 }
+                uint32_t glive = 0;
+#pragma unroll
+                for (int k = 0; k < KB; k++) glive |= (__ballot(pre[k]) != 0ull ? 1u : 0u) << k;
+                live |= glive << cs0;
                 wave_lds_sync();   // geometric panel visible
                 // (4) geometric sums: LPR lanes per (candidate, value) row, 64 / LPR pixels each
                 {
@@ -478,31 +444,27 @@ render_bwd_kernel(const RenderBwdArgs a) {
                     }
                 }
                 wave_lds_sync();   // geometric panel consumed before the next group overwrites it
-                }
             }
             DEV_TRACE_MARK(2);   // phase A
             if (live == 0) continue;  // uniform
             // (the weight panel was made visible by the fences of the last group)
 
             // ---------------- phase B: panel x G on the matrix pipe ----------------
-            if (MOM) wave_lds_sync();   // the panel rows of the block's groups are visible
             {
                 const float4* ap = reinterpret_cast<const float4*>(sP + colB * PS + 16 * grpB);
                 const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
                 const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w,
                                       a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
                 f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
-                const float* gB = sG + (16 * grpB) * GROW;
-                const int colP = colB < NC0 ? colB : 0, colV = NC0 + ((VC > 0 && colB < VC) ? colB : 0);
+                const float* gB = sG + (16 * grpB) * GV;
+                const int colV = colB < VC ? colB : 0;
 #pragma unroll
                 for (int kk = 0; kk < 16; kk++) {
-                    const float bp = BG::G_IN_REGS ? Bp[kk] : gB[kk * GROW + colP];
-                    accP = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], colB < NC0 ? bp : 0.f, accP, 0, 0, 0);
+                    accP = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Bp[kk], accP, 0, 0, 0);
                     if (VC > 0) {
-                        const float bv = gB[kk * GROW + colV];
+                        const float bv = gB[kk * GV + colV];
                         accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], colB < VC ? bv : 0.f, accV, 0, 0, 0);
                     }
-                    if (MOM) accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Mp[kk], accV, 0, 0, 0);
                 }
                 // D layout: lane l, register r -> row 4*(l>>4) + r, column l&15
                 if (VC > 0) {
@@ -521,44 +483,6 @@ render_bwd_kernel(const RenderBwdArgs a) {
                         if (colB < VC)
                             reinterpret_cast<float4*>(row + P4)[colB] =
                                 sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                } else if (MOM) {
-                    // ---- rgss: one packed gradient row per Gaussian, float atomics ----
-                    // panel rows 0..7 = blend weights of the 8 candidates (lanes 0..31 hold their products with G),
-                    // rows 8..15 = v of the same candidates (lanes 32..63, columns 0..5: the six pixel moments)
-                    if (grpB < 2) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int cB = 4 * grpB + r;
-                            const bool mine = c0 + cB < m && ((live >> cB) & 1u) && colB < NC0 && accP[r] != 0.f;
-                            if (mine) atomic_add_f32(a.grad_rows + ((size_t)sQ[base + c0 + cB].x * RS + (uint32_t)colB), accP[r]);
-                        }
-                    } else if (colB < 6) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) sPg[(4 * (grpB - 2) + r) * 8 + colB] = accV[r];
-                    }
-                    wave_lds_sync();
-                    // lane = (value j = lane >> 3, candidate c = lane & 7): the six geometric gradients from the moments
-                    const int cq = lane & 7, jq = lane >> 3;
-                    if (jq < 6 && c0 + cq < m && ((live >> cq) & 1u)) {
-                        const float4 m03 = *reinterpret_cast<const float4*>(sPg + cq * 8);
-                        const float2 m45 = *reinterpret_cast<const float2*>(sPg + cq * 8 + 4);
-                        const float Q = sp ? sPg[SB * 8 + cq] : 0.f;
-                        const float4* q = reinterpret_cast<const float4*>(sD + (c0 + cq) * SG::NF);
-                        const float4 Aq = q[0], Bq = q[1];
-                        const float DBq = q[3].x;
-                        const float Xc = Aq.x - cxs, Yc = Aq.y - cys;       // mean relative to the sub-tile centre
-                        const float M0 = m03.x, M1 = m03.y, M2 = m03.z, M3 = m03.w, M4 = m45.x, M5 = m45.y;
-                        const float Sx = Xc * M0 - M1, Sy = Yc * M0 - M2;  // sum v dx, sum v dy
-                        const float hf = Bq.y * -0.5f;                      // dL_ddist = v * hf
-                        float ge;
-                        if (jq == 0) ge = hf * 2.f * (Aq.z * Sx + Aq.w * Sy) * ddelx_dx + Q * Bq.w;
-                        else if (jq == 1) ge = hf * 2.f * (Bq.x * Sy + Aq.w * Sx) * ddely_dy + Q * DBq;
-                        else if (jq == 2) ge = hf * (Xc * (Sx - M1) + M3);              // sum v dx^2
-                        else if (jq == 3) ge = hf * ((Xc * Sy - Yc * M1) + M4);          // sum v dx dy
-                        else if (jq == 4) ge = hf * (Yc * (Sy - M2) + M5);              // sum v dy^2
-                        else ge = M0;
-                        if (ge != 0.f) atomic_add_f32(a.grad_rows + ((size_t)sQ[base + c0 + cq].x * RS + (uint32_t)(GEO + jq)), ge);
                     }
                 } else {
                     // ---- rgss: one packed gradient row per Gaussian, float atomics; rows of the panel = candidates ----
@@ -591,10 +515,9 @@ void launch(const RenderBwdArgs& a, hipStream_t s) {
 
 int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s) {
     const int VC = a.VS / 4;
-    if (VC == 0 && launch_render_bwd_plain(a, svgss, s) == 0) return 0;
+    if (VC == 0) return launch_render_bwd_plain(a, svgss, s);   // widths without vfeatures: render_bwd_plain.hip
 #define CASE(SV, VCV, SG) if (a.S == SV && VC == VCV && svgss == SG) { launch<SV, VCV, SG>(a, s); return 0; }
-    CASE(0, 0, true) CASE(4, 13, true) CASE(7, 16, true) CASE(3, 2, true) CASE(1, 1, true) CASE(5, 0, true)
-    CASE(0, 0, false) CASE(5, 0, false) CASE(3, 0, false) CASE(1, 0, false)
+    CASE(4, 13, true) CASE(7, 16, true) CASE(3, 2, true) CASE(1, 1, true)
 #undef CASE
     return -1;
 }

@@ -253,7 +253,10 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) shade_fwd_kernel(const ShadeArgs a) {
+#ifndef SHADE_FWPE
+#define SHADE_FWPE 5   // 96 VGPRs without spills; the default heuristic settles on 107 (4 waves per SIMD): 285 -> 252 us at P = 200k, Ns = 64
+#endif
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_FWPE, SHADE_FWPE))) shade_fwd_kernel(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
