@@ -53,7 +53,7 @@ def algorithmic_bytes(P, R, W, H, S, VS, svgss):
 
 
 # sources of the kernels whose HBM traffic is recorded in profiles/traffic_*.json (the composite and shading kernels)
-TRAFFIC_SOURCES = ("common.hpp", "stage.hpp", "pairstage.hpp", "dev_trace.hpp", "render_fwd.hip", "render_bwd.hip", "grad_reduce.hip",
+TRAFFIC_SOURCES = ("common.hpp", "stage.hpp", "pairstage.hpp", "dev_trace.hpp", "render_fwd.hip", "render_bwd.hip", "render_bwd_plain.hip", "grad_reduce.hip",
                    "shade.hip")
 
 
@@ -315,7 +315,7 @@ def roofline_of(wl, R, stage, workload):
     out = {}
     if "render_bwd" in stage:
         dom_ms = stage["render_bwd"][0]
-        dom_name = "render_bwd_kernel (backward composite)"
+        dom_name = ("render_bwd_plain_kernel" if wl.VS == 0 else "render_bwd_kernel") + " (backward composite)"
         if "grad_reduce" in stage:
             # svgss: the gradient read-modify-write part of B_bwd is carried out by the row stores of render_bwd plus the
             # per-Gaussian reduce kernel; the roofline is taken over both so that the byte model stays comparable
@@ -343,7 +343,7 @@ def roofline_of(wl, R, stage, workload):
         if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("library_hash") == library_hash():
             tr = 0
             for kname, kv in tj.get("kernels", {}).items():
-                if kname.startswith("render_bwd_kernel") or kname.startswith("grad_reduce_kernel"):
+                if kname.startswith("render_bwd") or kname.startswith("grad_reduce_kernel"):
                     tr += kv["read_bytes"] + kv["write_bytes"]
             out["traffic"] = tr or None
         else:
