@@ -22,6 +22,8 @@
 
 #include "common.hpp"
 
+#include "dev_trace.hpp"
+
 namespace svgir {
 
 namespace {
@@ -194,6 +196,27 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
     c.nom1 = NoV * (1.f - c.kk) + c.kk;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) c.fd[ch] = p.base_color[g * 12 + ch * 4 + k] * kInvPi;
+}
+
+// the same from staged rows (normals[12], roughness[4], base_color[12] of one Gaussian)
+__device__ __forceinline__ void load_corner_from(const float* nrm, const float* rough, const float* base, int k, const float* V, GaussConst& c) {
+    const float* n = nrm + k * 3;
+    c.nraw[0] = n[0]; c.nraw[1] = n[1]; c.nraw[2] = n[2];
+    const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+    c.inv_len = __builtin_amdgcn_rcpf(len);
+    float Nn[3] = {n[0] * c.inv_len, n[1] * c.inv_len, n[2] * c.inv_len};
+    const float nov = V[0] * Nn[0] + V[1] * Nn[1] + V[2] * Nn[2];
+    c.sgn = nov > 0.f ? 1.f : (nov < 0.f ? -1.f : 0.f);
+    c.Nh[0] = Nn[0] * c.sgn; c.Nh[1] = Nn[1] * c.sgn; c.Nh[2] = Nn[2] * c.sgn;
+    c.NoV_raw = c.Nh[0] * V[0] + c.Nh[1] * V[1] + c.Nh[2] * V[2];
+    const float NoV = fminf(1.f, fmaxf(1e-6f, c.NoV_raw));
+    c.r = rough[k];
+    const float a = c.r * c.r;
+    c.a2 = a * a;
+    c.kk = (a + 2.f * c.r + 1.0f) / 8.0f;
+    c.nom1 = NoV * (1.f - c.kk) + c.kk;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) c.fd[ch] = base[ch * 4 + k] * kInvPi;
 }
 
 // phase 1 for one chunk of <= 64 samples [s0, s0+cnt) of one Gaussian: fills the wave's sample records (slot =
@@ -370,12 +393,23 @@ struct ShadeBwdArgs {
 // clamp and visibility, + the bilinear footprint {x0 | y0 << 16, fx, fy} so the adjoint never re-evaluates acos/atan2.
 constexpr int BREC = 23;
 #ifndef SHADE_BWAVES
-#define SHADE_BWAVES 4   // measured on MI355X (P=200k, Ns=64): 4 waves x 3/SIMD 0.71 ms, 8x4 0.79, 8x2 0.83, 4x4 1.05
+#define SHADE_BWAVES 12   // one workgroup per CU: 12 x 5.9 KB of sample records + the fp64 env-gradient image (49 KB at 32x64)
 #endif
 #ifndef SHADE_BWPE
 #define SHADE_BWPE 3
 #endif
+#ifndef SHADE_PF
+#define SHADE_PF 0   // per-Gaussian inputs read straight from global memory (0) or through an LDS-DMA row fetched a Gaussian ahead (1):
+                      // measured 524 vs 556 us at P = 200k, Ns = 64 -- the top of a Gaussian is bound by instruction issue, not by latency
+#endif
+#ifndef SHADE_ABL
+#define SHADE_ABL 0   // (ablation experiments only, scripts/build_variant.sh: 1-4 switch parts of the kernel off -- wrong results)
+#endif
 constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
+// Per-Gaussian inputs of the backward, one LDS row per wave, fetched a whole Gaussian ahead by LDS-DMA (no registers, no
+// exposed latency at the top of a Gaussian): V[3] | normals[12] | roughness[4] | base_color[12] | (pad) | dL_dreduced[70]
+// | (pad) | dL_dvfeatures[<= 64] | dL_dfeatures[<= 7] | (pad)
+constexpr int GIN = 192, GIN_N = 3, GIN_R = 15, GIN_B = 19, GIN_RED = 32, GIN_VF = 104, GIN_F = 168;
 
 struct RawSample { float d[3], rad[3], vis, area; };
 
@@ -475,8 +509,11 @@ __device__ __forceinline__ float stride4_sum(float v) {
 // four corners of one incident sample sit in one DPP quad, so the per-sample light gradients are summed with two
 // quad_perm adds and the quad then shares the adjoint of the sample: lane k stores channel k of dL/dradiance and
 // scatters bilinear tap k of the env-lookup gradient into the workgroup-private LDS image (flushed with one global
-// atomic per texel per workgroup).  The next chunk of samples is prefetched into registers while the current one is
-// processed.
+// atomic per texel per workgroup).  That image is fp64: on gfx950 ds_add_f64 runs at the rate of the integer LDS atomics
+// (16 cycles per wave instruction per CU, scripts/probes/lds_atomic_probe.hip) while ds_add_f32 takes 128 -- with fp32
+// the 12 atomic instructions per 64 samples were ~500 of the kernel's 552 us of LDS time, hidden behind nothing.  (And
+// the per-workgroup partial sums are exact to fp32 precision whatever the order of the adds.)  The next chunk of samples
+// is prefetched into registers while the current one is processed.
 __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_eu(SHADE_BWPE, SHADE_BWPE))) shade_bwd_kernel(const ShadeBwdArgs a, int env_in_lds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
@@ -484,9 +521,10 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     const int Ns = p.Ns, We = p.env_w, He = p.env_h;
     const int ntex = He * We * 3;
     float* sS = smem + (size_t)wave * (64 * BREC);
-    float* sEnv = smem + (size_t)BWAVES * (64 * BREC);   // [ntex] (only when env_in_lds)
+    float* sG = smem + (size_t)BWAVES * (64 * BREC) + (size_t)wave * GIN;   // this wave's per-Gaussian inputs (prefetched)
+    double* sEnv = reinterpret_cast<double*>(smem + (size_t)BWAVES * (64 * BREC + GIN));   // [ntex] (only when env_in_lds)
     if (env_in_lds) {
-        for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) sEnv[i] = 0.f;
+        for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) sEnv[i] = 0.0;
     }
     __syncthreads();
     const float inv_ns = 1.f / (float)Ns;
@@ -495,25 +533,51 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     const int gstep = (int)gridDim.x * BWAVES;
     int g = (int)blockIdx.x * BWAVES + wave;   // wave-uniform
 
+    // slot j of the row <- which tensor, which element (computed per Gaussian: ~10 instructions per 64 slots)
+    const bool tr = p.training != 0;
+    const int nvf = tr ? 52 : 64, nf = tr ? 4 : 7;
+    auto prefetch_inputs = [&](int gi) {
+        if (!SHADE_PF) return;
+#pragma unroll
+        for (int j0 = 0; j0 < GIN; j0 += 64) {
+            const int j = j0 + lane;
+            const float* src = nullptr;
+            if (j < GIN_N) src = p.viewdirs + (size_t)gi * 3 + j;
+            else if (j < GIN_R) src = p.normals + (size_t)gi * 12 + (j - GIN_N);
+            else if (j < GIN_B) src = p.roughness + (size_t)gi * 4 + (j - GIN_R);
+            else if (j < GIN_B + 12) src = p.base_color + (size_t)gi * 12 + (j - GIN_B);
+            else if (j >= GIN_RED && j < GIN_RED + NRED) src = a.g_red ? a.g_red + (size_t)gi * NRED + (j - GIN_RED) : nullptr;
+            else if (j >= GIN_VF && j < GIN_VF + nvf) src = a.g_vfeat ? a.g_vfeat + (size_t)gi * nvf + (j - GIN_VF) : nullptr;
+            else if (j >= GIN_F && j < GIN_F + nf) src = a.g_feat ? a.g_feat + (size_t)gi * nf + (j - GIN_F) : nullptr;
+            if (src) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(sG + j0), 4, 0, 0);
+        }
+    };
+    DEV_TRACE_DECL();
+    [[maybe_unused]] unsigned dev_n = 0;
     RawSample raw;
-    if (g < P) raw = load_raw(p, (size_t)g, 0, lane, min(64, Ns));
+    if (g < P) { raw = load_raw(p, (size_t)g, 0, lane, min(64, Ns)); prefetch_inputs(g); }
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
     for (; g < P; g += gstep) {
         const size_t gg = (size_t)g;
-        float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
+        // (this Gaussian's inputs have landed in LDS: issued a whole Gaussian ago and waited for before the row stores below,
+        // so that nothing here waits for those stores)
+        wave_lds_sync();
+        const float* in_v = SHADE_PF ? sG : p.viewdirs + gg * 3;
+        float V[3] = {in_v[0], in_v[1], in_v[2]};
         {
             const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
             V[0] *= iv; V[1] *= iv; V[2] *= iv;
         }
         GaussConst c;
-        load_corner(p, gg, k, V, c);
+        if (SHADE_PF) load_corner_from(sG + GIN_N, sG + GIN_R, sG + GIN_B, k, V, c);
+        else load_corner_from(p.normals + gg * 12, p.roughness + gg * 4, p.base_color + gg * 12, k, V, c);
         // Upstream gradients of this (Gaussian, corner): dL_dreduced plus the rows of the packed features / vfeatures
-        // that alias it (see upstream()); all loads of a source are issued together under one uniform branch.
+        // that alias it (see upstream()).
         float gp[3] = {0, 0, 0}, gd[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gdi[3] = {0, 0, 0}, gin[3] = {0, 0, 0};
         float gmi[3] = {0, 0, 0}, gml[3] = {0, 0, 0}, gmg[3] = {0, 0, 0};
         float dir_b[3] = {0, 0, 0}, dir_n[3] = {0, 0, 0}, dir_r = 0.f;   // direct terms of the packing
-        const bool tr = p.training != 0;
         if (a.g_red) {
-            const float* gr = a.g_red + gg * NRED;
+            const float* gr = SHADE_PF ? sG + GIN_RED : a.g_red + gg * NRED;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 gp[ch] = gr[ch * 4 + k]; gd[ch] = gr[12 + ch * 4 + k]; gs[ch] = gr[24 + ch * 4 + k];
@@ -522,7 +586,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             }
         }
         if (a.g_vfeat) {
-            const float* vf = a.g_vfeat + gg * (tr ? 52 : 64);
+            const float* vf = SHADE_PF ? sG + GIN_VF : a.g_vfeat + gg * nvf;
             float t0[3], t1[3], t2[3], nv[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
@@ -541,7 +605,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 dir_n[j] = nv[0] * p.viewmatrix[j * 4 + 0] + nv[1] * p.viewmatrix[j * 4 + 1] + nv[2] * p.viewmatrix[j * 4 + 2];
         }
         if (a.g_feat) {
-            const float* f = a.g_feat + gg * (tr ? 4 : 7);
+            const float* f = SHADE_PF ? sG + GIN_F : a.g_feat + gg * nf;
             if (tr) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) gml[ch] += f[1 + ch];
@@ -550,6 +614,8 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 for (int ch = 0; ch < 3; ch++) { gmi[ch] += f[ch]; gml[ch] += f[3 + ch]; }
             }
         }
+        wave_lds_sync();   // the row has been read: the next Gaussian's inputs may land in it
+        if (g + gstep < P) prefetch_inputs(g + gstep);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             gp[ch] *= inv_ns; gd[ch] *= inv_ns; gs[ch] *= inv_ns; gdi[ch] *= inv_ns; gin[ch] *= inv_ns;
@@ -565,6 +631,8 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         const float gmig[3] = {gmi[0] + gmg[0], gmi[1] + gmg[1], gmi[2] + gmg[2]};   // constant part of the env gradient
         // lane k owns channel k (< 3) of dL/dradiance: constant part
         const float grad_const = k == 0 ? gmi[0] + gml[0] : (k == 1 ? gmi[1] + gml[1] : gmi[2] + gml[2]);
+        DEV_TRACE_MARK(0);   // inputs -> per-(Gaussian, corner) constants
+        dev_n++;
         float d_fd[3] = {0, 0, 0}, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
         float s_a2 = 0.f, s_nom1 = 0.f, s_kk2 = 0.f, s_nov = 0.f;   // per-Gaussian sums whose chain rule is applied once, below
         const float NoV = fminf(1.f, fmaxf(1e-6f, c.NoV_raw));
@@ -572,7 +640,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         for (int s0 = 0; s0 < Ns; s0 += 64) {
             const int cnt = min(64, Ns - s0);
             wave_lds_sync();   // previous chunk consumed
-            if (lane < cnt) stage_raw_bwd(p, raw, lane, V, sS);
+            if (lane < cnt && (SHADE_ABL != 3 || s0 + g == 0)) stage_raw_bwd(p, raw, lane, V, sS);
             {   // prefetch the next chunk (of this Gaussian or of the wave's next one)
                 const bool more = s0 + 64 < Ns;
                 const int gn = more ? g : g + gstep;
@@ -580,8 +648,9 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 if (gn < P) raw = load_raw(p, (size_t)gn, sn, lane, min(64, Ns - sn));
             }
             wave_lds_sync();
+            DEV_TRACE_MARK(1);   // staging of a chunk (+ issue of the prefetches)
 #pragma unroll 1
-            for (int it = 0; it < 4; it++) {
+            for (int it = 0; it < (SHADE_ABL == 4 ? 1 : 4); it++) {
                 const int s = sg + 16 * it;
                 if (16 * it >= cnt) break;   // wave-uniform
                 const bool act = s < cnt;
@@ -637,9 +706,9 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 for (int ch = 0; ch < 3; ch++) { xg[ch] = quad_sum(xg[ch]); xl[ch] = quad_sum(xl[ch]); }
                 if (act) {
                     const size_t o = gg * Ns + s0 + s;
-                    if (k < 3) {
+                    if (k < 3 && SHADE_ABL != 2) {   // parked in the sample's (consumed) local-light slot, written out below
                         const float v = k == 0 ? xl[0] : (k == 1 ? xl[1] : xl[2]);
-                        a.d_radiance[o * 3 + k] = v + grad_const;
+                        sS[s * BREC + 13 + k] = v + grad_const;
                     }
                     const uint32_t xy = __builtin_bit_cast(uint32_t, r[20]);
                     const int tx = (int)(xy & 0xffffu) - 1 + (k & 1), ty = (int)(xy >> 16) - 1 + (k >> 1);
@@ -650,14 +719,24 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
                             const float dt = (xg[ch] + gmig[ch]) * r[17 + ch] * w;
-                            if (dt != 0.f) {
-                                // (ds_add_f32 is ~10x slower than the integer LDS atomics on gfx950 -- measured
-                                // ~500 cycles per wave instruction; still far cheaper than L2 atomics on 6144 texels)
-                                if (env_in_lds) atomicAdd(&sEnv[idx + ch], dt);
+                            if (dt != 0.f && SHADE_ABL != 1) {
+                                if (env_in_lds) atomicAdd(&sEnv[idx + ch], (double)dt);   // ds_add_f64
                                 else atomic_add_f32(&a.d_envtab[idx + ch], dt);
                             }
                         }
                     }
+                }
+            }
+            DEV_TRACE_MARK(2);   // corner x sample loop
+            // dL/dradiance of the chunk: the values parked in the records leave as whole rows (3 cnt consecutive floats)
+            wave_lds_sync();
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next Gaussian's inputs (LDS-DMA) and the next chunk's samples, both issued an inner loop ago
+            if (SHADE_ABL != 2) {
+                float* out = a.d_radiance + (gg * Ns + s0) * 3;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int i = lane + 64 * j;
+                    if (i < 3 * cnt) out[i] = sS[(i / 3) * BREC + 13 + (i % 3)];
                 }
             }
         }
@@ -688,11 +767,13 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             }
             a.d_rough[gg * 4 + k] = d_r + dir_r;
         }
+        DEV_TRACE_MARK(3);   // row stores + per-Gaussian chain rule and stores
     }
+    DEV_TRACE_END(0, dev_n, (unsigned)Ns, 0u);
     __syncthreads();
     if (env_in_lds) {
         for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) {
-            const float v = sEnv[i];
+            const float v = (float)sEnv[i];
             if (v != 0.f) atomic_add_f32(&a.d_envtab[i], v);
         }
     }
@@ -712,6 +793,18 @@ __global__ void __launch_bounds__(BLOCK) env_grad_kernel(const float* __restrict
 }  // namespace svgir
 
 using namespace svgir;
+
+#ifdef SVGIR_DEV
+extern "C" int svgir_dev_trace_read_shade(unsigned long long* out, int cap_records) {
+    unsigned int n[2] = {0, 0};
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(svgir::g_dev_trace_n), sizeof(n)) != hipSuccess) return -1;
+    const int cnt = (int)std::min<unsigned>(n[0], (unsigned)std::min(cap_records, svgir::DEV_TRACE_CAP));
+    if (cnt > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(svgir::g_dev_trace), (size_t)cnt * svgir::DEV_TRACE_WORDS * 8, 0) != hipSuccess) return -1;
+    n[0] = n[1] = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_dev_trace_n), n, sizeof(n));
+    return cnt;
+}
+#endif
 
 extern "C" {
 
@@ -759,12 +852,23 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
-    const size_t per_wave = (size_t)(64 * BREC) * 4;
+    const size_t per_wave = (size_t)(64 * BREC + GIN) * 4;
     size_t lds = BWAVES * per_wave;
     int env_in_lds = 0;
     if (p->env_w > 65000 || p->env_h > 65000) return SVGIR_ERR_INVALID;
-    if (lds + (size_t)ntex * 4 <= 76 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 4; }   // >= two workgroups per CU
-    const int blocks = std::min((p->P + BWAVES - 1) / BWAVES, 256 * (SHADE_BWPE * 4 / BWAVES));
+    static_assert((BWAVES * (64 * BREC + GIN)) % 2 == 0, "the fp64 image behind the sample records is 8-byte aligned");
+    if (lds + (size_t)ntex * 8 <= 150 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 8; }   // one workgroup per CU
+    {
+        static bool attr_set[64] = {};   // per device (> 64 KB of dynamic LDS needs the opt-in; idempotent, so races are harmless)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return SVGIR_ERR_HIP;
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(shade_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return SVGIR_ERR_HIP;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    const int blocks = std::min((p->P + BWAVES - 1) / BWAVES, 256 * std::max(1, SHADE_BWPE * 4 / BWAVES));
     stage_mark(tm, "shade_bwd_prologue");
     hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(BWAVES * 64), lds, s, a, env_in_lds);
     stage_mark(tm, "shade_bwd");
