@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 6
+#define SVGIR_ABI_VERSION 7
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -374,6 +374,32 @@ int svgir_bvh_build(int32_t P, const float* means3D, const float* scales, const 
 int svgir_bvh_trace_visibility(int32_t P, char* bvh, int64_t num_rays, const float* rays_o, const float* rays_d, float t_offset,
                                const float* means3D, const float* cov_inv, const float* opacity, const float* normals,
                                int32_t* contribute, float* visibility, void* stream);
+
+/* The producer of the incident-radiance cache (the other half of row f3): the linear BVH and the closest-hit radiance
+ * tracer of the reference's point-based-GI renderer (pbgi/bvhhelpers.py:96-156 `get_gs_bvh`; pbgi/renderer.py:582-615
+ * `build_bvh`, `render_radiance_with_sampling_SH`; the slang kernels under pbgi/bvhworkers/: get_elements,
+ * lbvh_morton_codes, lbvh_single_radixsort, lbvh_hierarchy, lbvh_bounding_boxes, intersect_test:1879-1990, sh_utils),
+ * called by GaussianModel.update_radiace (scene/gaussian_model.py:469-522).
+ *   svgir_pbgi_bvh_bytes  : size of the opaque blob for P >= 1 primitives.
+ *   svgir_pbgi_bvh_build  : boxes centre +- 3 max|scale| (centers [P,3], scales [P,3]), 30-bit Morton codes of the box
+ *       centres in the scene extent, stable sort by code, Karras hierarchy (equal codes resolved by sorted position),
+ *       bottom-up box unions.  The tree is the reference's tree node for node (the tracer's result depends on it).
+ *   svgir_pbgi_bvh_export : the tree as the reference's tensors: info [2P-1][3] int32 = {left, right, primitive}
+ *       (`LBVHNode_info`), aabb [2P-1][6] (`LBVHNode_aabb`); optionally the sorted (code, primitive) pairs [P][2].
+ *   svgir_pbgi_trace_radiance : N rows x S rays; ray_o [N,3] (one origin per row), ray_d [N,S,3].  Per ray: repeated
+ *       closest-hit queries over t in [0.042 (0.01 after the first hit), 0.2] from the moving origin; each accepted hit adds
+ *       eval_sh(degree 3, shs [P,16,3], direction origin -> hit centre) * alpha * T and multiplies T by (1 - alpha), until
+ *       T <= 0.001, no hit, or the hit is the primitive whose index equals the ROW of the ray.  Outputs: radiance [N,S,3]
+ *       clamped to [0,10], visibility [N,S] (T, or 0 once T < 0.2), hit_indices [N,S] int32 (first hit or -1), uvs [N,S,2].
+ *       rotations [P,4] (r,x,y,z), normals [P,3], opacity [P], cov3D_inverse [P,6] (xx xy xz yy yz zz).
+ *       oracle/pbgi_oracle.cpp lists the reference's traversal quirks that are reproduced. */
+size_t svgir_pbgi_bvh_bytes(int32_t P);
+int svgir_pbgi_bvh_build(int32_t P, const float* centers, const float* scales, char* bvh, void* stream);
+int svgir_pbgi_bvh_export(int32_t P, char* bvh, int32_t* info, float* aabb, int32_t* sorted, void* stream);
+int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const float* ray_o, const float* ray_d, const float* centers,
+                              const float* scales, const float* rotations, const float* normals, const float* opacity,
+                              const float* cov3D_inverse, const float* shs, float* radiance, float* visibility, int32_t* hit_indices,
+                              float* uvs, void* stream);
 
 /* Densification (scene/gaussian_model.py:1064-1248).
  * svgir_densify_masks : the selection of densify_and_clone / densify_and_split from the statistics densify_and_prune

@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "lbvh.hpp"
 
 namespace svgir {
 
@@ -55,15 +56,6 @@ BvhLayout bvh_layout(char* base, int P) {
     return b;
 }
 constexpr int BVH_SORT_BITS = 30, BVH_SORT_PASSES = 4;   // 10 bits per axis; 8 + 8 + 8 + 6
-
-// order-preserving float <-> uint (for atomicMin / atomicMax on floats)
-__device__ __forceinline__ uint32_t f2ord(float f) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t o) {
-    return __builtin_bit_cast(float, (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
 
 // ---- leaf boxes (__init__.py:32-58) + whole box (construct.cu:164-173) -------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) bvh_leaf_kernel(int P, const float* __restrict__ means, const float* __restrict__ scales,
@@ -108,13 +100,6 @@ __global__ void __launch_bounds__(BLOCK) bvh_leaf_kernel(int P, const float* __r
 }
 
 // ---- Morton codes of the box centroids (construct.cu:6-52) -------------------------------------------------------------
-__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
 __global__ void __launch_bounds__(BLOCK) bvh_morton_kernel(int P, const float* __restrict__ leaf_box, const uint32_t* __restrict__ whole,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
 #pragma clang fp contract(off)

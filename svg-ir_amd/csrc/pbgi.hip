@@ -1,0 +1,465 @@
+// svg-ir_amd/csrc/pbgi.hip -- the radiance-cache producer of SURVEY 8f row f3: linear BVH over the surfels and the
+// closest-hit radiance tracer of the reference's point-based-GI renderer.
+//
+// Replaces (reference = slang kernels compiled by slangtorch at run time):
+//   * pbgi/bvhhelpers.py:96-156 get_gs_bvh + bvhworkers/{get_elements,lbvh_morton_codes,lbvh_single_radixsort,
+//     lbvh_hierarchy,lbvh_bounding_boxes}.slang: boxes centre +- 3 max|scale|, 30-bit Morton codes of the box centres in
+//     the scene extent, a stable sort by code, the Karras hierarchy with duplicate codes resolved by sorted position,
+//     bottom-up box unions.  The reference sorts with ONE 256-thread workgroup and refits with one launch per tree level
+//     (each with a host round trip for the height); here: the library's multi-block radix sort and ONE refit launch
+//     (arrival counters, device-scope acquire/release);
+//   * pbgi/renderer.py:596-615 render_radiance_with_sampling_SH + bvhworkers/intersect_test.slang:1879-1990 (the ray loop),
+//     :251-437 (gs_bvh_hit), :94-148 (ellipse_hit), :21-42 (aabb_hit), sh_utils.slang (eval_sh).
+//
+// Unlike the visibility tracer (bvh.hip) the result of this one DEPENDS on the tree and on the traversal order: the
+// transmittance factor a traversal returns is that of the LAST accepted leaf, not of the closest one (oracle/pbgi_oracle.cpp
+// lists this and the other reproduced quirks, Q-a .. Q-e).  So the tree is the reference's tree -- same node numbering
+// (internal nodes 0 .. P-2, leaf of sorted position j at P-1+j), children pushed left then right, boxes tested when popped
+// against the closest hit so far -- and the kernels keep fp contraction off.  What is ours is the data layout: 32-byte node
+// records {box, left, right} (one fetch per visited node instead of 3 + 6 scalar loads), and 96-byte leaf records in sorted
+// order prepared once per trace call (centre, scales, plane normal, the two rows of the inverse rotation the ellipse test
+// needs, unit normal, inverse covariance) instead of a quaternion -> matrix -> inverse evaluation at every visited leaf.
+// One lane per ray, rays in memory order ([rows, samples]: the 64 rays of a wave share their origin).
+#include <algorithm>
+
+#include "common.hpp"
+#include "lbvh.hpp"
+
+namespace svgir {
+
+namespace {
+
+struct PbgiNode { float lo[3], hi[3]; int32_t left, right; };   // 32 bytes
+static_assert(sizeof(PbgiNode) == 32, "node record");
+
+struct PbgiLayout {
+    float* box;             // [P][6] element boxes (primitive order)
+    uint32_t* whole;        // [8] scene extent as order-preserving integers: min xyz, max xyz
+    uint32_t* key[2];       // [P] Morton codes ping/pong
+    uint32_t* val[2];       // [P] primitive ids ping/pong
+    uint32_t* radix_tbl;
+    PbgiNode* node;         // [2P-1]
+    uint32_t* parent;       // [2P-1]
+    uint32_t* arrive;       // [P-1]
+    float4* rec;            // [P][6] leaf records (sorted order), filled per trace call
+    size_t bytes;
+};
+PbgiLayout pbgi_layout(char* base, int P) {
+    PbgiLayout b;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    const size_t p = (size_t)(P > 0 ? P : 1);
+    b.box = (float*)take(p * 24);
+    b.whole = (uint32_t*)take(32);
+    b.key[0] = (uint32_t*)take(p * 4); b.key[1] = (uint32_t*)take(p * 4);
+    b.val[0] = (uint32_t*)take(p * 4); b.val[1] = (uint32_t*)take(p * 4);
+    b.radix_tbl = (uint32_t*)take(radix_table_words(P) * 4);
+    b.node = (PbgiNode*)take(2 * p * 32);
+    b.parent = (uint32_t*)take(2 * p * 4);
+    b.arrive = (uint32_t*)take(p * 4);
+    b.rec = (float4*)take(p * 96);
+    b.bytes = off;
+    return b;
+}
+constexpr int PBGI_SORT_BITS = 30, PBGI_SORT_PASSES = 4;
+
+// ---- element boxes + scene extent (get_elements.slang:74-107, bvhhelpers.py:105-111) ---------------------------------------
+__global__ void __launch_bounds__(BLOCK) pbgi_box_kernel(int P, const float* __restrict__ centers, const float* __restrict__ scales,
+                                                         float* __restrict__ box, uint32_t* __restrict__ whole) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < P) {
+        const float len = 3.0f * fmaxf(fabsf(scales[3 * i]), fmaxf(fabsf(scales[3 * i + 1]), fabsf(scales[3 * i + 2])));
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            lo[c] = centers[3 * i + c] - len; hi[c] = centers[3 * i + c] + len;
+            box[6 * i + c] = lo[c]; box[6 * i + 3 + c] = hi[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float mn = lo[c], mx = hi[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { mn = fminf(mn, __shfl_xor(mn, d)); mx = fmaxf(mx, __shfl_xor(mx, d)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&whole[c], f2ord(mn)); atomicMax(&whole[3 + c], f2ord(mx)); }
+    }
+}
+
+// ---- Morton codes (lbvh_morton_codes.slang:22-80) ------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) pbgi_morton_kernel(int P, const float* __restrict__ box, const uint32_t* __restrict__ whole,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P) return;
+    uint32_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float gl = ord2f(whole[c]), gu = ord2f(whole[3 + c]);
+        const float lo = box[6 * i + c], hi = box[6 * i + 3 + c];
+        const float centre = lo + 0.5f * (hi - lo);
+        const float m = (centre - gl) / (gu - gl);
+        const float cell = fminf(fmaxf(m * 1024.0f, 0.0f), 1023.0f);
+        code += expand_bits((uint32_t)cell) << (2 - c);   // xx * 4 + yy * 2 + zz (disjoint bits)
+    }
+    keys[i] = code;
+    vals[i] = (uint32_t)i;
+}
+
+// ---- hierarchy (lbvh_hierarchy.slang:40-244): Karras 2012 on the sorted codes, equal codes told apart by position ----------
+__device__ __forceinline__ int pbgi_lcp(const uint32_t* __restrict__ code, int n, int i, uint32_t ci, int j) {
+    if (j < 0 || j > n - 1) return -1;
+    const uint32_t cj = code[j];
+    if (ci == cj) return 32 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+    return __clz((int)(ci ^ cj));
+}
+__global__ void __launch_bounds__(BLOCK) pbgi_hierarchy_kernel(int P, const uint32_t* __restrict__ code, const uint32_t* __restrict__ prim,
+                                                               const float* __restrict__ box, PbgiNode* __restrict__ node,
+                                                               uint32_t* __restrict__ parent) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const int L = P - 1;
+    {   // leaf of sorted position i
+        PbgiNode nd;
+        const uint32_t g = prim[i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { nd.lo[c] = box[6 * g + c]; nd.hi[c] = box[6 * g + 3 + c]; }
+        nd.left = 0; nd.right = 0;
+        node[L + i] = nd;
+    }
+    if (i >= P - 1) return;
+    const uint32_t ci = code[i];
+    const int dl = pbgi_lcp(code, P, i, ci, i - 1), dr = pbgi_lcp(code, P, i, ci, i + 1);
+    const int d = dr >= dl ? 1 : -1;
+    const int dmin = min(dl, dr);
+    int lmax = 2;
+    while (pbgi_lcp(code, P, i, ci, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t > 0; t >>= 1)
+        if (pbgi_lcp(code, P, i, ci, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int first = min(i, j), last = max(i, j);
+    const uint32_t cf = code[first];
+    const int common = pbgi_lcp(code, P, first, cf, last);
+    int split = first, stride = last - first;
+    do {
+        stride = (stride + 1) >> 1;
+        const int cand = split + stride;
+        if (cand < last && pbgi_lcp(code, P, first, cf, cand) > common) split = cand;
+    } while (stride > 1);
+    const int left = split == first ? L + split : split, right = split + 1 == last ? L + split + 1 : split + 1;
+    node[i].left = left; node[i].right = right;
+    parent[left] = (uint32_t)i; parent[right] = (uint32_t)i;
+    if (i == 0) parent[0] = 0xffffffffu;
+}
+
+// ---- boxes of the internal nodes, bottom-up in one launch (lbvh_bounding_boxes.slang does one launch per tree level) --------
+__global__ void __launch_bounds__(BLOCK) pbgi_refit_kernel(int P, PbgiNode* node, const uint32_t* __restrict__ parent, uint32_t* arrive) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P) return;
+    uint32_t p = parent[P - 1 + i];
+    for (int guard = 0; guard < 128 && p != 0xffffffffu; guard++) {
+        // the second child to arrive owns the node: release / acquire of the children's boxes on the arrival counter
+        const uint32_t old = __hip_atomic_fetch_add(&arrive[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        const int a = node[p].left, b = node[p].right;
+        const float* fa = reinterpret_cast<const float*>(node + a);
+        const float* fb = reinterpret_cast<const float*>(node + b);
+        float* fo = reinterpret_cast<float*>(node + p);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float la = __hip_atomic_load(fa + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), lb = __hip_atomic_load(fb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float ha = __hip_atomic_load(fa + 3 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hb = __hip_atomic_load(fb + 3 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fo + c, fminf(la, lb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fo + 3 + c, fmaxf(ha, hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        p = parent[p];
+    }
+}
+
+// ---- the tree in the reference's tensors: LBVHNode_info [2P-1][3] = {left, right, primitive}, LBVHNode_aabb [2P-1][6] ------
+__global__ void __launch_bounds__(BLOCK) pbgi_export_kernel(int P, const PbgiNode* __restrict__ node, const uint32_t* __restrict__ code,
+                                                            const uint32_t* __restrict__ prim, int32_t* __restrict__ info,
+                                                            float* __restrict__ aabb, int32_t* __restrict__ sorted) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= 2 * P - 1) return;
+    const PbgiNode nd = node[i];
+    info[3 * i] = nd.left; info[3 * i + 1] = nd.right; info[3 * i + 2] = i >= P - 1 ? (int32_t)prim[i - (P - 1)] : 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { aabb[6 * i + c] = nd.lo[c]; aabb[6 * i + 3 + c] = nd.hi[c]; }
+    if (sorted && i < P) { sorted[2 * i] = (int32_t)code[i]; sorted[2 * i + 1] = (int32_t)prim[i]; }
+}
+
+// ---- leaf records (per trace call: the reference reads these tensors at every visited leaf) --------------------------------
+// {c.xyz, sx} {sy, opacity, nw.xy} {nw.z, i00 i01 i02} {i10 i11 i12, n.x} {n.yz, ci0 ci1} {ci2 .. ci5}
+__global__ void __launch_bounds__(BLOCK) pbgi_leaf_rec_kernel(int P, const uint32_t* __restrict__ prim, const float* __restrict__ centers,
+                                                              const float* __restrict__ scales, const float* __restrict__ rot,
+                                                              const float* __restrict__ normals, const float* __restrict__ opacity,
+                                                              const float* __restrict__ cov_inv, float4* __restrict__ rec) {
+#pragma clang fp contract(off)
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= P) return;
+    const size_t g = prim[j];
+    // matrixFromRotationQuaternions, intersect_test.slang:224-248
+    const float q0 = rot[4 * g], q1 = rot[4 * g + 1], q2 = rot[4 * g + 2], q3 = rot[4 * g + 3];
+    const float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3 + 0.00000001f);
+    const float r = q0 / qn, x = q1 / qn, y = q2 / qn, z = q3 / qn;
+    const float m00 = 1 - 2 * (y * y + z * z), m01 = 2 * (x * y - r * z), m02 = 2 * (x * z + r * y);
+    const float m10 = 2 * (x * y + r * z), m11 = 1 - 2 * (x * x + z * z), m12 = 2 * (y * z - r * x);
+    const float m20 = 2 * (x * z - r * y), m21 = 2 * (y * z + r * x), m22 = 1 - 2 * (x * x + y * y);
+    // inverse(rotateMat) = adjugate * (1 / det): rows 0 and 1 (ellipse_hit only uses posM.x, posM.y)
+    const float det = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
+    const float id = 1.0f / det;
+    const float i00 = (m11 * m22 - m12 * m21) * id, i01 = (m02 * m21 - m01 * m22) * id, i02 = (m01 * m12 - m02 * m11) * id;
+    const float i10 = (m12 * m20 - m10 * m22) * id, i11 = (m00 * m22 - m02 * m20) * id, i12 = (m02 * m10 - m00 * m12) * id;
+    const float nx = normals[3 * g], ny = normals[3 * g + 1], nz = normals[3 * g + 2];
+    const float nl = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float* ci = cov_inv + 6 * g;
+    float4* o = rec + 6 * (size_t)j;
+    o[0] = make_float4(centers[3 * g], centers[3 * g + 1], centers[3 * g + 2], scales[3 * g]);
+    o[1] = make_float4(scales[3 * g + 1], opacity[g], m02, m12);
+    o[2] = make_float4(m22, i00, i01, i02);
+    o[3] = make_float4(i10, i11, i12, nx / nl);
+    o[4] = make_float4(ny / nl, nz / nl, ci[0], ci[1]);
+    o[5] = make_float4(ci[2], ci[3], ci[4], ci[5]);
+}
+
+// ---- tracing ---------------------------------------------------------------------------------------------------------------
+struct F3 { float x, y, z; };
+__device__ __forceinline__ float dot3(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+__device__ __forceinline__ F3 unit3(F3 v) {   // normalize(v) = v / sqrt(dot(v, v))
+#pragma clang fp contract(off)
+    const float l = sqrtf(dot3(v, v));
+    return {v.x / l, v.y / l, v.z / l};
+}
+struct SlabDir { float inv[3]; };
+__device__ __forceinline__ SlabDir slab_dir(F3 d) {   // aabb_hit's per-axis reciprocal (zero components become 1e-6), intersect_test.slang:25-27
+#pragma clang fp contract(off)
+    SlabDir s;
+    const float dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) s.inv[i] = 1.0f / (dd[i] == 0.f ? 0.000001f : dd[i]);
+    return s;
+}
+__device__ __forceinline__ bool box_hit(const float4 q0, const float4 q1, F3 o, const SlabDir& sd, float t_min, float t_max) {   // :21-42
+#pragma clang fp contract(off)
+    const float lo[3] = {q0.x, q0.y, q0.z}, hi[3] = {q0.w, q1.x, q1.y}, oo[3] = {o.x, o.y, o.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float inv = sd.inv[i];
+        float t0 = (lo[i] - oo[i]) * inv, t1 = (hi[i] - oo[i]) * inv;
+        if (inv < 0.0f) { const float t = t1; t1 = t0; t0 = t; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+constexpr int PBGI_STACK = 64;        // the reference's MAX_STACK_SIZE (a push beyond it is dropped here; undefined there)
+constexpr int PBGI_MAX_HITS = 4096;   // guard of the ray loop (every accepted hit removes >= 1/255 of the transmittance: < 1800 hits)
+
+struct PbgiHit { bool any; float t, keep, u, v; int index; };
+
+// gs_bvh_hit, intersect_test.slang:251-437
+__device__ __forceinline__ void closest_hit(const PbgiNode* __restrict__ node, const float4* __restrict__ rec, const uint32_t* __restrict__ prim,
+                                            int P, F3 o, F3 d, float t_min, float t_max, PbgiHit& h) {
+#pragma clang fp contract(off)
+    int stack[PBGI_STACK];
+    int count = 0;
+    stack[count++] = 0;
+    float closest = t_max, cu = 0.f, cv = 0.f, hit_t = 0.f, keep_l = 0.f, hu = 0.f, hv = 0.f;
+    uint32_t closest_index = 0;
+    bool any_hit = false;
+    SlabDir sd = slab_dir(d);
+    const int L = P - 1;
+    while (count > 0) {
+        const int n = stack[--count];
+        const float4* q = reinterpret_cast<const float4*>(node + n);
+        const float4 q0 = q[0], q1 = q[1];
+        if (!box_hit(q0, q1, o, sd, t_min, closest)) continue;
+        const int left = __builtin_bit_cast(int, q1.z), right = __builtin_bit_cast(int, q1.w);
+        if (left != 0 && right != 0) {
+            if (count < PBGI_STACK - 1) { stack[count++] = left; stack[count++] = right; }
+        } else if (left == 0 && right == 0) {
+            const int j = n - L;
+            const float4* lr = rec + 6 * (size_t)j;
+            const float4 A = lr[0], B = lr[1], C = lr[2], D = lr[3], E = lr[4], G = lr[5];
+            {   // :342 -- the re-normalised direction also serves the box tests that follow (Q-c).  A direction whose length
+                // already rounds to 1 is left bit-identical by the division: skip it and the three reciprocals then
+                const float l = sqrtf(dot3(d, d));
+                if (l != 1.0f) { d = {d.x / l, d.y / l, d.z / l}; sd = slab_dir(d); }
+            }
+            const F3 c = {A.x, A.y, A.z};
+            const float sx = A.w, sy = B.x;
+            // ---- ellipse_hit, :94-148 ----
+            bool hit = false;
+            float t_now = 0.f, uh = 0.5f, vh = 0.5f;
+            F3 pos = {0.f, 0.f, 0.f};
+            {
+                const F3 nw = {B.z, B.w, C.x};
+                const float denom = dot3(nw, d);
+                if (!(fabsf(denom) < 1e-6f)) {
+                    const F3 co = {c.x - o.x, c.y - o.y, c.z - o.z};
+                    t_now = dot3(co, nw) / denom;
+                    if (!(t_now < t_min)) {
+                        pos = {o.x + d.x * t_now, o.y + d.y * t_now, o.z + d.z * t_now};
+                        const F3 w = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
+                        const float px = C.y * w.x + C.z * w.y + C.w * w.z, py = D.x * w.x + D.y * w.y + D.z * w.z;
+                        float a = px / sx, b = py / sy;
+                        if (a < b) { const float t = a; a = b; b = t; }
+                        a = a * 0.5f + 0.5f; b = b * 0.5f + 0.5f;
+                        uh = fminf(fmaxf(a, 0.001f), 0.999f);
+                        vh = fminf(fmaxf(b, 0.001f), 0.999f);
+                        const float dis = (px * px) / (sx * sx) + (py * py) / (sy * sy);
+                        hit = dis <= 9.0f;
+                    }
+                }
+            }
+            if (t_now < t_min) continue;   // :367-371
+            const F3 dd = {c.x - pos.x, c.y - pos.y, c.z - pos.z};
+            const float power = -0.5f * (dd.x * dd.x * E.z + dd.y * dd.y * G.y + dd.z * dd.z * G.w + 2 * dd.x * dd.y * E.w + 2 * dd.x * dd.z * G.x +
+                                         2 * dd.y * dd.z * G.z);
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, B.y * expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const F3 nrm = {D.w, E.x, E.y};
+            if (!(dot3(d, nrm) < -0.0f)) hit = false;   // :399-404
+            const bool update = hit && t_now < closest;
+            closest = hit ? fminf(t_now, closest) : closest;
+            closest_index = update ? prim[j] : closest_index;
+            cu = update ? uh : cu; cv = update ? vh : cv;
+            if (hit) { any_hit = true; hit_t = closest; keep_l = 1 - alpha; hu = cu; hv = cv; }   // (Q-a, Q-b)
+        }
+    }
+    h.any = any_hit;
+    if (any_hit) { h.t = hit_t; h.keep = keep_l; h.index = (int)closest_index; h.u = hu; h.v = hv; }
+    else h.index = -1;
+}
+
+__device__ __forceinline__ void eval_sh3(const float* __restrict__ sh, F3 dir, float out[3]) {   // sh_utils.slang:3-67
+#pragma clang fp contract(off)
+    dir = unit3(dir);
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f, C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
+    const float C30 = -0.5900435899266435f, C31 = 2.890611442640554f, C32 = -0.4570457994644658f, C33 = 0.3731763325901154f,
+                C34 = -0.4570457994644658f, C35 = 1.445305721320277f, C36 = -0.5900435899266435f;
+    const float x = dir.x, y = dir.y, z = dir.z;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float r = C0 * sh[c];
+        r = r - C1 * y * sh[3 + c] + C1 * z * sh[6 + c] - C1 * x * sh[9 + c];
+        r = r + C20 * x * y * sh[12 + c] + C21 * y * z * sh[15 + c] + C22 * (2.0f * z * z - x * x - y * y) * sh[18 + c] + C23 * x * z * sh[21 + c] +
+            C24 * (x * x - y * y) * sh[24 + c];
+        r = r + C30 * y * (3.0f * x * x - y * y) * sh[27 + c] + C31 * x * y * z * sh[30 + c] + C32 * y * (4.0f * z * z - x * x - y * y) * sh[33 + c] +
+            C33 * z * (2.0f * z * z - 3.0f * x * x - 3.0f * y * y) * sh[36 + c] + C34 * x * (4.0f * z * z - x * x - y * y) * sh[39 + c] +
+            C35 * z * (x * x - y * y) * sh[42 + c] + C36 * x * (x * x - 3.0f * y * y) * sh[45 + c];
+        out[c] = r + 0.5f;
+    }
+}
+
+// render_radiance_with_sampling_SH, intersect_test.slang:1879-1990
+__global__ void __launch_bounds__(BLOCK) pbgi_trace_kernel(int P, const PbgiNode* __restrict__ node, const float4* __restrict__ rec,
+                                                           const uint32_t* __restrict__ prim, int N, int S, const float* __restrict__ ray_o,
+                                                           const float* __restrict__ ray_d, const float* __restrict__ centers,
+                                                           const float* __restrict__ shs, float* __restrict__ radiance,
+                                                           float* __restrict__ visibility, int32_t* __restrict__ hit_indices, float* __restrict__ uvs) {
+#pragma clang fp contract(off)
+    const long long ri = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (ri >= (long long)N * S) return;
+    const int row = (int)(ri / S);
+    const F3 dir = unit3(F3{ray_d[3 * ri], ray_d[3 * ri + 1], ray_d[3 * ri + 2]});
+    F3 o = {ray_o[3 * row], ray_o[3 * row + 1], ray_o[3 * row + 2]};
+    int first_hit = -1;
+    float fu = 0.f, fv = 0.f;
+    float T = 1.0f, t_min = 0.042f;
+    const float t_max = 0.2f;
+    bool done = false, visible = true;
+    float sh[3] = {0.f, 0.f, 0.f};
+    PbgiHit h = {false, 0.f, 0.f, 0.f, 0.f, -1};
+    for (int it = 0; it < PBGI_MAX_HITS && T > 0.001f && !done; it++) {
+        closest_hit(node, rec, prim, P, o, dir, t_min, t_max, h);
+        const bool hit = h.index == row ? false : h.any;   // (Q-d)
+        if (hit) {
+            if (first_hit == -1) { first_hit = h.index; fu = h.u; fv = h.v; t_min = 0.01f; }
+            const F3 sdir = {centers[3 * (size_t)h.index] - o.x, centers[3 * (size_t)h.index + 1] - o.y, centers[3 * (size_t)h.index + 2] - o.z};
+            o = {o.x + dir.x * h.t, o.y + dir.y * h.t, o.z + dir.z * h.t};
+            float e[3];
+            eval_sh3(shs + 48 * (size_t)h.index, sdir, e);
+#pragma unroll
+            for (int c = 0; c < 3; c++) sh[c] += e[c] * (1 - h.keep) * T;
+            T = T * h.keep;
+            if (T < 0.2f) visible = false;
+        } else {
+            done = true;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) radiance[3 * ri + c] = fminf(fmaxf(sh[c], 0.0f), 10.0f);
+    visibility[ri] = visible ? T : 0.0f;
+    hit_indices[ri] = first_hit;
+    uvs[2 * ri] = fu; uvs[2 * ri + 1] = fv;
+}
+
+}  // namespace
+
+}  // namespace svgir
+
+extern "C" {
+
+size_t svgir_pbgi_bvh_bytes(int32_t P) { return svgir::pbgi_layout(nullptr, P).bytes; }
+
+int svgir_pbgi_bvh_build(int32_t P, const float* centers, const float* scales, char* bvh, void* stream) {
+    using namespace svgir;
+    if (P <= 0 || !centers || !scales || !bvh) return SVGIR_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const PbgiLayout B = pbgi_layout(bvh, P);
+    const int nb = (P + BLOCK - 1) / BLOCK;
+    if (hipMemsetAsync(B.whole, 0xff, 12, s) != hipSuccess) return SVGIR_ERR_HIP;
+    if (hipMemsetAsync(B.whole + 3, 0, 12, s) != hipSuccess) return SVGIR_ERR_HIP;
+    if (hipMemsetAsync(radix_gtot(B.radix_tbl, P), 0, radix_gtot_words(P) * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
+    if (hipMemsetAsync(B.arrive, 0, (size_t)P * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
+    hipLaunchKernelGGL(pbgi_box_kernel, dim3(nb), dim3(BLOCK), 0, s, P, centers, scales, B.box, B.whole);
+    hipLaunchKernelGGL(pbgi_morton_kernel, dim3(nb), dim3(BLOCK), 0, s, P, B.box, B.whole, B.key[0], B.val[0]);
+    launch_radix_sort(B.key, B.val, P, nullptr, PBGI_SORT_BITS, 8, B.radix_tbl, s);
+    const int fin = PBGI_SORT_PASSES & 1;
+    hipLaunchKernelGGL(pbgi_hierarchy_kernel, dim3(nb), dim3(BLOCK), 0, s, P, B.key[fin], B.val[fin], B.box, B.node, B.parent);
+    if (P > 1) hipLaunchKernelGGL(pbgi_refit_kernel, dim3(nb), dim3(BLOCK), 0, s, P, B.node, B.parent, B.arrive);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_pbgi_bvh_export(int32_t P, char* bvh, int32_t* info, float* aabb, int32_t* sorted, void* stream) {
+    using namespace svgir;
+    if (P <= 0 || !bvh || !info || !aabb) return SVGIR_ERR_INVALID;
+    const PbgiLayout B = pbgi_layout(bvh, P);
+    const int fin = PBGI_SORT_PASSES & 1;
+    hipLaunchKernelGGL(pbgi_export_kernel, dim3((2 * P - 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, P, B.node, B.key[fin],
+                       B.val[fin], info, aabb, sorted);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const float* ray_o, const float* ray_d, const float* centers,
+                              const float* scales, const float* rotations, const float* normals, const float* opacity,
+                              const float* cov3D_inverse, const float* shs, float* radiance, float* visibility, int32_t* hit_indices,
+                              float* uvs, void* stream) {
+    using namespace svgir;
+    if (P <= 0 || N < 0 || S <= 0 || !bvh) return SVGIR_ERR_INVALID;
+    if (N == 0) return 0;
+    if (!ray_o || !ray_d || !centers || !scales || !rotations || !normals || !opacity || !cov3D_inverse || !shs || !radiance || !visibility ||
+        !hit_indices || !uvs)
+        return SVGIR_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const PbgiLayout B = pbgi_layout(bvh, P);
+    const int fin = PBGI_SORT_PASSES & 1;
+    hipLaunchKernelGGL(pbgi_leaf_rec_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, B.val[fin], centers, scales, rotations, normals,
+                       opacity, cov3D_inverse, B.rec);
+    const long long rays = (long long)N * S;
+    hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)((rays + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, P, B.node, B.rec, B.val[fin], N, S, ray_o,
+                       ray_d, centers, shs, radiance, visibility, hit_indices, uvs);
+    return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
+}
+
+}  // extern "C"
