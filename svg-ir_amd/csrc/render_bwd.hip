@@ -118,8 +118,12 @@ render_bwd_kernel(const RenderBwdArgs a) {
     for (int i = lane; i < (int)(BG::off_q / 16); i += 64) reinterpret_cast<float4*>(sD)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = lane; i < BG::PROWS * PS / 4; i += 64) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // the waves stride over the compact list of live depth segments (common.hpp SEG) the forward appended;
-    // entry = (sub-tile id << SEG_K_BITS) | k
+    // The waves stride over the list of live depth segments (common.hpp SEG; seg_build_kernel): one 32-byte descriptor per
+    // segment, fetched with scalar loads.  The count and this wave's first descriptor are independent loads (the list
+    // position of a work id does not depend on the count: common.hpp seg_item_of).
+    typedef const __attribute__((address_space(4))) uint32_t cu32;
+    cu32* dsc0 = (cu32*)(uintptr_t)(a.seg_desc + min(seg_item_of(blockIdx.x), (uint32_t)a.seg_cap));
+    uint32_t d_sm = dsc0[0], d_r0 = dsc0[1], d_len = dsc0[2], d_count = dsc0[3], d_ndump = dsc0[4];
     const uint32_t nlive = min(a.seg_count[0], (uint32_t)a.seg_cap);
     const uint32_t nwork = seg_work_ids(nlive);
     if (blockIdx.x >= nwork) return;
@@ -128,13 +132,17 @@ render_bwd_kernel(const RenderBwdArgs a) {
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const uint32_t item = seg_item_of(wi);   // longest-first list, dealt to the XCDs in blocks of consecutive items (common.hpp)
     if (item >= nlive) continue;
+    if (wi != blockIdx.x) {
+        cu32* dsc = (cu32*)(uintptr_t)(a.seg_desc + item);
+        d_sm = dsc[0]; d_r0 = dsc[1]; d_len = dsc[2]; d_count = dsc[3]; d_ndump = dsc[4];
+    }
     DEV_TRACE_MARK(3);
     wave_lds_sync();   // the previous segment's LDS traffic is complete before its buffers are reused
-    const uint32_t sm = a.seg_list[item];
+    const uint32_t sm = d_sm, r0 = d_r0, tlen = d_len;
     const int sid = (int)(sm >> SEG_K_BITS), kseg = (int)(sm & ((1u << SEG_K_BITS) - 1u));
     const int tile = sid >> 2, sub = sid & 3;
-    const int count = (int)a.sub_count[sid];
-    const int ndump = (int)a.sub_ndump[sid];
+    const int count = (int)d_count;
+    const int ndump = (int)d_ndump;
     const int seg_lo = kseg * SEG, seg_hi = min(count, seg_lo + SEG);
     if (seg_hi <= seg_lo) continue;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -142,10 +150,16 @@ render_bwd_kernel(const RenderBwdArgs a) {
     const int py = ty * TILE + (sub >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
-    const uint2* __restrict__ sub_in = a.sub_list + (size_t)4 * r0 + (size_t)sub * (r1 - r0);
+    const uint2* __restrict__ sub_in = a.sub_list + (size_t)4 * r0 + (size_t)sub * tlen;
     const size_t pid = inside ? (size_t)a.W * py + px : 0;
+    const int nent = seg_hi - seg_lo;
 
+    // ---- every load of the set-up that depends only on the descriptor is issued here, together: the segment's list entries
+    // (deepest first: the replay walks back to front), the pixel's forward results and upstream gradients, and the two dumped
+    // forward states -- one memory round trip instead of four dependent ones
+    static_assert(SEG == 64, "one list entry per lane");
+    uint2 ent = make_uint2(0u, 0u);
+    if (lane < nent) ent = sub_in[seg_hi - 1 - lane];
     const float T_final = inside ? a.final_T[pid] : 0.f;
     const float D_final = (inside && normalize_depth) ? a.final_D[pid] : 0.f;
     const uint32_t last_contributor = inside ? (uint32_t)a.n_contrib[pid] : 0u;
@@ -157,6 +171,19 @@ render_bwd_kernel(const RenderBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < VV; i++) gVF[i] = (inside && i < VC) ? a.g_vfeature[i * N_ + pid] : 0.f;
     if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
+    constexpr int NST = 8 + S + VC;
+    float st_T = 0.f, st_d[NST - 1];   // (final - prefix) of the dumped states, channel by channel (only when kseg < ndump)
+#pragma unroll
+    for (int i = 0; i < NST - 1; i++) st_d[i] = 0.f;
+    if (kseg < ndump) {
+        const uint32_t sbase = seg_state_base(r0, tlen, tile, sub);   // state slot of (sub-tile, 0)
+        const float* e = a.seg_state + ((size_t)(sbase + kseg) * NST) * 64 + lane;
+        const float* f = a.seg_state + ((size_t)(sbase + ndump) * NST) * 64 + lane;   // final state
+        st_T = e[0];
+#pragma unroll
+        for (int i = 0; i < NST - 1; i++) st_d[i] = f[(1 + i) * 64] - e[(1 + i) * 64];
+    }
+
     const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
     const float omt = 1.f - T_final;
     const float gDn = normalize_depth ? gD / omt : gD;  // depth gradient seen by the blended depth
@@ -170,6 +197,16 @@ render_bwd_kernel(const RenderBwdArgs a) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
     if (wmax == 0) continue;
+
+    // The list entries go to LDS; the first batch's gathers start now and overlap the rest of the set-up.
+    sQ[lane] = ent;
+    const int nskip = __popcll(__ballot(lane < nent && ent.y >= wmax));   // entries behind every pixel of this wave (a prefix: slots descend)
+    wave_lds_sync();
+    StageRegs<S, VC, CHB> sr;
+    int base = (nskip / CHB) * CHB;
+    if (base < nent)
+        stage_load<S, VC, CHB>(sr, min((int)CHB, nent - base), [&](int s) { return sQ[base + s].x; }, lane, a.rec,
+                               a.features, a.vfeatures);
 
     // G matrix of this sub-tile: row = pixel (lane), columns = [colour3 | normal3 x10 (Q4) | depth | feature S | vfeature VC].
     // Phase B needs it as the MFMA B operand (lane l: G[pixel = 16*(l>>4) + kk][channel = l&15], kk = 0..15): the NC0 plain
@@ -207,45 +244,26 @@ render_bwd_kernel(const RenderBwdArgs a) {
     if (kseg < ndump) {
         // Not the deepest live segment: start from the forward state dumped at this segment's far end.  With
         // last_alpha = 0 the recurrence takes accum = blend of everything behind = (final - prefix) / T_end.
-        constexpr int NST = 8 + S + VC;
-        const uint32_t sbase = seg_state_base(r0, r1 - r0, tile, sub);   // state slot of (sub-tile, 0)
-        const float* e = a.seg_state + ((size_t)(sbase + kseg) * NST) * 64 + lane;
-        const float* f = a.seg_state + ((size_t)(sbase + ndump) * NST) * 64 + lane;   // final state
-        T = e[0];
-        float dot = (f[7 * 64] - e[7 * 64]) * gDn;
+        // (state layout: T | colour 3 | normal 3 | depth | feature S | vfeature VC; st_d[i] = channel 1 + i)
+        T = st_T;
+        float dot = st_d[6] * gDn;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            dot += (f[(1 + i) * 64] - e[(1 + i) * 64]) * gC[i];
-            dot += (f[(4 + i) * 64] - e[(4 + i) * 64]) * gN[i];   // zero unless `surface` (the forward leaves N at 0)
+            dot += st_d[i] * gC[i];
+            dot += st_d[3 + i] * gN[i];   // zero unless `surface` (the forward leaves N at 0)
         }
         if (bgeom) {
 #pragma unroll
-            for (int i = 0; i < S; i++) dot += (f[(8 + i) * 64] - e[(8 + i) * 64]) * gF[i];
+            for (int i = 0; i < S; i++) dot += st_d[7 + i] * gF[i];
         }
 #pragma unroll
-        for (int i = 0; i < VC; i++) dot += (f[(8 + S + i) * 64] - e[(8 + S + i) * 64]) * gVF[i];
+        for (int i = 0; i < VC; i++) dot += st_d[7 + S + i] * gVF[i];
         A_acc = dot * __builtin_amdgcn_rcpf(T);
     }
-
-    // The segment's list entries go to LDS once, deepest first (the replay walks back to front).
-    const int nent = seg_hi - seg_lo;
-    int nskip = 0;   // entries that lie behind every pixel of this wave (a prefix: slots descend)
-    for (int i = lane; i < SEG; i += 64) {
-        uint2 e = make_uint2(0u, 0u);
-        if (i < nent) e = sub_in[seg_hi - 1 - i];
-        sQ[i] = e;
-        nskip += __popcll(__ballot(i < nent && e.y >= wmax));
-    }
-    wave_lds_sync();
     DEV_TRACE_MARK(0);   // segment setup
     dev_items++; dev_cands += (unsigned)nent;
     // Batches of CHB candidates; the gathers of batch b+1 are in flight (registers) while batch b is replayed, so
     // neither their latency nor the completion of this batch's gradient atomics is waited for.
-    StageRegs<S, VC, CHB> sr;
-    int base = (nskip / CHB) * CHB;
-    if (base < nent)
-        stage_load<S, VC, CHB>(sr, min((int)CHB, nent - base), [&](int s) { return sQ[base + s].x; }, lane, a.rec,
-                               a.features, a.vfeatures);
     for (; base < nent; base += CHB) {
         const int m = min((int)CHB, nent - base);
         wave_lds_sync();  // previous batch fully consumed
