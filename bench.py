@@ -75,6 +75,16 @@ def library_hash():
         return None
 
 
+def library_is_current():
+    """True when the library this process loads is at least as new as every kernel source (it was built from them)."""
+    lib = os.environ.get("SVGIR_RASTER_LIB") or os.path.join(ROOT, "svg-ir_amd", "libsvgir_raster.so")
+    d = os.path.join(ROOT, "svg-ir_amd", "csrc")
+    try:
+        return os.path.getmtime(lib) >= max(os.path.getmtime(os.path.join(d, f)) for f in TRAFFIC_SOURCES)
+    except OSError:
+        return False
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,7 +350,10 @@ def roofline_of(wl, R, stage, workload):
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("library_hash") == library_hash():
+        same_lib = tj.get("library_hash") == library_hash()
+        if tj.get("kernel_source_hash") == kernel_source_hash() and (same_lib or library_is_current()):
+            if not same_lib:   # another build of the SAME sources (e.g. rebuilt on the measuring machine)
+                out["traffic_note"] = "library rebuilt from the kernel sources profiles/traffic_%s.json was measured with" % workload
             tr = 0
             for kname, kv in tj.get("kernels", {}).items():
                 if kname.startswith("render_bwd") or kname.startswith("grad_reduce_kernel"):

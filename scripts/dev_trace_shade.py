@@ -19,13 +19,20 @@ dev = torch.device("cuda:0")
 wl = bench.Workload(name, dev, 0, 1, args)
 reader = _native.lib.svgir_dev_trace_read_shade
 reader.restype = C.c_int
-reader.argtypes = [C.c_void_p, C.c_int]
+reader.argtypes = [C.c_void_p, C.c_int, C.c_int]
 CAP = 1 << 17
 buf = np.zeros((CAP, 8), dtype=np.uint64)
+fbuf = np.zeros((CAP, 8), dtype=np.uint64)
 for it in range(3):
     wl.step()
     torch.cuda.synchronize()
-    n = reader(buf.ctypes.data, CAP)
+    nf = reader(fbuf.ctypes.data, CAP, 1)
+    n = reader(buf.ctypes.data, CAP, 0)
+fr = fbuf[:nf].astype(np.int64)
+ft = fr[:, 0].sum()
+print(f"{name} shade_fwd: {nf} reporting waves (one of four); kernel span {(fr[:, 2].max() - fr[:, 1].min()) / 100.0:.1f} us; cycles per surfel {ft / nf:.0f}: "
+      f"prologue {fr[:, 5].sum() / nf:.0f} staging {fr[:, 6].sum() / nf:.0f} corner-x-sample loop {(fr[:, 7] >> 32).sum() / nf:.0f} "
+      f"reductions + epilogue {(fr[:, 7] & 0xffffffff).sum() / nf:.0f}")
 rec = buf[:n].astype(np.int64)
 dur, r0, r1 = rec[:, 0], rec[:, 1], rec[:, 2]
 surfels = rec[:, 3] >> 32

@@ -178,8 +178,16 @@ struct GaussConst {  // per-(Gaussian, corner) constants of a phase-2 lane
     float sgn, inv_len, NoV_raw;  // for the backward
 };
 
-__device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t g, int k, const float* V, GaussConst& c) {
-    const float* n = p.normals + g * 12 + k * 3;
+struct CornerIn { float v[3], n[3], r, base[3]; };   // what the constants of one (Gaussian, corner) are made from
+__device__ __forceinline__ CornerIn load_corner_in(const svgir_shade_params& p, size_t g, int k) {
+    CornerIn ci;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { ci.v[j] = p.viewdirs[g * 3 + j]; ci.n[j] = p.normals[g * 12 + k * 3 + j]; ci.base[j] = p.base_color[g * 12 + j * 4 + k]; }
+    ci.r = p.roughness[g * 4 + k];
+    return ci;
+}
+__device__ __forceinline__ void corner_consts(const CornerIn& ci, const float* V, GaussConst& c) {
+    const float* n = ci.n;
     c.nraw[0] = n[0]; c.nraw[1] = n[1]; c.nraw[2] = n[2];
     const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
     c.inv_len = __builtin_amdgcn_rcpf(len);
@@ -189,34 +197,36 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
     c.Nh[0] = Nn[0] * c.sgn; c.Nh[1] = Nn[1] * c.sgn; c.Nh[2] = Nn[2] * c.sgn;
     c.NoV_raw = c.Nh[0] * V[0] + c.Nh[1] * V[1] + c.Nh[2] * V[2];
     const float NoV = fminf(1.f, fmaxf(1e-6f, c.NoV_raw));
-    c.r = p.roughness[g * 4 + k];
+    c.r = ci.r;
     const float a = c.r * c.r;
     c.a2 = a * a;
     c.kk = (a + 2.f * c.r + 1.0f) / 8.0f;
     c.nom1 = NoV * (1.f - c.kk) + c.kk;
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) c.fd[ch] = p.base_color[g * 12 + ch * 4 + k] * kInvPi;
+    for (int ch = 0; ch < 3; ch++) c.fd[ch] = ci.base[ch] * kInvPi;
+}
+__device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t g, int k, const float* V, GaussConst& c) {
+    corner_consts(load_corner_in(p, g, k), V, c);
 }
 
-// the same from staged rows (normals[12], roughness[4], base_color[12] of one Gaussian)
-__device__ __forceinline__ void load_corner_from(const float* nrm, const float* rough, const float* base, int k, const float* V, GaussConst& c) {
-    const float* n = nrm + k * 3;
-    c.nraw[0] = n[0]; c.nraw[1] = n[1]; c.nraw[2] = n[2];
-    const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
-    c.inv_len = __builtin_amdgcn_rcpf(len);
-    float Nn[3] = {n[0] * c.inv_len, n[1] * c.inv_len, n[2] * c.inv_len};
-    const float nov = V[0] * Nn[0] + V[1] * Nn[1] + V[2] * Nn[2];
-    c.sgn = nov > 0.f ? 1.f : (nov < 0.f ? -1.f : 0.f);
-    c.Nh[0] = Nn[0] * c.sgn; c.Nh[1] = Nn[1] * c.sgn; c.Nh[2] = Nn[2] * c.sgn;
-    c.NoV_raw = c.Nh[0] * V[0] + c.Nh[1] * V[1] + c.Nh[2] * V[2];
-    const float NoV = fminf(1.f, fmaxf(1e-6f, c.NoV_raw));
-    c.r = rough[k];
-    const float a = c.r * c.r;
-    c.a2 = a * a;
-    c.kk = (a + 2.f * c.r + 1.0f) / 8.0f;
-    c.nom1 = NoV * (1.f - c.kk) + c.kk;
+// the raw inputs of one incident sample (lane = sample), loadable a chunk / a Gaussian ahead of their use
+struct RawSample { float d[3], rad[3], vis, area; };
+
+__device__ __forceinline__ RawSample load_raw(const svgir_shade_params& p, size_t g, int s, int lane, int cnt) {
+    const int si = s + (lane < cnt ? lane : 0);
+    const size_t o = g * (size_t)p.Ns + (size_t)si;
+    RawSample r;
+    if (p.incident_dirs) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) c.fd[ch] = base[ch * 4 + k] * kInvPi;
+        for (int j = 0; j < 3; j++) r.d[j] = p.incident_dirs[o * 3 + j];
+    } else {   // directions from the lattice (3 (+1) floats per surfel instead of 12 bytes per sample)
+        const LatticeFrame lf = lattice_frame(p.lattice_normals, p.lattice_offsets, g);
+        lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[si], si, p.lattice_offsets != nullptr, r.d);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.rad[j] = p.radiance[o * 3 + j];
+    r.vis = p.visibility[o]; r.area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
+    return r;
 }
 
 // phase 1 for one chunk of <= 64 samples [s0, s0+cnt) of one Gaussian: fills the wave's sample records (slot =
@@ -279,13 +289,16 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
 #ifndef SHADE_FWPE
 #define SHADE_FWPE 5   // 96 VGPRs without spills; the default heuristic settles on 107 (4 waves per SIMD): 285 -> 252 us at P = 200k, Ns = 64
 #endif
+// One wave per Gaussian.  (A persistent variant that loads the next Gaussian's samples and corner data while the current one
+// is processed was built and measured: 282 us at 4 waves/SIMD, 332 us at 5 (spills) against 250 us for this one.)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_FWPE, SHADE_FWPE))) shade_fwd_kernel(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Ns = p.Ns;
-    float* sS = smem + (size_t)wave * (64 * SREC + 80);
+    float* sS = smem + (size_t)wave * (64 * SREC + 80 + 32);
     float* sOut = sS + 64 * SREC;
+    float* sIn = sOut + 80;   // base_color[12] | normals[12] | roughness[4] of this Gaussian, for the packing in the epilogue
     const size_t g = (size_t)blockIdx.x * 4 + wave;
     const bool valid = g < (size_t)p.P;
     const size_t gg = valid ? g : 0;
@@ -295,6 +308,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
     {
         const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
         V[0] *= iv; V[1] *= iv; V[2] *= iv;
+    }
+    DEV_TRACE_DECL();
+    if (a.vfeatures && lane < 28) {   // fetched with the rest of the set-up loads: the epilogue then waits for nothing
+        const float* src = lane < 12 ? p.base_color + gg * 12 + lane : (lane < 24 ? p.normals + gg * 12 + (lane - 12) : p.roughness + gg * 4 + (lane - 24));
+        sIn[lane] = *src;
     }
     float m[10];
 #pragma unroll
@@ -311,8 +329,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
     for (int s0 = 0; s0 < Ns; s0 += 64) {
       const int cnt = min(64, Ns - s0);
       wave_lds_sync();   // previous chunk consumed
+      DEV_TRACE_MARK(0);
       stage_samples(p, gg, lane, V, sS, m, s0, cnt, lf);
       wave_lds_sync();
+      DEV_TRACE_MARK(1);
       for (int s = sg; s < cnt; s += 16) {
         const float* r = sS + s * SREC;
         const float ndi = fmaxf(c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2], 0.f);
@@ -329,6 +349,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
         }
       }
     }
+    DEV_TRACE_MARK(2);
 #pragma unroll
     for (int i = 3; i < 10; i++) {   // local(3), global(3), visibility; incident = local + global
         const float t = wave_scan_last(m[i]);
@@ -366,17 +387,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
         if (lane < VS) {
             float v;
             if (lane < 12) v = sOut[lane];
-            else if (lane < 24) v = p.base_color[g * 12 + (lane - 12)];
+            else if (lane < 24) v = sIn[lane - 12];
             else if (lane < 36) {
                 const int e = lane - 24, ch = e >> 2, kc = e & 3;  // channel*4 + corner
-                const float* n = p.normals + g * 12 + kc * 3;
+                const float* n = sIn + 12 + kc * 3;
                 v = n[0] * p.viewmatrix[0 * 4 + ch] + n[1] * p.viewmatrix[1 * 4 + ch] + n[2] * p.viewmatrix[2 * 4 + ch];
-            } else if (lane < 40) v = p.roughness[g * 4 + (lane - 36)];
+            } else if (lane < 40) v = sIn[24 + (lane - 36)];
             else if (lane < 52) v = p.training ? sOut[12 + (lane - 40)] : sOut[36 + (lane - 40)];
             else v = sOut[48 + (lane - 52)];
             a.vfeatures[g * VS + lane] = v;
         }
     }
+    DEV_TRACE_MARK(3);
+    DEV_TRACE_END(1, 1u, (unsigned)Ns, 0u);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -398,37 +421,11 @@ constexpr int BREC = 23;
 #ifndef SHADE_BWPE
 #define SHADE_BWPE 3
 #endif
-#ifndef SHADE_PF
-#define SHADE_PF 0   // per-Gaussian inputs read straight from global memory (0) or through an LDS-DMA row fetched a Gaussian ahead (1):
-                      // measured 524 vs 556 us at P = 200k, Ns = 64 -- the top of a Gaussian is bound by instruction issue, not by latency
-#endif
 #ifndef SHADE_ABL
 #define SHADE_ABL 0   // (ablation experiments only, scripts/build_variant.sh: 1-4 switch parts of the kernel off -- wrong results)
 #endif
 constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
-// Per-Gaussian inputs of the backward, one LDS row per wave, fetched a whole Gaussian ahead by LDS-DMA (no registers, no
-// exposed latency at the top of a Gaussian): V[3] | normals[12] | roughness[4] | base_color[12] | (pad) | dL_dreduced[70]
-// | (pad) | dL_dvfeatures[<= 64] | dL_dfeatures[<= 7] | (pad)
-constexpr int GIN = 192, GIN_N = 3, GIN_R = 15, GIN_B = 19, GIN_RED = 32, GIN_VF = 104, GIN_F = 168;
-
-struct RawSample { float d[3], rad[3], vis, area; };
-
-__device__ __forceinline__ RawSample load_raw(const svgir_shade_params& p, size_t g, int s, int lane, int cnt) {
-    const int si = s + (lane < cnt ? lane : 0);
-    const size_t o = g * (size_t)p.Ns + (size_t)si;
-    RawSample r;
-    if (p.incident_dirs) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) r.d[j] = p.incident_dirs[o * 3 + j];
-    } else {   // directions from the lattice (3 (+1) floats per surfel instead of 12 bytes per sample)
-        const LatticeFrame lf = lattice_frame(p.lattice_normals, p.lattice_offsets, g);
-        lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[si], si, p.lattice_offsets != nullptr, r.d);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; j++) r.rad[j] = p.radiance[o * 3 + j];
-    r.vis = p.visibility[o]; r.area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
-    return r;
-}
+constexpr int KB_G = 4, KREC = 52;   // Gaussians prepared per batch; floats per (Gaussian, corner) record (13 float4)
 
 __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const RawSample& x, int lane, const float* V,
                                               float* __restrict__ sS) {
@@ -521,8 +518,8 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     const int Ns = p.Ns, We = p.env_w, He = p.env_h;
     const int ntex = He * We * 3;
     float* sS = smem + (size_t)wave * (64 * BREC);
-    float* sG = smem + (size_t)BWAVES * (64 * BREC) + (size_t)wave * GIN;   // this wave's per-Gaussian inputs (prefetched)
-    double* sEnv = reinterpret_cast<double*>(smem + (size_t)BWAVES * (64 * BREC + GIN));   // [ntex] (only when env_in_lds)
+    float* sK = smem + (size_t)BWAVES * (64 * BREC) + (size_t)wave * (4 * KB_G * KREC);   // this wave's batch of per-(Gaussian, corner) records
+    double* sEnv = reinterpret_cast<double*>(smem + (size_t)BWAVES * (64 * BREC + 4 * KB_G * KREC));   // [ntex] (only when env_in_lds)
     if (env_in_lds) {
         for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) sEnv[i] = 0.0;
     }
@@ -533,51 +530,36 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     const int gstep = (int)gridDim.x * BWAVES;
     int g = (int)blockIdx.x * BWAVES + wave;   // wave-uniform
 
-    // slot j of the row <- which tensor, which element (computed per Gaussian: ~10 instructions per 64 slots)
     const bool tr = p.training != 0;
     const int nvf = tr ? 52 : 64, nf = tr ? 4 : 7;
-    auto prefetch_inputs = [&](int gi) {
-        if (!SHADE_PF) return;
-#pragma unroll
-        for (int j0 = 0; j0 < GIN; j0 += 64) {
-            const int j = j0 + lane;
-            const float* src = nullptr;
-            if (j < GIN_N) src = p.viewdirs + (size_t)gi * 3 + j;
-            else if (j < GIN_R) src = p.normals + (size_t)gi * 12 + (j - GIN_N);
-            else if (j < GIN_B) src = p.roughness + (size_t)gi * 4 + (j - GIN_R);
-            else if (j < GIN_B + 12) src = p.base_color + (size_t)gi * 12 + (j - GIN_B);
-            else if (j >= GIN_RED && j < GIN_RED + NRED) src = a.g_red ? a.g_red + (size_t)gi * NRED + (j - GIN_RED) : nullptr;
-            else if (j >= GIN_VF && j < GIN_VF + nvf) src = a.g_vfeat ? a.g_vfeat + (size_t)gi * nvf + (j - GIN_VF) : nullptr;
-            else if (j >= GIN_F && j < GIN_F + nf) src = a.g_feat ? a.g_feat + (size_t)gi * nf + (j - GIN_F) : nullptr;
-            if (src) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(sG + j0), 4, 0, 0);
-        }
-    };
     DEV_TRACE_DECL();
     [[maybe_unused]] unsigned dev_n = 0;
     RawSample raw;
-    if (g < P) { raw = load_raw(p, (size_t)g, 0, lane, min(64, Ns)); prefetch_inputs(g); }
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-    for (; g < P; g += gstep) {
-        const size_t gg = (size_t)g;
-        // (this Gaussian's inputs have landed in LDS: issued a whole Gaussian ago and waited for before the row stores below,
-        // so that nothing here waits for those stores)
-        wave_lds_sync();
-        const float* in_v = SHADE_PF ? sG : p.viewdirs + gg * 3;
-        float V[3] = {in_v[0], in_v[1], in_v[2]};
+    if (g < P) raw = load_raw(p, (size_t)g, 0, lane, min(64, Ns));
+    // The per-(Gaussian, corner) constants -- unit view vector, corner frame, and the upstream gradients folded into the
+    // coefficients of the four light sums -- are ~130 scattered loads and ~400 instructions per corner.  With lane = (sample
+    // group, corner) all 64 lanes would repeat them for ONE Gaussian; instead the wave prepares its next KB_G Gaussians at once,
+    // lane = (Gaussian of the batch, corner), parks the KREC-float records in LDS and picks them up Gaussian by Gaussian.
+    for (int gb = g; gb < P; gb += KB_G * gstep) {
+    wave_lds_sync();   // the previous batch's records have been read
+    if (lane < 4 * KB_G) {
+        const int gj = gb + (lane >> 2) * gstep;
+        if (gj < P) {
+        const size_t gg = (size_t)gj;
+        float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
         {
             const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
             V[0] *= iv; V[1] *= iv; V[2] *= iv;
         }
         GaussConst c;
-        if (SHADE_PF) load_corner_from(sG + GIN_N, sG + GIN_R, sG + GIN_B, k, V, c);
-        else load_corner_from(p.normals + gg * 12, p.roughness + gg * 4, p.base_color + gg * 12, k, V, c);
+        load_corner(p, gg, k, V, c);
         // Upstream gradients of this (Gaussian, corner): dL_dreduced plus the rows of the packed features / vfeatures
         // that alias it (see upstream()).
         float gp[3] = {0, 0, 0}, gd[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gdi[3] = {0, 0, 0}, gin[3] = {0, 0, 0};
         float gmi[3] = {0, 0, 0}, gml[3] = {0, 0, 0}, gmg[3] = {0, 0, 0};
         float dir_b[3] = {0, 0, 0}, dir_n[3] = {0, 0, 0}, dir_r = 0.f;   // direct terms of the packing
         if (a.g_red) {
-            const float* gr = SHADE_PF ? sG + GIN_RED : a.g_red + gg * NRED;
+            const float* gr = a.g_red + gg * NRED;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 gp[ch] = gr[ch * 4 + k]; gd[ch] = gr[12 + ch * 4 + k]; gs[ch] = gr[24 + ch * 4 + k];
@@ -586,7 +568,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             }
         }
         if (a.g_vfeat) {
-            const float* vf = SHADE_PF ? sG + GIN_VF : a.g_vfeat + gg * nvf;
+            const float* vf = a.g_vfeat + gg * nvf;
             float t0[3], t1[3], t2[3], nv[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
@@ -605,7 +587,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 dir_n[j] = nv[0] * p.viewmatrix[j * 4 + 0] + nv[1] * p.viewmatrix[j * 4 + 1] + nv[2] * p.viewmatrix[j * 4 + 2];
         }
         if (a.g_feat) {
-            const float* f = SHADE_PF ? sG + GIN_F : a.g_feat + gg * nf;
+            const float* f = a.g_feat + gg * nf;
             if (tr) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) gml[ch] += f[1 + ch];
@@ -614,23 +596,47 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 for (int ch = 0; ch < 3; ch++) { gmi[ch] += f[ch]; gml[ch] += f[3 + ch]; }
             }
         }
-        wave_lds_sync();   // the row has been read: the next Gaussian's inputs may land in it
-        if (g + gstep < P) prefetch_inputs(g + gstep);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             gp[ch] *= inv_ns; gd[ch] *= inv_ns; gs[ch] *= inv_ns; gdi[ch] *= inv_ns; gin[ch] *= inv_ns;
             gmi[ch] *= inv_ns; gml[ch] *= inv_ns; gmg[ch] *= inv_ns;
         }
-        float kAd[3], kAl[3], kBd[3], kBl[3], qd[3], ql[3];
+        float* o = sK + lane * KREC;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            qd[ch] = gdi[ch] + gp[ch]; ql[ch] = gin[ch] + gp[ch];            // d/df_d = qd * A_d + ql * A_l
-            kAd[ch] = gd[ch] + c.fd[ch] * qd[ch]; kAl[ch] = gd[ch] + c.fd[ch] * ql[ch];
-            kBd[ch] = gs[ch] + qd[ch]; kBl[ch] = gs[ch] + ql[ch];
+            const float qd = gdi[ch] + gp[ch], ql = gin[ch] + gp[ch];            // d/df_d = qd * A_d + ql * A_l
+            o[ch] = V[ch]; o[3 + ch] = c.nraw[ch]; o[6 + ch] = c.Nh[ch]; o[12 + ch] = c.fd[ch];
+            o[20 + ch] = gd[ch] + c.fd[ch] * qd; o[23 + ch] = gd[ch] + c.fd[ch] * ql;   // kAd, kAl
+            o[26 + ch] = gs[ch] + qd; o[29 + ch] = gs[ch] + ql;                           // kBd, kBl
+            o[32 + ch] = qd; o[35 + ch] = ql;
+            o[38 + ch] = gmi[ch] + gmg[ch];   // constant part of the env gradient
+            o[41 + ch] = gmi[ch] + gml[ch];   // constant part of dL/dradiance
+            o[44 + ch] = dir_b[ch]; o[47 + ch] = dir_n[ch];
         }
-        const float gmig[3] = {gmi[0] + gmg[0], gmi[1] + gmg[1], gmi[2] + gmg[2]};   // constant part of the env gradient
-        // lane k owns channel k (< 3) of dL/dradiance: constant part
-        const float grad_const = k == 0 ? gmi[0] + gml[0] : (k == 1 ? gmi[1] + gml[1] : gmi[2] + gml[2]);
+        o[9] = c.a2; o[10] = c.kk; o[11] = c.nom1; o[15] = c.r; o[16] = c.sgn; o[17] = c.inv_len; o[18] = c.NoV_raw; o[19] = dir_r;
+        }
+    }
+    wave_lds_sync();
+    for (int jb = 0; jb < KB_G; jb++) {
+        g = gb + jb * gstep;
+        if (g >= P) break;
+        const size_t gg = (size_t)g;
+        float V[3], kAd[3], kAl[3], kBd[3], kBl[3], qd[3], ql[3], gmig[3], dir_b[3], dir_n[3], dir_r, grad_const;
+        GaussConst c;
+        {
+            const float4* q = reinterpret_cast<const float4*>(sK + (jb * 4 + k) * KREC);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8], q9 = q[9], q10 = q[10],
+                         q11 = q[11], q12 = q[12];
+            V[0] = q0.x; V[1] = q0.y; V[2] = q0.z; c.nraw[0] = q0.w; c.nraw[1] = q1.x; c.nraw[2] = q1.y;
+            c.Nh[0] = q1.z; c.Nh[1] = q1.w; c.Nh[2] = q2.x; c.a2 = q2.y; c.kk = q2.z; c.nom1 = q2.w;
+            c.fd[0] = q3.x; c.fd[1] = q3.y; c.fd[2] = q3.z; c.r = q3.w; c.sgn = q4.x; c.inv_len = q4.y; c.NoV_raw = q4.z; dir_r = q4.w;
+            kAd[0] = q5.x; kAd[1] = q5.y; kAd[2] = q5.z; kAl[0] = q5.w; kAl[1] = q6.x; kAl[2] = q6.y;
+            kBd[0] = q6.z; kBd[1] = q6.w; kBd[2] = q7.x; kBl[0] = q7.y; kBl[1] = q7.z; kBl[2] = q7.w;
+            qd[0] = q8.x; qd[1] = q8.y; qd[2] = q8.z; ql[0] = q8.w; ql[1] = q9.x; ql[2] = q9.y;
+            gmig[0] = q9.z; gmig[1] = q9.w; gmig[2] = q10.x;
+            grad_const = k == 0 ? q10.y : (k == 1 ? q10.z : q10.w);   // lane k owns channel k (< 3) of dL/dradiance
+            dir_b[0] = q11.x; dir_b[1] = q11.y; dir_b[2] = q11.z; dir_n[0] = q11.w; dir_n[1] = q12.x; dir_n[2] = q12.y;
+        }
         DEV_TRACE_MARK(0);   // inputs -> per-(Gaussian, corner) constants
         dev_n++;
         float d_fd[3] = {0, 0, 0}, d_n[3] = {0, 0, 0}, d_Nh[3] = {0, 0, 0};
@@ -769,6 +775,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         }
         DEV_TRACE_MARK(3);   // row stores + per-Gaussian chain rule and stores
     }
+    }
     DEV_TRACE_END(0, dev_n, (unsigned)Ns, 0u);
     __syncthreads();
     if (env_in_lds) {
@@ -795,12 +802,13 @@ __global__ void __launch_bounds__(BLOCK) env_grad_kernel(const float* __restrict
 using namespace svgir;
 
 #ifdef SVGIR_DEV
-extern "C" int svgir_dev_trace_read_shade(unsigned long long* out, int cap_records) {
+extern "C" int svgir_dev_trace_read_shade(unsigned long long* out, int cap_records, int slot) {   // slot 0: backward, 1: forward
     unsigned int n[2] = {0, 0};
     if (hipMemcpyFromSymbol(n, HIP_SYMBOL(svgir::g_dev_trace_n), sizeof(n)) != hipSuccess) return -1;
-    const int cnt = (int)std::min<unsigned>(n[0], (unsigned)std::min(cap_records, svgir::DEV_TRACE_CAP));
-    if (cnt > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(svgir::g_dev_trace), (size_t)cnt * svgir::DEV_TRACE_WORDS * 8, 0) != hipSuccess) return -1;
-    n[0] = n[1] = 0;
+    const int cnt = (int)std::min<unsigned>(n[slot & 1], (unsigned)std::min(cap_records, svgir::DEV_TRACE_CAP));
+    if (cnt > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(svgir::g_dev_trace), (size_t)cnt * svgir::DEV_TRACE_WORDS * 8,
+                                       (size_t)(slot & 1) * svgir::DEV_TRACE_CAP * svgir::DEV_TRACE_WORDS * 8) != hipSuccess) return -1;
+    n[slot & 1] = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_dev_trace_n), n, sizeof(n));
     return cnt;
 }
@@ -825,7 +833,7 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     stage_mark(tm, "shade_env_table");
     ShadeArgs a;
     a.p = *p; a.reduced = reduced; a.features = features; a.vfeatures = vfeatures;
-    const size_t lds = (size_t)4 * (64 * SREC + 80) * 4;
+    const size_t lds = (size_t)4 * (64 * SREC + 80 + 32) * 4;
     hipLaunchKernelGGL(shade_fwd_kernel, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
     stage_mark(tm, "shade_fwd");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
@@ -852,12 +860,12 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
-    const size_t per_wave = (size_t)(64 * BREC + GIN) * 4;
+    const size_t per_wave = (size_t)(64 * BREC + 4 * KB_G * KREC) * 4;
     size_t lds = BWAVES * per_wave;
     int env_in_lds = 0;
     if (p->env_w > 65000 || p->env_h > 65000) return SVGIR_ERR_INVALID;
-    static_assert((BWAVES * (64 * BREC + GIN)) % 2 == 0, "the fp64 image behind the sample records is 8-byte aligned");
-    if (lds + (size_t)ntex * 8 <= 150 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 8; }   // one workgroup per CU
+    static_assert((BWAVES * (64 * BREC + 4 * KB_G * KREC)) % 2 == 0, "the fp64 image behind the sample records is 8-byte aligned");
+    if (lds + (size_t)ntex * 8 <= 160 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 8; }   // one workgroup per CU
     {
         static bool attr_set[64] = {};   // per device (> 64 KB of dynamic LDS needs the opt-in; idempotent, so races are harmless)
         int dev = 0;
