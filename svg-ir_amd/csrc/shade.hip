@@ -414,7 +414,7 @@ struct ShadeBwdArgs {
 
 // ---- backward sample record (BREC floats): the forward's 17 + dmul(3) = d(global light)/d(env lookup) incl. the
 // clamp and visibility, + the bilinear footprint {x0 | y0 << 16, fx, fy} so the adjoint never re-evaluates acos/atan2.
-constexpr int BREC = 23;
+constexpr int BREC = 24;   // (23 used; 24 = six float4: the records are written and read with 128-bit LDS instructions)
 #ifndef SHADE_BWAVES
 #define SHADE_BWAVES 12   // one workgroup per CU: 12 x 5.9 KB of sample records + the fp64 env-gradient image (49 KB at 32x64)
 #endif
@@ -472,7 +472,7 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
             for (int ch = 0; ch < 3; ch++) E[ch] += tw[j] * tex[j][ch];
         }
     }
-    float* r = sS + lane * BREC;
+    float r[BREC];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         const float Es = E[ch] * p.env_scale;
@@ -484,7 +484,10 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     // footprint origin, biased by +1 (x0, y0 >= -1 by construction), 16 bits each
     const int xb = min(max(x0 + 1, 0), 65535), yb = min(max(y0 + 1, 0), 65535);
     r[20] = __builtin_bit_cast(float, (uint32_t)xb | ((uint32_t)yb << 16));
-    r[21] = fx; r[22] = fy;
+    r[21] = fx; r[22] = fy; r[23] = 0.f;
+    float4* o = reinterpret_cast<float4*>(sS + lane * BREC);
+#pragma unroll
+    for (int i = 0; i < BREC / 4; i++) o[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
 }
 
 __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of a quad, result in all 4
@@ -660,7 +663,12 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 const int s = sg + 16 * it;
                 if (16 * it >= cnt) break;   // wave-uniform
                 const bool act = s < cnt;
-                const float* r = sS + (act ? s : 0) * BREC;
+                float r[BREC];
+                {
+                    const float4* rq = reinterpret_cast<const float4*>(sS + (act ? s : 0) * BREC);
+#pragma unroll
+                    for (int i = 0; i < BREC / 4; i++) { const float4 q = rq[i]; r[4 * i] = q.x; r[4 * i + 1] = q.y; r[4 * i + 2] = q.z; r[4 * i + 3] = q.w; }
+                }
                 const float ndr = c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2];
                 const float ndi = fmaxf(ndr, 0.f);
                 const float NoLr = c.Nh[0] * r[3] + c.Nh[1] * r[4] + c.Nh[2] * r[5];
