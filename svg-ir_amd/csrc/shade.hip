@@ -696,9 +696,10 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                     d_fs += kBd[ch] * td + kBl[ch] * tl;
                     d_ndi += (cg * Lg + cl * Ll) * area;
                 }
-                if (ndr > 0.f) {
+                {
+                    const float dm = ndr > 0.f ? d_ndi : 0.f;
 #pragma unroll
-                    for (int j = 0; j < 3; j++) d_n[j] += d_ndi * r[j];
+                    for (int j = 0; j < 3; j++) d_n[j] += dm * r[j];
                 }
                 // fs = frac0 * a2 / nom
                 const float d_nom = (nomr >= 1e-6f && nomr <= 4.f * kPi) ? -d_fs * fs * inv_nom : 0.f;
@@ -718,25 +719,27 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 // ---- adjoint of the sample: sum the four corners (one quad), then lane k takes channel / tap k ----
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) { xg[ch] = quad_sum(xg[ch]); xl[ch] = quad_sum(xl[ch]); }
-                if (act) {
-                    const size_t o = gg * Ns + s0 + s;
-                    if (k < 3 && SHADE_ABL != 2) {   // parked in the sample's (consumed) local-light slot, written out below
+                {
+                    if (SHADE_ABL != 2) {   // parked in the sample's (consumed) local-light slots, written out below (lane k = 3: the pad
+                        // slot; lanes beyond the chunk: records nobody reads)
                         const float v = k == 0 ? xl[0] : (k == 1 ? xl[1] : xl[2]);
-                        sS[s * BREC + 13 + k] = v + grad_const;
+                        sS[s * BREC + (k < 3 ? 13 + k : BREC - 1)] = v + grad_const;
                     }
                     const uint32_t xy = __builtin_bit_cast(uint32_t, r[20]);
                     const int tx = (int)(xy & 0xffffu) - 1 + (k & 1), ty = (int)(xy >> 16) - 1 + (k >> 1);
-                    if (tx >= 0 && tx < We && ty >= 0 && ty < He) {
-                        const float fx = r[21], fy = r[22];
-                        const float w = ((k & 1) ? fx : 1.f - fx) * ((k >> 1) ? fy : 1.f - fy);
-                        const int idx = (ty * We + tx) * 3;
+                    const float fx = r[21], fy = r[22];
+                    const float w = ((k & 1) ? fx : 1.f - fx) * ((k >> 1) ? fy : 1.f - fy);
+                    const int idx = (ty * We + tx) * 3;
+                    float dt[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) dt[ch] = (xg[ch] + gmig[ch]) * r[17 + ch] * w;
+                    // ONE test per tap: inside the chunk and the image, and not all three channels zero (they vanish together:
+                    // zero weight or an occluded / clamped sample)
+                    if (act && tx >= 0 && tx < We && ty >= 0 && ty < He && (dt[0] != 0.f || dt[1] != 0.f || dt[2] != 0.f) && SHADE_ABL != 1) {
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
-                            const float dt = (xg[ch] + gmig[ch]) * r[17 + ch] * w;
-                            if (dt != 0.f && SHADE_ABL != 1) {
-                                if (env_in_lds) atomicAdd(&sEnv[idx + ch], (double)dt);   // ds_add_f64
-                                else atomic_add_f32(&a.d_envtab[idx + ch], dt);
-                            }
+                            if (env_in_lds) atomicAdd(&sEnv[idx + ch], (double)dt[ch]);   // ds_add_f64
+                            else atomic_add_f32(&a.d_envtab[idx + ch], dt[ch]);
                         }
                     }
                 }
