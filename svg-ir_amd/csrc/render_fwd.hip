@@ -84,14 +84,20 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
     uint2* __restrict__ out = a.sub_list + (size_t)4 * r0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t run[4] = {0u, 0u, 0u, 0u};   // survivors so far per sub-tile (uniform)
+    // software pipeline over the rounds: ids two rounds ahead, record headers one round ahead (a round was three dependent
+    // memory round trips; the longest lists set the kernel's duration)
+    uint32_t gid_n = t < len ? a.point_list[r0 + t] : 0u;           // round 0
+    uint32_t gid_nn = CT + t < len ? a.point_list[r0 + CT + t] : 0u;   // round 1
+    float4 A_n = rec4[(size_t)gid_n * 6], B_n = rec4[(size_t)gid_n * 6 + 1];
     for (int base = 0; base < len; base += CT) {
         const int i = base + t;
         bool m[4] = {false, false, false, false};
-        uint32_t gid = 0;
+        const uint32_t gid = gid_n;
+        const float4 A = A_n, B = B_n;
+        gid_n = gid_nn;
+        if (base + CT < len) { A_n = rec4[(size_t)gid_n * 6]; B_n = rec4[(size_t)gid_n * 6 + 1]; }
+        gid_nn = base + 2 * CT + t < len ? a.point_list[r0 + base + 2 * CT + t] : 0u;
         if (i < len) {
-            gid = a.point_list[r0 + i];
-            const float4 A = rec4[(size_t)gid * 6];
-            const float4 B = rec4[(size_t)gid * 6 + 1];
             const SplatCull sc = cull_prepare(A.x, A.y, A.z, A.w, B.x, B.y);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
