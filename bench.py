@@ -94,6 +94,7 @@ def parse():
     ap.add_argument("--workload", default=None, help="default: cfg2 (N = 1), cfg4 (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shaded", action="store_true", help="skip the extra cfg3_train (shaded + blended) record")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the supplementary two-views-on-two-streams record")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-oracle steps (0 = as many as fit ~12 s)")
     ap.add_argument("--no-shade", action="store_true", help="svgss workloads: skip the SV-BRDF shading stage")
     ap.add_argument("--streamed-dirs", action="store_true", help="shading reads [P,Ns,3] incident directions from HBM "
@@ -381,6 +382,41 @@ def shading_record(wl, stage):
     return rec
 
 
+def two_streams(wl, name, dev, args):
+    """Supplementary record (never the headline `value`): TWO views of the workload in flight on one GPU, one HIP stream and one
+    host thread each.  One view leaves the SIMDs under-occupied (cfg2: 2 930 forward waves for 1 024 SIMDs); a
+    per-GPU driver that keeps two views in flight fills those issue slots."""
+    import threading
+    import time
+    import torch
+    w2 = Workload(name, dev, 1, 2, args)   # the same replicated scene seen from a second camera
+    wls, streams = [wl, w2], [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    rounds = max(10, args.steps)
+
+    def work(w, s, k):
+        with torch.cuda.stream(s):
+            for _ in range(k):
+                w.step()
+
+    for w, s in zip(wls, streams):
+        work(w, s, 3)
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(5):
+        th = [threading.Thread(target=work, args=(w, s, rounds)) for w, s in zip(wls, streams)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    ms_view = best / rounds / 2 * 1e3
+    return {"views_in_flight": 2, "ms_per_view": ms_view, "value": wl.P / (ms_view * 1e-3), "unit": "surfels/s",
+            "note": "two views of the same workload on two HIP streams (two host threads), wall clock over %d rounds, best of 5; "
+                    "supplementary, the headline value is one view per step" % rounds}
+
+
 def cpu_baseline(wl, args):
     """The CPU oracle on the host cores: `-O3 -march=native` build (compiled here, on the machine that
     runs it) when the compiler is available, else the parity build."""
@@ -487,6 +523,8 @@ def main():
         if wl.shade:
             res["config"]["shading"] = shading_record(wl, stage)["config"]
             res["shading"] = {k: v for k, v in shading_record(wl, stage).items() if k != "config"}
+    if rank == 0 and world == 1 and not args.no_concurrent:
+        res["two_streams"] = two_streams(wl, name, dev, args)
     # the "shaded + blended" number of north_star: cfg3_train with the shading stage, same measurement, extra keys
     if world == 1 and args.workload is None and not args.no_shaded:
         wl.sct = wl.gt = None

@@ -19,7 +19,7 @@ for W in cfg3_train cfg3_eval cfg4 cfg5; do
   tail -c 3000 gpurun_out/${TAG}_bench_$W.json; tail -3 gpurun_out/${TAG}_bench_$W.err
 done
 for W in cfg2 cfg3_train cfg5; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$W -o p -- python3 $R/bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --workload $W > $R/gpurun_out/${TAG}_prof_$W.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$W -o p -- python3 $R/bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --no-concurrent --workload $W > $R/gpurun_out/${TAG}_prof_$W.log 2>&1)
   DB=$(find gpurun_out/${TAG}_prof_$W -name "*.db" | head -1)
-  python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_${W}_kernel_stats.txt "python3 bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --workload $W" | head -30
+  python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_${W}_kernel_stats.txt "python3 bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --no-concurrent --workload $W" | head -30
 done

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 W=${W:-cfg2}
 for V in product "$@"; do
   if [ "$V" = product ]; then unset SVGIR_RASTER_LIB; else export SVGIR_RASTER_LIB=$PWD/build/variants/$V/libsvgir_raster.so; fi
-  timeout 300 python bench.py --workload $W --steps 30 --warmup 5 --repeats ${REPEATS:-7} --no-cpu-baseline --no-shaded ${BENCH_FLAGS:---no-shade} \
+  timeout 300 python bench.py --workload $W --steps 30 --warmup 5 --repeats ${REPEATS:-7} --no-cpu-baseline --no-shaded --no-concurrent ${BENCH_FLAGS:---no-shade} \
       > gpurun_out/var_${V}_$W.json 2> gpurun_out/var_${V}_$W.err
   python - <<PY
 import json

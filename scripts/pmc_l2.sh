@@ -7,7 +7,7 @@ R=$PWD
 W=${1:-cfg2}
 TAG=${2:-l2}
 cd /tmp
-timeout 240 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${TAG}_l2 -o p -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-shaded --workload $W > $R/gpurun_out/${TAG}_l2.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${TAG}_l2 -o p -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-shaded --no-concurrent --workload $W > $R/gpurun_out/${TAG}_l2.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob
