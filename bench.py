@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shaded", action="store_true", help="skip the extra cfg3_train (shaded + blended) record")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the supplementary two-views-on-two-streams record")
+    ap.add_argument("--no-overlap", action="store_true", help="svgss workloads: run the shading forward on the rasterizer's stream "
+                    "instead of a side stream that overlaps the binning (svgir_forward_wait_features)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-oracle steps (0 = as many as fit ~12 s)")
     ap.add_argument("--no-shade", action="store_true", help="svgss workloads: skip the SV-BRDF shading stage")
     ap.add_argument("--streamed-dirs", action="store_true", help="shading reads [P,Ns,3] incident directions from HBM "
@@ -209,6 +211,10 @@ class Workload:
                 self.dirs, self.areas = shading.FibonacciLattice(torch.nn.functional.normalize(geo_n, dim=-1), self.Ns, offs), None
             self.leaves = {k: sd[k].clone().requires_grad_(self.training) for k in ("base_color", "roughness", "normals", "radiance", "env")}
             self.light = shade_inputs.Light(self.leaves["env"])
+            # the shading forward does not depend on the binning of the view (and vice versa): it runs on a side stream and only
+            # the composite kernel waits for it (include/svgir_raster.h: svgir_forward_wait_features)
+            self.side = None if getattr(args, "no_overlap", False) else torch.cuda.Stream(dev)
+            self.feat_ev = torch.cuda.Event() if self.side is not None else None
 
     def step(self):
         """One forward (+ backward) through the binding layer; returns (R, colour image, a gradient tensor)."""
@@ -220,15 +226,22 @@ class Workload:
                 for v in self.leaves.values():
                     v.grad = None
                 lv, sd = self.leaves, self.sd
-                with torch.set_grad_enabled(self.training):
+                main = torch.cuda.current_stream(self.dev)
+                if self.side is not None:
+                    self.side.wait_stream(main)
+                with torch.cuda.stream(self.side if self.side is not None else main), torch.set_grad_enabled(self.training):
                     feats_in, vfeats_in, _ = self.shading.shade_and_pack(
                         lv["base_color"], lv["roughness"], lv["normals"], sd["viewdirs"], lv["radiance"], self.light,
                         sd["visibility"], self.dirs, self.areas, st.viewmatrix, self.training)
+                if self.side is not None:
+                    self.feat_ev.record(self.side)
+                    feats_in.record_stream(main); vfeats_in.record_stream(main)
+            ready = self.feat_ev if (self.shade and self.side is not None) else None
             out = _C.rasterize_gaussians(st.bg, sct["means3D"], feats_in.detach(), vfeats_in.detach(), empty,
                                          sct["opacities"], sct["scales"], sct["rotations"], st.scale_modifier, empty,
                                          st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
                                          st.tanfovy, st.image_height, st.image_width, sct["shs"], st.sh_degree,
-                                         st.campos, False, False, st.config)
+                                         st.campos, False, False, st.config, features_ready=ready)
             (R, color, normal, depth, opac, feat, vfeat, weights, radii, gb, bb, ib) = out
             if not self.train:
                 return R, color, weights

@@ -12,6 +12,8 @@ The compute runs in libsvgir_raster.so (hand-written HIP for gfx950) through the
 """
 from typing import NamedTuple
 
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -29,7 +31,11 @@ class _CBinding:
     @staticmethod
     def rasterize_gaussians(background, means3D, features, vfeatures, colors, opacity, scales, rotations,
                             scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx,
-                            tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, config):
+                            tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, config, *,
+                            features_ready=None):
+        """`features_ready` (extension, keyword only): a torch.cuda.Event recorded on the stream that is still producing
+        `features` / `vfeatures` (the shading kernels on a side stream); only the composite kernel waits for it, so the
+        shading of a view overlaps its binning.  The caller keeps the tensors alive across streams (`record_stream`)."""
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:65-67
         dev = means3D.device
@@ -77,6 +83,8 @@ class _CBinding:
                                                                      out_depth.data_ptr(), out_opac.data_ptr())
             o.out_feature, o.out_vfeature = N.ptr(out_feature), N.ptr(out_vfeature)
             o.out_weights, o.radii = out_weights.data_ptr(), radii.data_ptr()
+            if features_ready is not None:
+                N.lib.svgir_forward_wait_features(C.c_void_p(features_ready.cuda_event))
             rendered = N.guarded(dev, "forward", N.lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
                                                    blobs.fn("image"), None, N.stream_ptr(dev))
         # note: C++ order is (..., depth, opac, ...) -- the Python wrapper re-orders (svgss_rasterization.py:175,183)

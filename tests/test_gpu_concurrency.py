@@ -79,3 +79,46 @@ def test_render_in_flight_helper(built):
     assert len(par) == 5 and all(np.array_equal(x, y) for x, y in zip(par, seq))
     with pytest.raises(ZeroDivisionError):
         vp.render_in_flight(lambda sc: 1 // 0, scs, dev)
+
+
+def test_shading_on_a_side_stream_overlapping_the_binning(built):
+    """svgir_forward_wait_features: the features / vfeatures of a view are produced by the shading kernels on a side stream
+    while the rasterizer's preprocess / sorts / cull of the same view run; only the composite kernel waits.  Same results as
+    the sequential order, bit for bit."""
+    from gaussian_renderer import shading
+    from gaussian_renderer.svgss_rasterization import _C
+    from svgir_harness import shade_inputs
+    dev = torch.device(DEV)
+    sc = scenes.surface_scene(P=6000, W=176, H=144, seed=41, sh_degree=2, variant="svgss", S=4, VS=52, scale_lo=0.01, scale_hi=0.06)
+    sct = runner.to_torch(sc, dev)
+    st = runner.settings(sct, "svgss")
+    d = shade_inputs.make(6000, 64, seed=3, device=dev)
+    light = shade_inputs.Light(d["env"])
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+
+    def shade():
+        f, vf, _ = shading.shade_and_pack(d["base_color"], d["roughness"], d["normals"], d["viewdirs"], d["radiance"], light,
+                                          d["visibility"], d["dirs"], d["areas"], st.viewmatrix, True)
+        return f, vf
+
+    def raster(f, vf, ready=None):
+        out = _C.rasterize_gaussians(st.bg, sct["means3D"], f, vf, empty, sct["opacities"], sct["scales"], sct["rotations"],
+                                     st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
+                                     st.tanfovy, st.image_height, st.image_width, sct["shs"], st.sh_degree, st.campos, False, False,
+                                     st.config, features_ready=ready)
+        return [o.clone() for o in out[1:7]], out[7].clone()   # images; out_weights (float atomics: order-dependent bits)
+
+    f, vf = shade()
+    ref, ref_w = raster(f, vf)
+    torch.cuda.synchronize()
+    main, side, ev = torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Event()
+    for _ in range(5):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            f2, vf2 = shade()
+        ev.record(side)
+        f2.record_stream(main); vf2.record_stream(main)
+        got, got_w = raster(f2, vf2, ready=ev)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+        assert torch.allclose(got_w, ref_w, rtol=1e-5, atol=1e-6)
