@@ -320,10 +320,17 @@ def timed(wl, args, world, dev, dry=None):
     # produce `value` run without them; this region is not part of `value`).
     stage = {}
     if not dry:
+        # (the stage marks sit on ONE stream: the shading goes back to the rasterizer's stream for this region, otherwise the
+        # composite's mark would include its wait for the side stream)
+        side = getattr(wl, "side", None)
+        if side is not None:
+            wl.side = None
         _native.set_profiling(True)
         region()
         stage = {n: (ms, cnt) for n, ms, cnt in _native.last_timings(with_counts=True)}
         _native.set_profiling(False)
+        if side is not None:
+            wl.side = side
     el = torch.tensor(regions, dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -395,15 +402,16 @@ def shading_record(wl, stage):
     return rec
 
 
-def two_streams(wl, name, dev, args):
+def two_streams(name, dev, args):
     """Supplementary record (never the headline `value`): TWO views of the workload in flight on one GPU, one HIP stream and one
     host thread each.  One view leaves the SIMDs under-occupied (cfg2: 2 930 forward waves for 1 024 SIMDs); a
     per-GPU driver that keeps two views in flight fills those issue slots."""
     import threading
     import time
     import torch
-    w2 = Workload(name, dev, 1, 2, args)   # the same replicated scene seen from a second camera
-    wls, streams = [wl, w2], [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    wls = [Workload(name, dev, 0, 1, args), Workload(name, dev, 1, 2, args)]   # the same replicated scene from two cameras
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    wl = wls[0]
     rounds = max(10, args.steps)
 
     def work(w, s, k):
@@ -536,8 +544,6 @@ def main():
         if wl.shade:
             res["config"]["shading"] = shading_record(wl, stage)["config"]
             res["shading"] = {k: v for k, v in shading_record(wl, stage).items() if k != "config"}
-    if rank == 0 and world == 1 and not args.no_concurrent:
-        res["two_streams"] = two_streams(wl, name, dev, args)
     # the "shaded + blended" number of north_star: cfg3_train with the shading stage, same measurement, extra keys
     if world == 1 and args.workload is None and not args.no_shaded:
         wl.sct = wl.gt = None
@@ -555,6 +561,9 @@ def main():
         del w3
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(wl, args)
+    if rank == 0 and world == 1 and not args.no_concurrent:   # (last: it creates streams of its own)
+        torch.cuda.empty_cache()
+        res["two_streams"] = two_streams(name, dev, args)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
