@@ -96,7 +96,7 @@ def parse():
     ap.add_argument("--no-shaded", action="store_true", help="skip the extra cfg3_train (shaded + blended) record")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the supplementary two-views-on-two-streams record")
     ap.add_argument("--no-overlap", action="store_true", help="svgss workloads: run the shading forward on the rasterizer's stream "
-                    "instead of a side stream that overlaps the binning (svgir_forward_wait_features)")
+                    "instead of a side stream that overlaps the binning (svgir_params.features_ready)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-oracle steps (0 = as many as fit ~12 s)")
     ap.add_argument("--no-shade", action="store_true", help="svgss workloads: skip the SV-BRDF shading stage")
     ap.add_argument("--streamed-dirs", action="store_true", help="shading reads [P,Ns,3] incident directions from HBM "
@@ -212,7 +212,7 @@ class Workload:
             self.leaves = {k: sd[k].clone().requires_grad_(self.training) for k in ("base_color", "roughness", "normals", "radiance", "env")}
             self.light = shade_inputs.Light(self.leaves["env"])
             # the shading forward does not depend on the binning of the view (and vice versa): it runs on a side stream and only
-            # the composite kernel waits for it (include/svgir_raster.h: svgir_forward_wait_features)
+            # the composite kernel waits for it (include/svgir_raster.h: svgir_params.features_ready)
             self.side = None if getattr(args, "no_overlap", False) else torch.cuda.Stream(dev)
             self.feat_ev = torch.cuda.Event() if self.side is not None else None
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 8
+#define SVGIR_ABI_VERSION 9
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -76,6 +76,14 @@ typedef struct svgir_params {
     int32_t computer_pseudo_normal; /* rgss */
     int32_t backward_geometry;      /* rgss */
     int32_t debug;                  /* synchronise + check after every kernel (reference CHECK_CUDA) */
+    void* features_ready;           /* optional (NULL: `features` / `vfeatures` are complete on `stream` at call time): a HIP
+                                       event (hipEvent_t) recorded on ANOTHER stream that is still producing them.  Only the
+                                       composite kernel of svgir_forward waits for it -- everything in front of the composite
+                                       (preprocess, sorts, emit, ranges, cull) neither reads the features nor waits -- which
+                                       is how the per-splat shading (svgir_shade_forward on a side stream) overlaps the
+                                       binning of the same view.  Must stay alive until svgir_forward returns; ignored by
+                                       svgir_backward.  (ABI 9: replaces the thread-local svgir_forward_wait_features of
+                                       ABI 8 -- no state survives between calls.) */
 } svgir_params;
 
 /* Outputs of forward.  Every buffer is written completely: the caller need not clear any of them (the reference's glue
@@ -147,12 +155,6 @@ size_t svgir_image_ncontrib_offset(int32_t W, int32_t H);
  * guess was too small, binning() is called again and those stages are re-run (only the LAST pointer it returned is
  * used).
  * Returns num_rendered (R >= 0) or a negative svgir_status. */
-/* Optional, per calling thread: the NEXT svgir_forward of this thread makes its composite kernel wait for `event` (a HIP
- * event recorded on another stream) before it reads `features` / `vfeatures` -- everything in front of the composite
- * (preprocess, sorts, emit, ranges, cull) neither reads them nor waits.  This is how the per-splat shading that produces
- * them (svgir_shade_forward on a side stream) overlaps the binning of the same view.  Pass NULL / do not call for the
- * ordinary behaviour (inputs complete on `stream` at call time).  The event must stay alive until svgir_forward returns. */
-int svgir_forward_wait_features(void* event);
 int svgir_forward(const svgir_params* p, const svgir_outputs* o,
                   svgir_alloc_fn geom, void* geom_ctx,
                   svgir_alloc_fn binning, void* binning_ctx,

@@ -77,7 +77,7 @@ void trace(int P, const float* boxes, long long num_rays, const float* rays_o, c
             const F t2 = c[0] * d[0] * d[0] + c[1] * d[0] * d[1] + c[2] * d[0] * d[2] + c[1] * d[1] * d[0] + c[3] * d[1] * d[1] +
                          c[4] * d[1] * d[2] + c[2] * d[2] * d[0] + c[4] * d[2] * d[1] + c[5] * d[2] * d[2];
             const F t = t1 / t2;
-            if (t < (F)0.01) continue;                                                           // :227 (0.01 is a double literal)
+            if ((double)t < 0.01) continue;                                                      // :227 (0.01 is a double literal: the float is promoted)
             const F pos[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
             const F dx = m[0] - pos[0], dy = m[1] - pos[1], dz = m[2] - pos[2];
             // utility.cuh:113-120: -0.5 (double) * float sum, returned as float
@@ -87,7 +87,7 @@ void trace(int P, const float* boxes, long long num_rays, const float* rays_o, c
             count += 1;
             const F alpha = (F)opacity[g] * (sizeof(F) == 4 ? (F)expf((float)power) : (F)exp((double)power));
             ray_opacity *= 1 - alpha;
-            if (ray_opacity < (F)0.9) blocked = true;                                             // :240-243 (0.9: double literal)
+            if ((double)ray_opacity < 0.9) blocked = true;                                        // :240-243 (0.9: double literal)
         }
         contribute[r] = blocked ? 0 : count;          // the early return leaves the zero-initialised count (bvh.cu:97)
         visibility[r] = blocked ? 0.0f : (float)ray_opacity;

@@ -29,7 +29,14 @@ ATTR = {"xyz": "_xyz", "normal": "_normal", "rotation": "_rotation", "scaling": 
         "incidents_rest": "_incidents_rest", "visibility_dc": "_visibility_dc", "visibility_rest": "_visibility_rest"}
 
 
-def main():
+POISON_ROWS = {5: (float("nan"),) * 3, 6: (float("nan"), None, None), 7: (100.0,) * 3, 8: (None, 100.0, None),
+               9: (float("nan"), float("nan"), None), 10: (None, None, float("nan"))}   # row -> per-axis override of the log-scale
+
+
+def main(fname="densify.npz", poison=False):
+    """`poison`: a second fixture (densify_nan.npz) whose `_scaling` has NaN / overflowing rows -- the case the reference's
+    get_scaling = nan_to_num(exp(.), nan=1e-6) exists for (scene/gaussian_model.py:270-272) -- all of them selected for
+    densification."""
     mgv.setup_reference()
     import torch.utils.cpp_extension as cpp
     cpp.load = lambda *a, **k: mg._Stub("_C")
@@ -47,6 +54,13 @@ def main():
             t = torch.randn((P,) + shp, generator=g)
             if name == "scaling":   # log-scales around the clone / split limit percent_dense * extent = 0.05
                 t = torch.log(torch.exp(torch.empty(P, 3).uniform_(np.log(0.01), np.log(0.2), generator=g)))
+            if name == "scaling" and poison:
+                for r, ov in POISON_ROWS.items():
+                    for ax, v in enumerate(ov):
+                        if v is not None:
+                            t[r, ax] = v
+            if name == "opacity" and poison:
+                t[sorted(POISON_ROWS)] = 2.0
             if name == "xyz":
                 t = t * 0.8
             init[name] = t.clone()
@@ -78,6 +92,12 @@ def main():
         gm.normal_gradient_accum = torch.rand(P, 1, generator=g) * 2e-4
         gm.denom = torch.randint(0, 3, (P, 1), generator=g).float()     # zeros -> NaN / inf grads
         gm.max_radii2D = torch.rand(P, generator=g) * 30
+        if poison:   # the poisoned rows pass the gradient test and survive the weight / screen-size pruning (their opacity: set at init)
+            rows = sorted(POISON_ROWS)
+            gm.xyz_gradient_accum[rows] = 1e-3
+            gm.denom[rows] = 1.0
+            gm.weights_accum[rows] = 2e-5
+            gm.max_radii2D[rows] = 1.0
         for k in ("weights_accum", "xyz_gradient_accum", "normal_gradient_accum", "denom", "max_radii2D"):
             out["stat_" + k] = getattr(gm, k).numpy().copy()
         Z = []
@@ -103,9 +123,11 @@ def main():
             out["dens_v_" + name] = st["exp_avg_sq"].numpy().copy()
         for k in ("weights_accum", "xyz_gradient_accum", "normal_gradient_accum", "denom", "max_radii2D"):
             out["dens_" + k] = getattr(gm, k).numpy().copy()
-    np.savez_compressed(os.path.join(OUT, "densify.npz"), **out)
-    print("wrote densify.npz: P", P, "->", out["dens_xyz"].shape[0], "split draws", out["split_z"].shape)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print("wrote", fname, ": P", P, "->", out["dens_xyz"].shape[0], "split draws", out["split_z"].shape,
+          "NaN scaling entries after densify:", int(np.isnan(out["dens_scaling"]).sum()))
 
 
 if __name__ == "__main__":
     main()
+    main("densify_nan.npz", poison=True)

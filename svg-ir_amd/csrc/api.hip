@@ -22,7 +22,6 @@ using namespace svgir;
 namespace {
 
 thread_local std::string g_err;
-thread_local hipEvent_t g_features_ready = nullptr;   // set by svgir_forward_wait_features, consumed by the next svgir_forward of the thread
 // Profiling state is process-wide (the autograd engine runs backward on its own thread).  Stage boundaries are
 // HIP events recorded on the launch stream; they are resolved lazily (svgir_last_timings), so enabling profiling
 // adds no synchronisation to forward/backward.
@@ -273,18 +272,12 @@ int svgir_last_timings(const char** names, float* avg_ms, int* counts, int cap) 
     return n;
 }
 
-int svgir_forward_wait_features(void* event) {
-    g_features_ready = (hipEvent_t)event;
-    return 0;
-}
-
 int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
                   svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream) {
+    if (int rc = validate(p, true)) return rc;
     // features / vfeatures may still be in production on another stream (the shading kernels do not depend on the binning and
     // the binning does not read them): only the composite kernel waits for the caller's event
-    const hipEvent_t features_ready = g_features_ready;
-    g_features_ready = nullptr;
-    if (int rc = validate(p, true)) return rc;
+    const hipEvent_t features_ready = (hipEvent_t)p->features_ready;
     if (!o || !geom || !binning || !image) return fail(SVGIR_ERR_INVALID, "outputs / allocators must be provided");
     hipStream_t s = (hipStream_t)stream;
     const int P = p->P, W = p->W, H = p->H;

@@ -213,17 +213,17 @@ __global__ void __launch_bounds__(BLOCK) bvh_leaf_rec_kernel(int P, const uint32
 }
 
 // ---- visibility tracing (trace.cu:186-262) -------------------------------------------------------------------------------
-// slab test of utility.cuh:35-90 with the reference's comparisons (NaNs from 0 * inf behave as in its 0 / 0): returns tmax, or
-// -1 for a miss -- the traversal only looks at tmax
-__device__ __forceinline__ float slab_tmax(const float lo[3], const float hi[3], const float o[3], const float inv[3]) {
-    float tmin = (lo[0] - o[0]) * inv[0], tmax = (hi[0] - o[0]) * inv[0];
+// slab test of utility.cuh:35-90 with the reference's operations (true divisions by the ray direction, its comparisons; NaNs
+// from 0 / 0 behave as there): returns tmax, or -1 for a miss -- the traversal only looks at tmax
+__device__ __forceinline__ float slab_tmax(const float lo[3], const float hi[3], const float o[3], const float d[3]) {
+    float tmin = (lo[0] - o[0]) / d[0], tmax = (hi[0] - o[0]) / d[0];
     if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
-    float tymin = (lo[1] - o[1]) * inv[1], tymax = (hi[1] - o[1]) * inv[1];
+    float tymin = (lo[1] - o[1]) / d[1], tymax = (hi[1] - o[1]) / d[1];
     if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
     if (tmin > tymax || tymin > tmax) return -1.f;
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmax) tmax = tymax;
-    float tzmin = (lo[2] - o[2]) * inv[2], tzmax = (hi[2] - o[2]) * inv[2];
+    float tzmin = (lo[2] - o[2]) / d[2], tzmax = (hi[2] - o[2]) / d[2];
     if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
     if (tmin > tzmax || tzmin > tmax) return -1.f;
     if (tzmax < tmax) tmax = tzmax;
@@ -243,14 +243,13 @@ __global__ void __launch_bounds__(BLOCK) bvh_trace_kernel(int P, long long num_r
                                                           int32_t* __restrict__ contribute, float* __restrict__ visibility) {
     const long long r = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= num_rays) return;
-    float o[3], d[3], inv[3];
+    float o[3], d[3];
     {
 #pragma clang fp contract(off)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             d[c] = rays_d[3 * r + c];
             o[c] = rays_o[3 * r + c] + d[c] * t_offset;   // RayTracer.trace_visibility: rays_o + rays_d * 0.05
-            inv[c] = 1.0f / d[c];
         }
     }
     uint32_t stack[BVH_STACK];
@@ -275,20 +274,20 @@ __global__ void __launch_bounds__(BLOCK) bvh_trace_kernel(int P, long long num_r
             const float t2 = c0 * d[0] * d[0] + c1 * d[0] * d[1] + c2 * d[0] * d[2] + c1 * d[1] * d[0] + c3 * d[1] * d[1] +
                              c4 * d[1] * d[2] + c2 * d[2] * d[0] + c4 * d[2] * d[1] + c5 * d[2] * d[2];
             const float t = t1 / t2;
-            if (t < 0.01f) continue;
+            if (t <= 0.01f) continue;   // trace.cu:227 compares with the DOUBLE literal: (double)t < 0.01  <=>  t <= 0.01f (0.01f < 0.01 < its successor)
             const float dx = A.x - (o[0] + t * d[0]), dy = A.y - (o[1] + t * d[1]), dz = A.z - (o[2] + t * d[2]);
             const float power = -0.5f * (dx * dx * c0 + dy * dy * c3 + dz * dz * c5 + 2 * dx * dy * c1 + 2 * dx * dz * c2 + 2 * dy * dz * c4);
             if (power > 0) continue;   // (a NaN power -- degenerate direction or covariance -- goes on and poisons the ray, as in the reference)
             count += 1;
             const float alpha = A.w * __expf(power);
             ray_opacity *= 1 - alpha;
-            if (ray_opacity < 0.9f) blocked = true;
+            if (ray_opacity <= 0.9f) blocked = true;   // trace.cu:240 (double)ray_opacity < 0.9  <=>  <= 0.9f (0.9f < 0.9 < its successor)
         } else {
             // ---- internal node: both child boxes come with it; the child with the larger exit distance is pushed first ----
             const float4* q = nodes + 4 * (size_t)nid;
             const float4 a = q[0], b = q[1], c = q[2], w = q[3];
             const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y}, lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
-            const float tl = slab_tmax(lo0, hi0, o, inv), tr = slab_tmax(lo1, hi1, o, inv);
+            const float tl = slab_tmax(lo0, hi0, o, d), tr = slab_tmax(lo1, hi1, o, d);
             const uint32_t lid = __builtin_bit_cast(uint32_t, w.x), rid = __builtin_bit_cast(uint32_t, w.y);
             if (tl > tr) {
                 if (tl > 0 && sp < BVH_STACK) stack[sp++] = lid;

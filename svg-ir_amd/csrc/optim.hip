@@ -153,6 +153,11 @@ __global__ void __launch_bounds__(BLOCK) gather_rows_kernel(const GatherTable t,
 }
 
 // ---- densification: selection masks, fused append, split transform (scene/gaussian_model.py:1136-1248) ---------------------
+// get_scaling = nan_to_num(exp(_scaling), nan = 1e-6) (scene/gaussian_model.py:270-272): NaN -> 1e-6, +inf -> FLT_MAX
+__device__ __forceinline__ float scaling_act(float raw) {
+    const float e = expf(raw);
+    return e != e ? 1e-6f : fminf(e, 3.402823466e+38f);
+}
 __global__ void __launch_bounds__(BLOCK) densify_masks_kernel(int P, const float* __restrict__ grad_accum, const float* __restrict__ normal_accum,
                                                               const float* __restrict__ denom, const float* __restrict__ scaling_raw,
                                                               float grad_threshold, float normal_threshold, float size_limit,
@@ -165,8 +170,8 @@ __global__ void __launch_bounds__(BLOCK) densify_masks_kernel(int P, const float
     g = g != g ? 0.f : fabsf(g);
     gn = gn != gn ? 0.f : fabsf(gn);
     const bool sel = g >= grad_threshold || gn >= normal_threshold;
-    // get_scaling = exp(_scaling); max over the three axes
-    const float s = fmaxf(fmaxf(expf(scaling_raw[3 * i]), expf(scaling_raw[3 * i + 1])), expf(scaling_raw[3 * i + 2]));
+    // max of get_scaling over the three axes (NaN axes count as 1e-6, like the reference's nan_to_num)
+    const float s = fmaxf(fmaxf(scaling_act(scaling_raw[3 * i]), scaling_act(scaling_raw[3 * i + 1])), scaling_act(scaling_raw[3 * i + 2]));
     clone_mask[i] = sel && s <= size_limit;
     split_mask[i] = sel && s > size_limit;
 }
@@ -204,7 +209,7 @@ __global__ void __launch_bounds__(BLOCK) split_transform_kernel(long long n_new,
 #pragma clang fp contract(off)
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_new) return;
-    const float s0 = expf(scaling[3 * i]), s1 = expf(scaling[3 * i + 1]), s2 = expf(scaling[3 * i + 2]);
+    const float s0 = scaling_act(scaling[3 * i]), s1 = scaling_act(scaling[3 * i + 1]), s2 = scaling_act(scaling[3 * i + 2]);   // get_scaling
     const float v[3] = {z[3 * i] * s0, z[3 * i + 1] * s1, z[3 * i + 2] * s2};
     float q0 = rotation[4 * i], q1 = rotation[4 * i + 1], q2 = rotation[4 * i + 2], q3 = rotation[4 * i + 3];
     const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);   // build_rotation (utils/general_utils.py:82-103)

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
 
 RGSS, SVGSS = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("cx", C.c_float),
         ("cy", C.c_float),
         ("prefiltered", C.c_int32), ("computer_pseudo_normal", C.c_int32), ("backward_geometry", C.c_int32),
-        ("debug", C.c_int32),
+        ("debug", C.c_int32), ("features_ready", C.c_void_p),
     ]
 
 
@@ -98,7 +98,7 @@ EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_
            "svgir_mask_scan_work_words", "svgir_mask_scan", "svgir_gather_rows", "svgir_densify_masks", "svgir_append_rows",
            "svgir_split_transform", "svgir_bvh_bytes", "svgir_bvh_build",
            "svgir_bvh_trace_visibility", "svgir_pbgi_bvh_bytes", "svgir_pbgi_bvh_build", "svgir_pbgi_bvh_export",
-           "svgir_pbgi_trace_radiance", "svgir_forward_wait_features")
+           "svgir_pbgi_trace_radiance")
 
 
 def last_error():

@@ -83,8 +83,8 @@ class _CBinding:
                                                                      out_depth.data_ptr(), out_opac.data_ptr())
             o.out_feature, o.out_vfeature = N.ptr(out_feature), N.ptr(out_vfeature)
             o.out_weights, o.radii = out_weights.data_ptr(), radii.data_ptr()
-            if features_ready is not None:
-                N.lib.svgir_forward_wait_features(C.c_void_p(features_ready.cuda_event))
+            if features_ready is not None:   # (a struct field of this call: nothing survives if anything below raises)
+                p.features_ready = features_ready.cuda_event
             rendered = N.guarded(dev, "forward", N.lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
                                                    blobs.fn("image"), None, N.stream_ptr(dev))
         # note: C++ order is (..., depth, opac, ...) -- the Python wrapper re-orders (svgss_rasterization.py:175,183)

@@ -66,8 +66,11 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, nan_values=None, zero_grad=False):
         """`nan_values`: {group name: replacement} -- NaN gradient entries of those groups are replaced (in the gradient
-        tensor too) before the update; `zero_grad`: the gradients are left zero-filled.  Both ride on the Adam kernel's one
-        pass over the gradients (GaussianModel.step = replace_nangrad_to_zero + optimizer.step + optimizer.zero_grad)."""
+        tensor too) before the update; `zero_grad`: the reference's `optimizer.zero_grad()` behind the step -- on torch >= 2 that is
+        `set_to_none=True`, so `p.grad` is None afterwards (a parameter that receives no gradient in a later iteration is then
+        SKIPPED by the next step, exactly as with torch.optim.Adam, instead of being stepped with g = 0).  The kernel still
+        scrubs NaNs in its one pass over the gradients (GaussianModel.step = replace_nangrad_to_zero + optimizer.step +
+        optimizer.zero_grad); `zero_grad="fill"` keeps the round-3 behaviour (gradient tensors kept and zero-filled by the kernel)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -89,7 +92,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if not p.grad.is_contiguous():
                     p.grad = p.grad.contiguous()
                 g = p.grad
-                flags = ADAM_ZERO_GRAD if zero_grad else 0
+                flags = ADAM_ZERO_GRAD if zero_grad == "fill" else 0
                 nanv = 0.0
                 if nan_values is not None and group.get("name") in nan_values:
                     flags |= ADAM_SCRUB_NAN
@@ -105,6 +108,10 @@ class FusedAdam(torch.optim.Optimizer):
                     a.n, a.lr, a.step, a.flags, a.nan_value = p.numel(), lr, step, flags, nanv
                 with torch.cuda.device(dev):
                     N.check(N.lib.svgir_adam_step(arr, len(chunk), b1, b2, eps, N.stream_ptr(dev)), "adam_step")
+        if zero_grad and zero_grad != "fill":   # (stream-ordered allocator: the gradient storage outlives the launch that reads it)
+            for ents in batches.values():
+                for ent in ents:
+                    ent[0].grad = None
         return loss
 
 
@@ -334,7 +341,7 @@ class DensifyState:
         prune_mask = torch.logical_or(self.weights_accum[:, 0] < weights_threshold, prune_mask)
         if max_screen_size:
             big_points_vs = self.max_radii2D > max_screen_size
-            big_points_ws = torch.exp(self.params["scaling"].detach()).max(dim=1).values > 0.1 * extent
+            big_points_ws = torch.nan_to_num(torch.exp(self.params["scaling"].detach()), nan=1e-6).max(dim=1).values > 0.1 * extent   # get_scaling
             prune_mask = torch.logical_or(torch.logical_or(prune_mask, big_points_vs), big_points_ws)
         return prune_mask
 

@@ -141,15 +141,22 @@ def render_in_flight(render_view, views, device, in_flight=2):
     (capacity cache, side stream, allocator callbacks) is thread-safe: tests/test_gpu_concurrency.py.
 
     render_view(v) runs inside `torch.cuda.stream(...)` of its worker and returns anything; results come back as a list in
-    the order of `views`.  Exceptions of a worker are re-raised here."""
+    the order of `views`.  Exceptions of a worker are re-raised here.  Every worker stream first waits for the caller's
+    current stream (parameters just written by the optimizer launch, densify appends, uploaded cameras are complete before a
+    view reads them), and the caller's stream waits for the workers at the end."""
     import threading
     views = list(views)
     out, err = [None] * len(views), []
     nxt = iter(range(len(views)))
     lock = threading.Lock()
+    cur = torch.cuda.current_stream(device)   # (captured here: the workers' "current stream" is their own)
+    streams = []
 
     def worker():
         s = torch.cuda.Stream(device)
+        s.wait_stream(cur)
+        with lock:
+            streams.append(s)
         with torch.cuda.stream(s):
             while True:
                 with lock:
@@ -168,6 +175,8 @@ def render_in_flight(render_view, views, device, in_flight=2):
         t.start()
     for t in th:
         t.join()
+    for s in streams:
+        cur.wait_stream(s)
     if err:
         raise err[0]
     return out

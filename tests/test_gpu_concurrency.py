@@ -82,7 +82,7 @@ def test_render_in_flight_helper(built):
 
 
 def test_shading_on_a_side_stream_overlapping_the_binning(built):
-    """svgir_forward_wait_features: the features / vfeatures of a view are produced by the shading kernels on a side stream
+    """svgir_params.features_ready: the features / vfeatures of a view are produced by the shading kernels on a side stream
     while the rasterizer's preprocess / sorts / cull of the same view run; only the composite kernel waits.  Same results as
     the sequential order, bit for bit."""
     from gaussian_renderer import shading

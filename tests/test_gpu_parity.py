@@ -18,13 +18,13 @@ from svgir_harness import runner, scenes
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4          # normalised tolerance (north_star)
-# Budgets ~10x what profiles/parity_r03.json measures on cfg1-cfg5 (0 threshold flips anywhere, worst normalised error 5.2e-5,
+# Budgets 2-10x what profiles/parity_r03.json measures (REL_TOL / REL_FRAC: 2x its p99.99 = 1.1e-3 and share 1.6e-4) on cfg1-cfg5 (0 threshold flips anywhere, worst normalised error 5.2e-5,
 # worst share beyond REL_TOL 1.6e-4): a regression that introduces real flips fails.
 FLIP_FRAC = 5e-6    # share of forward entries that may exceed TOL (threshold flips), each bounded by FLIP_BOUND * max|ref|
 GRAD_FLIP_FRAC = 2e-5
 FLIP_BOUND = 0.05
-REL_TOL = 5e-3      # element-wise relative tolerance on entries > 1e-3 max|ref| ...
-REL_FRAC = 1e-3     # ... for all but this share (differences of nearly cancelling sums)
+REL_TOL = 2e-3      # element-wise relative tolerance on entries > 1e-3 max|ref| ...
+REL_FRAC = 3e-4     # ... for all but this share (differences of nearly cancelling sums)
 
 
 def _dev():
