@@ -231,18 +231,23 @@ __device__ __forceinline__ float slab_tmax(const float lo[3], const float hi[3],
 }
 
 constexpr int BVH_STACK = 64;
+constexpr int BVH_LDS_DEPTH = 32;   // stack levels kept in LDS, [level][lane] (lanes at different depths never share a bank; a private array
+                                    // indexed by a lane-varying depth makes every push / pop 64 separate cache lines); deeper levels in scratch
+constexpr int BVH_WAVE = 64;        // one wave per workgroup
 
 __global__ void __launch_bounds__(BLOCK) bvh_fill_kernel(long long n, float v, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) out[i] = v;
 }
 
-__global__ void __launch_bounds__(BLOCK) bvh_trace_kernel(int P, long long num_rays, const float4* __restrict__ nodes,
+__global__ void __launch_bounds__(BVH_WAVE) bvh_trace_kernel(int P, long long num_rays, const float4* __restrict__ nodes,
                                                           const float4* __restrict__ rec, const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d, float t_offset,
                                                           int32_t* __restrict__ contribute, float* __restrict__ visibility) {
-    const long long r = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ uint32_t s_stack[BVH_LDS_DEPTH * BVH_WAVE];
+    const long long r = (long long)blockIdx.x * BVH_WAVE + threadIdx.x;
     if (r >= num_rays) return;
+    uint32_t* st = s_stack + threadIdx.x;
     float o[3], d[3];
     {
 #pragma clang fp contract(off)
@@ -252,14 +257,19 @@ __global__ void __launch_bounds__(BLOCK) bvh_trace_kernel(int P, long long num_r
             o[c] = rays_o[3 * r + c] + d[c] * t_offset;   // RayTracer.trace_visibility: rays_o + rays_d * 0.05
         }
     }
-    uint32_t stack[BVH_STACK];
+    uint32_t deep[BVH_STACK - BVH_LDS_DEPTH];
     int sp = 0;
-    stack[sp++] = P > 1 ? 0u : ~0u;   // (a single surfel: the root is its leaf, entered unconditionally like the reference's)
+    auto push = [&](uint32_t id) {
+        if (sp < BVH_LDS_DEPTH) st[sp * BVH_WAVE] = id; else deep[sp - BVH_LDS_DEPTH] = id;
+        sp++;
+    };
+    push(P > 1 ? 0u : ~0u);   // (a single surfel: the root is its leaf, entered unconditionally like the reference's)
     int count = 0;
     float ray_opacity = 1.0f;
     bool blocked = false;
     while (sp > 0 && !blocked) {
-        const uint32_t nid = stack[--sp];
+        --sp;
+        const uint32_t nid = sp < BVH_LDS_DEPTH ? st[sp * BVH_WAVE] : deep[sp - BVH_LDS_DEPTH];
         if (nid & 0x80000000u) {
             // ---- leaf: one surfel (trace.cu:218-247) ----
             const float4* q = rec + 4 * (size_t)(~nid);
@@ -290,11 +300,11 @@ __global__ void __launch_bounds__(BLOCK) bvh_trace_kernel(int P, long long num_r
             const float tl = slab_tmax(lo0, hi0, o, d), tr = slab_tmax(lo1, hi1, o, d);
             const uint32_t lid = __builtin_bit_cast(uint32_t, w.x), rid = __builtin_bit_cast(uint32_t, w.y);
             if (tl > tr) {
-                if (tl > 0 && sp < BVH_STACK) stack[sp++] = lid;
-                if (tr > 0 && sp < BVH_STACK) stack[sp++] = rid;
+                if (tl > 0 && sp < BVH_STACK) push(lid);
+                if (tr > 0 && sp < BVH_STACK) push(rid);
             } else {
-                if (tr > 0 && sp < BVH_STACK) stack[sp++] = rid;
-                if (tl > 0 && sp < BVH_STACK) stack[sp++] = lid;
+                if (tr > 0 && sp < BVH_STACK) push(rid);
+                if (tl > 0 && sp < BVH_STACK) push(lid);
             }
         }
     }
@@ -351,7 +361,7 @@ int svgir_bvh_trace_visibility(int32_t P, char* bvh, int64_t num_rays, const flo
     const int fin = BVH_SORT_PASSES & 1;
     hipLaunchKernelGGL(bvh_leaf_rec_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, B.val[fin], means3D, cov_inv, opacity,
                        normals, B.leaf_rec);
-    hipLaunchKernelGGL(bvh_trace_kernel, dim3((unsigned)((num_rays + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, P, (long long)num_rays,
+    hipLaunchKernelGGL(bvh_trace_kernel, dim3((unsigned)((num_rays + BVH_WAVE - 1) / BVH_WAVE)), dim3(BVH_WAVE), 0, s, P, (long long)num_rays,
                        B.nodes, B.leaf_rec, rays_o, rays_d, t_offset, contribute, visibility);
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }

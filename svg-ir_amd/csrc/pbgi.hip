@@ -39,6 +39,7 @@ struct PbgiLayout {
     uint32_t* val[2];       // [P] primitive ids ping/pong
     uint32_t* radix_tbl;
     PbgiNode* node;         // [2P-1]
+    float4* pair;           // [P-1][4] traversal records of the internal nodes: the boxes of BOTH children + their ids (64 bytes)
     uint32_t* parent;       // [2P-1]
     uint32_t* arrive;       // [P-1]
     float4* rec;            // [P][6] leaf records (sorted order), filled per trace call
@@ -55,6 +56,7 @@ PbgiLayout pbgi_layout(char* base, int P) {
     b.val[0] = (uint32_t*)take(p * 4); b.val[1] = (uint32_t*)take(p * 4);
     b.radix_tbl = (uint32_t*)take(radix_table_words(P) * 4);
     b.node = (PbgiNode*)take(2 * p * 32);
+    b.pair = (float4*)take(p * 64);
     b.parent = (uint32_t*)take(2 * p * 4);
     b.arrive = (uint32_t*)take(p * 4);
     b.rec = (float4*)take(p * 96);
@@ -177,6 +179,19 @@ __global__ void __launch_bounds__(BLOCK) pbgi_refit_kernel(int P, PbgiNode* node
     }
 }
 
+// ---- traversal records: {box of the left child, box of the right child, left, right} per internal node ------------------------
+__global__ void __launch_bounds__(BLOCK) pbgi_pair_kernel(int P, const PbgiNode* __restrict__ node, float4* __restrict__ pair) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P - 1) return;
+    const int l = node[i].left, r = node[i].right;
+    const PbgiNode a = node[l], b = node[r];
+    float4* o = pair + 4 * (size_t)i;
+    o[0] = make_float4(a.lo[0], a.lo[1], a.lo[2], a.hi[0]);
+    o[1] = make_float4(a.hi[1], a.hi[2], b.lo[0], b.lo[1]);
+    o[2] = make_float4(b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
+    o[3] = make_float4(__builtin_bit_cast(float, l), __builtin_bit_cast(float, r), 0.f, 0.f);
+}
+
 // ---- the tree in the reference's tensors: LBVHNode_info [2P-1][3] = {left, right, primitive}, LBVHNode_aabb [2P-1][6] ------
 __global__ void __launch_bounds__(BLOCK) pbgi_export_kernel(int P, const PbgiNode* __restrict__ node, const uint32_t* __restrict__ code,
                                                             const uint32_t* __restrict__ prim, int32_t* __restrict__ info,
@@ -259,85 +274,42 @@ __device__ __forceinline__ bool box_hit(const float4 q0, const float4 q1, F3 o, 
     return true;
 }
 
-constexpr int PBGI_STACK = 64;        // the reference's MAX_STACK_SIZE (a push beyond it is dropped here; undefined there)
+constexpr int PBGI_STACK = 64;        // the reference's MAX_STACK_SIZE; the tree is at most 30 + 32 - clz(P) + 1 < 63 levels deep (30-bit
+                                      // codes, equal codes split by position), and the stack holds at most one pending sibling per level
+constexpr int PBGI_LDS_DEPTH = 32;    // stack levels kept in LDS ([level][lane]: conflict-free whatever the lanes' depths); deeper ones in scratch
+constexpr int PBGI_WAVE = 64;         // one wave per workgroup
 constexpr int PBGI_MAX_HITS = 4096;   // guard of the ray loop (every accepted hit removes >= 1/255 of the transmittance: < 1800 hits)
 
-struct PbgiHit { bool any; float t, keep, u, v; int index; };
 
-// gs_bvh_hit, intersect_test.slang:251-437
-__device__ __forceinline__ void closest_hit(const PbgiNode* __restrict__ node, const float4* __restrict__ rec, const uint32_t* __restrict__ prim,
-                                            int P, F3 o, F3 d, float t_min, float t_max, PbgiHit& h) {
+#if defined(SVGIR_DEV)
+// development builds: traversal statistics of the last trace (queries, tested boxes, boxes passed, leaves visited, leaves accepted, rays)
+__device__ unsigned long long g_pbgi_stats[8];
+__device__ unsigned long long g_pbgi_qhist[16];   // rays by floor(log2(queries)); [12..15]: box tests spent by rays with >= 1, 16, 128, 1024 queries
+#define PBGI_STAT(i) st_[i]++
+#else
+#define PBGI_STAT(i)
+#endif
+
+// The per-axis part of aabb_hit (intersect_test.slang:21-42) split from its interval: aabb_hit narrows [t_min, t_max] axis by
+// axis and fails as soon as it is empty; because the lower end only grows and the upper end only shrinks this is exactly
+//     min(t_max, exit) > max(t_min, entry)   with   entry = max_i t0_i,  exit = min_i t1_i   (NaNs skipped by the same selects),
+// i.e.  exit > entry'  and  t_max > entry'  with entry' = max(t_min, entry).  entry' and exit do not depend on t_max (the closest hit so
+// far): a box tested when it is PUSHED keeps its entry', and the test the reference makes when it POPS the node -- against the
+// closest hit found meanwhile -- is the single comparison closest > entry'.
+__device__ __forceinline__ bool box_entry(const float lo[3], const float hi[3], F3 o, const SlabDir& sd, float t_min, float& entry) {
 #pragma clang fp contract(off)
-    int stack[PBGI_STACK];
-    int count = 0;
-    stack[count++] = 0;
-    float closest = t_max, cu = 0.f, cv = 0.f, hit_t = 0.f, keep_l = 0.f, hu = 0.f, hv = 0.f;
-    uint32_t closest_index = 0;
-    bool any_hit = false;
-    SlabDir sd = slab_dir(d);
-    const int L = P - 1;
-    while (count > 0) {
-        const int n = stack[--count];
-        const float4* q = reinterpret_cast<const float4*>(node + n);
-        const float4 q0 = q[0], q1 = q[1];
-        if (!box_hit(q0, q1, o, sd, t_min, closest)) continue;
-        const int left = __builtin_bit_cast(int, q1.z), right = __builtin_bit_cast(int, q1.w);
-        if (left != 0 && right != 0) {
-            if (count < PBGI_STACK - 1) { stack[count++] = left; stack[count++] = right; }
-        } else if (left == 0 && right == 0) {
-            const int j = n - L;
-            const float4* lr = rec + 6 * (size_t)j;
-            const float4 A = lr[0], B = lr[1], C = lr[2], D = lr[3], E = lr[4], G = lr[5];
-            {   // :342 -- the re-normalised direction also serves the box tests that follow (Q-c).  A direction whose length
-                // already rounds to 1 is left bit-identical by the division: skip it and the three reciprocals then
-                const float l = sqrtf(dot3(d, d));
-                if (l != 1.0f) { d = {d.x / l, d.y / l, d.z / l}; sd = slab_dir(d); }
-            }
-            const F3 c = {A.x, A.y, A.z};
-            const float sx = A.w, sy = B.x;
-            // ---- ellipse_hit, :94-148 ----
-            bool hit = false;
-            float t_now = 0.f, uh = 0.5f, vh = 0.5f;
-            F3 pos = {0.f, 0.f, 0.f};
-            {
-                const F3 nw = {B.z, B.w, C.x};
-                const float denom = dot3(nw, d);
-                if (!(fabsf(denom) < 1e-6f)) {
-                    const F3 co = {c.x - o.x, c.y - o.y, c.z - o.z};
-                    t_now = dot3(co, nw) / denom;
-                    if (!(t_now < t_min)) {
-                        pos = {o.x + d.x * t_now, o.y + d.y * t_now, o.z + d.z * t_now};
-                        const F3 w = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
-                        const float px = C.y * w.x + C.z * w.y + C.w * w.z, py = D.x * w.x + D.y * w.y + D.z * w.z;
-                        float a = px / sx, b = py / sy;
-                        if (a < b) { const float t = a; a = b; b = t; }
-                        a = a * 0.5f + 0.5f; b = b * 0.5f + 0.5f;
-                        uh = fminf(fmaxf(a, 0.001f), 0.999f);
-                        vh = fminf(fmaxf(b, 0.001f), 0.999f);
-                        const float dis = (px * px) / (sx * sx) + (py * py) / (sy * sy);
-                        hit = dis <= 9.0f;
-                    }
-                }
-            }
-            if (t_now < t_min) continue;   // :367-371
-            const F3 dd = {c.x - pos.x, c.y - pos.y, c.z - pos.z};
-            const float power = -0.5f * (dd.x * dd.x * E.z + dd.y * dd.y * G.y + dd.z * dd.z * G.w + 2 * dd.x * dd.y * E.w + 2 * dd.x * dd.z * G.x +
-                                         2 * dd.y * dd.z * G.z);
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, B.y * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const F3 nrm = {D.w, E.x, E.y};
-            if (!(dot3(d, nrm) < -0.0f)) hit = false;   // :399-404
-            const bool update = hit && t_now < closest;
-            closest = hit ? fminf(t_now, closest) : closest;
-            closest_index = update ? prim[j] : closest_index;
-            cu = update ? uh : cu; cv = update ? vh : cv;
-            if (hit) { any_hit = true; hit_t = closest; keep_l = 1 - alpha; hu = cu; hv = cv; }   // (Q-a, Q-b)
-        }
+    const float oo[3] = {o.x, o.y, o.z};
+    float ex = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float inv = sd.inv[i];
+        float t0 = (lo[i] - oo[i]) * inv, t1 = (hi[i] - oo[i]) * inv;
+        if (inv < 0.0f) { const float t = t1; t1 = t0; t0 = t; }
+        t_min = t0 > t_min ? t0 : t_min;
+        ex = t1 < ex ? t1 : ex;
     }
-    h.any = any_hit;
-    if (any_hit) { h.t = hit_t; h.keep = keep_l; h.index = (int)closest_index; h.u = hu; h.v = hv; }
-    else h.index = -1;
+    entry = t_min;
+    return ex > t_min;
 }
 
 __device__ __forceinline__ void eval_sh3(const float* __restrict__ sh, F3 dir, float out[3]) {   // sh_utils.slang:3-67
@@ -361,54 +333,267 @@ __device__ __forceinline__ void eval_sh3(const float* __restrict__ sh, F3 dir, f
     }
 }
 
-// render_radiance_with_sampling_SH, intersect_test.slang:1879-1990
-__global__ void __launch_bounds__(BLOCK) pbgi_trace_kernel(int P, const PbgiNode* __restrict__ node, const float4* __restrict__ rec,
-                                                           const uint32_t* __restrict__ prim, int N, int S, const float* __restrict__ ray_o,
-                                                           const float* __restrict__ ray_d, const float* __restrict__ centers,
-                                                           const float* __restrict__ shs, float* __restrict__ radiance,
-                                                           float* __restrict__ visibility, int32_t* __restrict__ hit_indices, float* __restrict__ uvs) {
+// gs_bvh_hit (intersect_test.slang:251-437) inside render_radiance_with_sampling_SH (:1879-1990).
+//
+// Per ray the reference runs closest-hit queries in a loop (one per accepted surfel, until the transmittance is used up or nothing is
+// hit); a query pops a node, tests its box against the closest hit so far, pushes left then right.  The results depend on that visit
+// order (Q-a .. Q-e), so every ray here makes exactly the reference's visits and decisions -- restated so that
+//   * a visit costs ONE fetch: an internal node's record holds the boxes of both children, tested when the parent is visited; the
+//     right child is visited next (it would be popped next), the left child is pushed with its entry distance and re-checked against
+//     the closest hit when popped (box_entry above): boxes that fail never reach the stack, popped entries that fail cost no memory
+//     access.  That needs the direction to be final: the reference re-normalises it at every visited leaf (Q-c) and later box tests
+//     use the new one.  While |d| does not round to exactly 1 the direction may still change; until then the left child is pushed
+//     untested (entry = -inf) and tested with its own 32-byte box when popped, exactly like the reference does;
+//   * the stack lives in LDS, [level][lane]: lanes at different depths never collide on a bank;
+//   * LANES NEVER WAIT FOR EACH OTHER'S RAYS: 19 % of the rays of a cache update hit something and then need 7 queries on average
+//     (some 30+), the others one -- with one ray per lane for the life of the wave, 64 lanes waited for the longest ray of the wave
+//     (measured: 3.5 s for 12.8 M rays, SIMD lanes ~10 % busy).  Here a wave owns a POOL of consecutive rays; a lane whose traversal
+//     ends finishes its query (shading update, next query or outputs) and pulls the next ray of the pool at once, while the other
+//     lanes keep walking: one loop, one traversal step per iteration, per-lane state.
+__global__ void __launch_bounds__(PBGI_WAVE) pbgi_trace_kernel(int P, const PbgiNode* __restrict__ node, const float4* __restrict__ pair, const float4* __restrict__ rec,
+                                                               const uint32_t* __restrict__ prim, int N, int S, const float* __restrict__ ray_o,
+                                                               const float* __restrict__ ray_d, const float* __restrict__ centers,
+                                                               const float* __restrict__ shs, float* __restrict__ radiance,
+                                                               float* __restrict__ visibility, int32_t* __restrict__ hit_indices, float* __restrict__ uvs,
+                                                               int pool) {
 #pragma clang fp contract(off)
-    const long long ri = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (ri >= (long long)N * S) return;
-    const int row = (int)(ri / S);
-    const F3 dir = unit3(F3{ray_d[3 * ri], ray_d[3 * ri + 1], ray_d[3 * ri + 2]});
-    F3 o = {ray_o[3 * row], ray_o[3 * row + 1], ray_o[3 * row + 2]};
-    int first_hit = -1;
-    float fu = 0.f, fv = 0.f;
-    float T = 1.0f, t_min = 0.042f;
+    __shared__ int s_ids[PBGI_LDS_DEPTH * PBGI_WAVE];
+    __shared__ float s_ens[PBGI_LDS_DEPTH * PBGI_WAVE];
+    const int lane = threadIdx.x;
+    int* s_id = s_ids + lane;
+    float* s_en = s_ens + lane;
+    const long long total = (long long)N * S;
+    long long next_ray = (long long)blockIdx.x * pool;                 // wave-uniform: first ray of the pool not handed out yet
+    const long long pool_end = min(total, next_ray + (long long)pool);
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const float t_max = 0.2f;
-    bool done = false, visible = true;
+    const int L = P - 1;
+#if defined(SVGIR_DEV)
+    unsigned st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // ---- per-lane ray state (the loop of :1879-1990) ----
+    bool have_ray = false;
+    long long ri = 0;
+    int row = 0, first_hit = -1, it = 0;
+    F3 dir = {0.f, 0.f, 1.f}, o = {0.f, 0.f, 0.f};
+    float fu = 0.f, fv = 0.f, T = 1.0f, t_min = 0.042f;
+    bool visible = true;
     float sh[3] = {0.f, 0.f, 0.f};
-    PbgiHit h = {false, 0.f, 0.f, 0.f, 0.f, -1};
-    for (int it = 0; it < PBGI_MAX_HITS && T > 0.001f && !done; it++) {
-        closest_hit(node, rec, prim, P, o, dir, t_min, t_max, h);
-        const bool hit = h.index == row ? false : h.any;   // (Q-d)
-        if (hit) {
-            if (first_hit == -1) { first_hit = h.index; fu = h.u; fv = h.v; t_min = 0.01f; }
-            const F3 sdir = {centers[3 * (size_t)h.index] - o.x, centers[3 * (size_t)h.index + 1] - o.y, centers[3 * (size_t)h.index + 2] - o.z};
-            o = {o.x + dir.x * h.t, o.y + dir.y * h.t, o.z + dir.z * h.t};
-            float e[3];
-            eval_sh3(shs + 48 * (size_t)h.index, sdir, e);
+    // ---- per-lane traversal state (gs_bvh_hit) ----
+    bool walking = false;   // a query is in progress
+    int deep_id[PBGI_STACK - PBGI_LDS_DEPTH];
+    float deep_en[PBGI_STACK - PBGI_LDS_DEPTH];
+    int count = 0, cur = 0;
+    bool own_test = true;   // `cur` still has to pass its own box test (root; nodes pushed while the direction could still change)
+    float closest = t_max, cu = 0.f, cv = 0.f, hit_t = 0.f, keep_l = 0.f, hu = 0.f, hv = 0.f;
+    uint32_t closest_index = 0;
+    bool any_hit = false, fixed = false;
+    F3 d = dir;
+    SlabDir sd = slab_dir(d);
+    auto push = [&](int id, float en) {
+        if (count < PBGI_LDS_DEPTH) { s_id[count * PBGI_WAVE] = id; s_en[count * PBGI_WAVE] = en; }
+        else if (count < PBGI_STACK) { deep_id[count - PBGI_LDS_DEPTH] = id; deep_en[count - PBGI_LDS_DEPTH] = en; }
+        count++;   // (count never reaches PBGI_STACK: see its definition)
+    };
+    for (;;) {
+        if (__any(!walking)) {
+            // ---- a query ended (or the lane has no ray yet): ray bookkeeping, :1925-1975 ----
+            if (!walking && have_ray) {
+                const int h_index = any_hit ? (int)closest_index : -1;
+                const bool hit = h_index == row ? false : any_hit;   // (Q-d)
+                bool more = false;
+                if (hit) {
+                    if (first_hit == -1) { first_hit = h_index; fu = hu; fv = hv; t_min = 0.01f; }
+                    const F3 sdir = {centers[3 * (size_t)h_index] - o.x, centers[3 * (size_t)h_index + 1] - o.y, centers[3 * (size_t)h_index + 2] - o.z};
+                    o = {o.x + dir.x * hit_t, o.y + dir.y * hit_t, o.z + dir.z * hit_t};
+                    float e[3];
+                    eval_sh3(shs + 48 * (size_t)h_index, sdir, e);
 #pragma unroll
-            for (int c = 0; c < 3; c++) sh[c] += e[c] * (1 - h.keep) * T;
-            T = T * h.keep;
-            if (T < 0.2f) visible = false;
-        } else {
-            done = true;
+                    for (int c = 0; c < 3; c++) sh[c] += e[c] * (1 - keep_l) * T;
+                    T = T * keep_l;
+                    if (T < 0.2f) visible = false;
+                    it++;
+                    more = it < PBGI_MAX_HITS && T > 0.001f;
+                }
+                if (!more) {
+#if defined(SVGIR_DEV)
+                    {
+                        const unsigned nq = (unsigned)it + (hit ? 0u : 1u);
+                        atomicAdd(&g_pbgi_qhist[min(11, 31 - __clz((int)max(nq, 1u)))], 1ull);
+                        atomicMax(&g_pbgi_stats[6], (unsigned long long)nq);
+                        const unsigned long long bt = st_[1] - st_[7];
+                        atomicAdd(&g_pbgi_qhist[12], bt);
+                        if (nq >= 16) atomicAdd(&g_pbgi_qhist[13], bt);
+                        if (nq >= 128) atomicAdd(&g_pbgi_qhist[14], bt);
+                        if (nq >= 1024) atomicAdd(&g_pbgi_qhist[15], bt);
+                        st_[7] = st_[1];
+                    }
+#endif
+#pragma unroll
+                    for (int c = 0; c < 3; c++) radiance[3 * ri + c] = fminf(fmaxf(sh[c], 0.0f), 10.0f);
+                    visibility[ri] = visible ? T : 0.0f;
+                    hit_indices[ri] = first_hit;
+                    uvs[2 * ri] = fu; uvs[2 * ri + 1] = fv;
+                    have_ray = false;
+                }
+            }
+            {   // lanes without a ray take the next rays of the pool, in lane order
+                const bool want = !walking && !have_ray;
+                const unsigned long long m = __ballot(want);
+                const long long mine = next_ray + (long long)__popcll(m & lt_mask);
+                next_ray += (long long)__popcll(m);
+                if (want && mine < pool_end) {
+                    ri = mine;
+                    row = (int)(ri / S);
+                    dir = unit3(F3{ray_d[3 * ri], ray_d[3 * ri + 1], ray_d[3 * ri + 2]});
+                    o = {ray_o[3 * (size_t)row], ray_o[3 * (size_t)row + 1], ray_o[3 * (size_t)row + 2]};
+                    first_hit = -1; fu = 0.f; fv = 0.f; T = 1.0f; t_min = 0.042f; visible = true; it = 0;
+                    sh[0] = 0.f; sh[1] = 0.f; sh[2] = 0.f;
+                    have_ray = true;
+                    PBGI_STAT(5);
+                }
+            }
+            if (!walking && have_ray) {   // next query of the lane's ray
+                PBGI_STAT(0);
+                count = 0; cur = 0; own_test = true;
+                closest = t_max; cu = 0.f; cv = 0.f; hit_t = 0.f; keep_l = 0.f; hu = 0.f; hv = 0.f;
+                closest_index = 0; any_hit = false;
+                d = dir; sd = slab_dir(d);
+                fixed = sqrtf(dot3(d, d)) == 1.0f;   // the re-normalisation at a visited leaf leaves d as it is
+                walking = true;
+            }
+            if (!__any(walking)) break;   // the pool is empty and every lane is done
+        }
+        if (walking) {
+            // ---- one traversal step ----
+            bool alive = true;
+            if (own_test) {
+                const float4* q = reinterpret_cast<const float4*>(node + cur);
+                const float4 q0 = q[0], q1 = q[1];
+                PBGI_STAT(1);
+                alive = box_hit(q0, q1, o, sd, t_min, closest);
+            }
+            bool descend = false;
+            if (alive) {
+                PBGI_STAT(2);
+                if (cur < L) {
+                    // ---- internal node: both children's boxes ----
+                    const float4* q = pair + 4 * (size_t)cur;
+                    const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
+                    const int left = __builtin_bit_cast(int, r3.x), right = __builtin_bit_cast(int, r3.y);
+                    const float lo0[3] = {r0.x, r0.y, r0.z}, hi0[3] = {r0.w, r1.x, r1.y}, lo1[3] = {r1.z, r1.w, r2.x}, hi1[3] = {r2.y, r2.z, r2.w};
+                    if (fixed) {
+                        float eL;
+                        PBGI_STAT(1);
+                        if (box_entry(lo0, hi0, o, sd, t_min, eL) && closest > eL) push(left, eL);
+                    } else {
+                        push(left, -INFINITY);
+                    }
+                    float eR;
+                    PBGI_STAT(1);
+                    if (box_entry(lo1, hi1, o, sd, t_min, eR) && closest > eR) { cur = right; own_test = false; descend = true; }
+                } else {
+                    // ---- leaf ----
+                    const int j = cur - L;
+                    PBGI_STAT(3);
+                    const float4* lr = rec + 6 * (size_t)j;
+                    const float4 A = lr[0], B = lr[1], C = lr[2], D = lr[3], E = lr[4], G = lr[5];
+                    if (!fixed) {   // :342 -- the re-normalised direction also serves the box tests that follow (Q-c).  A direction whose
+                        // length already rounds to 1 is left bit-identical by the division
+                        const float l = sqrtf(dot3(d, d));
+                        if (l != 1.0f) { d = {d.x / l, d.y / l, d.z / l}; sd = slab_dir(d); fixed = sqrtf(dot3(d, d)) == 1.0f; }
+                        else fixed = true;
+                    }
+                    const F3 c = {A.x, A.y, A.z};
+                    const float sx = A.w, sy = B.x;
+                    // ---- ellipse_hit, :94-148 ----
+                    bool hit = false;
+                    float t_now = 0.f, uh = 0.5f, vh = 0.5f;
+                    F3 pos = {0.f, 0.f, 0.f};
+                    {
+                        const F3 nw = {B.z, B.w, C.x};
+                        const float denom = dot3(nw, d);
+                        if (!(fabsf(denom) < 1e-6f)) {
+                            const F3 co = {c.x - o.x, c.y - o.y, c.z - o.z};
+                            t_now = dot3(co, nw) / denom;
+                            if (!(t_now < t_min)) {
+                                pos = {o.x + d.x * t_now, o.y + d.y * t_now, o.z + d.z * t_now};
+                                const F3 w = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
+                                const float px = C.y * w.x + C.z * w.y + C.w * w.z, py = D.x * w.x + D.y * w.y + D.z * w.z;
+                                float a = px / sx, b = py / sy;
+                                if (a < b) { const float t = a; a = b; b = t; }
+                                a = a * 0.5f + 0.5f; b = b * 0.5f + 0.5f;
+                                uh = fminf(fmaxf(a, 0.001f), 0.999f);
+                                vh = fminf(fmaxf(b, 0.001f), 0.999f);
+                                const float dis = (px * px) / (sx * sx) + (py * py) / (sy * sy);
+                                hit = dis <= 9.0f;
+                            }
+                        }
+                    }
+                    if (!(t_now < t_min)) {   // :367-371
+                        const F3 dd = {c.x - pos.x, c.y - pos.y, c.z - pos.z};
+                        const float power = -0.5f * (dd.x * dd.x * E.z + dd.y * dd.y * G.y + dd.z * dd.z * G.w + 2 * dd.x * dd.y * E.w + 2 * dd.x * dd.z * G.x +
+                                                     2 * dd.y * dd.z * G.z);
+                        if (!(power > 0.0f)) {
+                            const float alpha = fminf(0.99f, B.y * expf(power));
+                            if (!(alpha < 1.0f / 255.0f)) {
+                                PBGI_STAT(4);
+                                const F3 nrm = {D.w, E.x, E.y};
+                                if (!(dot3(d, nrm) < -0.0f)) hit = false;   // :399-404
+                                const bool update = hit && t_now < closest;
+                                closest = hit ? fminf(t_now, closest) : closest;
+                                closest_index = update ? prim[j] : closest_index;
+                                cu = update ? uh : cu; cv = update ? vh : cv;
+                                if (hit) { any_hit = true; hit_t = closest; keep_l = 1 - alpha; hu = cu; hv = cv; }   // (Q-a, Q-b)
+                            }
+                        }
+                    }
+                }
+            }
+            if (!descend) {
+                // ---- next node: the stack's top, unless the closest hit found since it was pushed already excludes its box ----
+                bool got = false;
+                while (count > 0) {
+                    count--;
+                    float en;
+                    if (count < PBGI_LDS_DEPTH) { cur = s_id[count * PBGI_WAVE]; en = s_en[count * PBGI_WAVE]; }
+                    else { cur = deep_id[count - PBGI_LDS_DEPTH]; en = deep_en[count - PBGI_LDS_DEPTH]; }
+                    if (en == -INFINITY) { own_test = true; got = true; break; }
+                    if (closest > en) { own_test = false; got = true; break; }
+                }
+                walking = got;
+            }
         }
     }
+#if defined(SVGIR_DEV)
 #pragma unroll
-    for (int c = 0; c < 3; c++) radiance[3 * ri + c] = fminf(fmaxf(sh[c], 0.0f), 10.0f);
-    visibility[ri] = visible ? T : 0.0f;
-    hit_indices[ri] = first_hit;
-    uvs[2 * ri] = fu; uvs[2 * ri + 1] = fv;
+    for (int i = 0; i < 6; i++) {
+        unsigned v = st_[i];
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) v += (unsigned)__shfl_xor((int)v, dd);
+        if (lane == 0) atomicAdd(&g_pbgi_stats[i], (unsigned long long)v);
+    }
+#endif
 }
+
 
 }  // namespace
 
 }  // namespace svgir
 
 extern "C" {
+
+#if defined(SVGIR_DEV)
+// development builds only: reads and clears the traversal statistics
+int svgir_dev_pbgi_stats(unsigned long long* out) {   // out[24]: 8 counters + 16 histogram words
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(svgir::g_pbgi_stats), 64) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(svgir::g_pbgi_qhist), 128) != hipSuccess) return -1;
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_pbgi_stats), z, 64);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(svgir::g_pbgi_qhist), z, 128);
+    return 0;
+}
+#endif
 
 size_t svgir_pbgi_bvh_bytes(int32_t P) { return svgir::pbgi_layout(nullptr, P).bytes; }
 
@@ -428,6 +613,7 @@ int svgir_pbgi_bvh_build(int32_t P, const float* centers, const float* scales, c
     const int fin = PBGI_SORT_PASSES & 1;
     hipLaunchKernelGGL(pbgi_hierarchy_kernel, dim3(nb), dim3(BLOCK), 0, s, P, B.key[fin], B.val[fin], B.box, B.node, B.parent);
     if (P > 1) hipLaunchKernelGGL(pbgi_refit_kernel, dim3(nb), dim3(BLOCK), 0, s, P, B.node, B.parent, B.arrive);
+    if (P > 1) hipLaunchKernelGGL(pbgi_pair_kernel, dim3(nb), dim3(BLOCK), 0, s, P, B.node, B.pair);
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 
@@ -457,8 +643,15 @@ int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const 
     hipLaunchKernelGGL(pbgi_leaf_rec_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, B.val[fin], centers, scales, rotations, normals,
                        opacity, cov3D_inverse, B.rec);
     const long long rays = (long long)N * S;
-    hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)((rays + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, P, B.node, B.rec, B.val[fin], N, S, ray_o,
-                       ray_d, centers, shs, radiance, visibility, hit_indices, uvs);
+    // a wave owns a pool of consecutive rays (whole rows: the rays of a row share their origin); ~8 waves per resident slot even out
+    // the tails, 256 rays at least amortise a lane's idle time at the end of its pool
+    const long long slots = 256ll * 10 * 8;
+    long long pool = (rays + slots - 1) / slots;
+    pool = std::max<long long>(256, (pool + S - 1) / S * S);
+    pool = std::min<long long>(pool, 1 << 20);
+    const long long nw = (rays + pool - 1) / pool;
+    hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)nw), dim3(PBGI_WAVE), 0, s, P, B.node, B.pair, B.rec, B.val[fin], N, S, ray_o,
+                       ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)pool);
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 

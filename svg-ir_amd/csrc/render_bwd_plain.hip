@@ -48,7 +48,12 @@ struct PlainGeom {
     static constexpr size_t off_m = (size_t)PROWS * PS * 4;            // moments + Q5 sums [SB][8]
     static constexpr size_t off_c = off_m + (size_t)SB * 8 * 4;        // per-candidate constants of the block [3][SB] float4 (LDS-DMA target)
     static constexpr size_t off_q = off_c + (size_t)3 * SB * 16;       // the segment's {gid, slot} entries, deepest first
+#if defined(BWDP_PF_L2)
+    static constexpr size_t off_pf = off_q + (size_t)SEG * 8;          // landing zone of the L2 prefetch (LDS-DMA, never read)
+    static constexpr size_t lds_bytes = off_pf + 256;
+#else
     static constexpr size_t lds_bytes = off_q + (size_t)SEG * 8;
+#endif
     static_assert(NC0 <= 16, "one 16-wide MFMA column tile");
     static_assert((size_t)64 * GROW * 4 <= off_m, "the G transposition tile aliases the panel");
 };
@@ -243,6 +248,22 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         if (lane < nent) e = sub_in[seg_hi - 1 - lane];
         sQ[lane] = e;
         nskip = __popcll(__ballot(lane < nent && e.y >= wmax));
+#if defined(BWDP_PF_L2)
+        // The scalar loads of the replay miss the scalar cache on every record (a record is touched once per wave); whether
+        // they then hit L2 or go to HBM decides their latency.  Every lane pulls the lines of ITS entry's record / features into
+        // this XCD's L2 now (LDS-DMA into a landing zone nobody reads: no VGPRs, nothing waits for it).
+        if (lane < nent) {
+            const char* rsrc = reinterpret_cast<const char*>(a.rec) + (uint32_t)(e.x * (uint32_t)(REC * 4));
+            __attribute__((address_space(3))) void* lz = (__attribute__((address_space(3))) void*)(smem + PG::off_pf);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(rsrc), lz, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(rsrc + 64), lz, 4, 0, 0);
+            if (S > 0) {
+                const char* fsrc = reinterpret_cast<const char*>(a.features) + (uint32_t)(e.x * (uint32_t)(S * 4));
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(fsrc), lz, 4, 0, 0);
+                if (S > 1) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(fsrc + (S - 1) * 4), lz, 4, 0, 0);
+            }
+        }
+#endif
     }
     // flags folded into the per-pixel factors: the replay itself is branch-free
     const float gNe0 = surface ? gN[0] : 0.f, gNe1 = surface ? gN[1] : 0.f, gNe2 = surface ? gN[2] : 0.f;
@@ -281,6 +302,26 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         // (scalar loads and LDS stores share one completion counter: the panel stores of candidate k are issued right AFTER the
         // wait for candidate k+1's attributes, so that wait never includes a fresh LDS store)
         float hw = 0.f, hv = 0.f, hu = 0.f;
+#if defined(BWDP_PF_K)
+        // Burst prefetch into the scalar cache: the records the NEXT block's scalar loads will ask for are touched now, all at
+        // once (dummy s_loads of their cache lines), and waited for ONCE at the end of this block's first candidate -- one exposed
+        // miss latency per block of SB candidates instead of one per candidate.
+        uint32_t pf_tmp = 0;
+        if (c0 + SB < nent) {
+            int lK = lane;
+            asm volatile("" : "+v"(lK));
+            const uint32_t gq = sQ[min(c0 + SB + 1 + (lK & 7), SEG - 1)].x;
+#pragma unroll
+            for (int j = 0; j < SB; j++) {
+                const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)gq, j);
+                const uint32_t ro = gj * (uint32_t)(REC * 4), fo = gj * (uint32_t)(S * 4);
+                asm volatile("s_load_dword %0, %1, %2 offset:0x0\n\ts_load_dword %0, %1, %2 offset:0x40"
+                             : "+s"(pf_tmp) : "s"(a.rec), "s"(ro));
+                if (S > 0) asm volatile("s_load_dword %0, %1, %2 offset:0x0\n\ts_load_dword %0, %1, %2 offset:%3"
+                                        : "+s"(pf_tmp) : "s"(a.features), "s"(fo), "n"((S - 1) * 4));
+            }
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < SB; k++) {
             const Cand nxt = fetch_rec(en1);
@@ -316,6 +357,9 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
             hu = pre ? q5g : 0.f;                  // u: its pixel sum is the Q5 term (0 unless per-pixel depth is on)
             live |= (__builtin_amdgcn_ballot_w64(pre) != 0ull ? 1u : 0u) << k;
             cur = nxt;
+#if defined(BWDP_PF_K)
+            if (k == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf_tmp));   // (the prefetch's scratch register is free again only now)
+#endif
 #ifdef BWDP_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);
 #endif
