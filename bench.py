@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Gaussian-surfels/s, forward + backward, one 800x800 view per step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3_train|cfg3_eval|cfg4|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3_train|cfg3_eval|cfg4|cfg5|cfg5_dense|train_step|tracers]
+
+`--workload train_step` times one whole stage-2 training iteration (shade -> rasterize -> unpack -> L1 + SSIM -> backward ->
+densification statistics -> fused Adam; reference: train.py:133-134, gaussian_renderer/svgss.py:15-262,
+scene/gaussian_model.py:775-813, :1270-1276) on the cfg3_train scene; `--workload tracers` times the visibility / radiance cache
+producers (scene/gaussian_model.py:435-522: BVH builds + trace_visibility + render_radiance_with_sampling_SH, P x 64 rays each, the
+reference's chunk loop) on the cfg3 geometry.  Both print the same kind of JSON line (their own metric / unit).
 
 One process per GPU.  Launched under torchrun (WORLD_SIZE set) every process is a rank; launched plainly with
 `--gpus N > 1` the script starts N rank processes itself BEFORE anything touches the GPU (fresh child processes, no
@@ -40,6 +46,33 @@ for p in (os.path.join(ROOT, "svg-ir_amd"), ROOT):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# Instruction-issue roof of the chip, measured (profiles/r03_valu_rate_probe.txt): a SIMD issues one wave64 VALU
+# instruction per 1.67 cycles at best (8 resident waves), a scalar instruction costs 1.3 more; 256 CUs x 4 SIMDs at 2.4 GHz
+SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES, SALU_ISSUE_CYCLES = 1024, 2.4e9, 1.67, 1.3
+
+
+def issue_record(workload, prefixes, launch_ms):
+    """Issue-side roofline of the kernels whose names start with `prefixes`: wave-level VALU / SALU instruction counts per launch
+    from the committed PMC pass (profiles/issue_<workload>.json, scripts/pmc_issue.sh; valid only for the kernel sources and
+    the library it was measured with) priced at the measured best-case issue rate, over the SIMD cycles of the launch as timed NOW:
+        issue_frac = (VALU * 1.67 + SALU * 1.3) cycles / (1024 SIMDs * launch seconds * 2.4 GHz)."""
+    path = os.path.join(ROOT, "profiles", f"issue_{workload}.json")
+    if not os.path.exists(path) or not launch_ms:
+        return None
+    with open(path) as f:
+        tj = json.load(f)
+    if tj.get("kernel_source_hash") != kernel_source_hash() or not (tj.get("library_hash") == library_hash() or library_is_current()):
+        return {"issue_frac": None, "note": f"profiles/issue_{workload}.json was measured with different kernel sources / another library build"}
+    valu = salu = 0.0
+    for kname, kv in tj.get("kernels", {}).items():
+        if kname.startswith(prefixes):
+            valu += kv["valu"]; salu += kv["salu"]
+    if valu == 0.0:
+        return None
+    cyc = valu * VALU_ISSUE_CYCLES + salu * SALU_ISSUE_CYCLES
+    return {"issue_frac": cyc / (SIMDS * launch_ms * 1e-3 * CLOCK_HZ), "valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
+            "method": "wave-level VALU / SALU instruction counts (rocprofv3 --pmc SQ_INSTS_*, profiles/issue_%s.json) x 1.67 / 1.3 issue cycles "
+                      "(profiles/r03_valu_rate_probe.txt) over 1024 SIMDs x launch time x 2.4 GHz" % workload}
 
 
 def algorithmic_bytes(P, R, W, H, S, VS, svgss):
@@ -90,8 +123,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=25, help="repetitions of the K-step timed region (median reported)")
-    ap.add_argument("--workload", default=None, help="default: cfg2 (N = 1), cfg4 (N > 1)")
+    ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step timed region (median reported); 0 = as many as "
+                    "keep the GPU busy for ~3 s (at least 25, at most 500)")
+    ap.add_argument("--workload", default=None, help="default: cfg2 (N = 1), cfg4 (N > 1); also cfg3_train, cfg3_eval, cfg5, cfg5_dense, "
+                    "train_step (whole stage-2 iteration), tracers (visibility / radiance cache producers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shaded", action="store_true", help="skip the extra cfg3_train (shaded + blended) record")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the supplementary two-views-on-two-streams record")
@@ -285,6 +320,7 @@ def timed(wl, args, world, dev, dry=None):
         return torch.stack([color.sum(), gmean.sum(), torch.tensor(float(R), device=dev)])
 
     sync = (lambda: None) if dry else torch.cuda.synchronize
+    coll = world > 1 or vp.FORCE   # (FORCE: a one-rank job that issues its collectives anyway, tests/test_gpu_view_parallel.py)
     step = dry or wl.step
     gatherer = vp.MetricsGatherer(3, dev)   # async: the collective of step i overlaps with step i+1
     R = 0
@@ -295,7 +331,7 @@ def timed(wl, args, world, dev, dry=None):
     if not dry:
         from gaussian_renderer import _native
     regions = []
-    nrep = max(1, args.repeats)
+    nrep = args.repeats
 
     def region():
         nonlocal R, color, gm
@@ -304,15 +340,22 @@ def timed(wl, args, world, dev, dry=None):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             R, color, gm = step()
-            if world > 1:   # (one rank: nothing to gather -- the checksums of the last step are taken after the region)
+            if coll:   # (one rank: nothing to gather -- the checksums of the last step are taken after the region)
                 gatherer.submit(metrics(R, color, gm))
-        if world > 1:
+        if coll:
             gatherer.results()   # inside the timed region: the last collective has completed
         vp.barrier()
         sync()
         return time.perf_counter() - t0
 
     color = gm = None
+    if nrep <= 0:   # size the measurement: enough regions for ~3 s of GPU work (an independent utilisation probe then sees the GPU busy)
+        probe = region()
+        nrep = 25 if dry else int(min(500, max(25, 3.0 / max(probe, 1e-4))))
+        if coll:   # every rank must run the same number of regions (they contain barriers)
+            t = torch.tensor([nrep], dtype=torch.int64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            nrep = int(t.item())
     for rep in range(nrep):
         regions.append(region())
     # Per-stage / per-kernel durations: ONE more region of the same K steps with the library's HIP-event stage marks on
@@ -332,13 +375,33 @@ def timed(wl, args, world, dev, dry=None):
         if side is not None:
             wl.side = side
     el = torch.tensor(regions, dtype=torch.float64, device=dev)
-    if world > 1:
+    if coll:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     if gatherer.results() is None:   # (no warm-up steps on one rank)
         gatherer.submit(metrics(R, color, gm))
     table = gatherer.results().clone()
     table[:, 1:] = vp.gather_rows(checksums(R, color, gm))[:, 1:]
     return el.cpu().numpy(), int(R), stage, table.cpu().numpy()
+
+
+def walked_instances(wl):
+    """Instances any implementation of the composite MUST touch: per tile, the entries in front of (and including) the deepest
+    contributor of its pixels, sum over tiles of max(n_contrib) -- what is left of R when every pixel of a tile saturates early
+    (dense scenes: cfg5_dense walks 17 % of its 18.3 M instances).  The SURVEY 8(d) byte model charges all R instances (the
+    reference's backward does fetch every tile's whole list, backward.cu:617-650); both are reported."""
+    import numpy as np
+    from svgir_harness import runner
+    if getattr(wl, "sct", None) is None:
+        return None
+    raw = runner.forward_raw(wl.sct, wl.variant)
+    nc = raw["n_contrib"]
+    H, W = nc.shape
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = np.zeros((gy * 16, gx * 16), dtype=nc.dtype)
+    pad[:H, :W] = nc
+    tmax = pad.reshape(gy, 16, gx, 16).max(axis=(1, 3)).reshape(-1).astype(np.int64)
+    lens = (raw["ranges"][:, 1].astype(np.int64) - raw["ranges"][:, 0].astype(np.int64))
+    return int(np.minimum(tmax, lens).sum())
 
 
 def roofline_of(wl, R, stage, workload):
@@ -382,6 +445,34 @@ def roofline_of(wl, R, stage, workload):
             out["traffic"] = tr or None
         else:
             out["traffic_note"] = "profiles/traffic_%s.json was measured with different kernel sources / another library build" % workload
+    try:
+        Rw = walked_instances(wl)
+    except Exception:   # noqa: BLE001 -- supplementary
+        Rw = None
+    if Rw:
+        abw = algorithmic_bytes(wl.P, Rw, wl.W, wl.H, wl.S, wl.VS, wl.variant == "svgss")
+        key = "bwd" if "render_bwd" in stage else "fwd"
+        out["walked"] = {"instances": Rw, "share_of_num_rendered": Rw / max(R, 1), "bytes_per_launch": abw[key],
+                         "frac": abw[key] / (out["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "the same byte model over the instances in front of each tile's deepest contributor (what any "
+                                 "implementation must touch); `frac` charges all num_rendered instances like SURVEY 8(d) and can exceed "
+                                 "1 when most of a tile's list lies behind saturated pixels"}
+    # which roof the kernel is nearer to: `frac` stays BASELINE's metric (algorithmic bytes / time / 8 TB/s); `issue_frac` prices the
+    # instructions the kernel issues (committed PMC pass) at the chip's measured issue rate; `bound` names the larger of the two
+    if "render_bwd" in stage:
+        ir = issue_record(workload, ("render_bwd", "grad_reduce"), out.get("avg_launch_ms"))
+    else:
+        ir = issue_record(workload, ("render_fwd", "cull_kernel"), out.get("avg_launch_ms"))
+    if ir:
+        out["issue_frac"] = ir.get("issue_frac")
+        out["issue"] = {k: v for k, v in ir.items() if k != "issue_frac"}
+        if ir.get("issue_frac") is not None:
+            out["bound"] = "issue" if ir["issue_frac"] > out["frac"] else "hbm"
+    if "fwd_composite" in out:
+        irf = issue_record(workload, ("render_fwd", "cull_kernel"), out["fwd_composite"]["avg_launch_ms"])
+        if irf and irf.get("issue_frac") is not None:
+            out["fwd_composite"]["issue_frac"] = irf["issue_frac"]
+            out["fwd_composite"]["bound"] = "issue" if irf["issue_frac"] > out["fwd_composite"]["frac"] else "hbm"
     return out
 
 
@@ -399,6 +490,13 @@ def shading_record(wl, stage):
         rec["bwd"] = {"avg_launch_ms": stage["shade_bwd"][0], "algorithmic_bytes_per_launch": sb,
                       "achieved": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
                       "frac": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    wname = getattr(wl, "name", None) or ("cfg3_train" if wl.training else "cfg3_eval")
+    for part, pre in (("fwd", ("shade_fwd",)), ("bwd", ("shade_bwd",))):
+        if part in rec:
+            ir = issue_record("cfg3_train" if wname == "train_step" else wname, pre, rec[part]["avg_launch_ms"])
+            if ir and ir.get("issue_frac") is not None:
+                rec[part]["issue_frac"] = ir["issue_frac"]
+                rec[part]["bound"] = "issue" if ir["issue_frac"] > rec[part]["frac"] else "hbm"
     return rec
 
 
@@ -476,6 +574,191 @@ def cpu_baseline(wl, args):
     return res
 
 
+def _time_regions(fn, args, dev):
+    """W warm-up calls, then `repeats` regions of K calls (synchronize on both sides); returns seconds per region."""
+    import torch
+    for _ in range(args.warmup):
+        fn()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(max(1, args.repeats or 25)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
+def bench_train_step(args, dev):
+    """One stage-2 training iteration per step (svgir_harness.workloads.TrainStep)."""
+    import numpy as np
+    import torch
+    from gaussian_renderer import _native
+    from svgir_harness import workloads
+    ts = workloads.TrainStep(dev)
+    regions = _time_regions(ts.step, args, dev)
+    med = float(np.median(regions))
+    # kernel-level stage marks of the library (rasterizer + shading stages) over one more region, and the phase table
+    _native.set_profiling(True)
+    for _ in range(args.steps):
+        R, _, _ = ts.step()
+    torch.cuda.synchronize()
+    stage = {n: (ms, cnt) for n, ms, cnt in _native.last_timings(with_counts=True)}
+    _native.set_profiling(False)
+    phases = ts.stage_table(min(10, args.steps))
+
+    class _W:   # what roofline_of / shading_record read
+        pass
+    w = _W()
+    w.P, w.W, w.H, w.S, w.VS, w.variant, w.Ns, w.training = ts.P, ts.W, ts.H, ts.S, ts.VS, "svgss", ts.Ns, True
+    w.shading, w.dirs = ts.shading, ts.shading.FibonacciLattice(ts.geo_n, ts.Ns, None)
+    n_adam = ts.n_param_elems
+    res = {
+        "metric": "Gaussian-surfels/sec, whole stage-2 training iteration @800x800 (shade + rasterize + unpack + L1/SSIM + backward + Adam)",
+        "value": ts.P * args.steps / med, "unit": "surfels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "repeats": len(regions), "ms_per_step_min": min(regions) / args.steps * 1e3,
+        "ms_per_step_max": max(regions) / args.steps * 1e3,
+        "config": {"workload": f"train_step: cfg3_train scene (svgss, P={ts.P}, {ts.W}x{ts.H}, S=4, VS=52, Ns={ts.Ns}), one optimisation step per "
+                               f"step: FibonacciLattice (random azimuths) -> shade_and_pack -> GaussianRasterizer -> unpack -> l1_ssim -> "
+                               f"loss.backward() -> add_densification_stats -> FusedAdam.step(nan scrub, zero_grad) over {n_adam} parameter "
+                               f"elements (geometry, SH, SV-BRDF, radiance cache, env map)",
+                   "num_rendered": int(R), "reference": "train.py:133-134, gaussian_renderer/svgss.py:15-262, scene/gaussian_model.py:775-813, 1270-1276"},
+        "phase_ms": {k: round(v, 4) for k, v in phases.items()},
+        "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
+        "roofline": roofline_of(w, R, stage, "cfg3_train"),
+        "shading": {k: v for k, v in shading_record(w, stage).items() if k != "config"},
+        "optimizer": {"kernel": "adam_kernel (multi-tensor, NaN scrub)", "algorithmic_bytes_per_launch": 28 * n_adam,
+                      "note": "28 B per parameter element (param, grad, two moments read; param, two moments written)"},
+    }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_train_step(ts, args)
+    return res
+
+
+def cpu_baseline_train_step(ts, args):
+    """CPU restatement of the same iteration on the host cores: the C++ rasterizer oracle (fwd + bwd, all threads) on the full
+    view; the torch-fp64 shading oracle with autograd, the numpy / torch epilogue + L1 / SSIM oracle and torch.optim.Adam on bounded
+    samples, scaled to the full sizes (the sample sizes are stated)."""
+    import numpy as np
+    import torch
+    from oracle import epilogue_oracle as eo
+    from oracle import oracle as orc
+    from oracle import shading_oracle as so
+    from svgir_harness import scenes, shade_inputs
+    fast = orc.build_fast()
+    o = orc.OracleRun(ts.sc, orc.SVGSS, fast=fast)
+    g = scenes.upstream_grads(ts.sc, "svgss")
+    t0 = time.perf_counter()
+    n_r = 2
+    for _ in range(n_r):
+        o.forward()
+        o.backward(g["color"], g["normal"], g["depth"], g["opacity"], g["feature"], g.get("vfeature"))
+    t_raster = (time.perf_counter() - t0) / n_r
+    # shading forward + backward (torch fp64, autograd) on a sample of the surfels
+    n_s = 4000
+    d = shade_inputs.make(n_s, ts.Ns, seed=3)
+    names = ("base_color", "roughness", "normals", "radiance", "env")
+    lo = {k: d[k].double().requires_grad_(True) for k in names}
+    t0 = time.perf_counter()
+    ref = so.shade(lo["base_color"], lo["roughness"], lo["normals"], d["viewdirs"].double(), lo["radiance"], d["visibility"].double(),
+                   d["dirs"].double(), d["areas"].double(), lo["env"])
+    (ref["pbr"].sum() + ref["diffuse_light"].sum()).backward()
+    t_shade = (time.perf_counter() - t0) * (ts.P / n_s)
+    # image-space epilogue + L1 / SSIM with autograd at full resolution
+    im = torch.rand(3, ts.H, ts.W, dtype=torch.float64, requires_grad=True)
+    gt = torch.rand(3, ts.H, ts.W, dtype=torch.float64)
+    t0 = time.perf_counter()
+    l1, ss = eo.l1_ssim_torch(im, gt)
+    (0.8 * l1 + 0.2 * (1 - ss)).backward()
+    t_loss = time.perf_counter() - t0
+    # Adam on a sample of the parameter block
+    n_a = 4_000_000
+    par = torch.nn.Parameter(torch.zeros(n_a))
+    opt = torch.optim.Adam([par], lr=1e-3, eps=1e-15)
+    par.grad = torch.ones(n_a)
+    opt.step()
+    t0 = time.perf_counter()
+    opt.step()
+    t_adam = (time.perf_counter() - t0) * (ts.n_param_elems / n_a)
+    total = t_raster + t_shade + t_loss + t_adam
+    return {"value": ts.P / total, "unit": "surfels/s", "cores": orc.max_threads(), "kind": "port",
+            "seconds": {"rasterizer_fwd_bwd": t_raster, "shading_fwd_bwd_scaled": t_shade, "l1_ssim_fwd_bwd": t_loss, "adam_scaled": t_adam},
+            "sample": f"{n_r} fwd+bwd rasterizer steps of the cfg3_train view (OpenMP oracle/svgir_oracle.cpp, {orc.max_threads()} threads); "
+                      f"shading oracle (torch fp64 + autograd) on {n_s} of {ts.P} surfels, scaled; L1 + SSIM oracle with autograd at "
+                      f"{ts.W}x{ts.H}; torch.optim.Adam on {n_a} of {ts.n_param_elems} elements, scaled (torch CPU threads: {torch.get_num_threads()})"}
+
+
+def bench_tracers(args, dev):
+    """update_visibility + update_radiace of the reference per step (svgir_harness.workloads.TracerCache, cfg3 geometry)."""
+    import numpy as np
+    import torch
+    from svgir_harness import workloads
+    tc = workloads.TracerCache(dev)
+    args = argparse.Namespace(**vars(args))
+    args.steps = min(args.steps, 3); args.warmup = min(args.warmup, 1); args.repeats = min(args.repeats or 3, 3)   # a step is ~1.5 s
+    regions = _time_regions(tc.step, args, dev)
+    med = float(np.median(regions))
+    ms_vis, vis = tc.timed(tc.update_visibility, n=2)
+    ms_rad, (rad, vis2, idx) = tc.timed(tc.update_radiance, n=1)
+    rays = 2 * tc.rays
+    res = {
+        "metric": "rays/sec, visibility + radiance cache update (BVH builds + trace_visibility + render_radiance_with_sampling_SH)",
+        "value": rays * args.steps / med, "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "repeats": len(regions),
+        "config": {"workload": f"tracers: cfg3 geometry (P={tc.P} flat surfels), {tc.sample_num} incident directions per surfel "
+                               f"(sample_incident_rays), the reference's chunk loop (P // 3 surfels per call); one step = update_visibility "
+                               f"+ update_radiace = {rays} rays",
+                   "reference": "scene/gaussian_model.py:435-522, submodules/bvh/src/{construct,trace}.cu, pbgi/bvhworkers/intersect_test.slang:1879-1990"},
+        "producers": {"update_visibility": {"ms": ms_vis, "rays_per_s": tc.rays / (ms_vis * 1e-3), "mean_visibility": float(vis.mean())},
+                      "update_radiance": {"ms": ms_rad, "rays_per_s": tc.rays / (ms_rad * 1e-3), "hit_fraction": float((idx >= 0).float().mean()),
+                                          "mean_radiance": float(rad.mean())}},
+        # data-dependent traversals: the byte model counts what every ray must move (origin / direction in, results out) -- the tree
+        # traffic (64 B per visited internal node, 96 B per visited leaf; ~2 400 visits per radiance ray on this scene,
+        # profiles/r04_tracer_stats.txt) is served by L2
+        "roofline": {"bound": "issue", "kernel": "pbgi_trace_kernel (radiance tracer)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": tc.rays * (12 + 12 + 4 + 4 + 8), "avg_launch_ms": ms_rad,
+                     "achieved": tc.rays * 40 / (ms_rad * 1e-3) / 1e9, "frac": tc.rays * 40 / (ms_rad * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "note": "divergent tree traversal: instruction-issue / latency bound (profiles/r04_tracer_pmc.txt), not an HBM stream"},
+    }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_tracers(tc, args)
+    return res
+
+
+def cpu_baseline_tracers(tc, args):
+    """The CPU oracles of both tracers on a bounded number of surfel rows (64 rays each), all host threads."""
+    import numpy as np
+    from oracle import bvh_oracle as bo
+    from oracle import pbgi_oracle as po
+    from gaussian_renderer import shading
+    f = lambda t: t.detach().cpu().numpy()   # noqa: E731
+    xyz, scales, rot, nrm, op, cov, shs = (f(t) for t in (tc.xyz, tc.scales, tc.rot, tc.normals, tc.opacity, tc.cov_inv, tc.shs))
+    rows = np.sort(np.random.default_rng(1).choice(tc.P, 2000, replace=False))
+    dirs, _ = shading.sample_incident_rays(tc.normals[rows], False, tc.sample_num)
+    dirs = f(dirs)
+    t0 = time.perf_counter()
+    info, aabb, _ = po.build(xyz, scales)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    po.trace(info, aabb, xyz[rows], dirs, xyz, scales, rot, nrm, op, cov, shs)
+    t_rad = time.perf_counter() - t0
+    nv = 40   # (the visibility oracle is a tree-free loop over ALL surfels per ray: O(P) per ray)
+    boxes = bo.leaf_boxes(xyz, scales, rot)
+    t0 = time.perf_counter()
+    bo.trace_visibility(boxes, np.repeat(xyz[rows[:nv], None], tc.sample_num, 1), dirs[:nv], xyz, cov, op.reshape(-1), nrm)
+    t_vis = time.perf_counter() - t0
+    rays_rad, rays_vis = len(rows) * tc.sample_num, nv * tc.sample_num
+    return {"value": rays_rad / t_rad, "unit": "rays/s (radiance tracer)", "cores": os.cpu_count(), "kind": "port",
+            "visibility_rays_per_s": rays_vis / t_vis, "pbgi_bvh_build_s": t_build,
+            "sample": f"oracle/pbgi_oracle.cpp (OpenMP) on {len(rows)} random rows x {tc.sample_num} rays of the same scene ({t_rad:.1f} s) after a "
+                      f"{t_build:.2f} s tree build; oracle/bvh_oracle.cpp (tree-free, O(P) per ray) on {nv} rows x {tc.sample_num} rays ({t_vis:.1f} s)"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -514,6 +797,12 @@ def main():
         sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if name in ("train_step", "tracers"):
+        if world != 1:
+            print(f"bench.py: --workload {name} is a single-GPU measurement", file=sys.stderr)
+            sys.exit(2)
+        print(json.dumps(bench_train_step(args, dev) if name == "train_step" else bench_tracers(args, dev)))
+        return
     wl = Workload(name, dev, rank, world, args)
     regions, R, stage, table = timed(wl, args, world, dev)
     # which physical GPU every rank ran on (a rank that silently fell back to another device would show up here)
@@ -549,7 +838,6 @@ def main():
         wl.sct = wl.gt = None
         torch.cuda.empty_cache()
         sa = argparse.Namespace(**vars(args))
-        sa.repeats = max(1, args.repeats // 5)
         w3 = Workload("cfg3_train", dev, rank, world, sa)
         reg3, R3, st3, _ = timed(w3, sa, world, dev)
         m3 = float(np.median(reg3))
@@ -558,6 +846,7 @@ def main():
                          "value": w3.P * sa.steps / m3, "unit": "surfels/s", "ms_per_step": m3 / sa.steps * 1e3, "repeats": len(reg3),
                          "num_rendered": int(R3), "roofline": roofline_of(w3, R3, st3, "cfg3_train"),
                          "shading": shading_record(w3, st3), "stage_ms": {k: round(v[0], 4) for k, v in st3.items()}}
+        res["value_shaded"] = res["shaded"]["value"]   # north_star's "shaded + blended" number (cfg3_train with the SV-BRDF shading)
         del w3
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(wl, args)
@@ -566,7 +855,7 @@ def main():
         res["two_streams"] = two_streams(name, dev, args)
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -9,16 +9,21 @@ if [ "${2:-}" != "quick" ]; then
   python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/${TAG}_tests.log
   cat gpurun_out/${TAG}_tests.log
 fi
-for W in cfg2 cfg3_train; do   # PMC traffic first: bench.py reports it as roofline.traffic (stamped with the kernel-source hash)
+for W in cfg2 cfg3_train; do   # PMC passes first: bench.py reports them as roofline.traffic / roofline.issue_frac (stamped with the kernel-source hash)
   scripts/pmc_traffic.sh $W ${TAG}_$W > /dev/null 2>&1 && cp gpurun_out/${TAG}_${W}_traffic.json profiles/traffic_$W.json && cp gpurun_out/${TAG}_${W}_traffic.json gpurun_out/traffic_$W.json
+  scripts/pmc_issue.sh $W ${TAG}_$W > /dev/null 2>&1 && cp gpurun_out/${TAG}_${W}_issue.json profiles/issue_$W.json && cp gpurun_out/${TAG}_${W}_issue.json gpurun_out/issue_$W.json
 done
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 tail -c 6000 gpurun_out/${TAG}_bench_default.json; tail -3 gpurun_out/${TAG}_bench_default.err
-for W in cfg3_train cfg3_eval cfg4 cfg5; do
+for W in cfg3_train cfg3_eval cfg4 cfg5 cfg5_dense; do
   python bench.py --workload $W --no-cpu-baseline --repeats 5 > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err
   tail -c 3000 gpurun_out/${TAG}_bench_$W.json; tail -3 gpurun_out/${TAG}_bench_$W.err
 done
-for W in cfg2 cfg3_train cfg5; do
+for W in train_step tracers; do   # the "next" rows of SURVEY 8: whole training iteration (f2 + f4), cache producers (f3)
+  python bench.py --workload $W > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err
+  tail -c 3000 gpurun_out/${TAG}_bench_$W.json; tail -3 gpurun_out/${TAG}_bench_$W.err
+done
+for W in cfg2 cfg3_train cfg5 train_step tracers; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$W -o p -- python3 $R/bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --no-concurrent --workload $W > $R/gpurun_out/${TAG}_prof_$W.log 2>&1)
   DB=$(find gpurun_out/${TAG}_prof_$W -name "*.db" | head -1)
   python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_${W}_kernel_stats.txt "python3 bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --no-concurrent --workload $W" | head -30

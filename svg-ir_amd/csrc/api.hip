@@ -387,10 +387,16 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         const bool clear_stencil = !svgss && !p->computer_pseudo_normal;
         ra.zero_a = clear_stencil ? o->out_pseudo_normal : nullptr;
         ra.zero_b = clear_stencil ? o->out_surface_xyz : nullptr;
+        ra.pair_stream = B.pair_stream;
         launch_cull(ra, s);
         launch_order_desc(I.sub_total, 4 * T, I.sub_order, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
+#if defined(BWDP_STREAM)
+        if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
+        launch_pair_stream(ra, s);
+        if (timed) tm.mark("pair_stream");
+#endif
         if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
         if (launch_render_fwd(ra, svgss, s) < 0) launch_render_fwd_generic(ra, svgss, s);   // run-time-width kernels
         if (int rc = check("render")) return rc;
@@ -489,6 +495,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count;
     ba.sub_ndump = I.sub_ndump; ba.seg_list = B.seg_list; ba.seg_desc = B.seg_desc; ba.seg_count = I.counters; ba.seg_state = B.seg_state;
     ba.seg_cap = (int)B.seg_cap;
+    ba.pair_stream = B.pair_stream;
     ba.backward_geometry = p->backward_geometry;
     ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;
     ba.g_color = g->dL_dout_color; ba.g_normal = g->dL_dout_normal; ba.g_depth = g->dL_dout_depth;

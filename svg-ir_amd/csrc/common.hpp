@@ -196,6 +196,7 @@ struct BinLayout {
     uint32_t* seg_list; // [seg_capacity] live backward segments, longest first (seg_build_kernel)
     SegDesc* seg_desc;  // [seg_capacity + 256] their descriptors (same order)
     float* seg_state;  // [seg_capacity][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
+    float* pair_stream; // (experiment builds, -DBWDP_STREAM) [4*R][24] per-(sub-tile, candidate) records in list order, else null
     size_t seg_cap;
     size_t bytes;
 };
@@ -215,6 +216,11 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     b.seg_list = (uint32_t*)take(b.seg_cap * 4);
     b.seg_desc = (SegDesc*)take((b.seg_cap + 8 * SEG_XCD_BLOCK) * sizeof(SegDesc));
     b.seg_state = (float*)take(b.seg_cap * (size_t)nstate * 64 * 4);
+#if defined(BWDP_STREAM)
+    b.pair_stream = (float*)take(r * 4 * 24 * 4);
+#else
+    b.pair_stream = nullptr;
+#endif
     b.bytes = off;
     return b;
 }
@@ -277,6 +283,7 @@ struct RenderArgs {
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
+    float* pair_stream;       // (experiment builds) see BinLayout
 };
 
 struct RenderBwdArgs {
@@ -291,6 +298,7 @@ struct RenderBwdArgs {
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
     float* grad_rows; uint8_t* row_flags;   // svgss (VS > 0): gradient rows + validity bytes; else: packed rows [P][RS]
+    const float* pair_stream;               // (experiment builds) see BinLayout
 };
 
 struct GradReduceArgs {
@@ -341,6 +349,8 @@ void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream
 void launch_cull(const RenderArgs& a, hipStream_t s);
 // tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump
 void launch_seg_build(const RenderArgs& a, hipStream_t s);
+// (experiment builds, -DBWDP_STREAM) gather-free candidate stream: one 24-float record per (sub-tile, candidate) pair, in list order
+void launch_pair_stream(const RenderArgs& a, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 (nothing launched) if (S,VS) has no specialised kernel
 int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 (nothing launched) if (S,VS) has no specialised kernel
 int launch_render_bwd_plain(const RenderBwdArgs& a, bool svgss, hipStream_t s);   // VS = 0 widths (render_bwd_plain.hip); <0 if not specialised

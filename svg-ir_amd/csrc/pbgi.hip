@@ -21,6 +21,7 @@
 // needs, unit normal, inverse covariance) instead of a quaternion -> matrix -> inverse evaluation at every visited leaf.
 // One lane per ray, rays in memory order ([rows, samples]: the 64 rays of a wave share their origin).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "lbvh.hpp"
@@ -506,45 +507,40 @@ __global__ void __launch_bounds__(PBGI_WAVE) pbgi_trace_kernel(int P, const Pbgi
                     }
                     const F3 c = {A.x, A.y, A.z};
                     const float sx = A.w, sy = B.x;
-                    // ---- ellipse_hit, :94-148 ----
-                    bool hit = false;
-                    float t_now = 0.f, uh = 0.5f, vh = 0.5f;
-                    F3 pos = {0.f, 0.f, 0.f};
-                    {
-                        const F3 nw = {B.z, B.w, C.x};
-                        const float denom = dot3(nw, d);
-                        if (!(fabsf(denom) < 1e-6f)) {
-                            const F3 co = {c.x - o.x, c.y - o.y, c.z - o.z};
-                            t_now = dot3(co, nw) / denom;
-                            if (!(t_now < t_min)) {
-                                pos = {o.x + d.x * t_now, o.y + d.y * t_now, o.z + d.z * t_now};
-                                const F3 w = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
-                                const float px = C.y * w.x + C.z * w.y + C.w * w.z, py = D.x * w.x + D.y * w.y + D.z * w.z;
-                                float a = px / sx, b = py / sy;
-                                if (a < b) { const float t = a; a = b; b = t; }
-                                a = a * 0.5f + 0.5f; b = b * 0.5f + 0.5f;
-                                uh = fminf(fmaxf(a, 0.001f), 0.999f);
-                                vh = fminf(fmaxf(b, 0.001f), 0.999f);
-                                const float dis = (px * px) / (sx * sx) + (py * py) / (sy * sy);
-                                hit = dis <= 9.0f;
-                            }
-                        }
-                    }
-                    if (!(t_now < t_min)) {   // :367-371
-                        const F3 dd = {c.x - pos.x, c.y - pos.y, c.z - pos.z};
-                        const float power = -0.5f * (dd.x * dd.x * E.z + dd.y * dd.y * G.y + dd.z * dd.z * G.w + 2 * dd.x * dd.y * E.w + 2 * dd.x * dd.z * G.x +
-                                                     2 * dd.y * dd.z * G.z);
-                        if (!(power > 0.0f)) {
-                            const float alpha = fminf(0.99f, B.y * expf(power));
-                            if (!(alpha < 1.0f / 255.0f)) {
-                                PBGI_STAT(4);
-                                const F3 nrm = {D.w, E.x, E.y};
-                                if (!(dot3(d, nrm) < -0.0f)) hit = false;   // :399-404
-                                const bool update = hit && t_now < closest;
-                                closest = hit ? fminf(t_now, closest) : closest;
-                                closest_index = update ? prim[j] : closest_index;
-                                cu = update ? uh : cu; cv = update ? vh : cv;
-                                if (hit) { any_hit = true; hit_t = closest; keep_l = 1 - alpha; hu = cu; hv = cv; }   // (Q-a, Q-b)
+                    // ---- ellipse_hit (:94-148) and the acceptance tests (:367-404).  The reference evaluates the ellipse first; its
+                    // results (hit, uv) are only read for ACCEPTED leaves (8 % of the visited ones: t >= t_min, power <= 0, alpha >=
+                    // 1/255), so the plane intersection and the acceptance come first and the ellipse -- four IEEE divisions -- last ----
+                    const F3 nw = {B.z, B.w, C.x};
+                    const float denom = dot3(nw, d);
+                    if (!(fabsf(denom) < 1e-6f)) {
+                        const F3 co = {c.x - o.x, c.y - o.y, c.z - o.z};
+                        const float t_now = dot3(co, nw) / denom;
+                        if (!(t_now < t_min)) {   // (:367-371; a parallel ray has t_now = 0 < t_min)
+                            const F3 pos = {o.x + d.x * t_now, o.y + d.y * t_now, o.z + d.z * t_now};
+                            const F3 dd = {c.x - pos.x, c.y - pos.y, c.z - pos.z};
+                            const float power = -0.5f * (dd.x * dd.x * E.z + dd.y * dd.y * G.y + dd.z * dd.z * G.w + 2 * dd.x * dd.y * E.w + 2 * dd.x * dd.z * G.x +
+                                                         2 * dd.y * dd.z * G.z);
+                            if (!(power > 0.0f)) {
+                                const float alpha = fminf(0.99f, B.y * expf(power));
+                                if (!(alpha < 1.0f / 255.0f)) {
+                                    PBGI_STAT(4);
+                                    const F3 w = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
+                                    const float px = C.y * w.x + C.z * w.y + C.w * w.z, py = D.x * w.x + D.y * w.y + D.z * w.z;
+                                    float a = px / sx, b = py / sy;
+                                    if (a < b) { const float t = a; a = b; b = t; }
+                                    a = a * 0.5f + 0.5f; b = b * 0.5f + 0.5f;
+                                    const float uh = fminf(fmaxf(a, 0.001f), 0.999f);
+                                    const float vh = fminf(fmaxf(b, 0.001f), 0.999f);
+                                    const float dis = (px * px) / (sx * sx) + (py * py) / (sy * sy);
+                                    bool hit = dis <= 9.0f;
+                                    const F3 nrm = {D.w, E.x, E.y};
+                                    if (!(dot3(d, nrm) < -0.0f)) hit = false;   // :399-404
+                                    const bool update = hit && t_now < closest;
+                                    closest = hit ? fminf(t_now, closest) : closest;
+                                    closest_index = update ? prim[j] : closest_index;
+                                    cu = update ? uh : cu; cv = update ? vh : cv;
+                                    if (hit) { any_hit = true; hit_t = closest; keep_l = 1 - alpha; hu = cu; hv = cv; }   // (Q-a, Q-b)
+                                }
                             }
                         }
                     }
@@ -643,12 +639,12 @@ int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const 
     hipLaunchKernelGGL(pbgi_leaf_rec_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, B.val[fin], centers, scales, rotations, normals,
                        opacity, cov3D_inverse, B.rec);
     const long long rays = (long long)N * S;
-    // a wave owns a pool of consecutive rays (whole rows: the rays of a row share their origin); ~8 waves per resident slot even out
-    // the tails, 256 rays at least amortise a lane's idle time at the end of its pool
-    const long long slots = 256ll * 10 * 8;
-    long long pool = (rays + slots - 1) / slots;
-    pool = std::max<long long>(256, (pool + S - 1) / S * S);
-    pool = std::min<long long>(pool, 1 << 20);
+    // a wave owns a pool of consecutive rays (whole rows: the rays of a row share their origin).  Measured on the cfg3 geometry
+    // (4.27 M rays per launch) and the shell scene (12.8 M): 256 / 1 024 / 4 096 / 16 384 rays per wave = 2 129 / 1 329 / 1 534 / 4 249 ms
+    // and 2 429 / 2 154 / 2 822 / 5 639 ms -- small pools end with 63 lanes waiting for one long ray, large ones leave wave slots empty
+    long long pool = std::max<long long>(S, (1024 + S - 1) / S * S);
+    pool = std::min<long long>(pool, std::max<long long>(S, (rays / 2560 + S - 1) / S * S));   // (small launches: at least one wave per slot)
+    if (const char* e = getenv("SVGIR_PBGI_POOL")) { const long long v = atoll(e); if (v > 0) pool = (v + S - 1) / S * S; }   // (tuning experiments)
     const long long nw = (rays + pool - 1) / pool;
     hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)nw), dim3(PBGI_WAVE), 0, s, P, B.node, B.pair, B.rec, B.val[fin], N, S, ray_o,
                        ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)pool);

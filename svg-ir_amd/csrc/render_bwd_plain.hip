@@ -146,6 +146,23 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         e.slot = i < nent ? sl : 0xffffffffu;   // (slot 2^32-1: never blends)
         return e;
     };
+#if defined(BWDP_STREAM)
+    // experiment: the candidate's attributes come from the sequential per-pair stream (launch_pair_stream): the address depends on
+    // the walk position only, not on a list entry
+    cchar* strm_b = (cchar*)(uintptr_t)(a.pair_stream + ((size_t)4 * r0 + (size_t)sub * tlen) * 24);
+    auto fetch_stream = [&](int i) -> Cand {
+        const int ci = seg_hi - 1 - min(i, nent - 1);
+        cfloat* r = (cfloat*)(strm_b + (uint32_t)ci * 96u);
+        Cand c;
+        c.X = r[0]; c.Y = r[1]; c.cxx = r[2]; c.cxy = r[3]; c.cyy = r[4]; c.op = r[5]; c.dep = r[6]; c.DA = r[7];
+        c.DB = r[8]; c.cr = r[9]; c.cg = r[10]; c.cb = r[11]; c.nx = r[12]; c.ny = r[13]; c.nz = r[14];
+#pragma unroll
+        for (int ch = 0; ch < SS; ch++) c.f[ch] = ch < S ? r[15 + ch] : 0.f;
+        const uint32_t sl = __builtin_bit_cast(uint32_t, r[20]);
+        c.slot = i < nent ? sl : 0xffffffffu;
+        return c;
+    };
+#endif
     auto fetch_rec = [&](const Entry& e) -> Cand {
         // 32-bit byte offsets: P * 96 B < 4 GiB (api.hip validate)
         cfloat* r = (cfloat*)(rec_b + (uint32_t)(e.gid * (uint32_t)(REC * 4)));
@@ -167,9 +184,15 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         return c;
     };
     // speculative: the replay usually starts at entry 0 -- its record is fetched while the per-pixel loads are in flight
+#if defined(BWDP_STREAM)
+    const Cand spec_cur = fetch_stream(0);
+    const Entry spec_en1 = {0u, 0u};
+    asm volatile("" :: "s"(spec_cur.X));
+#else
     const Cand spec_cur = fetch_rec(fetch_entry(0));
     const Entry spec_en1 = fetch_entry(1);
-    asm volatile("" :: "s"(spec_cur.X), "s"(spec_en1.gid));   // (keeps the scalar loads here instead of at their first use)
+    asm volatile("" :: "s"(spec_cur.X), "s"(spec_en1.gid));
+#endif   // (keeps the scalar loads here instead of at their first use)
 
     const float T_final = inside ? a.final_T[pid] : 0.f;
     const float D_final = (inside && normalize_depth) ? a.final_D[pid] : 0.f;
@@ -277,8 +300,12 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     Cand cur = spec_cur;
     Entry en1 = spec_en1;
     if (cstart != 0) {   // (uniform) the deepest entries lie behind every pixel of the wave: start further in
+#if defined(BWDP_STREAM)
+        cur = fetch_stream(cstart);
+#else
         cur = fetch_rec(fetch_entry(cstart));
         en1 = fetch_entry(cstart + 1);
+#endif
     }
     // Per-candidate constants of a block for its geometric epilogue (lane = (chunk, candidate)): copied global -> LDS by the
     // DMA path (no VGPRs, nothing waits) one block ahead -- issued here for the first block, then at the end of every block
@@ -324,8 +351,12 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
 #endif
 #pragma unroll
         for (int k = 0; k < SB; k++) {
+#if defined(BWDP_STREAM)
+            const Cand nxt = fetch_stream(c0 + k + 1);
+#else
             const Cand nxt = fetch_rec(en1);
             en1 = fetch_entry(c0 + k + 2);
+#endif
             const float dx = cur.X - pxf, dy = cur.Y - pyf;
             if (k > 0) {
                 sP[(k - 1) * PS + lane] = hw; sP[(SB + k - 1) * PS + lane] = hv; sP[(2 * SB + k - 1) * PS + lane] = hu;

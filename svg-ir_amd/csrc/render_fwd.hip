@@ -126,6 +126,36 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
     if (t < 4) a.sub_total[4 * tile + t] = t == 0 ? run[0] : t == 1 ? run[1] : t == 2 ? run[2] : run[3];
 }
 
+// ---- (experiment builds, -DBWDP_STREAM) gather-free candidate stream ---------------------------------------------------------
+// One 24-float record per (sub-tile, candidate) pair at the position of its list entry: what the plain backward replays per
+// candidate {x y cxx cxy | cyy op depth DA | DB r g b | nx ny nz f0 | f1..f4 | slot gid . .}, so that the replay reads a
+// sequential stream (scalar loads with known addresses) instead of list entry -> record -> features gathers.
+template <int S>
+__global__ void __launch_bounds__(256) pair_stream_kernel(const RenderArgs a) {
+    const int tile = blockIdx.x;
+    const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+    const int len = (int)(r1 - r0);
+    if (len == 0) return;
+    const float4* __restrict__ rec4 = reinterpret_cast<const float4*>(a.rec);
+    for (int w = 0; w < 4; w++) {
+        const int n = (int)a.sub_total[4 * tile + w];
+        const size_t base = (size_t)4 * r0 + (size_t)w * len;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const uint2 e = a.sub_list[base + i];
+            const float4 q0 = rec4[(size_t)e.x * 6], q1 = rec4[(size_t)e.x * 6 + 1], q3 = rec4[(size_t)e.x * 6 + 3], q4 = rec4[(size_t)e.x * 6 + 4];
+            float f[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < S && ch < 5; ch++) f[ch] = a.features[(size_t)e.x * S + ch];
+            float4* o = reinterpret_cast<float4*>(a.pair_stream + (base + i) * 24);
+            o[0] = q0; o[1] = q1;
+            o[2] = q3;                                        // DB, r, g, b
+            o[3] = make_float4(q4.x, q4.y, q4.z, f[0]);       // view normal, f0
+            o[4] = make_float4(f[1], f[2], f[3], f[4]);
+            o[5] = make_float4(__builtin_bit_cast(float, e.y), __builtin_bit_cast(float, e.x), 0.f, 0.f);
+        }
+    }
+}
+
 // ---- blend --------------------------------------------------------------------------------------------------
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(StageGeom<S, VC>::WPE, StageGeom<S, VC>::WPE)))
@@ -557,6 +587,14 @@ void launch(const RenderArgs& a, hipStream_t s) {
 void launch_seg_build(const RenderArgs& a, hipStream_t s) {
     const int T = a.gx * a.gy;
     hipLaunchKernelGGL(seg_build_kernel, dim3((T + 255) / 256), dim3(256), 0, s, a, T);
+}
+
+void launch_pair_stream(const RenderArgs& a, hipStream_t s) {
+    if (!a.pair_stream || a.VS != 0) return;   // (the experiment covers the plain backward's widths)
+    if (a.S == 5) hipLaunchKernelGGL((pair_stream_kernel<5>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
+    else if (a.S == 3) hipLaunchKernelGGL((pair_stream_kernel<3>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
+    else if (a.S == 1) hipLaunchKernelGGL((pair_stream_kernel<1>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
+    else if (a.S == 0) hipLaunchKernelGGL((pair_stream_kernel<0>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
 }
 
 void launch_cull(const RenderArgs& a, hipStream_t s) {

@@ -46,6 +46,12 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
     return v;
 }
 
+__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of a quad, result in all 4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    return v;
+}
+
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 __global__ void __launch_bounds__(BLOCK) env_table_kernel(const float* __restrict__ env, float* __restrict__ tab, int n,
@@ -403,6 +409,229 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// forward, quad layout (round 4): lane = (surfel q = lane / 4 of the wave's 16 consecutive surfels, corner k = lane % 4).
+//
+// The one-wave-per-surfel kernel above pays its fixed costs 200 k times: every lane repeats the surfel's prologue (view vector,
+// lattice frame incl. a sincos, corner constants 16x redundantly), and every surfel ends in 7 wave reductions + 12 row reductions
+// + a strip epilogue -- PMC: 885 VALU instructions per surfel at Ns = 64, of which the corner x sample loop is ~6 % of the wave's
+// life.  Here a lane owns ONE (surfel, corner) for all of its samples:
+//   * corner constants and the 12 light sums (A_d, A_l, B_d, B_l per channel) live in the lane's registers: no cross-lane
+//     reduction for any of the 60 corner outputs;
+//   * the corner-independent part of a sample (direction from the lattice, |d|, half vector, Schlick term, env lookup with
+//     acos / atan2 and 12 gathers) is computed ONCE per sample: in every step of 4 samples lane k of the quad stages sample
+//     4 i + k, then the quad walks the four samples, each staged record (12 floats) broadcast from its lane with quad_perm DPP;
+//   * H is never formed: N.H = (N.L + N.V) / (2 |(L + V) / 2|) needs the scalar 1 / |(L + V) / 2| only;
+//   * the per-surfel light means are four partial sums per quad (two DPP adds), and the outputs of the wave's 16 surfels go through
+//     one LDS strip so that `reduced`, `features` and `vfeatures` -- contiguous over consecutive surfels -- leave as full rows.
+// ~400 instructions per surfel at Ns = 64 instead of 885; 16 surfels per wave keep 16 x (48 + 16) bytes of samples in flight per step.
+#ifndef SHADE_FQ_WPE
+#define SHADE_FQ_WPE 4
+#endif
+constexpr int FQ_SURF = 16;                      // surfels per wave
+constexpr int FQ_ROW = NRED + 2;                 // LDS floats per surfel: the 70 reduced outputs (+ pad: rows of a quad group on distinct banks)
+constexpr int FQ_IN = 28;                        // base_color[12] | normals[12] | roughness[4] of a surfel (for the packing)
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {   // value of lane (quad base + J) in all four lanes of the quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false));
+}
+
+struct FqSample { float d[3], il, ih, frac0, LgA[3], LlA[3]; };   // the staged, corner-independent part of one incident sample
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_FQ_WPE, SHADE_FQ_WPE))) shade_fwd_quad_kernel(const ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const svgir_shade_params& p = a.p;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int Ns = p.Ns;
+    float* sOut = smem + (size_t)wave * (FQ_SURF * (FQ_ROW + FQ_IN));
+    float* sIn = sOut + FQ_SURF * FQ_ROW;
+    const int q = lane >> 2, k = lane & 3;
+    const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * FQ_SURF;       // first surfel of the wave
+    if (g0 >= (size_t)p.P) return;
+    const int nsurf = (int)min((size_t)FQ_SURF, (size_t)p.P - g0);
+    const bool valid = q < nsurf;
+    const size_t gg = g0 + (valid ? q : 0);
+    const float inv_ns = 1.f / (float)Ns;
+
+    float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
+    {
+        const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+        V[0] *= iv; V[1] *= iv; V[2] *= iv;
+    }
+    GaussConst c;
+    {
+        const CornerIn ci = load_corner_in(p, gg, k);
+        corner_consts(ci, V, c);
+        if (a.vfeatures) {   // the quad holds exactly the surfel's 28 packing inputs
+            float* si = sIn + q * FQ_IN;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { si[j * 4 + k] = ci.base[j]; si[12 + k * 3 + j] = ci.n[j]; }
+            si[24 + k] = ci.r;
+        }
+    }
+    const bool lattice = !p.incident_dirs;
+    const bool has_off = p.lattice_offsets != nullptr;
+    LatticeFrame lf = {};
+    if (lattice) lf = lattice_frame(p.lattice_normals, p.lattice_offsets, gg);
+    const float4* ltab = reinterpret_cast<const float4*>(p.lattice_work);
+    float m[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // this lane's samples: local light (3), global light (3), visibility
+    float Ad[3] = {0, 0, 0}, Al[3] = {0, 0, 0}, Bd[3] = {0, 0, 0}, Bl[3] = {0, 0, 0};
+    const float omk = 1.f - c.kk, a2m1 = c.a2 - 1.f;
+
+    // raw inputs of the lane's sample of a step, fetched one step ahead
+    struct Raw { float d[3], rad[3], vis, area; };
+    auto load_raw_q = [&](int s) -> Raw {
+        Raw r;
+        const int sc = min(s, Ns - 1);
+        const size_t o = gg * (size_t)Ns + (size_t)sc;
+        if (!lattice) { r.d[0] = p.incident_dirs[o * 3]; r.d[1] = p.incident_dirs[o * 3 + 1]; r.d[2] = p.incident_dirs[o * 3 + 2]; }
+        else { r.d[0] = r.d[1] = r.d[2] = 0.f; }
+        r.rad[0] = p.radiance[o * 3]; r.rad[1] = p.radiance[o * 3 + 1]; r.rad[2] = p.radiance[o * 3 + 2];
+        r.vis = p.visibility[o];
+        r.area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
+        return r;
+    };
+    Raw raw = load_raw_q(k);
+    for (int s0 = 0; s0 < Ns; s0 += 4) {
+        const int s = s0 + k;
+        const bool act = s < Ns;
+        const Raw x = raw;
+        raw = load_raw_q(s + 4);
+        // ---- stage the lane's sample (stage_samples above, without the record) ----
+        FqSample f;
+        {
+            float d[3] = {x.d[0], x.d[1], x.d[2]};
+            if (lattice) lattice_dir(lf, ltab[min(s, Ns - 1)], min(s, Ns - 1), has_off, d);
+            const float il = fminf(__builtin_amdgcn_rsqf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+            const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
+            float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
+            const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+            const float VoH = fminf(1.f, fmaxf(1e-6f, (V[0] * H[0] + V[1] * H[1] + V[2] * H[2]) * ih));
+            f.frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+            EnvTap t;
+            float dl[3] = {d[0], d[1], d[2]};
+            if (p.env_transform) {
+                const float* mt = p.env_transform;
+#pragma unroll
+                for (int j = 0; j < 3; j++) dl[j] = mt[3 * j] * d[0] + mt[3 * j + 1] * d[1] + mt[3 * j + 2] * d[2];
+            }
+            env_taps(dl, p.env_h, p.env_w, t);
+            float E[3] = {0.f, 0.f, 0.f};
+            {   // 12 unconditional gathers (out-of-range taps: texel 0 with weight 0), one memory latency for all of them
+                float tex[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float* tp = p.env_work + (t.idx[j] >= 0 ? t.idx[j] : 0);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) tex[j][ch] = tp[ch];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float w = t.idx[j] >= 0 ? t.w[j] : 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) E[ch] += w * tex[j][ch];
+                }
+            }
+            const float area = act ? x.area : 0.f;   // samples beyond Ns (Ns not a multiple of 4) carry weight 0
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float Lg = fminf(64.f, fmaxf(0.f, E[ch] * p.env_scale)) * x.vis;
+                f.d[ch] = d[ch];
+                f.LgA[ch] = Lg * area; f.LlA[ch] = x.rad[ch] * area;
+                if (act) { m[ch] += x.rad[ch]; m[3 + ch] += Lg; }
+            }
+            if (act) m[6] += x.vis;
+            f.il = il; f.ih = ih;
+        }
+        // ---- the quad's four samples against this lane's corner ----
+        auto corner = [&](const FqSample& r) {
+            const float ndi = fmaxf(c.nraw[0] * r.d[0] + c.nraw[1] * r.d[1] + c.nraw[2] * r.d[2], 0.f);
+            const float nl = (c.Nh[0] * r.d[0] + c.Nh[1] * r.d[1] + c.Nh[2] * r.d[2]) * r.il;     // Nh . L
+            const float NoL = fminf(1.f, fmaxf(1e-6f, nl));
+            const float NoH = fminf(1.f, fmaxf(1e-6f, (nl + c.NoV_raw) * 0.5f * r.ih));           // Nh . H,  H = (L + V) / 2 * ih
+            const float nom0 = NoH * NoH * a2m1 + 1.f;
+            const float nom = fminf(4.f * kPi, fmaxf(1e-6f, 4.f * kPi * nom0 * nom0 * c.nom1 * (NoL * omk + c.kk)));
+            const float fs = r.frac0 * c.a2 * __builtin_amdgcn_rcpf(nom);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float td = r.LgA[ch] * ndi, tl = r.LlA[ch] * ndi;
+                Ad[ch] += td; Al[ch] += tl; Bd[ch] += fs * td; Bl[ch] += fs * tl;
+            }
+        };
+#define FQ_STEP(J)                                                                                                       \
+        {                                                                                                                \
+            FqSample r;                                                                                                  \
+            r.d[0] = quad_bcast<J>(f.d[0]); r.d[1] = quad_bcast<J>(f.d[1]); r.d[2] = quad_bcast<J>(f.d[2]);              \
+            r.il = quad_bcast<J>(f.il); r.ih = quad_bcast<J>(f.ih); r.frac0 = quad_bcast<J>(f.frac0);                    \
+            r.LgA[0] = quad_bcast<J>(f.LgA[0]); r.LgA[1] = quad_bcast<J>(f.LgA[1]); r.LgA[2] = quad_bcast<J>(f.LgA[2]);  \
+            r.LlA[0] = quad_bcast<J>(f.LlA[0]); r.LlA[1] = quad_bcast<J>(f.LlA[1]); r.LlA[2] = quad_bcast<J>(f.LlA[2]);  \
+            corner(r);                                                                                                   \
+        }
+        FQ_STEP(0) FQ_STEP(1) FQ_STEP(2) FQ_STEP(3)
+#undef FQ_STEP
+    }
+    // ---- per-surfel results into the wave's LDS strip ----
+    {
+        float* so = sOut + q * FQ_ROW;
+#pragma unroll
+        for (int i = 0; i < 7; i++) m[i] = quad_sum(m[i]);
+        if (k == 0) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float loc = m[ch] * inv_ns, glo = m[3 + ch] * inv_ns;
+                so[60 + ch] = loc + glo; so[63 + ch] = loc; so[66 + ch] = glo;
+            }
+            so[69] = m[6] * inv_ns;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float ad = Ad[ch], al = Al[ch], bd = Bd[ch], bl = Bl[ch];
+            const float v1 = ad + al, v2 = bd + bl, v3 = c.fd[ch] * ad + bd, v4 = c.fd[ch] * al + bl, v0 = v3 + v4;
+            so[0 + ch * 4 + k] = v0 * inv_ns; so[12 + ch * 4 + k] = v1 * inv_ns; so[24 + ch * 4 + k] = v2 * inv_ns;
+            so[36 + ch * 4 + k] = v3 * inv_ns; so[48 + ch * 4 + k] = v4 * inv_ns;
+        }
+    }
+    wave_lds_sync();
+    // ---- epilogue: the rows of the wave's surfels are contiguous in every output: consecutive lanes write consecutive floats ----
+    if (a.reduced) {
+        float* out = a.reduced + g0 * NRED;
+        for (int i = lane; i < nsurf * NRED; i += 64) { const int qq = i / NRED, e = i - qq * NRED; out[i] = sOut[qq * FQ_ROW + e]; }
+    }
+    if (a.features) {
+        if (p.training) {
+            if (lane < nsurf * 4) { const int qq = lane >> 2, e = lane & 3; a.features[g0 * 4 + lane] = sOut[qq * FQ_ROW + (e == 0 ? 69 : 63 + (e - 1))]; }
+        } else {
+            for (int i = lane; i < nsurf * 7; i += 64) {
+                const int qq = i / 7, e = i - qq * 7;
+                a.features[g0 * 7 + i] = sOut[qq * FQ_ROW + (e < 3 ? 60 + e : (e < 6 ? 63 + (e - 3) : 69))];
+            }
+        }
+    }
+    if (a.vfeatures) {
+        auto pack = [&](int qq, int e, bool training) -> float {
+            const float* so = sOut + qq * FQ_ROW;
+            const float* si = sIn + qq * FQ_IN;
+            if (e < 12) return so[e];
+            if (e < 24) return si[e - 12];
+            if (e < 36) {
+                const int ee = e - 24, ch = ee >> 2, kc = ee & 3;  // channel*4 + corner
+                const float* n = si + 12 + kc * 3;
+                return n[0] * p.viewmatrix[0 * 4 + ch] + n[1] * p.viewmatrix[1 * 4 + ch] + n[2] * p.viewmatrix[2 * 4 + ch];
+            }
+            if (e < 40) return si[24 + (e - 36)];
+            if (e < 52) return training ? so[12 + (e - 40)] : so[36 + (e - 40)];
+            return so[48 + (e - 52)];
+        };
+        if (p.training) {
+            float* out = a.vfeatures + g0 * 52;
+            for (int i = lane; i < nsurf * 52; i += 64) { const int qq = i / 52; out[i] = pack(qq, i - qq * 52, true); }
+        } else {
+            float* out = a.vfeatures + g0 * 64;
+            for (int i = lane; i < nsurf * 64; i += 64) out[i] = pack(i >> 6, i & 63, false);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------
 struct ShadeBwdArgs {
@@ -490,11 +719,6 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     for (int i = 0; i < BREC / 4; i++) o[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
 }
 
-__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of a quad, result in all 4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    return v;
-}
 // sum over the 16 lanes of the wave that share (lane & 3); result in all of them
 __device__ __forceinline__ float stride4_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
@@ -844,8 +1068,22 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     stage_mark(tm, "shade_env_table");
     ShadeArgs a;
     a.p = *p; a.reduced = reduced; a.features = features; a.vfeatures = vfeatures;
-    const size_t lds = (size_t)4 * (64 * SREC + 80 + 32) * 4;
-    hipLaunchKernelGGL(shade_fwd_kernel, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
+#ifndef SHADE_FWD_QUAD
+#define SHADE_FWD_QUAD 1
+#endif
+#ifndef SHADE_FWD_QUAD_MAX_NS
+#define SHADE_FWD_QUAD_MAX_NS 128
+#endif
+    // The quad layout removes the per-surfel fixed costs (250 -> 202 us at P = 200 k, Ns = 64); with hundreds of samples per surfel
+    // those are amortised anyway and the one-wave-per-surfel kernel streams the samples better (lane = sample: 768 contiguous bytes
+    // per load; 771 us against 1 001 us at Ns = 384)
+    if (SHADE_FWD_QUAD && p->Ns <= SHADE_FWD_QUAD_MAX_NS) {
+        const size_t lds = (size_t)4 * FQ_SURF * (FQ_ROW + FQ_IN) * 4;
+        hipLaunchKernelGGL(shade_fwd_quad_kernel, dim3((p->P + 4 * FQ_SURF - 1) / (4 * FQ_SURF)), dim3(BLOCK), lds, s, a);
+    } else {
+        const size_t lds = (size_t)4 * (64 * SREC + 80 + 32) * 4;
+        hipLaunchKernelGGL(shade_fwd_kernel, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
+    }
     stage_mark(tm, "shade_fwd");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }

@@ -173,6 +173,10 @@ CONFIGS = {
     "cfg4": (surface_scene, dict(P=300000, W=800, H=800, seed=3, sh_degree=3, variant="svgss", S=7, VS=64, bg=1.0)),
     "cfg5": (surface_scene, dict(P=2000000, W=1600, H=1600, seed=4, sh_degree=3, variant="svgss", S=7, VS=64, bg=1.0,
                                  scale_lo=0.002, scale_hi=0.012)),
+    # the same 2 M-surfel stress scene at the generator's default surfel scales (0.004-0.03, as in cfg2-cfg4): ~4x the instances
+    # (R = 18.3 M), the size SURVEY 8(a) a1 budgets the state blobs for -- the configuration where the composite kernels are nearest
+    # to the HBM roof
+    "cfg5_dense": (surface_scene, dict(P=2000000, W=1600, H=1600, seed=4, sh_degree=3, variant="svgss", S=7, VS=64, bg=1.0)),
 }
 
 

@@ -13,17 +13,32 @@ import torch
 import torch.distributed as dist
 
 
+# With one rank nothing needs exchanging and every helper below returns at once.  SVGIR_VP_FORCE_COLLECTIVES=1 makes a one-rank
+# job create its process group and issue the collectives anyway: tests/test_gpu_view_parallel.py runs the whole driver on ONE
+# real GPU with backend "nccl" (RCCL init, device binding, broadcast / all_gather_into_tensor on HIP tensors, async work handles),
+# so that the first multi-GPU run is not also the first RCCL run.
+FORCE = os.environ.get("SVGIR_VP_FORCE_COLLECTIVES", "") not in ("", "0")
+
+
+def _collective():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":   # one process per GPU: bind the device BEFORE the communicator is created
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -34,7 +49,7 @@ def shard_views(num_views, rank, world):
 
 def broadcast_scene(tensors, src=0):
     """One-time replication of the per-Gaussian arrays (dict name -> tensor), in place."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return tensors
     for k in sorted(tensors):
         if torch.is_tensor(tensors[k]):
@@ -44,7 +59,7 @@ def broadcast_scene(tensors, src=0):
 
 def gather_metrics(vec):
     """vec: 1-D fp32 tensor of k per-rank scalars -> [world, k] on every rank with ONE all_gather."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return vec.reshape(1, -1).clone()
     world = dist.get_world_size()
     out = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
@@ -59,6 +74,7 @@ class MetricsGatherer:
 
     def __init__(self, k, device, dtype=torch.float32):
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.collective = _collective()
         self.k = k
         self.bufs = [torch.zeros(self.world * k, dtype=dtype, device=device) for _ in range(2)]
         self.src = [torch.zeros(k, dtype=dtype, device=device) for _ in range(2)]
@@ -71,7 +87,7 @@ class MetricsGatherer:
         if self.pending[i] is not None:          # the gather issued two steps ago used this slot
             self.pending[i].wait()
             self.pending[i] = None
-        if self.world == 1:       # nothing to exchange: the table is the vector itself
+        if not self.collective:       # nothing to exchange: the table is the vector itself
             self.bufs[i] = vec.reshape(-1)
         else:
             self.src[i].copy_(vec.reshape(-1))
@@ -98,7 +114,7 @@ class MetricsGatherer:
 def gather_rows(vec):
     """[world, k] table of every rank's 1-D `vec` (blocking; one all_gather)."""
     vec = vec.reshape(-1)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return vec[None, :].clone()
     out = torch.empty(dist.get_world_size() * vec.numel(), dtype=vec.dtype, device=vec.device)
     dist.all_gather_into_tensor(out, vec.contiguous())
@@ -106,7 +122,7 @@ def gather_rows(vec):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         dist.barrier()
 
 
