@@ -401,9 +401,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         if (launch_render_fwd(ra, svgss, s) < 0) launch_render_fwd_generic(ra, svgss, s);   // run-time-width kernels
         if (int rc = check("render")) return rc;
         if (timed) tm.mark("render");
-        launch_seg_build(ra, s);
-        if (int rc = check("segment list")) return rc;
-        if (timed) tm.mark("seg_build");
+        // (the list of live backward segments is built by svgir_backward, next to its clears: a forward-only call never pays for it)
         return 0;
     };
 
@@ -511,11 +509,15 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes() = %zu",
                     scratch ? scratch_bytes : (size_t)0, need);
     const bool rows = ba.VS > 0 && !generic;
-    // The dL_d* outputs start from zero (the kernels write the visible Gaussians only).  The specialised composite
-    // backward does not touch them (it accumulates in the scratch), so the clear runs on a side stream next to it and
-    // is joined before the per-Gaussian kernels; the run-time-width composite adds into them, so there the clear comes first.
-    // (scope guard: every exit path -- including the error returns below -- joins the side-stream clear with the caller's
-    // stream and releases the event)
+    // Clears:
+    //   1. the backward scratch (gradient-row validity bytes / packed rows), needed by the composite backward: it rides on the launch
+    //      that builds the list of live segments (one kernel in front of the composite instead of a memset + that kernel);
+    //   2. the dL_d* outputs, which start from zero (the kernels write the visible Gaussians only): the specialised composite
+    //      backward does not touch them (it accumulates in the scratch), so this clear runs on a side stream next to it and is joined
+    //      before the per-Gaussian kernels; the run-time-width composite adds into them, so there the clear comes first, on the
+    //      caller's stream.
+    // (scope guard: every exit path -- including the error returns below -- joins the side stream with the caller's stream and
+    // releases the event)
     struct ClearJoin {
         hipStream_t s; hipEvent_t ev = nullptr;
         void join() {
@@ -523,7 +525,6 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         }
         ~ClearJoin() { join(); }
     } cleared{s};
-    hipEvent_t& ev_cleared = cleared.ev;
     {
         hipStream_t cs = generic ? s : side_stream(s);
         if (!cs) cs = s;
@@ -548,28 +549,41 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
                 if (e.p && e.n) HIP_OK(hipMemsetAsync(e.p, 0, e.n, cs));
         }
         if (cs != s) {
-            HIP_OK(hipEventCreateWithFlags(&ev_cleared, hipEventDisableTiming));
-            HIP_OK(hipEventRecord(ev_cleared, cs));
+            HIP_OK(hipEventCreateWithFlags(&cleared.ev, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(cleared.ev, cs));
         }
     }
-    auto join_clear = [&]() { cleared.join(); };
     const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
     ba.grad_rows = generic ? nullptr : (float*)scratch;
     ba.row_flags = nullptr;
-    if (generic) {
-    } else if (rows) {
-        ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
-        if (R > 0) HIP_OK(hipMemsetAsync(ba.row_flags, 0, (size_t)4 * cap, s));
-    } else {
-        HIP_OK(hipMemsetAsync(ba.grad_rows, 0, (size_t)P * rg.RS * 4, s));
+    void* sc_clear = nullptr;
+    size_t sc_bytes = 0;
+    if (!generic) {
+        if (rows) {
+            ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
+            sc_clear = ba.row_flags; sc_bytes = align_up((size_t)4 * cap);
+        } else {
+            sc_clear = ba.grad_rows; sc_bytes = align_up((size_t)P * rg.RS * 4);
+        }
     }
-    tm.mark("bwd_clear");   // scratch / validity clears and the side-stream fork: the composite's own mark brackets the kernel only
+    if (R > 0) {
+        // live backward segments, longest first (common.hpp SEG), from the forward's per-sub-tile counts: built here -- a forward-only
+        // call never pays for it -- together with the scratch clear
+        RenderArgs sa{};
+        sa.W = W; sa.H = H; sa.gx = gx; sa.gy = gy; sa.S = p->S; sa.VS = ba.VS;
+        sa.ranges = I.ranges; sa.sub_count = I.sub_count; sa.sub_ndump = I.sub_ndump; sa.seg_list = B.seg_list; sa.seg_desc = B.seg_desc;
+        sa.seg_count = I.counters; sa.seg_block = I.seg_block;
+        launch_seg_build(sa, sc_clear, sc_bytes, s);
+    } else if (sc_clear && !rows) {
+        HIP_OK(hipMemsetAsync(sc_clear, 0, sc_bytes, s));   // (nothing rendered: geom_bwd still unpacks the -- zero -- packed rows)
+    }
+    tm.mark("seg_build");
     if (R > 0) {
         if (generic) launch_render_bwd_generic(ba, svgss, s);
         else (void)launch_render_bwd(ba, svgss, s);
     }
     tm.mark("render_bwd");
-    join_clear();
+    cleared.join();
     if (R > 0 && rows) {
         GradReduceArgs ra;
         ra.P = P; ra.S = p->S; ra.VS = ba.VS; ra.radii = radii; ra.tiles = G.tiles; ra.rec = G.rec;

@@ -347,8 +347,9 @@ void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
-// tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump
-void launch_seg_build(const RenderArgs& a, hipStream_t s);
+// tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump; also zeroes
+// `clear_bytes` bytes at `clear` (a multiple of 16; the backward's scratch clear rides on this launch)
+void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, hipStream_t s);
 // (experiment builds, -DBWDP_STREAM) gather-free candidate stream: one 24-float record per (sub-tile, candidate) pair, in list order
 void launch_pair_stream(const RenderArgs& a, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 (nothing launched) if (S,VS) has no specialised kernel

@@ -44,6 +44,7 @@ struct PbgiLayout {
     uint32_t* parent;       // [2P-1]
     uint32_t* arrive;       // [P-1]
     float4* rec;            // [P][6] leaf records (sorted order), filled per trace call
+    unsigned long long* queue;   // [1] next ray of the launch that no wave has claimed yet (reset per trace call)
     size_t bytes;
 };
 PbgiLayout pbgi_layout(char* base, int P) {
@@ -61,6 +62,7 @@ PbgiLayout pbgi_layout(char* base, int P) {
     b.parent = (uint32_t*)take(2 * p * 4);
     b.arrive = (uint32_t*)take(p * 4);
     b.rec = (float4*)take(p * 96);
+    b.queue = (unsigned long long*)take(64);
     b.bytes = off;
     return b;
 }
@@ -206,6 +208,8 @@ __global__ void __launch_bounds__(BLOCK) pbgi_export_kernel(int P, const PbgiNod
     if (sorted && i < P) { sorted[2 * i] = (int32_t)code[i]; sorted[2 * i + 1] = (int32_t)prim[i]; }
 }
 
+__global__ void pbgi_queue_init_kernel(unsigned long long* queue, unsigned long long first) { queue[0] = first; }
+
 // ---- leaf records (per trace call: the reference reads these tensors at every visited leaf) --------------------------------
 // {c.xyz, sx} {sy, opacity, nw.xy} {nw.z, i00 i01 i02} {i10 i11 i12, n.x} {n.yz, ci0 ci1} {ci2 .. ci5}
 __global__ void __launch_bounds__(BLOCK) pbgi_leaf_rec_kernel(int P, const uint32_t* __restrict__ prim, const float* __restrict__ centers,
@@ -277,7 +281,10 @@ __device__ __forceinline__ bool box_hit(const float4 q0, const float4 q1, F3 o, 
 
 constexpr int PBGI_STACK = 64;        // the reference's MAX_STACK_SIZE; the tree is at most 30 + 32 - clz(P) + 1 < 63 levels deep (30-bit
                                       // codes, equal codes split by position), and the stack holds at most one pending sibling per level
-constexpr int PBGI_LDS_DEPTH = 32;    // stack levels kept in LDS ([level][lane]: conflict-free whatever the lanes' depths); deeper ones in scratch
+#ifndef PBGI_LDS_DEPTH_V
+#define PBGI_LDS_DEPTH_V 24
+#endif
+constexpr int PBGI_LDS_DEPTH = PBGI_LDS_DEPTH_V;   // (32 / 24 / 16 levels in LDS = 10 / 13 / 16 waves per CU: 1 017 / 963 / 1 023 ms on the cfg3 geometry, 1 735 / 1 392 / 1 238 ms on the shell scene)    // stack levels kept in LDS ([level][lane]: conflict-free whatever the lanes' depths); deeper ones in scratch
 constexpr int PBGI_WAVE = 64;         // one wave per workgroup
 constexpr int PBGI_MAX_HITS = 4096;   // guard of the ray loop (every accepted hit removes >= 1/255 of the transmittance: < 1800 hits)
 
@@ -351,12 +358,15 @@ __device__ __forceinline__ void eval_sh3(const float* __restrict__ sh, F3 dir, f
 //     (measured: 3.5 s for 12.8 M rays, SIMD lanes ~10 % busy).  Here a wave owns a POOL of consecutive rays; a lane whose traversal
 //     ends finishes its query (shading update, next query or outputs) and pulls the next ray of the pool at once, while the other
 //     lanes keep walking: one loop, one traversal step per iteration, per-lane state.
-__global__ void __launch_bounds__(PBGI_WAVE) pbgi_trace_kernel(int P, const PbgiNode* __restrict__ node, const float4* __restrict__ pair, const float4* __restrict__ rec,
+#ifndef PBGI_WPE
+#define PBGI_WPE 3
+#endif
+__global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(PBGI_WPE, 8))) pbgi_trace_kernel(int P, const PbgiNode* __restrict__ node, const float4* __restrict__ pair, const float4* __restrict__ rec,
                                                                const uint32_t* __restrict__ prim, int N, int S, const float* __restrict__ ray_o,
                                                                const float* __restrict__ ray_d, const float* __restrict__ centers,
                                                                const float* __restrict__ shs, float* __restrict__ radiance,
                                                                float* __restrict__ visibility, int32_t* __restrict__ hit_indices, float* __restrict__ uvs,
-                                                               int pool) {
+                                                               int chunk, unsigned long long* __restrict__ queue) {
 #pragma clang fp contract(off)
     __shared__ int s_ids[PBGI_LDS_DEPTH * PBGI_WAVE];
     __shared__ float s_ens[PBGI_LDS_DEPTH * PBGI_WAVE];
@@ -364,8 +374,10 @@ __global__ void __launch_bounds__(PBGI_WAVE) pbgi_trace_kernel(int P, const Pbgi
     int* s_id = s_ids + lane;
     float* s_en = s_ens + lane;
     const long long total = (long long)N * S;
-    long long next_ray = (long long)blockIdx.x * pool;                 // wave-uniform: first ray of the pool not handed out yet
-    const long long pool_end = min(total, next_ray + (long long)pool);
+    // wave-uniform: the wave's current chunk of consecutive rays [next_ray, pool_end); further chunks come from the launch-wide queue
+    long long next_ray = (long long)blockIdx.x * chunk;
+    long long pool_end = min(total, next_ray + (long long)chunk);
+    bool drained = false;   // the launch-wide queue is empty
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const float t_max = 0.2f;
     const int L = P - 1;
@@ -438,8 +450,16 @@ __global__ void __launch_bounds__(PBGI_WAVE) pbgi_trace_kernel(int P, const Pbgi
                     have_ray = false;
                 }
             }
-            {   // lanes without a ray take the next rays of the pool, in lane order
+            {   // lanes without a ray take the next rays of the wave's chunk, in lane order; an empty chunk is replaced from the queue
                 const bool want = !walking && !have_ray;
+                if (next_ray >= pool_end && !drained && __any(want)) {
+                    unsigned long long got = 0;
+                    if (lane == 0) got = atomicAdd(queue, (unsigned long long)chunk);
+                    got = (unsigned long long)__shfl((long long)got, 0);
+                    next_ray = (long long)got;
+                    pool_end = min(total, next_ray + (long long)chunk);
+                    drained = next_ray >= total;
+                }
                 const unsigned long long m = __ballot(want);
                 const long long mine = next_ray + (long long)__popcll(m & lt_mask);
                 next_ray += (long long)__popcll(m);
@@ -639,15 +659,17 @@ int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const 
     hipLaunchKernelGGL(pbgi_leaf_rec_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, B.val[fin], centers, scales, rotations, normals,
                        opacity, cov3D_inverse, B.rec);
     const long long rays = (long long)N * S;
-    // a wave owns a pool of consecutive rays (whole rows: the rays of a row share their origin).  Measured on the cfg3 geometry
-    // (4.27 M rays per launch) and the shell scene (12.8 M): 256 / 1 024 / 4 096 / 16 384 rays per wave = 2 129 / 1 329 / 1 534 / 4 249 ms
-    // and 2 429 / 2 154 / 2 822 / 5 639 ms -- small pools end with 63 lanes waiting for one long ray, large ones leave wave slots empty
-    long long pool = std::max<long long>(S, (1024 + S - 1) / S * S);
-    pool = std::min<long long>(pool, std::max<long long>(S, (rays / 2560 + S - 1) / S * S));   // (small launches: at least one wave per slot)
-    if (const char* e = getenv("SVGIR_PBGI_POOL")) { const long long v = atoll(e); if (v > 0) pool = (v + S - 1) / S * S; }   // (tuning experiments)
-    const long long nw = (rays + pool - 1) / pool;
+    // Persistent waves (one per resident slot: 16 KB of LDS each, 10 per CU) take chunks of consecutive rays (whole rows: the rays of a row
+    // share their origin) from a launch-wide queue, so no wave slot idles while rays are left and the end of the launch is one ray deep.
+    // (Static pools, measured on the cfg3 geometry, 4.27 M rays per launch: 256 / 1 024 / 4 096 / 16 384 rays per wave = 2 129 / 1 329 /
+    // 1 534 / 4 249 ms -- small pools end with 63 lanes waiting for one long ray, large ones leave wave slots empty.)
+    long long chunk = std::max<long long>(S, (64 + S - 1) / S * S);   // (64 / 256 / 1 024 rays per chunk: 1 005 / 1 046 / 1 178 ms on the cfg3 geometry)
+    if (const char* e = getenv("SVGIR_PBGI_POOL")) { const long long v = atoll(e); if (v > 0) chunk = (v + S - 1) / S * S; }   // (tuning experiments)
+    const long long nw = std::min<long long>((rays + chunk - 1) / chunk, 256ll * std::min(8 * 4, (160 * 1024) / (PBGI_LDS_DEPTH * PBGI_WAVE * 8)));   // one wave per resident slot
+    const unsigned long long first = (unsigned long long)(nw * chunk);   // the chunks [0, nw) belong to the waves from the start
+    hipLaunchKernelGGL(pbgi_queue_init_kernel, dim3(1), dim3(1), 0, s, B.queue, first);
     hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)nw), dim3(PBGI_WAVE), 0, s, P, B.node, B.pair, B.rec, B.val[fin], N, S, ray_o,
-                       ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)pool);
+                       ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)chunk, B.queue);
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 

@@ -484,7 +484,11 @@ render_fwd_kernel(const RenderArgs a) {
 // `ndump` states has min(ceil(count / SEG), ndump + 1) live segments: all full but possibly the last.  The forward has
 // already summed them per workgroup and length class (seg_block), so every workgroup derives its own bases, scans its 256
 // tiles and writes ids + descriptors: class-major, tile order inside a class.  Deterministic.
-__global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int T) {
+__global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int T, int nblk, uint4* __restrict__ clear, size_t clear_n16) {
+    // piggy-backed: the backward's scratch clear (validity bytes / packed gradient rows), grid-stride over all workgroups -- one
+    // launch in front of the composite backward instead of a memset + this kernel
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < clear_n16; i += (size_t)gridDim.x * 256) clear[i] = make_uint4(0u, 0u, 0u, 0u);
+    if ((int)blockIdx.x >= nblk) return;   // (workgroups beyond the tile blocks only clear)
     __shared__ uint32_t red_b[SEG_CLASSES][4], red_t[SEG_CLASSES][4], wfull[4];
     __shared__ unsigned long long wpart[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -493,7 +497,7 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
     uint32_t bef[SEG_CLASSES], tot[SEG_CLASSES];
 #pragma unroll
     for (int c = 0; c < SEG_CLASSES; c++) bef[c] = tot[c] = 0u;
-    for (int j = t; j < (int)gridDim.x; j += 256) {
+    for (int j = t; j < nblk; j += 256) {
 #pragma unroll
         for (int c = 0; c < SEG_CLASSES; c++) {
             const uint32_t v = a.seg_block[j * SEG_BLOCK_STRIDE + c];
@@ -584,9 +588,11 @@ void launch(const RenderArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void launch_seg_build(const RenderArgs& a, hipStream_t s) {
-    const int T = a.gx * a.gy;
-    hipLaunchKernelGGL(seg_build_kernel, dim3((T + 255) / 256), dim3(256), 0, s, a, T);
+void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, hipStream_t s) {
+    const int T = a.gx * a.gy, nblk = (T + 255) / 256;
+    const size_t n16 = clear ? (clear_bytes + 15) / 16 : 0;   // (the scratch regions are 256-byte aligned and padded: common.hpp align_up)
+    const int grid = (int)std::max<size_t>((size_t)nblk, std::min<size_t>((n16 + 255) / 256, 2048));
+    hipLaunchKernelGGL(seg_build_kernel, dim3(grid), dim3(256), 0, s, a, T, nblk, (uint4*)clear, n16);
 }
 
 void launch_pair_stream(const RenderArgs& a, hipStream_t s) {
