@@ -202,7 +202,7 @@ int svgir_mark_visible(int32_t variant, int32_t P, const float* means3D, const f
  * space), viewdirs [P,3], radiance / incident_dirs [P,Ns,3], visibility / incident_areas [P,Ns,1],
  * env [env_h, env_w, 3].  The looked-up light is env_scale * bilinear(f(env)) with f = softplus when
  * env_softplus != 0 (DirectLightMap: softplus, scale 2) or identity (EnvLight: scale 1), clamped to [0, 64].
- * `env_work` is a caller-provided scratch of env_h*env_w*3 floats (holds f(env)).
+ * `env_work` is a caller-provided, 16-byte aligned scratch of env_h*env_w*4 floats (holds f(env) as one float4 per texel).
  *
  * reduced [P,70]: pbr[12] diffuse_light[12] specular[12] direct[12] indirect[12] mean_incident[3] mean_local[3]
  *                 mean_global[3] mean_visibility[1]   (means over the Ns samples, like `.mean(-2)` in svgss.py)

@@ -27,4 +27,13 @@ for W in cfg2 cfg3_train cfg5 train_step tracers; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$W -o p -- python3 $R/bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --no-concurrent --workload $W > $R/gpurun_out/${TAG}_prof_$W.log 2>&1)
   DB=$(find gpurun_out/${TAG}_prof_$W -name "*.db" | head -1)
   python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_${W}_kernel_stats.txt "python3 bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-shaded --no-concurrent --workload $W" | head -30
+  rm -rf gpurun_out/${TAG}_prof_$W   # (the summary is what is kept: gpurun_out/ travels back only while it is below 64 MiB)
 done
+# tracers: traversal statistics (dev build, if present) and SQ counters of the two trace kernels
+if [ -f build/variants/dev/libsvgir_raster.so ]; then
+  SVGIR_RASTER_LIB=$PWD/build/variants/dev/libsvgir_raster.so timeout 900 python scripts/tracer_cfg3_probe.py 200000 shell > gpurun_out/${TAG}_tracer_stats.txt 2>&1
+  tail -12 gpurun_out/${TAG}_tracer_stats.txt
+fi
+bash scripts/pmc_tracer.sh ${TAG}_pmct > gpurun_out/${TAG}_tracer_pmc.txt 2>&1; tail -6 gpurun_out/${TAG}_tracer_pmc.txt
+rm -rf gpurun_out/${TAG}_pmct_a gpurun_out/${TAG}_pmct_b gpurun_out/${TAG}_*_rd gpurun_out/${TAG}_*_wr gpurun_out/${TAG}_*_iss
+python scripts/parity_report.py r04 cfg1 cfg2 cfg3_train cfg3_eval cfg4 cfg5 cfg5_dense > gpurun_out/${TAG}_parity.log 2>&1; tail -30 gpurun_out/${TAG}_parity.log

@@ -14,14 +14,14 @@ import parity_util as pu
 from oracle import oracle as orc
 from svgir_harness import runner, scenes
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 cfgs = sys.argv[2:] or ["cfg1", "cfg2", "cfg3_train", "cfg3_eval", "cfg4", "cfg5"]
 dev = torch.device("cuda:0")
 rep = {}
 for cfg in cfgs:
     variant = scenes.CONFIGS[cfg][1]["variant"]
     sc = scenes.make(cfg)
-    train = cfg in ("cfg2", "cfg3_train", "cfg4", "cfg5")
+    train = cfg in ("cfg2", "cfg3_train", "cfg4", "cfg5", "cfg5_dense")
     grads = scenes.upstream_grads(sc, variant) if train else None
     sct = runner.to_torch(sc, dev)
     t0 = time.time()

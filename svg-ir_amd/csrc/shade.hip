@@ -54,10 +54,13 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-__global__ void __launch_bounds__(BLOCK) env_table_kernel(const float* __restrict__ env, float* __restrict__ tab, int n,
+// f(env) as one float4 per texel {f(r), f(g), f(b), 0}: a bilinear tap is ONE 16-byte gather instead of three dwords
+__global__ void __launch_bounds__(BLOCK) env_table_kernel(const float* __restrict__ env, float4* __restrict__ tab, int ntexel,
                                                           int softplus) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) tab[i] = softplus ? softplus_f(env[i]) : env[i];
+    if (i >= ntexel) return;
+    const float r = env[3 * i], g = env[3 * i + 1], b = env[3 * i + 2];
+    tab[i] = softplus ? make_float4(softplus_f(r), softplus_f(g), softplus_f(b), 0.f) : make_float4(r, g, b, 0.f);
 }
 
 // Lat-long bilinear lookup (grid_sample, align_corners=True, zero padding) of direction d.
@@ -76,7 +79,7 @@ __device__ __forceinline__ void env_taps(const float* d, int He, int We, EnvTap&
     for (int j = 0; j < 4; j++) {
         const int xi = x0 + (j & 1), yi = y0 + (j >> 1);
         const bool ok = xi >= 0 && xi < We && yi >= 0 && yi < He;
-        t.idx[j] = ok ? (yi * We + xi) * 3 : -1;
+        t.idx[j] = ok ? yi * We + xi : -1;   // texel index (the table holds one float4 per texel)
         t.w[j] = ((j & 1) ? fx : 1.f - fx) * ((j >> 1) ? fy : 1.f - fy);
     }
 }
@@ -254,7 +257,7 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
         H[0] *= ih; H[1] *= ih; H[2] *= ih;
         const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
-        const float frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+        const float frac0 = 0.04f + (1.f - 0.04f) * __builtin_amdgcn_exp2f((-5.55473f * VoH - 6.98316f) * VoH);
         EnvTap t;
         float dl[3] = {d[0], d[1], d[2]};
         if (p.env_transform) {
@@ -268,9 +271,8 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
             float tex[4][3];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float* tp = p.env_work + (t.idx[j] >= 0 ? t.idx[j] : 0);
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) tex[j][ch] = tp[ch];
+                const float4 tq = reinterpret_cast<const float4*>(p.env_work)[t.idx[j] >= 0 ? t.idx[j] : 0];
+                tex[j][0] = tq.x; tex[j][1] = tq.y; tex[j][2] = tq.z;
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -506,7 +508,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
             float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
             const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
             const float VoH = fminf(1.f, fmaxf(1e-6f, (V[0] * H[0] + V[1] * H[1] + V[2] * H[2]) * ih));
-            f.frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+            f.frac0 = 0.04f + (1.f - 0.04f) * __builtin_amdgcn_exp2f((-5.55473f * VoH - 6.98316f) * VoH);
             EnvTap t;
             float dl[3] = {d[0], d[1], d[2]};
             if (p.env_transform) {
@@ -520,9 +522,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
                 float tex[4][3];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float* tp = p.env_work + (t.idx[j] >= 0 ? t.idx[j] : 0);
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) tex[j][ch] = tp[ch];
+                    const float4 tq = reinterpret_cast<const float4*>(p.env_work)[t.idx[j] >= 0 ? t.idx[j] : 0];
+                    tex[j][0] = tq.x; tex[j][1] = tq.y; tex[j][2] = tq.z;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -665,7 +666,7 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
     H[0] *= ih; H[1] *= ih; H[2] *= ih;
     const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
-    const float frac0 = 0.04f + (1.f - 0.04f) * exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+    const float frac0 = 0.04f + (1.f - 0.04f) * __builtin_amdgcn_exp2f((-5.55473f * VoH - 6.98316f) * VoH);
     // bilinear footprint (same arithmetic as env_taps)
     const int He = p.env_h, We = p.env_w;
     float dl[3] = {d[0], d[1], d[2]};
@@ -691,9 +692,8 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
             const int xi = x0 + (j & 1), yi = y0 + (j >> 1);
             const bool ok = xi >= 0 && xi < We && yi >= 0 && yi < He;
             tw[j] = ok ? ((j & 1) ? fx : 1.f - fx) * ((j >> 1) ? fy : 1.f - fy) : 0.f;
-            const float* t = p.env_work + (ok ? (yi * We + xi) * 3 : 0);
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) tex[j][ch] = t[ch];
+            const float4 tq = reinterpret_cast<const float4*>(p.env_work)[ok ? yi * We + xi : 0];
+            tex[j][0] = tq.x; tex[j][1] = tq.y; tex[j][2] = tq.z;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1063,7 +1063,7 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     StageMarks tm = stage_begin(s);
     if (!p->incident_dirs)
         hipLaunchKernelGGL(lattice_table_kernel, dim3((p->Ns + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->Ns, (float4*)p->lattice_work);
-    hipLaunchKernelGGL(env_table_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, p->env_work, ntex,
+    hipLaunchKernelGGL(env_table_kernel, dim3((ntex / 3 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, (float4*)p->env_work, ntex / 3,
                        p->env_softplus);
     stage_mark(tm, "shade_env_table");
     ShadeArgs a;
@@ -1103,7 +1103,7 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     StageMarks tm = stage_begin(s);
     if (!p->incident_dirs)
         hipLaunchKernelGGL(lattice_table_kernel, dim3((p->Ns + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->Ns, (float4*)p->lattice_work);
-    hipLaunchKernelGGL(env_table_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, p->env_work, ntex,
+    hipLaunchKernelGGL(env_table_kernel, dim3((ntex / 3 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, (float4*)p->env_work, ntex / 3,
                        p->env_softplus);
     if (hipMemsetAsync(env_grad_work, 0, (size_t)ntex * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
     ShadeBwdArgs a;

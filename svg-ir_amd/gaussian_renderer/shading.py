@@ -100,7 +100,7 @@ def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs
     bc, ro, nr, vd, ra, vi, di, ar, en, vm, et = keep
     P, Ns = ra.shape[0], ra.shape[1]
     env_h, env_w = en.shape[-3], en.shape[-2]
-    work = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+    work = torch.empty(env_h * env_w * 4, dtype=torch.float32, device=dev)   # f(env), one float4 per texel
     p = ShadeParams()
     p.P, p.Ns, p.env_h, p.env_w = P, Ns, env_h, env_w
     p.env_softplus, p.training, p.env_scale = int(bool(softplus)), int(bool(training)), float(scale)
