@@ -45,6 +45,8 @@ struct PbgiLayout {
     uint32_t* arrive;       // [P-1]
     float4* rec;            // [P][6] leaf records (sorted order), filled per trace call
     unsigned long long* queue;   // [1] next ray of the launch that no wave has claimed yet (reset per trace call)
+    uint32_t* rkey[2];      // [P] Morton codes of the ray origins of a trace call (rows are traced in that order), ping/pong
+    uint32_t* rval[2];      // [P] row ids, ping/pong
     size_t bytes;
 };
 PbgiLayout pbgi_layout(char* base, int P) {
@@ -63,6 +65,8 @@ PbgiLayout pbgi_layout(char* base, int P) {
     b.arrive = (uint32_t*)take(p * 4);
     b.rec = (float4*)take(p * 96);
     b.queue = (unsigned long long*)take(64);
+    b.rkey[0] = (uint32_t*)take(p * 4); b.rkey[1] = (uint32_t*)take(p * 4);
+    b.rval[0] = (uint32_t*)take(p * 4); b.rval[1] = (uint32_t*)take(p * 4);
     b.bytes = off;
     return b;
 }
@@ -208,6 +212,25 @@ __global__ void __launch_bounds__(BLOCK) pbgi_export_kernel(int P, const PbgiNod
     if (sorted && i < P) { sorted[2 * i] = (int32_t)code[i]; sorted[2 * i + 1] = (int32_t)prim[i]; }
 }
 
+// Morton codes of the ray origins of a trace call, in the tree's own grid: rows are traced in this order, so that the waves that run
+// at the same time walk neighbouring parts of the tree (the 38 MB of node / leaf records of a 200 k-surfel tree do not fit a 4 MB L2;
+// with rows in memory order -- random in space -- nearly every visit was a trip to HBM)
+__global__ void __launch_bounds__(BLOCK) pbgi_row_code_kernel(int n, const float* __restrict__ ray_o, const uint32_t* __restrict__ whole,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float gl = ord2f(whole[c]), gu = ord2f(whole[3 + c]);
+        const float m = (ray_o[3 * (size_t)i + c] - gl) / fmaxf(gu - gl, 1e-30f);
+        const float cell = fminf(fmaxf(m * 1024.0f, 0.0f), 1023.0f);   // (NaN -> 0)
+        code += expand_bits((uint32_t)cell) << (2 - c);
+    }
+    keys[i] = code;
+    vals[i] = (uint32_t)i;
+}
+
 __global__ void pbgi_queue_init_kernel(unsigned long long* queue, unsigned long long first) { queue[0] = first; }
 
 // ---- leaf records (per trace call: the reference reads these tensors at every visited leaf) --------------------------------
@@ -286,6 +309,17 @@ constexpr int PBGI_STACK = 64;        // the reference's MAX_STACK_SIZE; the tre
 #endif
 constexpr int PBGI_LDS_DEPTH = PBGI_LDS_DEPTH_V;   // (32 / 24 / 16 levels in LDS = 10 / 13 / 16 waves per CU: 1 017 / 963 / 1 023 ms on the cfg3 geometry, 1 735 / 1 392 / 1 238 ms on the shell scene)    // stack levels kept in LDS ([level][lane]: conflict-free whatever the lanes' depths); deeper ones in scratch
 constexpr int PBGI_WAVE = 64;         // one wave per workgroup
+#ifndef PBGI_COOP_CAP_V
+#define PBGI_COOP_CAP_V 512
+#endif
+constexpr int PBGI_COOP_CAP = PBGI_COOP_CAP_V;    // entries of the wave's ordered worklist (cooperative queries at the end of a launch)
+#ifndef PBGI_COOP_LANES
+#define PBGI_COOP_LANES 0             // > 0: the wave switches to cooperative queries when at most this many of its lanes still hold a ray.
+                                      // Exact (tests/test_gpu_pbgi.py passes with 8 and 32) but OFF: measured 868 -> 828 ms on the cfg3 geometry
+                                      // with 32 and 1 614 -> 1 857 ms on the shell scene (4 KB more LDS and 12 more VGPRs per wave cost more
+                                      // throughput than the shorter tail gives back; a round of the cooperative walk is still one dependent
+                                      // fetch deep).  -DPBGI_COOP_LANES=32 builds it.
+#endif
 constexpr int PBGI_MAX_HITS = 4096;   // guard of the ray loop (every accepted hit removes >= 1/255 of the transmittance: < 1800 hits)
 
 
@@ -341,6 +375,50 @@ __device__ __forceinline__ void eval_sh3(const float* __restrict__ sh, F3 dir, f
     }
 }
 
+// One visited leaf of gs_bvh_hit: ellipse_hit (:94-148) and the acceptance tests (:367-404) for the surfel of sorted position j.
+// The reference evaluates the ellipse first; its results (hit, uv) are only read for ACCEPTED leaves (8 % of the visited ones:
+// t >= t_min, power <= 0, alpha >= 1/255), so the plane intersection and the acceptance come first and the ellipse -- four IEEE
+// divisions -- last.  `d` is the direction in effect at this visit (re-normalised by the caller, Q-c).
+struct LeafRes { bool acc, hit; float t, alpha, u, v; };
+__device__ __forceinline__ LeafRes leaf_eval(const float4* __restrict__ rec, int j, F3 o, F3 d, float t_min) {
+#pragma clang fp contract(off)
+    LeafRes r = {false, false, 0.f, 0.f, 0.5f, 0.5f};
+    const float4* lr = rec + 6 * (size_t)j;
+    const float4 A = lr[0], B = lr[1], C = lr[2], D = lr[3], E = lr[4], G = lr[5];
+    const F3 c = {A.x, A.y, A.z};
+    const float sx = A.w, sy = B.x;
+    const F3 nw = {B.z, B.w, C.x};
+    const float denom = dot3(nw, d);
+    if (!(fabsf(denom) < 1e-6f)) {
+        const F3 co = {c.x - o.x, c.y - o.y, c.z - o.z};
+        const float t_now = dot3(co, nw) / denom;
+        if (!(t_now < t_min)) {   // (:367-371; a parallel ray has t_now = 0 < t_min)
+            const F3 pos = {o.x + d.x * t_now, o.y + d.y * t_now, o.z + d.z * t_now};
+            const F3 dd = {c.x - pos.x, c.y - pos.y, c.z - pos.z};
+            const float power = -0.5f * (dd.x * dd.x * E.z + dd.y * dd.y * G.y + dd.z * dd.z * G.w + 2 * dd.x * dd.y * E.w + 2 * dd.x * dd.z * G.x +
+                                         2 * dd.y * dd.z * G.z);
+            if (!(power > 0.0f)) {
+                const float alpha = fminf(0.99f, B.y * expf(power));
+                if (!(alpha < 1.0f / 255.0f)) {
+                    const F3 w = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
+                    const float px = C.y * w.x + C.z * w.y + C.w * w.z, py = D.x * w.x + D.y * w.y + D.z * w.z;
+                    float a = px / sx, b = py / sy;
+                    if (a < b) { const float t = a; a = b; b = t; }
+                    a = a * 0.5f + 0.5f; b = b * 0.5f + 0.5f;
+                    r.u = fminf(fmaxf(a, 0.001f), 0.999f);
+                    r.v = fminf(fmaxf(b, 0.001f), 0.999f);
+                    const float dis = (px * px) / (sx * sx) + (py * py) / (sy * sy);
+                    bool hit = dis <= 9.0f;
+                    const F3 nrm = {D.w, E.x, E.y};
+                    if (!(dot3(d, nrm) < -0.0f)) hit = false;   // :399-404
+                    r.acc = true; r.hit = hit; r.t = t_now; r.alpha = alpha;
+                }
+            }
+        }
+    }
+    return r;
+}
+
 // gs_bvh_hit (intersect_test.slang:251-437) inside render_radiance_with_sampling_SH (:1879-1990).
 //
 // Per ray the reference runs closest-hit queries in a loop (one per accepted surfel, until the transmittance is used up or nothing is
@@ -366,10 +444,15 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
                                                                const float* __restrict__ ray_d, const float* __restrict__ centers,
                                                                const float* __restrict__ shs, float* __restrict__ radiance,
                                                                float* __restrict__ visibility, int32_t* __restrict__ hit_indices, float* __restrict__ uvs,
-                                                               int chunk, unsigned long long* __restrict__ queue) {
+                                                               int chunk, unsigned long long* __restrict__ queue,
+                                                               const uint32_t* __restrict__ row_order, int row_base) {
 #pragma clang fp contract(off)
     __shared__ int s_ids[PBGI_LDS_DEPTH * PBGI_WAVE];
     __shared__ float s_ens[PBGI_LDS_DEPTH * PBGI_WAVE];
+#if PBGI_COOP_LANES > 0
+    __shared__ int wl_id[PBGI_COOP_CAP];      // cooperative queries: the pending nodes of ONE ray in visit order (top = next)
+    __shared__ float wl_en[PBGI_COOP_CAP];
+#endif
     const int lane = threadIdx.x;
     int* s_id = s_ids + lane;
     float* s_en = s_ens + lane;
@@ -464,8 +547,10 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
                 const long long mine = next_ray + (long long)__popcll(m & lt_mask);
                 next_ray += (long long)__popcll(m);
                 if (want && mine < pool_end) {
-                    ri = mine;
-                    row = (int)(ri / S);
+                    // `mine` counts the rays of this launch in TRACING order (rows sorted by the Morton code of their origin)
+                    const long long pr = mine / S;
+                    row = row_base + (int)row_order[pr];
+                    ri = (long long)row * S + (mine - pr * S);
                     dir = unit3(F3{ray_d[3 * ri], ray_d[3 * ri + 1], ray_d[3 * ri + 2]});
                     o = {ray_o[3 * (size_t)row], ray_o[3 * (size_t)row + 1], ray_o[3 * (size_t)row + 2]};
                     first_hit = -1; fu = 0.f; fv = 0.f; T = 1.0f; t_min = 0.042f; visible = true; it = 0;
@@ -485,6 +570,128 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
             }
             if (!__any(walking)) break;   // the pool is empty and every lane is done
         }
+#if PBGI_COOP_LANES > 0
+        {
+            // ---- the end of the launch: few rays left, each of them a long chain of queries ----
+            // A ray's queries are sequential, a query's visits are sequential per lane (~1 200 visits of ~2 us each): one ray with
+            // 90 queries keeps a lane -- and the launch -- busy for 0.25 s after everything else is done.  When the queue is empty
+            // and at most PBGI_COOP_LANES lanes of the wave still hold a ray, the WAVE finishes their queries one at a time with all 64
+            // lanes.  What makes that exact: with the direction final, a leaf is visited if and only if its own box still beats the
+            // closest hit when its turn comes (its ancestors' boxes contain it, their tests used the same direction and a closest hit
+            // that was no smaller), and the turns are the tree's right-first leaf order.  So the wave keeps the ray's pending nodes
+            // in visit order, expands the next 64 of them a level per round in parallel (children that fail now can never pass
+            // later), evaluates the leaves at the front in parallel and applies the accepted ones strictly in order -- the same
+            // visits, the same decisions, the same last-accepted-leaf side effects (Q-a, Q-b) as the lane's own walk.
+            if (drained && next_ray >= pool_end) {
+                const unsigned long long wm = __ballot(walking);
+                if (wm != 0ull && __popcll(wm) <= PBGI_COOP_LANES) {
+                    unsigned long long todo = __ballot(walking && fixed && count <= PBGI_LDS_DEPTH - 1);
+                    while (todo != 0ull) {
+                        const int Ls = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        auto rlf = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), Ls)); };
+                        auto rli = [&](int v) { return __builtin_amdgcn_readlane(v, Ls); };
+                        // the ray's query state, wave-uniform
+                        const F3 qo = {rlf(o.x), rlf(o.y), rlf(o.z)}, qd = {rlf(d.x), rlf(d.y), rlf(d.z)};
+                        const SlabDir qsd = slab_dir(qd);
+                        const float qtmin = rlf(t_min);
+                        float q_closest = rlf(closest), q_cu = rlf(cu), q_cv = rlf(cv), q_hit_t = rlf(hit_t), q_keep = rlf(keep_l), q_hu = rlf(hu), q_hv = rlf(hv);
+                        int q_index = rli((int)closest_index);
+                        bool q_any = rli(any_hit ? 1 : 0) != 0;
+                        int len = rli(count);
+                        // the lane's stack, bottom first, then the node it was about to visit (a passed node: entry below every t)
+                        if (lane < len) { wl_id[lane] = s_ids[lane * PBGI_WAVE + Ls]; wl_en[lane] = s_ens[lane * PBGI_WAVE + Ls]; }
+                        if (lane == 0) { wl_id[len] = rli(cur); wl_en[len] = rli(own_test ? 1 : 0) != 0 ? -INFINITY : -3.0e38f; }
+                        len += 1;
+                        wave_lds_sync();
+                        while (len > 0) {
+                            const int m = len > PBGI_COOP_CAP - 128 ? 1 : min(64, len);   // (full rounds add at most 64 entries; PBGI_COOP_CAP >= 192)   // (one node at a time when the list is nearly full:
+                            // a depth-first walk then adds at most the tree's height)
+                            const bool have = lane < m;
+                            int id = 0;
+                            float en = 0.f;
+                            if (have) { id = wl_id[len - 1 - lane]; en = wl_en[len - 1 - lane]; }
+                            bool alive = have && (en == -INFINITY || q_closest > en);
+                            if (alive && en == -INFINITY) {   // pushed before the direction was final: its own box, now
+                                const float4* qn = reinterpret_cast<const float4*>(node + id);
+                                const float4 q0 = qn[0], q1 = qn[1];
+                                const float lo[3] = {q0.x, q0.y, q0.z}, hi[3] = {q0.w, q1.x, q1.y};
+                                PBGI_STAT(1);
+                                alive = box_entry(lo, hi, qo, qsd, qtmin, en) && q_closest > en;
+                            }
+                            const bool is_leaf = id >= L;
+                            // leaves in front of the first pending internal node are due now
+                            const unsigned long long inner = __ballot(alive && !is_leaf);
+                            const int pfx = inner ? __builtin_ctzll(inner) : 64;
+                            const bool due = alive && is_leaf && lane < pfx;
+                            int c0 = 0, c1 = 0, n_out = 0;
+                            float e0 = 0.f, e1 = 0.f;
+                            LeafRes lf = {false, false, 0.f, 0.f, 0.5f, 0.5f};
+                            int lprim = 0;
+                            if (alive && !is_leaf) {
+                                PBGI_STAT(2);
+                                const float4* qp = pair + 4 * (size_t)id;
+                                const float4 r0 = qp[0], r1 = qp[1], r2 = qp[2], r3 = qp[3];
+                                const int left = __builtin_bit_cast(int, r3.x), right = __builtin_bit_cast(int, r3.y);
+                                const float lo0[3] = {r0.x, r0.y, r0.z}, hi0[3] = {r0.w, r1.x, r1.y}, lo1[3] = {r1.z, r1.w, r2.x}, hi1[3] = {r2.y, r2.z, r2.w};
+                                float eL, eR;
+                                PBGI_STAT(1); PBGI_STAT(1);
+                                const bool pr = box_entry(lo1, hi1, qo, qsd, qtmin, eR) && q_closest > eR;
+                                const bool pl = box_entry(lo0, hi0, qo, qsd, qtmin, eL) && q_closest > eL;
+                                if (pr) { c0 = right; e0 = eR; n_out = 1; }
+                                if (pl) { if (n_out == 0) { c0 = left; e0 = eL; } else { c1 = left; e1 = eL; } n_out++; }
+                            } else if (alive && is_leaf && !due) {
+                                c0 = id; e0 = en; n_out = 1;   // a leaf behind a pending internal node: waits
+                            } else if (due) {
+                                PBGI_STAT(2); PBGI_STAT(3);
+                                lf = leaf_eval(rec, id - L, qo, qd, qtmin);
+                                if (lf.acc) lprim = (int)prim[id - L];
+                            }
+                            // accepted leaves, strictly in visit order
+                            unsigned long long accm = __ballot(due && lf.acc);
+                            while (accm != 0ull) {
+                                const int a = __builtin_ctzll(accm);
+                                accm &= accm - 1ull;
+                                const float ea = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, en), a));
+                                if (q_closest > ea) {   // (visited: its box still beats the closest hit)
+                                    PBGI_STAT(4);
+                                    const float ta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.t), a));
+                                    const bool ha = __builtin_amdgcn_readlane(lf.hit ? 1 : 0, a) != 0;
+                                    const bool update = ha && ta < q_closest;
+                                    q_closest = ha ? fminf(ta, q_closest) : q_closest;
+                                    if (update) {
+                                        q_index = __builtin_amdgcn_readlane(lprim, a);
+                                        q_cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.u), a));
+                                        q_cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.v), a));
+                                    }
+                                    if (ha) {
+                                        q_any = true; q_hit_t = q_closest; q_hu = q_cu; q_hv = q_cv;
+                                        q_keep = 1 - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.alpha), a));
+                                    }
+                                }
+                            }
+                            // the batch's successors go back on the list, in visit order (first = top)
+                            const unsigned long long b1 = __ballot(n_out >= 1), b2 = __ballot(n_out == 2);
+                            const int before = __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
+                            const int total_out = __popcll(b1) + __popcll(b2);
+                            const int nlen = len - m + total_out;
+                            wave_lds_sync();   // every lane has read its item
+                            if (n_out >= 1) { wl_id[nlen - 1 - before] = c0; wl_en[nlen - 1 - before] = e0; }
+                            if (n_out == 2) { wl_id[nlen - 2 - before] = c1; wl_en[nlen - 2 - before] = e1; }
+                            wave_lds_sync();
+                            len = nlen;
+                        }
+                        if (lane == Ls) {   // the query is over: its results, as the lane's own walk would have left them
+                            closest = q_closest; cu = q_cu; cv = q_cv; hit_t = q_hit_t; keep_l = q_keep; hu = q_hu; hv = q_hv;
+                            closest_index = (uint32_t)q_index; any_hit = q_any;
+                            count = 0; walking = false;
+                        }
+                    }
+                    if (!__any(walking)) continue;   // (every remaining query was finished here: back to the ray bookkeeping)
+                }
+            }
+        }
+#endif
         if (walking) {
             // ---- one traversal step ----
             bool alive = true;
@@ -517,52 +724,20 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
                     // ---- leaf ----
                     const int j = cur - L;
                     PBGI_STAT(3);
-                    const float4* lr = rec + 6 * (size_t)j;
-                    const float4 A = lr[0], B = lr[1], C = lr[2], D = lr[3], E = lr[4], G = lr[5];
                     if (!fixed) {   // :342 -- the re-normalised direction also serves the box tests that follow (Q-c).  A direction whose
                         // length already rounds to 1 is left bit-identical by the division
                         const float l = sqrtf(dot3(d, d));
                         if (l != 1.0f) { d = {d.x / l, d.y / l, d.z / l}; sd = slab_dir(d); fixed = sqrtf(dot3(d, d)) == 1.0f; }
                         else fixed = true;
                     }
-                    const F3 c = {A.x, A.y, A.z};
-                    const float sx = A.w, sy = B.x;
-                    // ---- ellipse_hit (:94-148) and the acceptance tests (:367-404).  The reference evaluates the ellipse first; its
-                    // results (hit, uv) are only read for ACCEPTED leaves (8 % of the visited ones: t >= t_min, power <= 0, alpha >=
-                    // 1/255), so the plane intersection and the acceptance come first and the ellipse -- four IEEE divisions -- last ----
-                    const F3 nw = {B.z, B.w, C.x};
-                    const float denom = dot3(nw, d);
-                    if (!(fabsf(denom) < 1e-6f)) {
-                        const F3 co = {c.x - o.x, c.y - o.y, c.z - o.z};
-                        const float t_now = dot3(co, nw) / denom;
-                        if (!(t_now < t_min)) {   // (:367-371; a parallel ray has t_now = 0 < t_min)
-                            const F3 pos = {o.x + d.x * t_now, o.y + d.y * t_now, o.z + d.z * t_now};
-                            const F3 dd = {c.x - pos.x, c.y - pos.y, c.z - pos.z};
-                            const float power = -0.5f * (dd.x * dd.x * E.z + dd.y * dd.y * G.y + dd.z * dd.z * G.w + 2 * dd.x * dd.y * E.w + 2 * dd.x * dd.z * G.x +
-                                                         2 * dd.y * dd.z * G.z);
-                            if (!(power > 0.0f)) {
-                                const float alpha = fminf(0.99f, B.y * expf(power));
-                                if (!(alpha < 1.0f / 255.0f)) {
-                                    PBGI_STAT(4);
-                                    const F3 w = {pos.x - c.x, pos.y - c.y, pos.z - c.z};
-                                    const float px = C.y * w.x + C.z * w.y + C.w * w.z, py = D.x * w.x + D.y * w.y + D.z * w.z;
-                                    float a = px / sx, b = py / sy;
-                                    if (a < b) { const float t = a; a = b; b = t; }
-                                    a = a * 0.5f + 0.5f; b = b * 0.5f + 0.5f;
-                                    const float uh = fminf(fmaxf(a, 0.001f), 0.999f);
-                                    const float vh = fminf(fmaxf(b, 0.001f), 0.999f);
-                                    const float dis = (px * px) / (sx * sx) + (py * py) / (sy * sy);
-                                    bool hit = dis <= 9.0f;
-                                    const F3 nrm = {D.w, E.x, E.y};
-                                    if (!(dot3(d, nrm) < -0.0f)) hit = false;   // :399-404
-                                    const bool update = hit && t_now < closest;
-                                    closest = hit ? fminf(t_now, closest) : closest;
-                                    closest_index = update ? prim[j] : closest_index;
-                                    cu = update ? uh : cu; cv = update ? vh : cv;
-                                    if (hit) { any_hit = true; hit_t = closest; keep_l = 1 - alpha; hu = cu; hv = cv; }   // (Q-a, Q-b)
-                                }
-                            }
-                        }
+                    const LeafRes lf = leaf_eval(rec, j, o, d, t_min);
+                    if (lf.acc) {
+                        PBGI_STAT(4);
+                        const bool update = lf.hit && lf.t < closest;
+                        closest = lf.hit ? fminf(lf.t, closest) : closest;
+                        closest_index = update ? prim[j] : closest_index;
+                        cu = update ? lf.u : cu; cv = update ? lf.v : cv;
+                        if (lf.hit) { any_hit = true; hit_t = closest; keep_l = 1 - lf.alpha; hu = cu; hv = cv; }   // (Q-a, Q-b)
                     }
                 }
             }
@@ -658,18 +833,26 @@ int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const 
     const int fin = PBGI_SORT_PASSES & 1;
     hipLaunchKernelGGL(pbgi_leaf_rec_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, B.val[fin], centers, scales, rotations, normals,
                        opacity, cov3D_inverse, B.rec);
-    const long long rays = (long long)N * S;
     // Persistent waves (one per resident slot: 16 KB of LDS each, 10 per CU) take chunks of consecutive rays (whole rows: the rays of a row
     // share their origin) from a launch-wide queue, so no wave slot idles while rays are left and the end of the launch is one ray deep.
     // (Static pools, measured on the cfg3 geometry, 4.27 M rays per launch: 256 / 1 024 / 4 096 / 16 384 rays per wave = 2 129 / 1 329 /
     // 1 534 / 4 249 ms -- small pools end with 63 lanes waiting for one long ray, large ones leave wave slots empty.)
     long long chunk = std::max<long long>(S, (64 + S - 1) / S * S);   // (64 / 256 / 1 024 rays per chunk: 1 005 / 1 046 / 1 178 ms on the cfg3 geometry)
     if (const char* e = getenv("SVGIR_PBGI_POOL")) { const long long v = atoll(e); if (v > 0) chunk = (v + S - 1) / S * S; }   // (tuning experiments)
-    const long long nw = std::min<long long>((rays + chunk - 1) / chunk, 256ll * std::min(8 * 4, (160 * 1024) / (PBGI_LDS_DEPTH * PBGI_WAVE * 8)));   // one wave per resident slot
-    const unsigned long long first = (unsigned long long)(nw * chunk);   // the chunks [0, nw) belong to the waves from the start
-    hipLaunchKernelGGL(pbgi_queue_init_kernel, dim3(1), dim3(1), 0, s, B.queue, first);
-    hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)nw), dim3(PBGI_WAVE), 0, s, P, B.node, B.pair, B.rec, B.val[fin], N, S, ray_o,
-                       ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)chunk, B.queue);
+    const int slots = 256 * std::min(8 * 4, (160 * 1024) / (PBGI_LDS_DEPTH * PBGI_WAVE * 8 + (PBGI_COOP_LANES > 0 ? PBGI_COOP_CAP * 8 : 0)));   // resident waves
+    for (int row0 = 0; row0 < N; row0 += P) {   // (the row-order buffers hold P rows: more rows than surfels go in blocks)
+        const int n = std::min(P, N - row0);
+        // rows in the Morton order of their origins
+        if (hipMemsetAsync(radix_gtot(B.radix_tbl, n), 0, radix_gtot_words(n) * 4, s) != hipSuccess) return SVGIR_ERR_HIP;   // (n <= P: within the table)
+        hipLaunchKernelGGL(pbgi_row_code_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, n, ray_o + 3 * (size_t)row0, B.whole, B.rkey[0], B.rval[0]);
+        launch_radix_sort(B.rkey, B.rval, n, nullptr, PBGI_SORT_BITS, 8, B.radix_tbl, s);
+        const long long rays = (long long)n * S;
+        const long long nw = std::min<long long>((rays + chunk - 1) / chunk, slots);
+        const unsigned long long first = (unsigned long long)(nw * chunk);   // the chunks [0, nw) belong to the waves from the start
+        hipLaunchKernelGGL(pbgi_queue_init_kernel, dim3(1), dim3(1), 0, s, B.queue, first);
+        hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)nw), dim3(PBGI_WAVE), 0, s, P, B.node, B.pair, B.rec, B.val[fin], n, S, ray_o,
+                           ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)chunk, B.queue, B.rval[PBGI_SORT_PASSES & 1], row0);
+    }
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 
