@@ -10,9 +10,9 @@ from svgir_harness import scenes
 
 # tiny images / tiny scenes: one threshold flip (a pixel = 3 entries) must not exceed the allowed *fraction*
 _cmp0 = T._cmp
-def _cmp(name, a, b, tol=T.TOL, flip_frac=T.FLIP_FRAC, flip_bound=T.FLIP_BOUND, rel=True):
+def _cmp(name, a, b, tol=T.TOL, flip_frac=T.FLIP_FRAC, flip_bound=T.FLIP_BOUND, rel=True, **kw):
     n = max(1, int(np.asarray(b).size))
-    return _cmp0(name, a, b, tol=tol, flip_frac=max(flip_frac, 8.0 / n), flip_bound=flip_bound, rel=rel)
+    return _cmp0(name, a, b, tol=tol, flip_frac=max(flip_frac, 8.0 / n), flip_bound=flip_bound, rel=rel, **kw)
 T._cmp = _cmp
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
