@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 9
+#define SVGIR_ABI_VERSION 10
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -171,13 +171,21 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
 /* Size of the backward scratch (device memory, contents irrelevant on entry, only needed during the call; REQUIRED).
  * The composite backward reduces every per-Gaussian gradient over the 64 pixels of a wave and then
  *   svgss: stores one complete gradient row per (instance, sub-tile) pair, summed per Gaussian in a fixed order by a
- *          second kernel (no atomics, bit-reproducible gradients): 4 * capacity rows + one validity byte per row;
+ *          second kernel (no atomics, bit-reproducible gradients): a 4-byte reverse-map entry per possible pair (4 * capacity)
+ *          + the rows (worst case 4 * capacity; see svgir_backward_scratch_bytes_for);
  *   rgss : accumulates with float atomics into ONE packed row per Gaussian (P rows), unpacked into the dL_d* tensors
  *          by the per-Gaussian backward kernel.
  * The reference accumulates with one global float atomic per (pixel, splat, output) straight into its dL_d* tensors
  * (backward.cu:880-930) and needs no scratch; a binder allocates this buffer next to them. */
 size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_bytes, int32_t W, int32_t H, int32_t S,
                                     int32_t VS);
+/* The same for ONE view: `image_blob` is the image blob of the svgir_forward whose backward is about to run.  svgss with vfeatures
+ * then gets one gradient row per (sub-tile, instance) pair that survived that view's cull (1.2 per instance on the BASELINE scenes)
+ * instead of four per instance: the forward reads the pair count back asynchronously behind its cull, and this call returns at once
+ * unless that copy is still in flight.  An unknown blob (NULL, or one the library has not seen in its last 64 forwards) gets the
+ * worst case; svgir_backward accepts either size for the view it belongs to.  (ABI 10) */
+size_t svgir_backward_scratch_bytes_for(int32_t variant, int32_t P, size_t binning_bytes, const char* image_blob, int32_t W, int32_t H,
+                                        int32_t S, int32_t VS);
 
 /* Introspection of the state blobs for tests / debugging (the blobs stay opaque to the rendering path): byte offset of
  * the depth-sorted instance list `point_list` (uint32 Gaussian ids, R entries; BinningState::point_list,

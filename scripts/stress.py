@@ -32,7 +32,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     # surfels of scale 0.08-0.4 make cov2D^-1 ill-conditioned in fp32: the oracle's own fp32-vs-fp64 gap on grad_scales /
     # grad_cov3D then exceeds the per-element relative criterion (1.2 % of the entries at seed 7, scene 18), so that criterion is
     # relaxed for those scenes; the normalised criterion (1e-4 of the tensor's scale) stays
-    T.REL_FRAC = 2e-2 if lo >= 0.08 else 1e-3
+    translucent = float(sc['opacities'].max()) < 0.06   # hundreds of blended terms per pixel: longer, more cancelling sums
+    T.REL_FRAC = 2e-2 if lo >= 0.08 else (5e-3 if translucent else 1e-3)
+    T.REL_TOL = 5e-3   # (tiny tensors: a dozen nearly cancelling sums are already 0.5 % of the entries; the full-size tests keep 2e-3)
     out, leaves, o, R = T._run_both(sc, variant, grads)
     tag = f"{it:2d} {variant} P={P} {W}x{H} S={S} VS={VS} R={R} scale_lo={lo} translucent={float(sc['opacities'].max()) < 0.06}"
     try:

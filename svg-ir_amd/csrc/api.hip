@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <atomic>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -75,6 +76,56 @@ uint32_t* pinned_slot() {
     });
     return g_pinned ? g_pinned + 2 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
 }   // instance count of the previous forward: sizes the speculative binning blob
+// Pair counts (surviving (sub-tile, instance) pairs = gradient rows the svgss backward needs), read back asynchronously behind the cull
+// of every svgss forward and kept per image blob: svgir_backward_scratch_bytes_for() sizes the backward scratch from it.  By the time a
+// binder asks, the copy -- issued in the middle of the forward -- has long completed (a host wait right behind the cull costs nothing:
+// the composite is still queued, measured 0.4353 vs 0.4361 ms per cfg2 step).
+struct PairEntry { const void* key = nullptr; uint32_t tag = 0; unsigned long long stamp = 0; };
+constexpr int kPairEntries = 64;
+std::mutex g_pair_mu;
+PairEntry g_pair[kPairEntries];
+unsigned long long* g_pair_pinned = nullptr;   // [kPairEntries] {tag << 32 | pairs}, written by order_desc_kernel straight into host memory
+unsigned long long g_pair_clock = 0;
+uint32_t g_pair_tag = 0;
+// reserves the slot of the forward that owns `image_blob`: returns where order_desc_kernel writes its total and the tag it writes with it
+unsigned long long* pair_count_slot(const void* image_blob, uint32_t* tag) {
+    std::lock_guard<std::mutex> lk(g_pair_mu);
+    if (!g_pair_pinned) {
+        void* ptr = nullptr;
+        if (hipHostMalloc(&ptr, kPairEntries * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return nullptr;
+        g_pair_pinned = (unsigned long long*)ptr;
+        for (int i = 0; i < kPairEntries; i++) g_pair_pinned[i] = 0ull;
+    }
+    int slot = 0;
+    for (int i = 0; i < kPairEntries; i++) {
+        if (g_pair[i].key == image_blob) { slot = i; break; }
+        if (g_pair[i].stamp < g_pair[slot].stamp) slot = i;
+    }
+    PairEntry& e = g_pair[slot];
+    e.key = image_blob; e.stamp = ++g_pair_clock;
+    e.tag = ++g_pair_tag ? g_pair_tag : ++g_pair_tag;   // (never 0: the slots start as 0)
+    *tag = e.tag;
+    return g_pair_pinned + slot;
+}
+// the pair count of the forward that owns `image_blob`, or -1 (unknown: the caller falls back to the worst case).  The value is in host
+// memory as soon as the forward's order kernel has run -- long before a binder asks; the wait below only ever spins when the host is
+// far ahead of the GPU, and gives up after 2 s (a forward that failed on the device never writes it).
+long long pair_count_of(const void* image_blob) {
+    volatile unsigned long long* slot = nullptr;
+    uint32_t tag = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pair_mu);
+        for (int i = 0; i < kPairEntries; i++)
+            if (g_pair[i].key == image_blob && g_pair_pinned) { slot = g_pair_pinned + i; tag = g_pair[i].tag; break; }
+    }
+    if (!slot) return -1;
+    for (long long spin = 0; spin < 2000000; spin++) {
+        const unsigned long long v = *slot;
+        if ((uint32_t)(v >> 32) == tag) return (long long)(uint32_t)v;
+        if (spin > 1000) { struct timespec ts = {0, 1000}; nanosleep(&ts, nullptr); }
+    }
+    return -1;
+}
 // Side stream of the backward: the gradient tensors are cleared there while the composite backward (which only writes the
 // scratch) runs on the caller's stream.  One per device, created on first use; fork / join through events.
 struct SideStream { hipStream_t s = nullptr; bool ok = false; };
@@ -360,6 +411,9 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     // Everything from here on depends on the instance count R that the GPU is still computing.  The stages are
     // launched for an instance CAPACITY `cap` and read R on the device (min(cap, R)); the binning blob is laid out
     // for `cap`.  `timed`: stage marks are only recorded for the launch sequence that counts.
+#if defined(SVGIR_EXP_SYNC_AFTER_CULL)
+    hipEvent_t sync_after_cull = nullptr;
+#endif
     auto run_binning_and_render = [&](char* bblob, int cap, bool timed) -> int {
         const BinLayout B = bin_layout(bblob, cap, T, nstate);
         launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
@@ -389,9 +443,20 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         ra.zero_b = clear_stencil ? o->out_surface_xyz : nullptr;
         ra.pair_stream = B.pair_stream;
         launch_cull(ra, s);
-        launch_order_desc(I.sub_total, 4 * T, I.sub_order, s);
+        const bool row_path = svgss && p->VS > 0 && render_specialised(p->S, p->VS, true);   // the backward writes gradient rows
+        uint32_t ptag = 0;
+        unsigned long long* pslot = row_path ? pair_count_slot(iblob, &ptag) : nullptr;
+        launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, row_path ? I.counters + 1 : nullptr, pslot, ptag, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
+#if defined(SVGIR_EXP_SYNC_AFTER_CULL)
+        {   // experiment: what a second host read-back behind the cull would cost (blob sizing from the pair count, DESIGN.md 7 open 6)
+            hipEvent_t evc;
+            HIP_OK(hipEventCreateWithFlags(&evc, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(evc, s));
+            sync_after_cull = evc;
+        }
+#endif
 #if defined(BWDP_STREAM)
         if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
         launch_pair_stream(ra, s);
@@ -443,6 +508,9 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         if (int rc = run_binning_and_render(bblob, cap, !redo)) return rc;
     }
 
+#if defined(SVGIR_EXP_SYNC_AFTER_CULL)
+    if (sync_after_cull) { (void)hipEventSynchronize(sync_after_cull); (void)hipEventDestroy(sync_after_cull); }
+#endif
     if (!svgss && p->computer_pseudo_normal) {
         launch_image_ops(W, H, p->viewmatrix, focal_x, focal_y, p->cx, p->cy, o->out_opacity, o->out_depth,
                          o->out_pseudo_normal, o->out_surface_xyz, s);
@@ -454,13 +522,21 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
 
 size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_bytes, int32_t W, int32_t H, int32_t S,
                                     int32_t VS) {
+    return svgir_backward_scratch_bytes_for(variant, P, binning_bytes, nullptr, W, H, S, VS);
+}
+
+size_t svgir_backward_scratch_bytes_for(int32_t variant, int32_t P, size_t binning_bytes, const char* image_blob, int32_t W, int32_t H,
+                                        int32_t S, int32_t VS) {
     if (!render_specialised(S, variant == SVGIR_SVGSS ? VS : 0, variant == SVGIR_SVGSS))
         return 256;   // run-time-width kernels accumulate straight into the dL_d* tensors: no scratch (a token size, never touched)
     if (variant != SVGIR_SVGSS || VS == 0)   // one packed gradient row per Gaussian
         return align_up((size_t)(P > 0 ? P : 1) * grad_row_geom(S, 0).RS * 4);
     const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const int cap = binning_capacity_from_bytes(binning_bytes, T, seg_nstate(S, VS));
-    return grad_scratch_bytes(cap, S, VS);
+    // one gradient row per (sub-tile, instance) pair that survived the cull of THIS view when its count is known, else four per instance
+    const long long pairs = image_blob ? pair_count_of(image_blob) : -1;
+    const size_t rows = pairs >= 0 ? (size_t)std::min<long long>(pairs, (long long)4 * cap) : (size_t)4 * cap;
+    return grad_scratch_bytes(cap, rows > 0 ? rows : 1, S, VS);
 }
 
 int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const int32_t* radii, char* geom_blob,
@@ -504,9 +580,10 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     // Gaussian by grad_reduce (no atomics, deterministic); otherwise one packed row per Gaussian accumulated with float
     // atomics and unpacked by geom_bwd.
     const bool generic = !render_specialised(p->S, ba.VS, svgss);   // run-time-width kernels: atomics on the dL_d* tensors
-    const size_t need = svgir_backward_scratch_bytes(p->variant, P, binning_bytes, W, H, p->S, ba.VS);
+    // (svgss rows: sized for the pair count of this view when the forward's read-back of it is at hand, else for the worst case)
+    const size_t need = svgir_backward_scratch_bytes_for(p->variant, P, binning_bytes, image_blob, W, H, p->S, ba.VS);
     if (!generic && (!scratch || scratch_bytes < need))
-        return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes() = %zu",
+        return fail(SVGIR_ERR_INVALID, "backward scratch of %zu bytes is smaller than svgir_backward_scratch_bytes_for() = %zu",
                     scratch ? scratch_bytes : (size_t)0, need);
     const bool rows = ba.VS > 0 && !generic;
     // Clears:
@@ -555,13 +632,15 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     }
     const GradRowGeom rg = grad_row_geom(p->S, ba.VS);
     ba.grad_rows = generic ? nullptr : (float*)scratch;
-    ba.row_flags = nullptr;
+    ba.row_of = nullptr; ba.rows_cap = 0;
     void* sc_clear = nullptr;
     size_t sc_bytes = 0;
     if (!generic) {
-        if (rows) {
-            ba.row_flags = (uint8_t*)(scratch + align_up((size_t)4 * cap * rg.RS * 4));
-            sc_clear = ba.row_flags; sc_bytes = align_up((size_t)4 * cap);
+        if (rows) {   // reverse map (cleared) | compact rows
+            ba.row_of = (uint32_t*)scratch;
+            ba.grad_rows = (float*)(scratch + grad_rowof_bytes(cap));
+            ba.rows_cap = (uint32_t)std::min<size_t>((scratch_bytes - grad_rowof_bytes(cap)) / ((size_t)rg.RS * 4), 0xfffffff0u);
+            sc_clear = ba.row_of; sc_bytes = grad_rowof_bytes(cap);
         } else {
             sc_clear = ba.grad_rows; sc_bytes = align_up((size_t)P * rg.RS * 4);
         }
@@ -572,7 +651,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         RenderArgs sa{};
         sa.W = W; sa.H = H; sa.gx = gx; sa.gy = gy; sa.S = p->S; sa.VS = ba.VS;
         sa.ranges = I.ranges; sa.sub_count = I.sub_count; sa.sub_ndump = I.sub_ndump; sa.seg_list = B.seg_list; sa.seg_desc = B.seg_desc;
-        sa.seg_count = I.counters; sa.seg_block = I.seg_block;
+        sa.seg_count = I.counters; sa.seg_block = I.seg_block; sa.sub_pair_base = I.sub_pair_base;
         launch_seg_build(sa, sc_clear, sc_bytes, s);
     } else if (sc_clear && !rows) {
         HIP_OK(hipMemsetAsync(sc_clear, 0, sc_bytes, s));   // (nothing rendered: geom_bwd still unpacks the -- zero -- packed rows)
@@ -587,7 +666,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     if (R > 0 && rows) {
         GradReduceArgs ra;
         ra.P = P; ra.S = p->S; ra.VS = ba.VS; ra.radii = radii; ra.tiles = G.tiles; ra.rec = G.rec;
-        ra.grad_rows = ba.grad_rows; ra.row_flags = ba.row_flags;
+        ra.grad_rows = ba.grad_rows; ra.row_of = ba.row_of;
         ra.dL_dmean2D = g->dL_dmeans2D; ra.dL_dconic = g->dL_dconic; ra.dL_dopacity = g->dL_dopacity; ra.dL_dcolor = g->dL_dcolors;
         ra.dL_dfeature = g->dL_dfeatures; ra.dL_dvfeature = g->dL_dvfeatures; ra.dL_dnormal = g->dL_dnormal; ra.dL_ddepth = g->dL_ddepth;
         launch_grad_reduce(ra, s);

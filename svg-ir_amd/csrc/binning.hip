@@ -265,7 +265,9 @@ __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t
 // One-block counting sort of n work items by descending size: order[] = item ids, largest first.  1024 size buckets, one
 // per count below 1023 (exact order there; everything longer shares the first bucket -- those waves start first anyway).
 __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __restrict__ counts, int n,
-                                                          uint32_t* __restrict__ order) {
+                                                          uint32_t* __restrict__ order, uint32_t* __restrict__ prefix,
+                                                          uint32_t* __restrict__ total, unsigned long long* __restrict__ host_total,
+                                                          uint32_t host_tag) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -328,12 +330,46 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
         zbase = (uint32_t)__shfl((int)zbase, 0);
         if (z) order[zbase + (uint32_t)__popcll(zero & lt_mask)] = (uint32_t)i;
     }
+    if (!prefix && !total && !host_total) return;
+    // exclusive prefix sum of the counts in index order (the first gradient row of every sub-tile) and their total: every thread owns
+    // k consecutive items -- one block scan over the threads' sums, whatever n
+    const int k = (n + 1023) / 1024;
+    const int first = t * k;
+    uint32_t mine = 0;
+    for (int j = 0; j < k; j++) mine += first + j < n ? counts[first + j] : 0u;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();   // (wsum of the ordering pass consumed)
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t wo = 0, running = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const uint32_t x = wsum[w]; wo += w < wave ? x : 0u; running += x; }
+    if (prefix) {
+        uint32_t at = wo + inc - mine;
+        for (int j = 0; j < k; j++) {
+            if (first + j < n) { prefix[first + j] = at; at += counts[first + j]; }
+        }
+    }
+    if (t == 0) {
+        if (total) total[0] = running;
+        // the host's copy: {total, tag of this forward} as ONE 8-byte store into pinned host memory -- no copy operation and no event
+        // on the stream; the host recognises the value by its tag (api.hip pair_count_of)
+        if (host_total) {
+            __hip_atomic_store(host_total, ((unsigned long long)host_tag << 32) | (unsigned long long)running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (self-contained: no ordering with other memory needed)
+        }
+    }
 }
 
 }  // namespace
 
-void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s) {
-    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order);
+void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* total, unsigned long long* host_total,
+                       uint32_t host_tag, hipStream_t s) {
+    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order, prefix, total, host_total, host_tag);
 }
 
 template <int ITEMS>

@@ -97,7 +97,8 @@ struct ImageLayout {
     uint32_t* sub_order; // [4*T] sub-tiles sorted by descending candidate count (heaviest work is dispatched first)
     uint32_t* sub_count; // [4*T] #candidates the forward composite consumed before every pixel was done (<= sub_total)
     uint32_t* sub_ndump; // [4*T] #segment-boundary states the forward dumped for the sub-tile (see SEG)
-    uint32_t* counters;  // [4]: [0] = number of live backward segments (entries of BinLayout::seg_list)
+    uint32_t* sub_pair_base; // [4*T] exclusive prefix of sub_total over the sub-tiles: first gradient row of a sub-tile's candidates
+    uint32_t* counters;  // [4]: [0] = number of live backward segments (entries of BinLayout::seg_list); [1] = sum of sub_total (pairs)
     size_t ncontrib_off;
     size_t bytes;
 };
@@ -117,14 +118,18 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.sub_order = (uint32_t*)take(T * 4 * 4);
     im.sub_count = (uint32_t*)take(T * 4 * 4);
     im.sub_ndump = (uint32_t*)take(T * 4 * 4);
+    im.sub_pair_base = (uint32_t*)take(T * 4 * 4);
     im.counters = (uint32_t*)take(16);
     im.bytes = off;
     return im;
 }
 
 // Gradient rows.  Instead of one float atomic per (wave, splat, output), a backward wave writes the complete gradient
-// row of its (instance, sub-tile) pair -- slot 4 * (emit-order instance index) + sub-tile, so the rows of one Gaussian
-// are contiguous -- and a second kernel sums each Gaussian's valid rows: no atomics, deterministic gradients.
+// row of its (instance, sub-tile) pair and a second kernel sums each Gaussian's rows in a fixed order: no atomics, deterministic
+// gradients.  Rows are COMPACT (round 4): row = sub_pair_base[sub-tile] + position of the candidate in the sub-tile's list, i.e. one
+// row per pair that survived the cull (1.22 per instance at cfg2) instead of four per instance; the wave also records the row in the
+// reverse map row_of[4 * (emit-order instance index) + sub-tile] = row + 1 (0: no row), where the reduce kernel -- which walks a
+// Gaussian's instances -- finds it.  Scratch layout: row_of[4 * capacity] | rows[row capacity][RS].
 // Row layout (floats): [0, NC0) colour3, normal3 (x10), depth, features S | pad to 4 | [P4, P4+VS) vfeatures |
 // [P4+VS, P4+VS+6) mean2D.xy, conic.xyz, opacity | pad to 4.
 struct GradRowGeom { int NC0, P4, VS, GEO, RS; };
@@ -133,8 +138,9 @@ inline GradRowGeom grad_row_geom(int S, int VS) {
     g.NC0 = 7 + S; g.P4 = (g.NC0 + 3) / 4 * 4; g.VS = VS; g.GEO = g.P4 + VS; g.RS = (g.GEO + 6 + 3) / 4 * 4;
     return g;
 }
-inline size_t grad_scratch_bytes(int cap, int S, int VS) {   // rows + one validity byte per slot
-    return align_up((size_t)4 * cap * grad_row_geom(S, VS).RS * 4) + align_up((size_t)4 * cap);
+inline size_t grad_rowof_bytes(int cap) { return align_up((size_t)4 * cap * 4); }
+inline size_t grad_scratch_bytes(int cap, size_t rows, int S, int VS) {   // reverse map + `rows` gradient rows
+    return grad_rowof_bytes(cap) + align_up(rows * grad_row_geom(S, VS).RS * 4);
 }
 
 // Backward segments.  The backward composite is parallelised over depth: one wave per SEG consecutive candidates of a
@@ -158,7 +164,7 @@ inline uint32_t seg_state_base(uint32_t r0, uint32_t len, int tile, int sub) {
 }
 inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
 constexpr int SEG_K_BITS = 14;   // seg_list entry = (sub-tile id << SEG_K_BITS) | k
-struct SegDesc { uint32_t sm, r0, len, count, ndump, pad0, pad1, pad2; };   // 32 B: seg_list entry, tile range start / length, sub_count, sub_ndump
+struct SegDesc { uint32_t sm, r0, len, count, ndump, pair_base, pad1, pad2; };   // 32 B: seg_list entry, tile range start / length, sub_count, sub_ndump, first gradient row of the sub-tile
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -280,6 +286,7 @@ struct RenderArgs {
     CfgRef cfg;
     uint2* sub_list; uint32_t* sub_total; uint32_t* sub_order; uint32_t* sub_count;
     uint32_t* sub_ndump; uint32_t* seg_list; SegDesc* seg_desc; uint32_t* seg_count; uint32_t* seg_block; float* seg_state;
+    uint32_t* sub_pair_base;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
@@ -297,14 +304,14 @@ struct RenderBwdArgs {
     const float *final_T, *final_D; const int32_t* n_contrib;
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
-    float* grad_rows; uint8_t* row_flags;   // svgss (VS > 0): gradient rows + validity bytes; else: packed rows [P][RS]
+    float* grad_rows; uint32_t* row_of; uint32_t rows_cap;   // svgss (VS > 0): compact gradient rows + reverse map; else: packed rows [P][RS]
     const float* pair_stream;               // (experiment builds) see BinLayout
 };
 
 struct GradReduceArgs {
     int P, S, VS;
     const int32_t* radii; const uint32_t* tiles; const float* rec;
-    const float* grad_rows; const uint8_t* row_flags;
+    const float* grad_rows; const uint32_t* row_of;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
 };
 
@@ -343,8 +350,11 @@ void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
                  uint32_t* seg_count, uint32_t* sort_table, hipStream_t s);
 void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
-// order[] = item ids sorted by descending counts[] (longest-processing-time-first dispatch of the composite waves)
-void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, hipStream_t s);
+// order[] = item ids sorted by descending counts[] (longest-processing-time-first dispatch of the composite waves); also
+// prefix[i] = exclusive prefix sum of counts[], total[0] = their sum, host_total[0] = host_tag << 32 | sum in pinned host memory
+// (any of them may be null)
+void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* total, unsigned long long* host_total,
+                       uint32_t host_tag, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
 // tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump; also zeroes

@@ -3,11 +3,12 @@
 // The reference accumulates the composite's per-Gaussian gradients with one global float atomic per (pixel, splat,
 // output) (backward.cu:880-930); the first version here issued one per (wave, splat, output) -- still 18 / 69 / 84
 // memory-side atomics per pair, 30 % of the backward composite at the svgss widths.  Now a backward wave stores the
-// complete gradient row of its (instance, sub-tile) pair (common.hpp GradRowGeom; slot = 4 * emit-order instance index
-// + sub-tile, so all rows of one Gaussian are contiguous) and this kernel adds up each Gaussian's valid rows in slot
-// order: streaming stores + one coalesced pass, no atomics, bit-reproducible gradients.
+// complete gradient row of its (instance, sub-tile) pair (common.hpp GradRowGeom) -- compact rows, one per pair that survived
+// the cull -- and notes it in the reverse map row_of[4 * emit-order instance index + sub-tile] = row + 1; the entries of one
+// Gaussian are contiguous there, and this kernel adds up the Gaussian's rows in that order: streaming stores + one pass, no
+// atomics, bit-reproducible gradients.
 //
-// One wave per Gaussian: the 64 lanes first look at 64 validity bytes at a time (ballot), then walk the set bits;
+// One wave per Gaussian: the 64 lanes first look at 64 reverse-map entries at a time (ballot), then walk the set bits;
 // lane l accumulates row element l (and l + 64 for rows longer than 64 floats).
 #include "common.hpp"
 
@@ -34,7 +35,8 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
     bool any = false;
     for (uint32_t s0 = 0; s0 < nslots; s0 += 64) {
         const uint32_t s = s0 + (uint32_t)lane;
-        unsigned long long m = __ballot(s < nslots && a.row_flags[base + s] != 0);
+        const uint32_t rv = s < nslots ? a.row_of[base + s] : 0u;   // row + 1, or 0
+        unsigned long long m = __ballot(rv != 0u);
         any = any || m != 0ull;
         // up to RB valid rows per step: all their loads are issued before the first add (one memory latency per RB rows
         // instead of one per row -- most Gaussians have fewer than RB valid rows, i.e. one round trip); the adds keep slot
@@ -49,7 +51,8 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
             float v0[RB], v1[RB];
 #pragma unroll
             for (int k = 0; k < RB; k++) {
-                const float* row = a.grad_rows + (base + s0 + (uint32_t)(b[k] >= 0 ? b[k] : b[0])) * (size_t)rg.RS;
+                const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)rv, b[k] >= 0 ? b[k] : b[0]) - 1u;
+                const float* row = a.grad_rows + (size_t)ri * (size_t)rg.RS;
                 v0[k] = lane < rg.RS ? row[lane] : 0.f;
                 v1[k] = lane + 64 < rg.RS ? row[lane + 64] : 0.f;
             }

@@ -123,7 +123,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
     // position of a work id does not depend on the count: common.hpp seg_item_of).
     typedef const __attribute__((address_space(4))) uint32_t cu32;
     cu32* dsc0 = (cu32*)(uintptr_t)(a.seg_desc + min(seg_item_of(blockIdx.x), (uint32_t)a.seg_cap));
-    uint32_t d_sm = dsc0[0], d_r0 = dsc0[1], d_len = dsc0[2], d_count = dsc0[3], d_ndump = dsc0[4];
+    uint32_t d_sm = dsc0[0], d_r0 = dsc0[1], d_len = dsc0[2], d_count = dsc0[3], d_ndump = dsc0[4], d_pb = dsc0[5];
     const uint32_t nlive = min(a.seg_count[0], (uint32_t)a.seg_cap);
     const uint32_t nwork = seg_work_ids(nlive);
     if (blockIdx.x >= nwork) return;
@@ -134,7 +134,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
     if (item >= nlive) continue;
     if (wi != blockIdx.x) {
         cu32* dsc = (cu32*)(uintptr_t)(a.seg_desc + item);
-        d_sm = dsc[0]; d_r0 = dsc[1]; d_len = dsc[2]; d_count = dsc[3]; d_ndump = dsc[4];
+        d_sm = dsc[0]; d_r0 = dsc[1]; d_len = dsc[2]; d_count = dsc[3]; d_ndump = dsc[4]; d_pb = dsc[5];
     }
     DEV_TRACE_MARK(3);
     wave_lds_sync();   // the previous segment's LDS traffic is complete before its buffers are reused
@@ -153,6 +153,8 @@ render_bwd_kernel(const RenderBwdArgs a) {
     const uint2* __restrict__ sub_in = a.sub_list + (size_t)4 * r0 + (size_t)sub * tlen;
     const size_t pid = inside ? (size_t)a.W * py + px : 0;
     const int nent = seg_hi - seg_lo;
+    // gradient row of the candidate at segment position i (0 = deepest): compact, in list order (common.hpp)
+    const uint32_t row_top = d_pb + (uint32_t)(seg_hi - 1);
 
     // ---- every load of the set-up that depends only on the descriptor is issued here, together: the segment's list entries
     // (deepest first: the replay walks back to front), the pixel's forward results and upstream gradients, and the two dumped
@@ -454,8 +456,11 @@ render_bwd_kernel(const RenderBwdArgs a) {
                             const uint32_t rc = __builtin_bit_cast(uint32_t, rr[R_RECT]);
                             const uint32_t x0 = rc & 1023u, y0 = (rc >> 10) & 1023u, wr = rc >> 20;
                             const size_t sl = (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
-                            a.grad_rows[sl * RS + GEO + jq] = v;
-                            if (jq == 0) a.row_flags[sl] = 1;
+                            const uint32_t row = row_top - (uint32_t)(base + cb + kq);
+                            if (row < a.rows_cap) {
+                                a.grad_rows[(size_t)row * RS + GEO + jq] = v;
+                                if (jq == 0) a.row_of[sl] = row + 1u;   // where grad_reduce finds this pair's row
+                            }
                         } else if (v != 0.f) {
                             atomic_add_f32(a.grad_rows + ((size_t)sQ[base + cb + kq].x * RS + (uint32_t)(GEO + jq)), v);
                         }
@@ -487,20 +492,17 @@ render_bwd_kernel(const RenderBwdArgs a) {
                 // D layout: lane l, register r -> row 4*(l>>4) + r, column l&15
                 if (VC > 0) {
                     // ---- svgss: gradient rows (common.hpp GradRowGeom): plain stores, summed per Gaussian afterwards ----
-                    // rows of the panel = (candidate grpB, corner r); slot of the candidate: 4 * (first instance of the
-                    // Gaussian + index of this tile inside the Gaussian's tile rectangle, emit order) + sub-tile
+                    // rows of the panel = (candidate grpB, corner r); the candidate's gradient row: compact, in list order
                     const bool mine = c0 + grpB < m && ((live >> grpB) & 1u);
                     if (mine) {
-                        const float* rr = sD + (c0 + grpB) * SG::NF;
-                        const uint32_t ib = __builtin_bit_cast(uint32_t, rr[R_IBASE]);
-                        const uint32_t rc = __builtin_bit_cast(uint32_t, rr[R_RECT]);
-                        const uint32_t x0 = rc & 1023u, y0 = (rc >> 10) & 1023u, wr = rc >> 20;
-                        const size_t sl = (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
-                        float* row = a.grad_rows + sl * RS;
-                        if (colB < NC0) row[colB] = (accP[0] + accP[1]) + (accP[2] + accP[3]);
-                        if (colB < VC)
-                            reinterpret_cast<float4*>(row + P4)[colB] =
-                                sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const uint32_t rowi = row_top - (uint32_t)(base + c0 + grpB);
+                        float* row = a.grad_rows + (size_t)rowi * RS;
+                        if (rowi < a.rows_cap) {
+                            if (colB < NC0) row[colB] = (accP[0] + accP[1]) + (accP[2] + accP[3]);
+                            if (colB < VC)
+                                reinterpret_cast<float4*>(row + P4)[colB] =
+                                    sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
                 } else {
                     // ---- rgss: one packed gradient row per Gaussian, float atomics; rows of the panel = candidates ----

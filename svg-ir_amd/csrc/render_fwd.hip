@@ -511,10 +511,12 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
         for (int d = 32; d >= 1; d >>= 1) { bef[c] += (uint32_t)__shfl_xor((int)bef[c], d); tot[c] += (uint32_t)__shfl_xor((int)tot[c], d); }
         if (lane == 0) { red_b[c][wave] = bef[c]; red_t[c][wave] = tot[c]; }
     }
-    uint32_t nseg[4] = {0u, 0u, 0u, 0u}, head[4] = {0u, 0u, 0u, 0u}, nd[4] = {0u, 0u, 0u, 0u}, r0 = 0, r1 = 0;
+    uint32_t nseg[4] = {0u, 0u, 0u, 0u}, head[4] = {0u, 0u, 0u, 0u}, nd[4] = {0u, 0u, 0u, 0u}, pb[4] = {0u, 0u, 0u, 0u}, r0 = 0, r1 = 0;
     int lcls[4] = {0, 0, 0, 0};
     if (tile < T) {
         const uint4 c4 = reinterpret_cast<const uint4*>(a.sub_count)[tile], d4 = reinterpret_cast<const uint4*>(a.sub_ndump)[tile];
+        const uint4 b4 = reinterpret_cast<const uint4*>(a.sub_pair_base)[tile];
+        pb[0] = b4.x; pb[1] = b4.y; pb[2] = b4.z; pb[3] = b4.w;
         const uint2 rr = reinterpret_cast<const uint2*>(a.ranges)[tile];
         r0 = rr.x; r1 = rr.y;
         head[0] = c4.x; head[1] = c4.y; head[2] = c4.z; head[3] = c4.w;
@@ -570,7 +572,7 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
             a.seg_list[pos] = sm;
             uint4* d = reinterpret_cast<uint4*>(a.seg_desc + pos);
             d[0] = make_uint4(sm, r0, r1 - r0, head[w]);
-            d[1] = make_uint4(nd[w], 0u, 0u, 0u);
+            d[1] = make_uint4(nd[w], pb[w], 0u, 0u);
         }
     }
 }

@@ -135,8 +135,9 @@ class _CBinding:
                 g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
             g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
             rad = radii.contiguous()
-            # scratch for the gradient accumulation (rows per (instance, sub-tile), summed per Gaussian)
-            nscr = N.lib.svgir_backward_scratch_bytes(N.SVGSS, P, binningBuffer.numel(), W, H, S, VS)
+            # scratch for the gradient accumulation: one row per (instance, sub-tile) pair that survived this view's cull (the
+            # forward read the count back behind its cull), summed per Gaussian
+            nscr = N.lib.svgir_backward_scratch_bytes_for(N.SVGSS, P, binningBuffer.numel(), imageBuffer.data_ptr(), W, H, S, VS)
             scratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
             N.guarded(dev, "backward", N.lib.svgir_backward, p, g, int(R), rad.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
                                          binningBuffer.numel(), imageBuffer.data_ptr(), scratch.data_ptr(), nscr,

@@ -371,6 +371,49 @@ def test_svgss_gradients_bit_reproducible(built):
         assert torch.equal(runs[0][k], runs[1][k]), k
 
 
+def test_svgss_backward_scratch_is_sized_by_the_views_pair_count(built, monkeypatch):
+    """svgir_backward_scratch_bytes_for(): one gradient row per (sub-tile, instance) pair that survived THIS view's cull (the forward
+    reads the count back behind its cull) instead of four per instance -- well under half the worst case on a surface scene -- and
+    the gradients are bit-identical to a run with the worst-case scratch (same rows, same summation order)."""
+    from gaussian_renderer import _native as N
+    sc = scenes.surface_scene(P=20000, W=320, H=256, seed=72, sh_degree=2, variant="svgss", S=4, VS=52, scale_lo=0.01, scale_hi=0.05)
+    grads = scenes.upstream_grads(sc, "svgss", seed=4)
+    sct = runner.to_torch(sc, _dev())
+    sizes = []
+    real = N.lib.svgir_backward_scratch_bytes_for
+
+    def spy(variant, P, nbin, iblob, W, H, S, VS):
+        n = real(variant, P, nbin, iblob, W, H, S, VS)
+        sizes.append((int(n), int(N.lib.svgir_backward_scratch_bytes(variant, P, nbin, W, H, S, VS))))
+        return n
+
+    class _Lib:   # (ctypes function pointers cannot be monkeypatched on the CDLL: wrap the library object)
+        def __getattr__(self, k):
+            return spy if k == "svgir_backward_scratch_bytes_for" else getattr(N_lib, k)
+
+    N_lib = N.lib
+    monkeypatch.setattr(N, "lib", _Lib())
+    out, leaves = runner.render(sct, "svgss", requires_grad=True)
+    runner.backward(out, grads, "svgss")
+    torch.cuda.synchronize()
+    compact = {k: v.grad.clone() for k, v in leaves.items() if v.grad is not None}
+    assert sizes and sizes[-1][0] < 0.55 * sizes[-1][1], sizes
+
+    class _LibWorst:
+        def __getattr__(self, k):
+            if k == "svgir_backward_scratch_bytes_for":
+                return lambda variant, P, nbin, iblob, W, H, S, VS: N_lib.svgir_backward_scratch_bytes(variant, P, nbin, W, H, S, VS)
+            return getattr(N_lib, k)
+
+    monkeypatch.setattr(N, "lib", _LibWorst())
+    out, leaves = runner.render(sct, "svgss", requires_grad=True)
+    runner.backward(out, grads, "svgss")
+    torch.cuda.synchronize()
+    for k, v in leaves.items():
+        if v.grad is not None:
+            assert torch.equal(v.grad, compact[k]), k
+
+
 def test_speculative_capacity_small_large_small(built):
     """The count-dependent forward stages are launched speculatively for a capacity guessed from the previous call's
     instance count (csrc/api.hip): a much larger scene after a small one must take the re-run path, a small one after
