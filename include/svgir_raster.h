@@ -143,7 +143,9 @@ size_t svgir_geom_bytes(int32_t P);
 size_t svgir_image_bytes(int32_t W, int32_t H);
 /* The binning blob also holds the per-segment forward states that parallelise the backward over depth, hence the
  * dependence on the image size and channel counts (S features, VS vfeature floats; VS = 0 for rgss). */
-size_t svgir_binning_bytes(int32_t num_rendered, int32_t W, int32_t H, int32_t S, int32_t VS);
+size_t svgir_binning_bytes(int32_t num_rendered, int32_t W, int32_t H, int32_t S, int32_t VS);   /* worst case: the forward asks its
+ * allocator for less once it has seen a view of the workload (state slots from the pair statistics of recent views; such blobs are
+ * an odd multiple of 128 bytes long and belong to the forward that laid them out: pass them to svgir_backward unchanged) */
 /* Byte offset of the int32 n_contrib[H*W] plane inside the image blob (rgss returns a view of it, Q10). */
 size_t svgir_image_ncontrib_offset(int32_t W, int32_t H);
 
@@ -182,7 +184,7 @@ size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_b
 /* The same for ONE view: `image_blob` is the image blob of the svgir_forward whose backward is about to run.  svgss with vfeatures
  * then gets one gradient row per (sub-tile, instance) pair that survived that view's cull (1.2 per instance on the BASELINE scenes)
  * instead of four per instance: the forward reads the pair count back asynchronously behind its cull, and this call returns at once
- * unless that copy is still in flight.  An unknown blob (NULL, or one the library has not seen in its last 64 forwards) gets the
+ * unless that copy is still in flight.  An unknown blob (NULL, or one the library has not seen in its last 1024 forwards) gets the
  * worst case; svgir_backward accepts either size for the view it belongs to.  (ABI 10) */
 size_t svgir_backward_scratch_bytes_for(int32_t variant, int32_t P, size_t binning_bytes, const char* image_blob, int32_t W, int32_t H,
                                         int32_t S, int32_t VS);
@@ -191,7 +193,7 @@ size_t svgir_backward_scratch_bytes_for(int32_t variant, int32_t P, size_t binni
  * the depth-sorted instance list `point_list` (uint32 Gaussian ids, R entries; BinningState::point_list,
  * rasterizer_impl.h:66-76) inside the binning blob, and of the per-tile `ranges` (uint2 per tile; ImageState::ranges,
  * rasterizer_impl.h:49-63) inside the image blob. */
-size_t svgir_binning_point_list_offset(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS);
+size_t svgir_binning_point_list_offset(size_t binning_bytes, const char* image_blob, int32_t W, int32_t H, int32_t S, int32_t VS);
 size_t svgir_image_ranges_offset(int32_t W, int32_t H);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:141-153).  `present` is a byte per

@@ -32,7 +32,7 @@ std::atomic<bool> g_prof{false};
 // preview next to a 1600x1600 render, several scenes, several devices) neither re-run each other's dependent stages nor
 // over-allocate each other's blobs.  A small fixed table, least-recently-used replacement.
 struct CapKey { int dev, W, H, P, S, VS, variant; };
-struct CapEntry { CapKey key; int hist[8]; unsigned next; unsigned long long stamp; bool used; };
+struct CapEntry { CapKey key; int hist[8]; long long hist_slots[8]; unsigned next, next_slots; unsigned long long stamp; bool used; };
 std::mutex g_cap_mu;
 CapEntry g_cap[16];
 unsigned long long g_cap_clock = 0;
@@ -63,6 +63,19 @@ void record_R(const CapKey& k, int R) {
     CapEntry* e = cap_entry(k, true);
     e->hist[e->next++ % 8] = R;
 }
+// state slots (common.hpp seg_slots summed over the sub-tiles) of recent views of the workload: -1 = none seen yet
+long long guess_slots(const CapKey& k) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    const CapEntry* e = cap_entry(k, false);
+    long long m = -1;
+    if (e && e->next_slots) for (unsigned i = 0; i < std::min(e->next_slots, 8u); i++) m = std::max(m, e->hist_slots[i]);
+    return m;
+}
+void record_slots(const CapKey& k, long long slots) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    CapEntry* e = cap_entry(k, true);
+    e->hist_slots[e->next_slots++ % 8] = slots;
+}
 // Pinned landing slots for the 4-byte instance-count read-back (a pageable destination would make the "async" copy a
 // blocking staged one).  A small ring: concurrent forwards on different threads/streams get different slots.
 uint32_t* g_pinned = nullptr;
@@ -76,55 +89,78 @@ uint32_t* pinned_slot() {
     });
     return g_pinned ? g_pinned + 2 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
 }   // instance count of the previous forward: sizes the speculative binning blob
-// Pair counts (surviving (sub-tile, instance) pairs = gradient rows the svgss backward needs), read back asynchronously behind the cull
-// of every svgss forward and kept per image blob: svgir_backward_scratch_bytes_for() sizes the backward scratch from it.  By the time a
-// binder asks, the copy -- issued in the middle of the forward -- has long completed (a host wait right behind the cull costs nothing:
-// the composite is still queued, measured 0.4353 vs 0.4361 ms per cfg2 step).
-struct PairEntry { const void* key = nullptr; uint32_t tag = 0; unsigned long long stamp = 0; };
-constexpr int kPairEntries = 64;
-std::mutex g_pair_mu;
-PairEntry g_pair[kPairEntries];
-unsigned long long* g_pair_pinned = nullptr;   // [kPairEntries] {tag << 32 | pairs}, written by order_desc_kernel straight into host memory
-unsigned long long g_pair_clock = 0;
-uint32_t g_pair_tag = 0;
-// reserves the slot of the forward that owns `image_blob`: returns where order_desc_kernel writes its total and the tag it writes with it
-unsigned long long* pair_count_slot(const void* image_blob, uint32_t* tag) {
-    std::lock_guard<std::mutex> lk(g_pair_mu);
-    if (!g_pair_pinned) {
+// Per-view counts that exist only behind the cull -- the surviving (sub-tile, instance) pairs (= gradient rows the svgss backward needs)
+// and the state slots the composite forward may dump into -- reach the host as tagged 8-byte stores of order_desc_kernel into pinned
+// memory (no copy operation, no event on the stream) and are kept per IMAGE BLOB together with the capacities the forward laid the
+// binning blob out for: the backward and svgir_backward_scratch_bytes_for() find them there.  A host wait right behind the cull costs
+// nothing: the composite is still queued (measured with a full event synchronisation there: 0.4353 vs 0.4361 ms per cfg2 step).
+struct ViewEntry { const void* key = nullptr; uint32_t tag = 0; int cap_R = 0; long long cap_slots = -1; unsigned long long stamp = 0; };
+constexpr int kViewEntries = 1024;   // forwards whose backward may still come (least recently used entry replaced)
+std::mutex g_view_mu;
+ViewEntry g_view[kViewEntries];
+unsigned long long* g_view_pinned = nullptr;   // [kViewEntries][2] {tag << 32 | pairs, tag << 32 | slots}
+unsigned long long g_view_clock = 0;
+uint32_t g_view_tag = 0;
+// registers the launch sequence of the forward that owns `image_blob`: returns where order_desc_kernel writes its totals and the tag
+unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_slots, uint32_t* tag) {
+    std::lock_guard<std::mutex> lk(g_view_mu);
+    if (!g_view_pinned) {
         void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, kPairEntries * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return nullptr;
-        g_pair_pinned = (unsigned long long*)ptr;
-        for (int i = 0; i < kPairEntries; i++) g_pair_pinned[i] = 0ull;
+        if (hipHostMalloc(&ptr, kViewEntries * 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return nullptr;
+        g_view_pinned = (unsigned long long*)ptr;
+        for (int i = 0; i < 2 * kViewEntries; i++) g_view_pinned[i] = 0ull;
     }
     int slot = 0;
-    for (int i = 0; i < kPairEntries; i++) {
-        if (g_pair[i].key == image_blob) { slot = i; break; }
-        if (g_pair[i].stamp < g_pair[slot].stamp) slot = i;
+    for (int i = 0; i < kViewEntries; i++) {
+        if (g_view[i].key == image_blob) { slot = i; break; }
+        if (g_view[i].stamp < g_view[slot].stamp) slot = i;
     }
-    PairEntry& e = g_pair[slot];
-    e.key = image_blob; e.stamp = ++g_pair_clock;
-    e.tag = ++g_pair_tag ? g_pair_tag : ++g_pair_tag;   // (never 0: the slots start as 0)
+    ViewEntry& e = g_view[slot];
+    e.key = image_blob; e.stamp = ++g_view_clock; e.cap_R = cap_R; e.cap_slots = cap_slots;
+    e.tag = ++g_view_tag ? g_view_tag : ++g_view_tag;   // (never 0: the slots start as 0)
     *tag = e.tag;
-    return g_pair_pinned + slot;
+    return g_view_pinned + 2 * slot;
 }
-// the pair count of the forward that owns `image_blob`, or -1 (unknown: the caller falls back to the worst case).  The value is in host
-// memory as soon as the forward's order kernel has run -- long before a binder asks; the wait below only ever spins when the host is
-// far ahead of the GPU, and gives up after 2 s (a forward that failed on the device never writes it).
-long long pair_count_of(const void* image_blob) {
-    volatile unsigned long long* slot = nullptr;
+// the entry of the forward that owns `image_blob` (capacities; counts when `wait`): false = unknown blob.  The counts are in host memory
+// as soon as the forward's order kernel has run; the wait only ever spins when the host is ahead of the GPU and gives up after ~2 s
+// (a forward that failed on the device never writes them): pairs / slots stay -1 then.
+bool view_lookup(const void* image_blob, bool wait, int* cap_R, long long* cap_slots, long long* pairs, long long* slots) {
+    volatile unsigned long long* at = nullptr;
     uint32_t tag = 0;
     {
-        std::lock_guard<std::mutex> lk(g_pair_mu);
-        for (int i = 0; i < kPairEntries; i++)
-            if (g_pair[i].key == image_blob && g_pair_pinned) { slot = g_pair_pinned + i; tag = g_pair[i].tag; break; }
+        std::lock_guard<std::mutex> lk(g_view_mu);
+        for (int i = 0; i < kViewEntries; i++)
+            if (g_view[i].key == image_blob && g_view_pinned) {
+                at = g_view_pinned + 2 * i; tag = g_view[i].tag;
+                if (cap_R) *cap_R = g_view[i].cap_R;
+                if (cap_slots) *cap_slots = g_view[i].cap_slots;
+                break;
+            }
     }
-    if (!slot) return -1;
-    for (long long spin = 0; spin < 2000000; spin++) {
-        const unsigned long long v = *slot;
-        if ((uint32_t)(v >> 32) == tag) return (long long)(uint32_t)v;
-        if (spin > 1000) { struct timespec ts = {0, 1000}; nanosleep(&ts, nullptr); }
+    if (pairs) *pairs = -1;
+    if (slots) *slots = -1;
+    if (!at) return false;
+    if (!wait) return true;
+    // (a pure spin on host memory: the value is typically 100-200 us away -- the rest of the binning -- and a sleep's granularity of
+    // ~60 us would hand the GPU an idle gap; after 5 ms the waits become sleeps, after ~2 s the lookup gives up)
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long long spin = 0;; spin++) {
+        const unsigned long long v0 = at[0], v1 = at[1];
+        if ((uint32_t)(v0 >> 32) == tag && (uint32_t)(v1 >> 32) == tag) {
+            if (pairs) *pairs = (long long)(uint32_t)v0;
+            if (slots) *slots = (long long)(uint32_t)v1;
+            return true;
+        }
+        if ((spin & 255) == 255) {
+            struct timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            if (el > 2.0) break;
+            if (el > 5e-3) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+        }
     }
-    return -1;
+    return true;
 }
 // Side stream of the backward: the gradient tensors are cleared there while the composite backward (which only writes the
 // scratch) runs on the caller's stream.  One per device, created on first use; fork / join through events.
@@ -293,11 +329,16 @@ size_t svgir_image_ranges_offset(int32_t W, int32_t H) {
     const ImageLayout I = image_layout((char*)256, W, H);   // (non-null dummy base: the layout returns pointers)
     return (size_t)((char*)I.ranges - (char*)256);
 }
-size_t svgir_binning_point_list_offset(size_t binning_bytes, int32_t W, int32_t H, int32_t S, int32_t VS) {
+size_t svgir_binning_point_list_offset(size_t binning_bytes, const char* image_blob, int32_t W, int32_t H, int32_t S, int32_t VS) {
     const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const int nstate = seg_nstate(S, VS);
-    const int cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
-    const BinLayout B = bin_layout((char*)256, cap, T, nstate);
+    int cap = 0;
+    if (bin_bytes_compact(binning_bytes)) {   // laid out for a state-slot capacity of the forward's choosing: the view's entry knows
+        if (!image_blob || !view_lookup(image_blob, false, &cap, nullptr, nullptr, nullptr)) return (size_t)-1;
+    } else {
+        cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
+    }
+    const BinLayout B = bin_layout((char*)256, cap, T, nstate);   // (the instance arrays come first: independent of the slot capacity)
     return (size_t)((char*)B.val[tile_sort_plan(T).passes & 1] - (char*)256);
 }
 const char* svgir_last_error(void) { return g_err.c_str(); }
@@ -414,8 +455,8 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
 #if defined(SVGIR_EXP_SYNC_AFTER_CULL)
     hipEvent_t sync_after_cull = nullptr;
 #endif
-    auto run_binning_and_render = [&](char* bblob, int cap, bool timed) -> int {
-        const BinLayout B = bin_layout(bblob, cap, T, nstate);
+    auto run_binning_and_render = [&](char* bblob, int cap, long long cap_slots, bool timed) -> int {
+        const BinLayout B = bin_layout(bblob, cap, T, nstate, cap_slots);
         launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
                     I.counters, B.radix_tbl, s);
         if (int rc = check("emit")) return rc;
@@ -432,6 +473,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
         ra.bg = p->background;
         ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_total = I.sub_total; ra.sub_order = I.sub_order;
+        ra.sub_pair_base = I.sub_pair_base; ra.sub_slot_base = I.sub_slot_base; ra.slot_cap = (uint32_t)std::min<size_t>(B.slot_cap, 0xffffffffu);
         ra.sub_count = I.sub_count;
         ra.sub_ndump = I.sub_ndump; ra.seg_list = B.seg_list; ra.seg_desc = B.seg_desc; ra.seg_count = I.counters; ra.seg_block = I.seg_block; ra.seg_state = B.seg_state;
         ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
@@ -443,10 +485,11 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         ra.zero_b = clear_stencil ? o->out_surface_xyz : nullptr;
         ra.pair_stream = B.pair_stream;
         launch_cull(ra, s);
-        const bool row_path = svgss && p->VS > 0 && render_specialised(p->S, p->VS, true);   // the backward writes gradient rows
-        uint32_t ptag = 0;
-        unsigned long long* pslot = row_path ? pair_count_slot(iblob, &ptag) : nullptr;
-        launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, row_path ? I.counters + 1 : nullptr, pslot, ptag, s);
+        // dispatch order of the sub-tiles, first gradient row / first state slot of each, and the two totals (device + tagged host copy)
+        uint32_t vtag = 0;
+        unsigned long long* vslot = view_note(iblob, cap, cap_slots, &vtag);
+        const bool row_path = svgss && p->VS > 0 && render_specialised(p->S, p->VS, true);   // (only the svgss backward writes gradient rows)
+        launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, I.sub_slot_base, I.counters, vslot, vtag, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
 #if defined(SVGIR_EXP_SYNC_AFTER_CULL)
@@ -470,19 +513,24 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         return 0;
     };
 
-    // Speculative launch: capacity from this workload's recent instance counts (+12.5 %), no host round trip in between.
+    // Speculative launch: capacities from this workload's recent views (+12.5 %) -- instances (binning arrays) and state slots
+    // (seg_state) -- no host round trip in between.  The first view of a workload gets the exact instance capacity and the worst-case
+    // slot count (4 full lists per tile); later ones typically a third of that.
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
     int cap = 0;
+    long long cap_slots = -1;
     char* bblob = nullptr;
     if (const int guess = guess_R(ckey)) {
         cap = binning_capacity((long long)guess + guess / 8 + 1024);
-        bblob = binning(bin_layout(nullptr, cap, T, nstate).bytes, binning_ctx);
+        const long long gs = guess_slots(ckey);
+        cap_slots = gs < 0 ? -1 : std::min<long long>(gs + gs / 8 + 64, (long long)seg_capacity(cap, T));
+        bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
         // (a failed speculative allocation is not an error: the guess may be far larger than this view needs; fall
         // through to the exact-size path below)
         if (bblob) {
-            if (int rc = run_binning_and_render(bblob, cap, true)) { (void)hipEventDestroy(evR); return rc; }
+            if (int rc = run_binning_and_render(bblob, cap, cap_slots, true)) { (void)hipEventDestroy(evR); return rc; }
         } else {
             cap = 0;
         }
@@ -497,16 +545,28 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
     const int R = (int)R_host;
     record_R(ckey, R);
-    if (!bblob || R > cap) {
-        // first call, or the scene grew past the guess: (re)do the dependent stages with the exact capacity
+    // the view's state-slot count (behind the cull; the composite is still queued, so this wait is free): did the guess hold?
+    long long slots = -1;
+    bool slots_fit = true;
+    if (bblob && R <= cap) {
+        (void)view_lookup(iblob, true, nullptr, nullptr, nullptr, &slots);
+        if (slots >= 0 && cap_slots >= 0 && slots > cap_slots) slots_fit = false;
+    }
+    if (!bblob || R > cap || !slots_fit) {
+        // first view, or the scene grew past a guess: (re)do the dependent stages -- exact instance capacity; exact slot count when this
+        // view's cull has already produced it (complete lists: R fitted), else the worst case
         const bool redo = bblob != nullptr;
+        const bool lists_complete = redo && R <= cap && slots >= 0;
         if (redo) HIP_OK(hipStreamSynchronize(s));
         cap = binning_capacity(R);
-        bblob = binning(bin_layout(nullptr, cap, T, nstate).bytes, binning_ctx);
+        cap_slots = lists_complete ? slots : -1;
+        bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
         if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
         if (redo && o->out_weights) HIP_OK(hipMemsetAsync(o->out_weights, 0, (size_t)P * 4, s));   // accumulated by atomics
-        if (int rc = run_binning_and_render(bblob, cap, !redo)) return rc;
+        if (int rc = run_binning_and_render(bblob, cap, cap_slots, !redo)) return rc;
+        (void)view_lookup(iblob, true, nullptr, nullptr, nullptr, &slots);   // (for the next view's guess)
     }
+    if (slots >= 0) record_slots(ckey, slots);
 
 #if defined(SVGIR_EXP_SYNC_AFTER_CULL)
     if (sync_after_cull) { (void)hipEventSynchronize(sync_after_cull); (void)hipEventDestroy(sync_after_cull); }
@@ -532,9 +592,14 @@ size_t svgir_backward_scratch_bytes_for(int32_t variant, int32_t P, size_t binni
     if (variant != SVGIR_SVGSS || VS == 0)   // one packed gradient row per Gaussian
         return align_up((size_t)(P > 0 ? P : 1) * grad_row_geom(S, 0).RS * 4);
     const int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    const int cap = binning_capacity_from_bytes(binning_bytes, T, seg_nstate(S, VS));
-    // one gradient row per (sub-tile, instance) pair that survived the cull of THIS view when its count is known, else four per instance
-    const long long pairs = image_blob ? pair_count_of(image_blob) : -1;
+    // the binning blob's instance capacity: from its size (worst-case state slots) or, for a blob laid out for a slot capacity of the
+    // forward's choosing, from the view's entry; and one gradient row per (sub-tile, instance) pair that survived the cull of THIS
+    // view when its count is known, else four per instance
+    int cap = 0;
+    long long pairs = -1;
+    const bool known = image_blob && view_lookup(image_blob, true, &cap, nullptr, &pairs, nullptr);
+    if (!bin_bytes_compact(binning_bytes)) cap = binning_capacity_from_bytes(binning_bytes, T, seg_nstate(S, VS));
+    else if (!known) cap = binning_capacity((long long)(binning_bytes / 48));   // (no view given: an upper bound -- every instance owns 48 B of the blob)
     const size_t rows = pairs >= 0 ? (size_t)std::min<long long>(pairs, (long long)4 * cap) : (size_t)4 * cap;
     return grad_scratch_bytes(cap, rows > 0 ? rows : 1, S, VS);
 }
@@ -555,10 +620,18 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     const GeomLayout G = geom_layout(geom_blob, P);
     const ImageLayout I = image_layout(image_blob, W, H);
     const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
-    const int cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
-    if (cap < R || bin_layout(nullptr, cap, T, nstate).bytes != binning_bytes)
+    int cap = 0;
+    long long cap_slots = -1;
+    if (bin_bytes_compact(binning_bytes)) {   // laid out by the forward for a state-slot capacity of its choosing: the view's entry knows
+        if (!view_lookup(image_blob, false, &cap, &cap_slots, nullptr, nullptr) || cap_slots < 0)
+            return fail(SVGIR_ERR_INVALID, "the binning blob (%zu bytes) was laid out by a forward this library no longer knows "
+                                           "(more than 1024 forwards ago, or the image blob was copied)", binning_bytes);
+    } else {
+        cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
+    }
+    if (cap < R || bin_layout(nullptr, cap, T, nstate, cap_slots).bytes != binning_bytes)
         return fail(SVGIR_ERR_INVALID, "binning blob of %zu bytes does not match any layout for R=%d", binning_bytes, R);
-    const BinLayout B = bin_layout(binning_blob, cap, T, nstate);
+    const BinLayout B = bin_layout(binning_blob, cap, T, nstate, cap_slots);
     const int fin = tile_sort_plan(T).passes & 1;
     StageTimer tm(s);
 
@@ -651,7 +724,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         RenderArgs sa{};
         sa.W = W; sa.H = H; sa.gx = gx; sa.gy = gy; sa.S = p->S; sa.VS = ba.VS;
         sa.ranges = I.ranges; sa.sub_count = I.sub_count; sa.sub_ndump = I.sub_ndump; sa.seg_list = B.seg_list; sa.seg_desc = B.seg_desc;
-        sa.seg_count = I.counters; sa.seg_block = I.seg_block; sa.sub_pair_base = I.sub_pair_base;
+        sa.seg_count = I.counters; sa.seg_block = I.seg_block; sa.sub_pair_base = I.sub_pair_base; sa.sub_slot_base = I.sub_slot_base;
         launch_seg_build(sa, sc_clear, sc_bytes, s);
     } else if (sc_clear && !rows) {
         HIP_OK(hipMemsetAsync(sc_clear, 0, sc_bytes, s));   // (nothing rendered: geom_bwd still unpacks the -- zero -- packed rows)

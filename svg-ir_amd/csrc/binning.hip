@@ -266,8 +266,8 @@ __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t
 // per count below 1023 (exact order there; everything longer shares the first bucket -- those waves start first anyway).
 __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __restrict__ counts, int n,
                                                           uint32_t* __restrict__ order, uint32_t* __restrict__ prefix,
-                                                          uint32_t* __restrict__ total, unsigned long long* __restrict__ host_total,
-                                                          uint32_t host_tag) {
+                                                          uint32_t* __restrict__ slot_prefix, uint32_t* __restrict__ total,
+                                                          unsigned long long* __restrict__ host_total, uint32_t host_tag) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -330,46 +330,81 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
         zbase = (uint32_t)__shfl((int)zbase, 0);
         if (z) order[zbase + (uint32_t)__popcll(zero & lt_mask)] = (uint32_t)i;
     }
-    if (!prefix && !total && !host_total) return;
-    // exclusive prefix sum of the counts in index order (the first gradient row of every sub-tile) and their total: every thread owns
-    // k consecutive items -- one block scan over the threads' sums, whatever n
-    const int k = (n + 1023) / 1024;
-    const int first = t * k;
-    uint32_t mine = 0;
-    for (int j = 0; j < k; j++) mine += first + j < n ? counts[first + j] : 0u;
-    uint32_t inc = mine;
+    if (!prefix && !slot_prefix && !total && !host_total) return;
+    // exclusive prefix sums in index order of the counts (the first gradient row of every sub-tile) and of seg_slots(count) (its first
+    // dumped-state slot), and their totals.  Every wave owns a contiguous chunk of the items and walks it 64 at a time (coalesced loads
+    // and stores, wave scans on DPP): first its total, then -- behind ONE barrier -- the running prefixes.
+    const int chunk = ((n + 15) / 16 + 63) / 64 * 64;   // items per wave
+    const int c0 = wave * chunk, c1 = min(n, c0 + chunk);
+    // inclusive wave scans on the VALU (DPP row shifts + row broadcasts; a __shfl_up scan is 6 LDS permutes per word)
+    auto scan32 = [](uint32_t v) {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+        return v;
+    };
+    auto wave_incl = [&](unsigned long long v) {   // (two independent 32-bit scans: neither half overflows into the other)
+        return (unsigned long long)scan32((uint32_t)v) | ((unsigned long long)scan32((uint32_t)(v >> 32)) << 32);
+    };
+    auto both = [](uint32_t c) { return (unsigned long long)c | ((unsigned long long)seg_slots(c) << 32); };   // low word: counts, high word: slots
+    constexpr int PIT = 12;   // chunk rounds held in registers (n <= 12288; beyond that the rounds re-read the counts)
+    const bool in_regs = chunk <= PIT * 64;
+    uint32_t cv[PIT];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
+    for (int r = 0; r < PIT; r++) cv[r] = (in_regs && c0 + r * 64 + lane < c1) ? counts[c0 + r * 64 + lane] : 0u;   // all loads in flight together
+    unsigned long long wtot = 0;
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < PIT; r++) wtot += both(cv[r]);
+    } else {
+        for (int i0 = c0; i0 < c1; i0 += 64) wtot += both(i0 + lane < c1 ? counts[i0 + lane] : 0u);
     }
-    __syncthreads();   // (wsum of the ordering pass consumed)
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t wo = 0, running = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) { const uint32_t x = wsum[w]; wo += w < wave ? x : 0u; running += x; }
-    if (prefix) {
-        uint32_t at = wo + inc - mine;
-        for (int j = 0; j < k; j++) {
-            if (first + j < n) { prefix[first + j] = at; at += counts[first + j]; }
+    for (int d = 32; d >= 1; d >>= 1) wtot += (unsigned long long)__shfl_xor((long long)wtot, d);
+    __shared__ unsigned long long wsum2[16];
+    if (lane == 0) wsum2[wave] = wtot;
+    __syncthreads();
+    unsigned long long run = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const unsigned long long x = wsum2[w]; run += w < wave ? x : 0ull; all += x; }
+    if (prefix || slot_prefix) {
+        auto round = [&](int i0, uint32_t c) {
+            const int i = i0 + lane;
+            const unsigned long long v = both(c), inc = wave_incl(v);
+            if (i < c1) {
+                if (prefix) prefix[i] = (uint32_t)(run + inc - v);
+                if (slot_prefix) slot_prefix[i] = (uint32_t)((run + inc - v) >> 32);
+            }
+            run += ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)inc, 63)) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(inc >> 32), 63) << 32);
+        };
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < PIT; r++)
+                if (c0 + r * 64 < c1) round(c0 + r * 64, cv[r]);   // (uniform)
+        } else {
+            for (int i0 = c0; i0 < c1; i0 += 64) round(i0, i0 + lane < c1 ? counts[i0 + lane] : 0u);
         }
     }
     if (t == 0) {
-        if (total) total[0] = running;
-        // the host's copy: {total, tag of this forward} as ONE 8-byte store into pinned host memory -- no copy operation and no event
-        // on the stream; the host recognises the value by its tag (api.hip pair_count_of)
+        if (total) { total[1] = (uint32_t)all; total[2] = (uint32_t)(all >> 32); }
+        // the host's copy: {sum, tag of this forward} as 8-byte stores into pinned host memory -- no copy operation and no event on the
+        // stream; the host recognises the values by their tag (api.hip view_lookup)
         if (host_total) {
-            __hip_atomic_store(host_total, ((unsigned long long)host_tag << 32) | (unsigned long long)running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (self-contained: no ordering with other memory needed)
+            __hip_atomic_store(host_total, ((unsigned long long)host_tag << 32) | (all & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_total + 1, ((unsigned long long)host_tag << 32) | (all >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
 }  // namespace
 
-void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* total, unsigned long long* host_total,
-                       uint32_t host_tag, hipStream_t s) {
-    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order, prefix, total, host_total, host_tag);
+void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* slot_prefix, uint32_t* totals,
+                       unsigned long long* host_totals, uint32_t host_tag, hipStream_t s) {
+    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order, prefix, slot_prefix, totals, host_totals, host_tag);
 }
 
 template <int ITEMS>

@@ -98,7 +98,9 @@ struct ImageLayout {
     uint32_t* sub_count; // [4*T] #candidates the forward composite consumed before every pixel was done (<= sub_total)
     uint32_t* sub_ndump; // [4*T] #segment-boundary states the forward dumped for the sub-tile (see SEG)
     uint32_t* sub_pair_base; // [4*T] exclusive prefix of sub_total over the sub-tiles: first gradient row of a sub-tile's candidates
-    uint32_t* counters;  // [4]: [0] = number of live backward segments (entries of BinLayout::seg_list); [1] = sum of sub_total (pairs)
+    uint32_t* sub_slot_base; // [4*T] exclusive prefix of seg_slots(sub_total): first dumped-state slot of a sub-tile (BinLayout::seg_state)
+    uint32_t* counters;  // [4]: [0] = number of live backward segments (entries of BinLayout::seg_list); [1] = sum of sub_total (pairs);
+                         // [2] = sum of seg_slots(sub_total) (state slots)
     size_t ncontrib_off;
     size_t bytes;
 };
@@ -119,6 +121,7 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.sub_count = (uint32_t*)take(T * 4 * 4);
     im.sub_ndump = (uint32_t*)take(T * 4 * 4);
     im.sub_pair_base = (uint32_t*)take(T * 4 * 4);
+    im.sub_slot_base = (uint32_t*)take(T * 4 * 4);
     im.counters = (uint32_t*)take(16);
     im.bytes = off;
     return im;
@@ -147,7 +150,9 @@ inline size_t grad_scratch_bytes(int cap, size_t rows, int S, int VS) {   // rev
 // sub-tile's compact list.  The forward dumps its per-pixel blend state (T and every accumulator) after each SEG-th
 // candidate and once at the end; a backward segment starts its back-to-front replay from the state at its far end
 // (transmittance there, and "everything behind" = (final - prefix) / T) instead of from the end of the list.
-// State slot of sub-tile i = 4*tile+w, segment k:  (4*r0 + w*len) / SEG + i + k   (disjoint by construction).
+// State slots are COMPACT (round 4): a sub-tile whose list has `total` candidates dumps at most total / SEG boundary states + the final
+// one, and none at all below SEG candidates -- seg_slots(total) -- and its first slot is the exclusive prefix of that over the
+// sub-tiles (ImageLayout::sub_slot_base, a by-product of order_desc_kernel); slot of (sub-tile, segment k) = sub_slot_base + k.
 // After the forward composite seg_build_kernel lists the live segments -- seg_list (compact ids) and seg_desc (everything a
 // backward wave needs to start: SegDesc) -- LONGEST FIRST: class 0 = full segments (SEG candidates), classes 1..4 = the
 // partial last segments of the sub-tiles by length quarter; tile order inside a class.  The backward's waves take the list
@@ -159,12 +164,12 @@ constexpr int SEG = 64;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline uint32_t seg_state_base(uint32_t r0, uint32_t len, int tile, int sub) {
-    return (uint32_t)(((size_t)4 * r0 + (size_t)sub * len) / SEG) + (uint32_t)(4 * tile + sub);
-}
+inline uint32_t seg_slots(uint32_t total) { return total >= (uint32_t)SEG ? total / (uint32_t)SEG + 1u : 0u; }
+// upper bound of the number of live segments (seg_list / seg_desc) and -- the worst case over the cull, 4 full lists per tile -- of
+// the state slots
 inline size_t seg_capacity(int R, int T) { return (size_t)4 * (size_t)(R > 0 ? R : 0) / SEG + (size_t)4 * T + 1; }
 constexpr int SEG_K_BITS = 14;   // seg_list entry = (sub-tile id << SEG_K_BITS) | k
-struct SegDesc { uint32_t sm, r0, len, count, ndump, pair_base, pad1, pad2; };   // 32 B: seg_list entry, tile range start / length, sub_count, sub_ndump, first gradient row of the sub-tile
+struct SegDesc { uint32_t sm, r0, len, count, ndump, pair_base, slot_base, pad2; };   // 32 B: seg_list entry, tile range start / length, sub_count, sub_ndump, first gradient row / first state slot of the sub-tile
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -201,13 +206,16 @@ struct BinLayout {
                        // of a tile with range [r0,r1) owns entries [4*r0 + w*(r1-r0), 4*r0 + (w+1)*(r1-r0))
     uint32_t* seg_list; // [seg_capacity] live backward segments, longest first (seg_build_kernel)
     SegDesc* seg_desc;  // [seg_capacity + 256] their descriptors (same order)
-    float* seg_state;  // [seg_capacity][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
+    float* seg_state;  // [slot_cap][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
     float* pair_stream; // (experiment builds, -DBWDP_STREAM) [4*R][24] per-(sub-tile, candidate) records in list order, else null
-    size_t seg_cap;
+    size_t seg_cap;    // entries of seg_list / seg_desc
+    size_t slot_cap;   // state slots of seg_state
     size_t bytes;
 };
 inline int seg_nstate(int S, int VS) { return 8 + S + VS / 4; }
-inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
+// `slots` < 0: the worst case (seg_capacity); else a state-slot capacity chosen by the forward (from the pair statistics of recent
+// views); such blobs are marked by an odd multiple of 128 bytes, so a size alone tells which kind it is
+inline BinLayout bin_layout(char* base, int R, int T, int nstate, long long slots = -1) {
     BinLayout b;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
@@ -221,17 +229,19 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate) {
     b.seg_cap = seg_capacity(R, T);
     b.seg_list = (uint32_t*)take(b.seg_cap * 4);
     b.seg_desc = (SegDesc*)take((b.seg_cap + 8 * SEG_XCD_BLOCK) * sizeof(SegDesc));
-    b.seg_state = (float*)take(b.seg_cap * (size_t)nstate * 64 * 4);
+    b.slot_cap = slots < 0 ? b.seg_cap : (size_t)slots;
+    b.seg_state = (float*)take((b.slot_cap > 0 ? b.slot_cap : 1) * (size_t)nstate * 64 * 4);
 #if defined(BWDP_STREAM)
     b.pair_stream = (float*)take(r * 4 * 24 * 4);
 #else
     b.pair_stream = nullptr;
 #endif
-    b.bytes = off;
+    b.bytes = off + (slots < 0 ? 0 : 128);
     return b;
 }
+inline bool bin_bytes_compact(size_t bytes) { return bytes % 256 == 128; }
 
-// inverse of bin_layout(...).bytes over the capacities binning_capacity() produces (bytes is strictly increasing in it)
+// inverse of bin_layout(...).bytes (worst-case state slots) over the capacities binning_capacity() produces (bytes is strictly increasing in it)
 inline int binning_capacity_from_bytes(size_t bytes, int T, int nstate) {
     long long lo = 1, hi = 0x7ffff000LL / 4096;
     while (lo < hi) {
@@ -286,7 +296,7 @@ struct RenderArgs {
     CfgRef cfg;
     uint2* sub_list; uint32_t* sub_total; uint32_t* sub_order; uint32_t* sub_count;
     uint32_t* sub_ndump; uint32_t* seg_list; SegDesc* seg_desc; uint32_t* seg_count; uint32_t* seg_block; float* seg_state;
-    uint32_t* sub_pair_base;
+    uint32_t* sub_pair_base; uint32_t* sub_slot_base; uint32_t slot_cap;
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
@@ -351,10 +361,10 @@ void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint
                  uint32_t* seg_count, uint32_t* sort_table, hipStream_t s);
 void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
 // order[] = item ids sorted by descending counts[] (longest-processing-time-first dispatch of the composite waves); also
-// prefix[i] = exclusive prefix sum of counts[], total[0] = their sum, host_total[0] = host_tag << 32 | sum in pinned host memory
-// (any of them may be null)
-void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* total, unsigned long long* host_total,
-                       uint32_t host_tag, hipStream_t s);
+// prefix[i] = exclusive prefix sum of counts[], slot_prefix[i] = the same of seg_slots(counts[]), totals[1] / totals[2] = the two sums,
+// host_totals[0] / [1] = host_tag << 32 | sum in pinned host memory (any of them may be null)
+void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* slot_prefix, uint32_t* totals,
+                       unsigned long long* host_totals, uint32_t host_tag, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
 // tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump; also zeroes

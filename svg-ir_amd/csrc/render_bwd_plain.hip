@@ -100,7 +100,7 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     // the segment count and this wave's first descriptor are independent loads (the list position of a work id does not
     // depend on the count: common.hpp seg_item_of)
     cu32* dsc0 = (cu32*)(uintptr_t)(a.seg_desc + min(seg_item_of(blockIdx.x), (uint32_t)a.seg_cap));
-    uint32_t d_sm = dsc0[0], d_r0 = dsc0[1], d_len = dsc0[2], d_count = dsc0[3], d_ndump = dsc0[4];
+    uint32_t d_sm = dsc0[0], d_r0 = dsc0[1], d_len = dsc0[2], d_count = dsc0[3], d_ndump = dsc0[4], d_sb = dsc0[6];
     const uint32_t nlive = min(a.seg_count[0], (uint32_t)a.seg_cap);
     const uint32_t nwork = seg_work_ids(nlive);
     if (blockIdx.x >= nwork) return;
@@ -112,7 +112,7 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     if (item >= nlive) continue;
     if (w != blockIdx.x) {
         cu32* dsc = (cu32*)(uintptr_t)(a.seg_desc + item);
-        d_sm = dsc[0]; d_r0 = dsc[1]; d_len = dsc[2]; d_count = dsc[3]; d_ndump = dsc[4];
+        d_sm = dsc[0]; d_r0 = dsc[1]; d_len = dsc[2]; d_count = dsc[3]; d_ndump = dsc[4]; d_sb = dsc[6];
     }
     wave_lds_sync();   // the previous segment's LDS traffic is complete before its buffers are reused
     const uint32_t sm = d_sm, r0 = d_r0, tlen = d_len;
@@ -227,7 +227,7 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         // Not the deepest live segment: start from the forward state dumped at this segment's far end.  With
         // last_alpha = 0 the recurrence takes accum = blend of everything behind = (final - prefix) / T_end.
         constexpr int NST = 8 + S;
-        const uint32_t sbase = seg_state_base(r0, tlen, tile, sub);   // state slot of (sub-tile, 0)
+        const uint32_t sbase = d_sb;   // state slot of (sub-tile, 0)
         const float* e = a.seg_state + ((size_t)(sbase + kseg) * NST) * 64 + lane;
         const float* f = a.seg_state + ((size_t)(sbase + ndump) * NST) * 64 + lane;   // final state
         T = e[0];

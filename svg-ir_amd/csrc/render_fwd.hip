@@ -253,10 +253,11 @@ render_fwd_kernel(const RenderArgs a) {
 
     // segment-boundary state dumps (see common.hpp SEG)
     constexpr int NST = 8 + S + VC;
-    const uint32_t dump_base = seg_state_base(r0, (uint32_t)len, tile, sub);
+    const uint32_t dump_base = a.sub_slot_base[sid];   // first state slot of this sub-tile (compact: common.hpp SEG)
     uint32_t ndump = 0;
     auto dump_state = [&](uint32_t j) {
         gather_acc();
+        if (dump_base + j >= a.slot_cap) return;   // (only in a speculative launch whose capacity guess was too small: the forward re-runs)
         float* d = a.seg_state + ((size_t)(dump_base + j) * NST) * 64 + lane;
         d[0] = T; d[64] = chan(0); d[128] = chan(1); d[192] = chan(2);
         // (the normal channels are blended unconditionally; without `surface` they do not exist for the consumers)
@@ -511,12 +512,13 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
         for (int d = 32; d >= 1; d >>= 1) { bef[c] += (uint32_t)__shfl_xor((int)bef[c], d); tot[c] += (uint32_t)__shfl_xor((int)tot[c], d); }
         if (lane == 0) { red_b[c][wave] = bef[c]; red_t[c][wave] = tot[c]; }
     }
-    uint32_t nseg[4] = {0u, 0u, 0u, 0u}, head[4] = {0u, 0u, 0u, 0u}, nd[4] = {0u, 0u, 0u, 0u}, pb[4] = {0u, 0u, 0u, 0u}, r0 = 0, r1 = 0;
+    uint32_t nseg[4] = {0u, 0u, 0u, 0u}, head[4] = {0u, 0u, 0u, 0u}, nd[4] = {0u, 0u, 0u, 0u}, pb[4] = {0u, 0u, 0u, 0u}, sb[4] = {0u, 0u, 0u, 0u}, r0 = 0, r1 = 0;
     int lcls[4] = {0, 0, 0, 0};
     if (tile < T) {
         const uint4 c4 = reinterpret_cast<const uint4*>(a.sub_count)[tile], d4 = reinterpret_cast<const uint4*>(a.sub_ndump)[tile];
-        const uint4 b4 = reinterpret_cast<const uint4*>(a.sub_pair_base)[tile];
+        const uint4 b4 = reinterpret_cast<const uint4*>(a.sub_pair_base)[tile], s4 = reinterpret_cast<const uint4*>(a.sub_slot_base)[tile];
         pb[0] = b4.x; pb[1] = b4.y; pb[2] = b4.z; pb[3] = b4.w;
+        sb[0] = s4.x; sb[1] = s4.y; sb[2] = s4.z; sb[3] = s4.w;
         const uint2 rr = reinterpret_cast<const uint2*>(a.ranges)[tile];
         r0 = rr.x; r1 = rr.y;
         head[0] = c4.x; head[1] = c4.y; head[2] = c4.z; head[3] = c4.w;
@@ -572,7 +574,7 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
             a.seg_list[pos] = sm;
             uint4* d = reinterpret_cast<uint4*>(a.seg_desc + pos);
             d[0] = make_uint4(sm, r0, r1 - r0, head[w]);
-            d[1] = make_uint4(nd[w], pb[w], 0u, 0u);
+            d[1] = make_uint4(nd[w], pb[w], sb[w], 0u);
         }
     }
 }

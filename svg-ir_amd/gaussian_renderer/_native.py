@@ -66,7 +66,7 @@ def _load():
     lib.svgir_image_ranges_offset.restype = C.c_size_t
     lib.svgir_image_ranges_offset.argtypes = [C.c_int32, C.c_int32]
     lib.svgir_binning_point_list_offset.restype = C.c_size_t
-    lib.svgir_binning_point_list_offset.argtypes = [C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.svgir_binning_point_list_offset.argtypes = [C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.svgir_forward.restype = C.c_int
     lib.svgir_forward.argtypes = [C.POINTER(Params), C.POINTER(Outputs), ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
                                   ALLOC_FN, C.c_void_p, C.c_void_p]

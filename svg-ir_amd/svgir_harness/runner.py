@@ -108,7 +108,7 @@ def forward_raw(sc, variant):
                    radii=radii)
     W, H = st.image_width, st.image_height
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    off = N.lib.svgir_binning_point_list_offset(bb.numel(), W, H, S, VS)
+    off = N.lib.svgir_binning_point_list_offset(bb.numel(), ib.data_ptr(), W, H, S, VS)
     res["point_list"] = bb[off:off + 4 * R].view(torch.int32).cpu().numpy().astype("uint32")
     roff = N.lib.svgir_image_ranges_offset(W, H)
     res["ranges"] = ib[roff:roff + 8 * T].view(torch.int32).cpu().numpy().astype("uint32").reshape(T, 2)

@@ -433,6 +433,24 @@ def test_speculative_capacity_small_large_small(built):
         last_R = R
 
 
+def test_state_slot_capacity_guess_too_small_reruns(built):
+    """The composite forward dumps its blend state every 64 candidates of a sub-tile; the slots it may use are allocated from the
+    pair statistics of the workload's recent views (csrc/api.hip).  A view whose lists are suddenly much longer -- the same surfels,
+    the same instance count, but all of them on top of each other -- exceeds that guess and must take the re-run path; before and
+    after it, views with short lists run inside their (tiny / over-sized) allocations.  All three match the oracle, forward and
+    backward."""
+    spread = scenes.surface_scene(P=20000, W=256, H=256, seed=91, sh_degree=1, variant="svgss", S=4, VS=52, scale_lo=0.004, scale_hi=0.006)
+    stacked = dict(spread)
+    rng = np.random.default_rng(92)
+    stacked["means3D"] = (0.03 * rng.normal(size=spread["means3D"].shape)).astype(np.float32)
+    stacked["opacities"] = (spread["opacities"] * 0.02).astype(np.float32)   # translucent: the lists are consumed to the end
+    for sc in (spread, spread, stacked, spread):
+        grads = scenes.upstream_grads(sc, "svgss", seed=5)
+        out, leaves, o, R = _run_both(sc, "svgss", grads)
+        _check_forward(out, o, R, "svgss")
+        _check_backward(leaves, o, "svgss")
+
+
 def test_prefiltered_flag_reports_culled_points(built):
     """`prefiltered=True` asserts that the caller has already removed every point the frustum / back-face tests would
     cull; the reference traps the device when one is culled anyway (auxiliary.h:163-167, 195-199).  Here the forward
