@@ -8,6 +8,11 @@
 //
 // The reference launches two kernels with a round trip of dL_dcov3D / dL_dmean3D through HBM; here one lane does
 // both halves for its Gaussian.  Contraction is off so results track the oracle's un-fused arithmetic.
+//
+// Memory order: the kernel is one round of waves (3 per SIMD at P = 200 k), i.e. it costs its chain of dependent memory
+// latencies.  As far as the compiler knows every tensor may alias every other, so a load written below a store waits for that store:
+// all inputs of a Gaussian are therefore requested at the top (one latency behind the radius test) and every gradient leaves at the
+// bottom -- dL_dcov3D and the unpacked composite gradients are used from registers, not re-read (stage 40.5 -> 35.6 us at cfg2).
 #include "common.hpp"
 
 #pragma clang fp contract(off)
@@ -45,30 +50,76 @@ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    const bool surface = cfg_flag(a.cfg, 0);
+    const bool lrn_cam = a.svgss && a.cfg.len >= 0 && cfg_flag(a.cfg, 3);
+    // (the uniform inputs as well: a load the compiler cannot prove untouched by an earlier store is not a scalar load any more)
+    float V[16], PR[16], campos[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; i++) { V[i] = a.view[i]; PR[i] = a.proj[i]; }
+    if (a.shs) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
+
+    // ---------------- every input of this Gaussian ----------------
+    float in_color[3], in_normal[3], in_depth, in_m2d[2], in_conic[3], in_opacity = 0.f;
     if (a.packed) {
         // rgss: the backward composite accumulated this Gaussian's gradients in one packed row (common.hpp GradRowGeom:
-        // colour3, normal3, depth, feature S | pad | mean2D.xy, conic.xyz, opacity); unpack it into the caller's tensors
+        // colour3, normal3, depth, feature S | pad | mean2D.xy, conic.xyz, opacity); it is unpacked into the caller's tensors below
         const int P4 = (7 + a.S + 3) / 4 * 4, RS = (P4 + 6 + 3) / 4 * 4;
         const float* row = a.packed + (size_t)idx * RS;
 #pragma unroll
-        for (int c = 0; c < 3; c++) { a.dL_dcolor[3 * idx + c] = row[c]; a.dL_dnormal[3 * idx + c] = row[3 + c]; }
-        a.dL_ddepth[idx] = row[6];
-        for (int c = 0; c < a.S; c++) a.dL_dfeature[(size_t)idx * a.S + c] = row[7 + c];
-        a.dL_dmean2D[3 * idx] = row[P4]; a.dL_dmean2D[3 * idx + 1] = row[P4 + 1];
-        a.dL_dconic[4 * idx] = row[P4 + 2]; a.dL_dconic[4 * idx + 1] = row[P4 + 3]; a.dL_dconic[4 * idx + 3] = row[P4 + 4];
-        a.dL_dopacity[idx] = row[P4 + 5];
+        for (int c = 0; c < 3; c++) { in_color[c] = row[c]; in_normal[c] = row[3 + c]; in_conic[c] = row[P4 + 2 + c]; }
+        in_depth = row[6];
+        in_m2d[0] = row[P4]; in_m2d[1] = row[P4 + 1];
+        in_opacity = row[P4 + 5];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { in_color[c] = a.dL_dcolor[3 * idx + c]; in_normal[c] = a.dL_dnormal[3 * idx + c]; }
+        in_depth = a.dL_ddepth[idx];
+        in_m2d[0] = a.dL_dmean2D[3 * idx]; in_m2d[1] = a.dL_dmean2D[3 * idx + 1];
+        in_conic[0] = a.dL_dconic[4 * idx]; in_conic[1] = a.dL_dconic[4 * idx + 1]; in_conic[2] = a.dL_dconic[4 * idx + 3];
     }
-    const bool surface = cfg_flag(a.cfg, 0);
-    const bool lrn_cam = a.svgss && a.cfg.len >= 0 && cfg_flag(a.cfg, 3);
-    const float* V = a.view;
-    const float* PR = a.proj;
     const float mean[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    float c3[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) c3[i] = a.cov3D[6 * idx + i];
+    // The 48-float coefficient row of a Gaussian (M = 16) is contiguous and 16-byte aligned: it is read and its
+    // gradient row written with 12 float4 accesses per lane instead of 48 dword accesses (the lanes of a wave are
+    // 192 bytes apart, so the number of memory transactions is what this stage costs).
+    const bool vec = a.shs && a.M == 16 && ((((size_t)a.shs) | ((size_t)a.dL_dsh)) & 15) == 0;
+    const int nk = (a.D + 1) * (a.D + 1);
+    float sh[48];
+    uint32_t cm = 0;
+    if (a.shs) {
+        const float* shp = a.shs + (size_t)idx * a.M * 3;
+        cm = a.clamped[idx];
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const float4 v = reinterpret_cast<const float4*>(shp)[i];
+                sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 48; i++) sh[i] = i < 3 * nk ? shp[i] : 0.f;
+        }
+    }
+    float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc_in[3] = {0.f, 0.f, 0.f};
+    if (a.scales) {
+        qq = reinterpret_cast<const float4*>(a.rotations)[idx];
+#pragma unroll
+        for (int i = 0; i < 3; i++) sc_in[i] = a.scales[3 * idx + i];
+    }
+    if (a.packed) {   // (run-time feature width: row -> tensor, behind the loads above)
+        const int P4 = (7 + a.S + 3) / 4 * 4, RS = (P4 + 6 + 3) / 4 * 4;
+        const float* row = a.packed + (size_t)idx * RS;
+        for (int c = 0; c < a.S; c++) a.dL_dfeature[(size_t)idx * a.S + c] = row[7 + c];
+    }
     float dmean[3];
+    float dcv[6];
 
     // ---------------- conic -> cov2D -> (cov3D, mean) ----------------
     {
-        const float* c3 = a.cov3D + 6 * idx;
-        const float dcon[3] = {a.dL_dconic[4 * idx], a.dL_dconic[4 * idx + 1], a.dL_dconic[4 * idx + 3]};
+        const float dcon[3] = {in_conic[0], in_conic[1], in_conic[2]};
         float t[3] = {V[0] * mean[0] + V[4] * mean[1] + V[8] * mean[2] + V[12],
                       V[1] * mean[0] + V[5] * mean[1] + V[9] * mean[2] + V[13],
                       V[2] * mean[0] + V[6] * mean[1] + V[10] * mean[2] + V[14]};
@@ -96,7 +147,6 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         const float denom = ca * cc - cb * cb;
         float da = 0.f, db = 0.f, dc = 0.f;
         const float d2i = 1.0f / ((denom * denom) + 0.0000001f);
-        float* dcv = a.dL_dcov3D + 6 * idx;
 #define TC(i, j) Tm.m[i][j]
 #define VC_(i, j) Vk.m[i][j]
         if (d2i != 0) {
@@ -151,12 +201,12 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         const float mw = 1.0f / (mhw + 0.0000001f);
         const float mul1 = (PR[0] * mean[0] + PR[4] * mean[1] + PR[8] * mean[2] + PR[12]) * mw * mw;
         const float mul2 = (PR[1] * mean[0] + PR[5] * mean[1] + PR[9] * mean[2] + PR[13]) * mw * mw;
-        const float g2x = a.dL_dmean2D[3 * idx], g2y = a.dL_dmean2D[3 * idx + 1];
+        const float g2x = in_m2d[0], g2y = in_m2d[1];
         float dm[3];
         dm[0] = (PR[0] * mw - PR[3] * mul1) * g2x + (PR[1] * mw - PR[3] * mul2) * g2y;
         dm[1] = (PR[4] * mw - PR[7] * mul1) * g2x + (PR[5] * mw - PR[7] * mul2) * g2y;
         dm[2] = (PR[8] * mw - PR[11] * mul1) * g2x + (PR[9] * mw - PR[11] * mul2) * g2y;
-        const float dd = a.dL_ddepth[idx];
+        const float dd = in_depth;
         const float fd[3] = {dd * V[2], dd * V[6], dd * V[10]};
 #pragma unroll
         for (int i = 0; i < 3; i++) dmean[i] += dm[i] + fd[i];
@@ -176,34 +226,16 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     // ---------------- colour -> SH, view direction -> mean ----------------
     if (a.shs) {
         const float kC0 = 0.28209479177387814f, kC1 = 0.4886025119029199f;
-        const float dor[3] = {mean[0] - a.campos[0], mean[1] - a.campos[1], mean[2] - a.campos[2]};
+        const float dor[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
         const float len = sqrtf(dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2]);
         const float x = dor[0] / len, y = dor[1] / len, z = dor[2] / len;
-        const float* shp = a.shs + (size_t)idx * a.M * 3;
-        const uint32_t cm = a.clamped[idx];
         float g[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) g[c] = a.dL_dcolor[3 * idx + c] * (((cm >> c) & 1u) ? 0.f : 1.f);
-        float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+        for (int c = 0; c < 3; c++) g[c] = in_color[c] * (((cm >> c) & 1u) ? 0.f : 1.f);
         float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
-        // The 48-float coefficient row of a Gaussian (M = 16) is contiguous and 16-byte aligned: it is read and its
-        // gradient row written with 12 float4 accesses per lane instead of 48 dword accesses (the lanes of a wave are
-        // 192 bytes apart, so the number of memory transactions is what this stage costs).
-        const bool vec = a.M == 16 && ((((size_t)a.shs) | ((size_t)a.dL_dsh)) & 15) == 0;
-        const int nk = (a.D + 1) * (a.D + 1);
-        float sh[48], cf[16];
+        float cf[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) cf[k] = 0.f;
-        if (vec) {
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const float4 v = reinterpret_cast<const float4*>(shp)[i];
-                sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 48; i++) sh[i] = i < 3 * nk ? shp[i] : 0.f;
-        }
 #define SET(k, coef) cf[k] = (coef);
 #define SH(k, c) sh[3 * (k) + (c)]
         SET(0, kC0)
@@ -243,6 +275,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
 #undef SET
 #undef SH
         // dL_dsh[k][c] = cf[k] * g[c]; coefficients above the active degree are left untouched (the caller zero-fills)
+        float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
         if (vec && a.D == 3) {
             float o[48];
 #pragma unroll
@@ -268,25 +301,22 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 3; i++) dmean[i] += dm[i];
     }
-#pragma unroll
-    for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * idx + i] = dmean[i];
 
     // ---------------- cov3D -> scale, rotation (+ normal gradient into R) ----------------
+    float dsc[3] = {0.f, 0.f, 0.f};
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.scales) {
-        const float4 qq = reinterpret_cast<const float4*>(a.rotations)[idx];
         const float r = qq.x, x = qq.y, y = qq.z, z = qq.w;
         Mat3 Rm;
         Rm.m[0][0] = 1.f - 2.f * (y * y + z * z); Rm.m[0][1] = 2.f * (x * y - r * z); Rm.m[0][2] = 2.f * (x * z + r * y);
         Rm.m[1][0] = 2.f * (x * y + r * z); Rm.m[1][1] = 1.f - 2.f * (x * x + z * z); Rm.m[1][2] = 2.f * (y * z - r * x);
         Rm.m[2][0] = 2.f * (x * z - r * y); Rm.m[2][1] = 2.f * (y * z + r * x); Rm.m[2][2] = 1.f - 2.f * (x * x + y * y);
-        const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                            a.scale_modifier * a.scales[3 * idx + 2]};
+        const float s[3] = {a.scale_modifier * sc_in[0], a.scale_modifier * sc_in[1], a.scale_modifier * sc_in[2]};
         Mat3 Mm;  // S * R with S = diag(s): M[c][row] = s[row] * R[c][row]
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
             for (int row = 0; row < 3; row++) Mm.m[c][row] = s[row] * Rm.m[c][row];
-        const float* dcv = a.dL_dcov3D + 6 * idx;
         Mat3 dSig, twoM;
         dSig.m[0][0] = dcv[0]; dSig.m[0][1] = 0.5f * dcv[1]; dSig.m[0][2] = 0.5f * dcv[2];
         dSig.m[1][0] = 0.5f * dcv[1]; dSig.m[1][1] = dcv[3]; dSig.m[1][2] = 0.5f * dcv[4];
@@ -297,14 +327,13 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
             for (int row = 0; row < 3; row++) twoM.m[c][row] = 2.0f * Mm.m[c][row];
         const Mat3 dM = mmul(twoM, dSig);
         const Mat3 Rt = mtr(Rm), dMt = mtr(dM);
-        float* dsc = a.dL_dscale + 3 * idx;
         dsc[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
         dsc[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
         dsc[2] = surface ? 0.f : (Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2]);
         Mat3 dRt = dMt;
 #pragma unroll
         for (int k = 0; k < 3; k++) { dRt.m[0][k] *= s[0]; dRt.m[1][k] *= s[1]; dRt.m[2][k] *= s[2]; }
-        const float gn[3] = {a.dL_dnormal[3 * idx], a.dL_dnormal[3 * idx + 1], a.dL_dnormal[3 * idx + 2]};
+        const float gn[3] = {in_normal[0], in_normal[1], in_normal[2]};
         dRt.m[2][0] += gn[0] * V[0] + gn[1] * V[1] + gn[2] * V[2];
         dRt.m[2][1] += gn[0] * V[4] + gn[1] * V[5] + gn[2] * V[6];
         dRt.m[2][2] += gn[0] * V[8] + gn[1] * V[9] + gn[2] * V[10];
@@ -315,12 +344,29 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
             for (int i = 0; i < 16; i++) if (dv[i] != 0.f) atomic_add_f32(&a.dL_dviewmat[i], dv[i]);
         }
 #define DR(i, j) dRt.m[i][j]
-        float4 dq;
         dq.x = 2 * z * (DR(0, 1) - DR(1, 0)) + 2 * y * (DR(2, 0) - DR(0, 2)) + 2 * x * (DR(1, 2) - DR(2, 1));
         dq.y = 2 * y * (DR(1, 0) + DR(0, 1)) + 2 * z * (DR(2, 0) + DR(0, 2)) + 2 * r * (DR(1, 2) - DR(2, 1)) - 4 * x * (DR(2, 2) + DR(1, 1));
         dq.z = 2 * x * (DR(1, 0) + DR(0, 1)) + 2 * r * (DR(2, 0) - DR(0, 2)) + 2 * z * (DR(1, 2) + DR(2, 1)) - 4 * y * (DR(2, 2) + DR(0, 0));
         dq.w = 2 * r * (DR(0, 1) - DR(1, 0)) + 2 * x * (DR(2, 0) + DR(0, 2)) + 2 * y * (DR(1, 2) + DR(2, 1)) - 4 * z * (DR(1, 1) + DR(0, 0));
 #undef DR
+    }
+
+    // ---------------- every gradient of this Gaussian ----------------
+    if (a.packed) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { a.dL_dcolor[3 * idx + c] = in_color[c]; a.dL_dnormal[3 * idx + c] = in_normal[c]; }
+        a.dL_ddepth[idx] = in_depth;
+        a.dL_dmean2D[3 * idx] = in_m2d[0]; a.dL_dmean2D[3 * idx + 1] = in_m2d[1];
+        a.dL_dconic[4 * idx] = in_conic[0]; a.dL_dconic[4 * idx + 1] = in_conic[1]; a.dL_dconic[4 * idx + 3] = in_conic[2];
+        a.dL_dopacity[idx] = in_opacity;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * idx + i] = dcv[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * idx + i] = dmean[i];
+    if (a.scales) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) a.dL_dscale[3 * idx + i] = dsc[i];
         reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
     }
 }

@@ -61,16 +61,11 @@ __constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315391
 __constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
-// SH -> RGB, degrees 0..3; returns clamp mask in the low 3 bits.
-__device__ __forceinline__ uint32_t sh_to_rgb(const PreArgs& a, int idx, const float* pos, float* rgb) {
-    const float kC0 = 0.28209479177387814f, kC1 = 0.4886025119029199f;
-    float dir[3] = {pos[0] - a.campos[0], pos[1] - a.campos[1], pos[2] - a.campos[2]};
-    const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-    const float x = dir[0] / len, y = dir[1] / len, z = dir[2] / len;
+// The SH coefficient row of Gaussian idx (zero above the active degree).
+__device__ __forceinline__ void load_sh(const PreArgs& a, int idx, float* sh) {
     const float* shp = a.shs + (size_t)idx * a.M * 3;
     // M = 16: the 48-float coefficient row is contiguous and 16-byte aligned -> 12 float4 loads instead of 48 dword
     // loads (only the loads change, the arithmetic below is untouched)
-    float sh[48];
     if (a.M == 16 && (((size_t)a.shs) & 15) == 0) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -82,6 +77,14 @@ __device__ __forceinline__ uint32_t sh_to_rgb(const PreArgs& a, int idx, const f
 #pragma unroll
         for (int i = 0; i < 48; i++) sh[i] = i < n ? shp[i] : 0.f;
     }
+}
+
+// SH -> RGB, degrees 0..3; returns clamp mask in the low 3 bits.
+__device__ __forceinline__ uint32_t sh_to_rgb(const PreArgs& a, const float* sh, const float* campos, const float* pos, float* rgb) {
+    const float kC0 = 0.28209479177387814f, kC1 = 0.4886025119029199f;
+    float dir[3] = {pos[0] - campos[0], pos[1] - campos[1], pos[2] - campos[2]};
+    const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const float x = dir[0] / len, y = dir[1] / len, z = dir[2] / len;
     float res[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) res[c] = kC0 * sh[c];
@@ -119,6 +122,14 @@ __device__ __forceinline__ uint32_t sh_to_rgb(const PreArgs& a, int idx, const f
 template <bool SVGSS>
 __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    // Memory order (one round of waves: the kernel costs its chain of dependent memory latencies): the uniform inputs are read
+    // before the first store (behind one, the compiler can no longer prove them unclobbered and they stop being scalar loads); a
+    // Gaussian's own inputs are requested together right behind the frustum test, not where the arithmetic first needs them.
+    float V[16], PM[16], campos[3] = {0.f, 0.f, 0.f}, pbb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; i++) { V[i] = a.view[i]; PM[i] = a.proj[i]; }
+    if (!a.colors_precomp) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
+    if (SVGSS) { pbb[0] = a.patchbbox[0]; pbb[1] = a.patchbbox[1]; pbb[2] = a.patchbbox[2]; pbb[3] = a.patchbbox[3]; }
     for (int j = idx; j < a.n_zero_words; j += gridDim.x * BLOCK) a.zero_words[j] = 0u;
     if (idx >= a.P) return;
     const bool surface = cfg_flag(a.cfg, 0), pix_depth = cfg_flag(a.cfg, 2);
@@ -129,9 +140,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     a.key[idx] = 0xFFFFFFFFu;
     a.idx[idx] = (uint32_t)idx;
 
-    const float* V = a.view;
-    const float* PM = a.proj;
     const float po[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    float q[4] = {1.f, 0.f, 0.f, 0.f};
+    if (a.rotations) {
+        const float4 qq = reinterpret_cast<const float4*>(a.rotations)[idx];
+        q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+    }
     const float hx = PM[0] * po[0] + PM[4] * po[1] + PM[8] * po[2] + PM[12];
     const float hy = PM[1] * po[0] + PM[5] * po[1] + PM[9] * po[2] + PM[13];
     const float hw = PM[3] * po[0] + PM[7] * po[1] + PM[11] * po[2] + PM[15];
@@ -142,7 +156,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
                          V[2] * po[0] + V[6] * po[1] + V[10] * po[2] + V[14]};
     const float pix[2] = {ndc2pix(ppx, a.W), ndc2pix(ppy, a.H)};
     if (SVGSS) {
-        const float x0 = a.patchbbox[1], y0 = a.patchbbox[0], x1 = a.patchbbox[3], y1 = a.patchbbox[2];
+        const float x0 = pbb[1], y0 = pbb[0], x1 = pbb[3], y1 = pbb[2];
         const float w = x1 - x0, h = y1 - y0, e = (float)0.2;
         if (pv[2] < 0 || pix[0] < x0 - w * e || pix[0] >= x1 + w * e || pix[1] < y0 - h * e || pix[1] >= y1 + h * e) {
             if (a.prefilter_violation) *a.prefilter_violation = 1u;   // the reference traps here (auxiliary.h:163-167)
@@ -155,11 +169,6 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
         }
     }
 
-    float q[4] = {1.f, 0.f, 0.f, 0.f};
-    if (a.rotations) {
-        const float4 qq = reinterpret_cast<const float4*>(a.rotations)[idx];
-        q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-    }
     const float r = q[0], x = q[1], y = q[2], z = q[3];
     Mat3 Rm;
     Rm.m[0][0] = 1.f - 2.f * (y * y + z * z); Rm.m[0][1] = 2.f * (x * y - r * z); Rm.m[0][2] = 2.f * (x * z + r * y);
@@ -211,20 +220,30 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
         }
     }
 
-    float c3[6];
+    // ---- every remaining input of this Gaussian (half of the surfels of a closed surface never get here: back-facing) ----
+    float sc_in[3] = {0.f, 0.f, 0.f}, c3[6], rgb[3] = {0.f, 0.f, 0.f}, sh[48];
+    if (a.scales) { sc_in[0] = a.scales[3 * idx]; sc_in[1] = a.scales[3 * idx + 1]; sc_in[2] = a.scales[3 * idx + 2]; }
     if (a.cov3D_precomp) {
 #pragma unroll
         for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * idx + i];
+    }
+    const float opacity = a.opacities[idx];
+    if (a.colors_precomp) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) rgb[c] = a.colors_precomp[3 * idx + c];
     } else {
+        load_sh(a, idx, sh);
+    }
+    if (!a.cov3D_precomp) {
         // quirk Q1: `mod * surface ? 0 : scale.z`
         Mat3 Sm;
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
             for (int rr = 0; rr < 3; rr++) Sm.m[c][rr] = 0.f;
-        Sm.m[0][0] = a.scale_modifier * a.scales[3 * idx];
-        Sm.m[1][1] = a.scale_modifier * a.scales[3 * idx + 1];
-        Sm.m[2][2] = (a.scale_modifier * (surface ? 1.0f : 0.0f)) != 0.0f ? 0.0f : a.scales[3 * idx + 2];
+        Sm.m[0][0] = a.scale_modifier * sc_in[0];
+        Sm.m[1][1] = a.scale_modifier * sc_in[1];
+        Sm.m[2][2] = (a.scale_modifier * (surface ? 1.0f : 0.0f)) != 0.0f ? 0.0f : sc_in[2];
         const Mat3 Mm = mmul(Sm, Rm);
         const Mat3 Sg = mmul(mtr(Mm), Mm);
         c3[0] = Sg.m[0][0]; c3[1] = Sg.m[0][1]; c3[2] = Sg.m[0][2];
@@ -265,14 +284,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     const int area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
     if (area == 0) return;
 
-    float rgb[3];
     uint32_t cmask = 0;
-    if (a.colors_precomp) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) rgb[c] = a.colors_precomp[3 * idx + c];
-    } else {
-        cmask = sh_to_rgb(a, idx, po, rgb);
-    }
+    if (!a.colors_precomp) cmask = sh_to_rgb(a, sh, campos, po, rgb);
     a.clamped[idx] = cmask;
     a.radii[idx] = (int)my_radius;
     a.tiles[idx] = (uint32_t)area;
@@ -280,15 +293,15 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
 
     float iu = 0.f, iv = 0.f;
     if (SVGSS && a.scales) {
-        const float umx = (float)(0.5 * (double)a.scales[3 * idx] + 0.1);
-        const float umy = (float)(0.5 * (double)a.scales[3 * idx + 1] + 0.1);
+        const float umx = (float)(0.5 * (double)sc_in[0] + 0.1);
+        const float umy = (float)(0.5 * (double)sc_in[1] + 0.1);
         iu = 1.0f / umx; iv = 1.0f / umy;
     }
     float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC);
     rec[0] = make_float4(pix[0], pix[1], conic[0], conic[1]);
     // depth-differencing coefficients (common.hpp R_DA / R_DB)
     const float da = J[0] * J[6] + J[2] * J[9], db = J[1] * J[6] + J[3] * J[9];
-    rec[1] = make_float4(conic[2], a.opacities[idx], pv[2], da);
+    rec[1] = make_float4(conic[2], opacity, pv[2], da);
     rec[2] = make_float4(J[0], J[1], J[2], J[3]);
     rec[3] = make_float4(db, rgb[0], rgb[1], rgb[2]);
     rec[4] = make_float4(nv[0], nv[1], nv[2], iu);

@@ -642,20 +642,27 @@ struct ShadeBwdArgs {
     float *d_base, *d_rough, *d_normals, *d_radiance, *d_envtab;  // d_envtab: gradient w.r.t. the f(env) table
 };
 
-// ---- backward sample record (BREC floats): the forward's 17 + dmul(3) = d(global light)/d(env lookup) incl. the
-// clamp and visibility, + the bilinear footprint {x0 | y0 << 16, fx, fy} so the adjoint never re-evaluates acos/atan2.
-constexpr int BREC = 24;   // (23 used; 24 = six float4: the records are written and read with 128-bit LDS instructions)
+// ---- backward sample record (BREC = 20 floats = five float4, written and read with 128-bit LDS instructions):
+//   d(3) il | H(3) frac0 | Lg(3) area | Ll(3) ve | footprint, fx, fy, pad
+// il = 1 / |d| (L = d * il is three multiplies in the consumer instead of three floats here), ve = visibility * env_scale =
+// d(global light) / d(env lookup) where the lookup is inside its clamp -- the three per-channel clamp flags ride in the
+// footprint word {x0 + 1 : 14 bits | y0 + 1 : 14 bits | flags : 3 bits}, so the adjoint never re-evaluates acos / atan2.
+// (20 floats instead of 24: 435 -> 427 us.)
+constexpr int BREC = 20;
 #ifndef SHADE_BWAVES
-#define SHADE_BWAVES 12   // one workgroup per CU: 12 x 5.9 KB of sample records + the fp64 env-gradient image (49 KB at 32x64)
+#define SHADE_BWAVES 12   // one workgroup per CU: 12 x (5 KB of sample records + 3.3 KB of surfel records) + the fp64 env-gradient image (48 KB at 32x64); 16 waves with KB_G = 2 fit as well and are slower (467 vs 427 us)
 #endif
 #ifndef SHADE_BWPE
 #define SHADE_BWPE 3
+#endif
+#ifndef SHADE_KB_G
+#define SHADE_KB_G 4
 #endif
 #ifndef SHADE_ABL
 #define SHADE_ABL 0   // (ablation experiments only, scripts/build_variant.sh: 1-4 switch parts of the kernel off -- wrong results)
 #endif
 constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
-constexpr int KB_G = 4, KREC = 52;   // Gaussians prepared per batch; floats per (Gaussian, corner) record (13 float4)
+constexpr int KB_G = SHADE_KB_G, KREC = 52;   // Gaussians prepared per batch; floats per (Gaussian, corner) record (13 float4)
 
 __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const RawSample& x, int lane, const float* V,
                                               float* __restrict__ sS) {
@@ -702,18 +709,19 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
         }
     }
     float r[BREC];
+    uint32_t flags = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         const float Es = E[ch] * p.env_scale;
-        r[ch] = d[ch]; r[3 + ch] = L[ch]; r[6 + ch] = H[ch];
-        r[10 + ch] = fminf(64.f, fmaxf(0.f, Es)) * x.vis; r[13 + ch] = x.rad[ch];
-        r[17 + ch] = (Es >= 0.f && Es <= 64.f) ? x.vis * p.env_scale : 0.f;
+        r[ch] = d[ch]; r[4 + ch] = H[ch];
+        r[8 + ch] = fminf(64.f, fmaxf(0.f, Es)) * x.vis; r[12 + ch] = x.rad[ch];
+        flags |= (Es >= 0.f && Es <= 64.f) ? (1u << ch) : 0u;
     }
-    r[9] = frac0; r[16] = x.area;
-    // footprint origin, biased by +1 (x0, y0 >= -1 by construction), 16 bits each
-    const int xb = min(max(x0 + 1, 0), 65535), yb = min(max(y0 + 1, 0), 65535);
-    r[20] = __builtin_bit_cast(float, (uint32_t)xb | ((uint32_t)yb << 16));
-    r[21] = fx; r[22] = fy; r[23] = 0.f;
+    r[3] = il; r[7] = frac0; r[11] = x.area; r[15] = x.vis * p.env_scale;
+    // footprint origin, biased by +1 (x0, y0 >= -1 by construction), 14 bits each (the launcher checks the map's size)
+    const int xb = min(max(x0 + 1, 0), 16383), yb = min(max(y0 + 1, 0), 16383);
+    r[16] = __builtin_bit_cast(float, (uint32_t)xb | ((uint32_t)yb << 14) | (flags << 28));
+    r[17] = fx; r[18] = fy; r[19] = 0.f;
     float4* o = reinterpret_cast<float4*>(sS + lane * BREC);
 #pragma unroll
     for (int i = 0; i < BREC / 4; i++) o[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
@@ -895,16 +903,17 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 }
                 const float ndr = c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2];
                 const float ndi = fmaxf(ndr, 0.f);
-                const float NoLr = c.Nh[0] * r[3] + c.Nh[1] * r[4] + c.Nh[2] * r[5];
-                const float NoHr = c.Nh[0] * r[6] + c.Nh[1] * r[7] + c.Nh[2] * r[8];
+                const float Lv[3] = {r[0] * r[3], r[1] * r[3], r[2] * r[3]};
+                const float NoLr = c.Nh[0] * Lv[0] + c.Nh[1] * Lv[1] + c.Nh[2] * Lv[2];
+                const float NoHr = c.Nh[0] * r[4] + c.Nh[1] * r[5] + c.Nh[2] * r[6];
                 const float NoL = fminf(1.f, fmaxf(1e-6f, NoLr)), NoH = fminf(1.f, fmaxf(1e-6f, NoHr));
                 const float nom0 = NoH * NoH * (c.a2 - 1.f) + 1.f;
                 const float nom2 = NoL * (1.f - c.kk) + c.kk;
                 const float nomr = 4.f * kPi * nom0 * nom0 * c.nom1 * nom2;
                 const float nom = fminf(4.f * kPi, fmaxf(1e-6f, nomr));
                 const float inv_nom = __builtin_amdgcn_rcpf(nom);
-                const float fs = r[9] * c.a2 * inv_nom;
-                const float area = act ? r[16] : 0.f, ge = area * ndi;
+                const float fs = r[7] * c.a2 * inv_nom;
+                const float area = act ? r[11] : 0.f, ge = area * ndi;
                 float d_fs = 0.f, d_ndi = 0.f;
                 float xg[3], xl[3];   // d/d(global light), d/d(local light) of this (corner, sample)
 #pragma unroll
@@ -912,7 +921,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                     // The five outputs are linear in  A_d = Lg*ge, A_l = Ll*ge, B_d = fs*A_d, B_l = fs*A_l  (see the
                     // forward): dL/dA_d = kAd, dL/dA_l = kAl, dL/dB_d = kBd, dL/dB_l = kBl are per-(corner, channel)
                     // constants computed once per Gaussian.
-                    const float Lg = r[10 + ch], Ll = r[13 + ch];
+                    const float Lg = r[8 + ch], Ll = r[12 + ch];
                     const float td = Lg * ge, tl = Ll * ge;
                     const float cg = kAd[ch] + fs * kBd[ch], cl = kAl[ch] + fs * kBl[ch];
                     xg[ch] = cg * ge; xl[ch] = cl * ge;
@@ -932,13 +941,13 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 const float d_nom1 = d_nom * t4 * nom0 * nom0 * nom2;
                 const float d_nom2 = d_nom * t4 * nom0 * nom0 * c.nom1;
                 // a2 enters frac (fs/a2) and nom0; kk enters nom1, nom2
-                s_a2 += d_fs * r[9] * inv_nom + d_nom0 * NoH * NoH;   // dL/da2
+                s_a2 += d_fs * r[7] * inv_nom + d_nom0 * NoH * NoH;   // dL/da2
                 s_nom1 += d_nom1;                                      // nom1 = NoV (1 - kk) + kk is per-Gaussian
                 s_kk2 += d_nom2 * (1.f - NoL);                         // kk through nom2
                 const float d_NoH = (NoHr >= 1e-6f && NoHr <= 1.f) ? d_nom0 * 2.f * NoH * (c.a2 - 1.f) : 0.f;
                 const float d_NoL = (NoLr >= 1e-6f && NoLr <= 1.f) ? d_nom2 * (1.f - c.kk) : 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; j++) d_Nh[j] += d_NoH * r[6 + j] + d_NoL * r[3 + j];
+                for (int j = 0; j < 3; j++) d_Nh[j] += d_NoH * r[4 + j] + d_NoL * Lv[j];
 
                 // ---- adjoint of the sample: sum the four corners (one quad), then lane k takes channel / tap k ----
 #pragma unroll
@@ -947,16 +956,16 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                     if (SHADE_ABL != 2) {   // parked in the sample's (consumed) local-light slots, written out below (lane k = 3: the pad
                         // slot; lanes beyond the chunk: records nobody reads)
                         const float v = k == 0 ? xl[0] : (k == 1 ? xl[1] : xl[2]);
-                        sS[s * BREC + (k < 3 ? 13 + k : BREC - 1)] = v + grad_const;
+                        sS[s * BREC + (k < 3 ? 12 + k : BREC - 1)] = v + grad_const;
                     }
-                    const uint32_t xy = __builtin_bit_cast(uint32_t, r[20]);
-                    const int tx = (int)(xy & 0xffffu) - 1 + (k & 1), ty = (int)(xy >> 16) - 1 + (k >> 1);
-                    const float fx = r[21], fy = r[22];
-                    const float w = ((k & 1) ? fx : 1.f - fx) * ((k >> 1) ? fy : 1.f - fy);
+                    const uint32_t xy = __builtin_bit_cast(uint32_t, r[16]);
+                    const int tx = (int)(xy & 0x3fffu) - 1 + (k & 1), ty = (int)((xy >> 14) & 0x3fffu) - 1 + (k >> 1);
+                    const float fx = r[17], fy = r[18];
+                    const float w = ((k & 1) ? fx : 1.f - fx) * ((k >> 1) ? fy : 1.f - fy) * r[15];
                     const int idx = (ty * We + tx) * 3;
                     float dt[3];
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) dt[ch] = (xg[ch] + gmig[ch]) * r[17 + ch] * w;
+                    for (int ch = 0; ch < 3; ch++) dt[ch] = ((xy >> (28 + ch)) & 1u) ? (xg[ch] + gmig[ch]) * w : 0.f;
                     // ONE test per tap: inside the chunk and the image, and not all three channels zero (they vanish together:
                     // zero weight or an occluded / clamped sample)
                     if (act && tx >= 0 && tx < We && ty >= 0 && ty < He && (dt[0] != 0.f || dt[1] != 0.f || dt[2] != 0.f) && SHADE_ABL != 1) {
@@ -977,7 +986,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int i = lane + 64 * j;
-                    if (i < 3 * cnt) out[i] = sS[(i / 3) * BREC + 13 + (i % 3)];
+                    if (i < 3 * cnt) out[i] = sS[(i / 3) * BREC + 12 + (i % 3)];
                 }
             }
         }
@@ -1112,7 +1121,7 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     const size_t per_wave = (size_t)(64 * BREC + 4 * KB_G * KREC) * 4;
     size_t lds = BWAVES * per_wave;
     int env_in_lds = 0;
-    if (p->env_w > 65000 || p->env_h > 65000) return SVGIR_ERR_INVALID;
+    if (p->env_w > 16000 || p->env_h > 16000) return SVGIR_ERR_INVALID;   // (14-bit footprint origins in the sample records)
     static_assert((BWAVES * (64 * BREC + 4 * KB_G * KREC)) % 2 == 0, "the fp64 image behind the sample records is 8-byte aligned");
     if (lds + (size_t)ntex * 8 <= 160 * 1024) { env_in_lds = 1; lds += (size_t)ntex * 8; }   // one workgroup per CU
     {
