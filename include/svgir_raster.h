@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 10
+#define SVGIR_ABI_VERSION 11
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -162,6 +162,13 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o,
                   svgir_alloc_fn binning, void* binning_ctx,
                   svgir_alloc_fn image, void* image_ctx,
                   void* stream);
+
+/* What the speculative launches of svgir_forward did so far in this process (monitoring / tests; ABI 11):
+ * out5 = {forwards, views re-run because the instance capacity guessed from the previous views was too small, ... because the state-slot
+ * capacity was, ... because a visible depth key did not carry the top byte the last views' keys shared (the depth sort then runs three
+ * 8-bit passes instead of four), views whose depth sort ran three passes}.  The reference has no counterpart: its forward waits for the
+ * instance count (rasterizer_impl.cu:307-312) and always sorts 64-bit keys. */
+void svgir_speculation_stats(int64_t* out5);
 
 /* Backward pass.  Replaces CudaRasterizer::Rasterizer::backward (svgss rasterizer_impl.cu:386-523,
  * rgss :411-535).  `R` and the three blobs are what the matching svgir_forward produced; `radii` is its

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <mutex>
@@ -32,7 +33,8 @@ std::atomic<bool> g_prof{false};
 // preview next to a 1600x1600 render, several scenes, several devices) neither re-run each other's dependent stages nor
 // over-allocate each other's blobs.  A small fixed table, least-recently-used replacement.
 struct CapKey { int dev, W, H, P, S, VS, variant; };
-struct CapEntry { CapKey key; int hist[8]; long long hist_slots[8]; unsigned next, next_slots; unsigned long long stamp; bool used; };
+struct CapEntry { CapKey key; int hist[8]; long long hist_slots[8]; unsigned next, next_slots; unsigned long long stamp; bool used;
+                  int top_byte, top_streak; };   // common top byte of the visible depth keys of the last `top_streak` views (0: none / not common)
 std::mutex g_cap_mu;
 CapEntry g_cap[16];
 unsigned long long g_cap_clock = 0;
@@ -76,6 +78,28 @@ void record_slots(const CapKey& k, long long slots) {
     CapEntry* e = cap_entry(k, true);
     e->hist_slots[e->next_slots++ % 8] = slots;
 }
+// Depth-key speculation.  The depth keys are positive floats; in a bounded scene they share their top byte (sign + 7 exponent bits: all
+// depths in [2, 8), or [8, 32) ...), and then the fourth 8-bit pass of the depth sort orders nothing.  The preprocess reports AND / OR of
+// the visible keys' top bytes (read back with the instance count); once kTopStreak consecutive views of a workload had one common byte, the
+// next view is launched with three passes, its culled keys carrying that byte -- and re-run from scratch, with four, if a visible key
+// turns out to differ (the streak then starts over, so at most one view in kTopStreak + 1 can ever be re-run).
+constexpr int kTopStreak = 3;
+// {forwards, re-runs for the instance capacity, for the state-slot capacity, for the depth-key byte, views sorted in three passes}
+std::atomic<long long> g_spec_stats[5];
+int guess_top(const CapKey& k) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    const CapEntry* e = cap_entry(k, false);
+    return (e && e->top_streak >= kTopStreak) ? e->top_byte : -1;
+}
+void record_top(const CapKey& k, uint32_t summary) {   // {AND << 8 | OR}; AND = 0xff, OR = 0: nothing visible (no information)
+    const int av = (int)((summary >> 8) & 0xffu), ov = (int)(summary & 0xffu);
+    if (av == 0xff && ov == 0) return;
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    CapEntry* e = cap_entry(k, true);
+    if (av != ov) { e->top_streak = 0; return; }
+    if (e->top_streak > 0 && e->top_byte == av) e->top_streak = std::min(e->top_streak + 1, 1 << 20);
+    else { e->top_byte = av; e->top_streak = 1; }
+}
 // Pinned landing slots for the 4-byte instance-count read-back (a pageable destination would make the "async" copy a
 // blocking staged one).  A small ring: concurrent forwards on different threads/streams get different slots.
 uint32_t* g_pinned = nullptr;
@@ -85,9 +109,9 @@ std::once_flag g_pinned_once;
 uint32_t* pinned_slot() {
     std::call_once(g_pinned_once, [] {
         void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, kPinnedSlots * 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) g_pinned = (uint32_t*)ptr;
+        if (hipHostMalloc(&ptr, kPinnedSlots * 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) g_pinned = (uint32_t*)ptr;
     });
-    return g_pinned ? g_pinned + 2 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
+    return g_pinned ? g_pinned + 4 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
 }   // instance count of the previous forward: sizes the speculative binning blob
 // Per-view counts that exist only behind the cull -- the surviving (sub-tile, instance) pairs (= gradient rows the svgss backward needs)
 // and the state slots the composite forward may dump into -- reach the host as tagged 8-byte stores of order_desc_kernel into pinned
@@ -364,8 +388,16 @@ int svgir_last_timings(const char** names, float* avg_ms, int* counts, int cap) 
     return n;
 }
 
+static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
+                        svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream, bool key_spec);
+
 int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
                   svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream) {
+    return forward_impl(p, o, geom, geom_ctx, binning, binning_ctx, image, image_ctx, stream, true);
+}
+
+static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
+                        svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream, bool key_spec) {
     if (int rc = validate(p, true)) return rc;
     // features / vfeatures may still be in production on another stream (the shading kernels do not depend on the binning and
     // the binning does not read them): only the composite kernel waits for the caller's event
@@ -420,6 +452,12 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     pa.radii = o->radii;
     pa.out_weights = o->out_weights;
     pa.zero_words = radix_gtot(G.radix_tbl, P); pa.n_zero_words = (int)radix_gtot_words(P);
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
+    static const bool key_spec_env = getenv("SVGIR_NO_KEY_SPEC") == nullptr;
+    const int spec_top = (key_spec && key_spec_env) ? guess_top(ckey) : -1;
+    pa.spec_top = spec_top; pa.key_top = G.key_top;
     pa.prefilter_violation = nullptr;
     if (p->prefiltered) {   // the violation flag sits next to the instance counter and is read back with it
         HIP_OK(hipMemsetAsync(G.counters, 0, 16, s));
@@ -429,18 +467,20 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     if (int rc = check("preprocess")) return rc;
     tm.mark("preprocess");
 
-    // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in slot 0
-    launch_radix_sort(G.key, G.idx, P, nullptr, 32, 8, G.radix_tbl, s);
+    // depth sort of the P Gaussians: 4 x 8-bit stable passes (ends in slot 0), or 3 when the top byte is speculated to be common (slot 1)
+    const int depth_bits = spec_top >= 0 ? 24 : 32;
+    const uint32_t* depth_order = G.idx[(depth_bits / 8) & 1];
+    launch_radix_sort(G.key, G.idx, P, nullptr, depth_bits, 8, G.radix_tbl, s);
     if (int rc = check("depth sort")) return rc;
     tm.mark("sort_depth");
 
-    launch_offsets_scan(G.tiles, G.idx[0], G.offsets, G.scan_tmp, P, G.counters, s);
+    launch_offsets_scan(G.tiles, depth_order, G.offsets, G.scan_tmp, P, G.counters, G.key_top, (P + 63) / 64, s);
     if (int rc = check("offsets scan")) return rc;
     tm.mark("scan");
-    uint32_t R_pageable[2] = {0, 0};
+    uint32_t R_pageable[4] = {0, 0, 0, 0};
     uint32_t* R_slot = pinned_slot();
     if (!R_slot) R_slot = R_pageable;
-    HIP_OK(hipMemcpyAsync(R_slot, G.counters, p->prefiltered ? 8 : 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(R_slot, G.counters, 12, hipMemcpyDeviceToHost, s));   // R, prefilter violation, depth-key summary
     hipEvent_t evR;
     HIP_OK(hipEventCreateWithFlags(&evR, hipEventDisableTiming));
     HIP_OK(hipEventRecord(evR, s));
@@ -457,7 +497,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
 #endif
     auto run_binning_and_render = [&](char* bblob, int cap, long long cap_slots, bool timed) -> int {
         const BinLayout B = bin_layout(bblob, cap, T, nstate, cap_slots);
-        launch_emit(P, G.idx[0], G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
+        launch_emit(P, depth_order, G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
                     I.counters, B.radix_tbl, s);
         if (int rc = check("emit")) return rc;
         if (timed) tm.mark("emit");
@@ -516,9 +556,6 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     // Speculative launch: capacities from this workload's recent views (+12.5 %) -- instances (binning arrays) and state slots
     // (seg_state) -- no host round trip in between.  The first view of a workload gets the exact instance capacity and the worst-case
     // slot count (4 full lists per tile); later ones typically a third of that.
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
     int cap = 0;
     long long cap_slots = -1;
     char* bblob = nullptr;
@@ -544,6 +581,18 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
     }
     if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
     const int R = (int)R_host;
+    {   // the visible depth keys' top bytes: history for the next view; and did this view's speculation hold?
+        const uint32_t summary = ((volatile uint32_t*)R_slot)[2];
+        if (key_spec) { record_top(ckey, summary); g_spec_stats[0]++; }
+        if (spec_top >= 0) g_spec_stats[4]++;
+        const int av = (int)((summary >> 8) & 0xffu), ov = (int)(summary & 0xffu);
+        if (spec_top >= 0 && !(av == 0xff && ov == 0) && (av != spec_top || ov != spec_top)) {
+            // a visible key outside the speculated byte: the three-pass order is wrong -- run the whole view again, four passes
+            HIP_OK(hipStreamSynchronize(s));
+            g_spec_stats[3]++;
+            return forward_impl(p, o, geom, geom_ctx, binning, binning_ctx, image, image_ctx, stream, false);
+        }
+    }
     record_R(ckey, R);
     // the view's state-slot count (behind the cull; the composite is still queued, so this wait is free): did the guess hold?
     long long slots = -1;
@@ -557,6 +606,7 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         // view's cull has already produced it (complete lists: R fitted), else the worst case
         const bool redo = bblob != nullptr;
         const bool lists_complete = redo && R <= cap && slots >= 0;
+        if (redo) g_spec_stats[R > cap ? 1 : 2]++;
         if (redo) HIP_OK(hipStreamSynchronize(s));
         cap = binning_capacity(R);
         cap_slots = lists_complete ? slots : -1;
@@ -578,6 +628,10 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn 
         tm.mark("image");
     }
     return R;
+}
+
+void svgir_speculation_stats(int64_t* out5) {
+    if (out5) for (int i = 0; i < 5; i++) out5[i] = (int64_t)g_spec_stats[i].load();
 }
 
 size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_bytes, int32_t W, int32_t H, int32_t S,

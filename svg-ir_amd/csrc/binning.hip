@@ -161,8 +161,17 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_2048(uint32_t (&v)[8], 
 
 __global__ void __launch_bounds__(BLOCK) offsets_reduce_kernel(const uint32_t* __restrict__ tiles,
                                                                const uint32_t* __restrict__ order, int n,
-                                                               uint32_t* __restrict__ block_sums) {
+                                                               uint32_t* __restrict__ block_sums,
+                                                               const uint32_t* __restrict__ key_top, int n_key_top,
+                                                               uint32_t* __restrict__ block_key) {
     __shared__ uint32_t wsum[4];
+    if (threadIdx.x < 64) {   // this block's slice of the preprocess waves' depth-key summaries {AND << 8 | OR}: SCAN_BLOCK_ELEMS / 64 = 32 entries
+        const int j = blockIdx.x * (SCAN_BLOCK_ELEMS / 64) + (int)threadIdx.x;
+        uint32_t kv = (threadIdx.x < SCAN_BLOCK_ELEMS / 64 && j < n_key_top) ? key_top[j] : 0xff00u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kv, d); kv = (kv & o & 0xff00u) | ((kv | o) & 0xffu); }
+        if (threadIdx.x == 0) block_key[blockIdx.x] = kv;
+    }
     uint32_t v[8];
     const int base = blockIdx.x * SCAN_BLOCK_ELEMS + threadIdx.x * 8;
     uint32_t oi[8];   // two rounds of independent loads instead of 8 dependent pairs
@@ -181,9 +190,18 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ order, int n,
                                                               const uint32_t* __restrict__ block_sums,
                                                               uint32_t* __restrict__ offsets, int nblocks,
-                                                              uint32_t* __restrict__ total_out) {
+                                                              uint32_t* __restrict__ total_out,
+                                                              const uint32_t* __restrict__ block_key) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t psum[4];
+    __shared__ uint32_t ksum[4];
+    if (blockIdx.x == 0) {   // (block 0 has no preceding block sums to add up) fold the blocks' depth-key summaries: {AND << 8 | OR}
+        uint32_t kv = 0xff00u;
+        for (int j = threadIdx.x; j < nblocks; j += BLOCK) { const uint32_t v = block_key[j]; kv = (kv & v & 0xff00u) | ((kv | v) & 0xffu); }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kv, d); kv = (kv & o & 0xff00u) | ((kv | o) & 0xffu); }
+        if ((threadIdx.x & 63) == 0) ksum[threadIdx.x >> 6] = kv;
+    }
     uint32_t v[8];
     const int base = blockIdx.x * SCAN_BLOCK_ELEMS + threadIdx.x * 8;
     uint32_t oi[8];   // two rounds of independent loads instead of 8 dependent pairs
@@ -209,6 +227,8 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
         run += v[i];
     }
     if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) total_out[0] = before + total;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        total_out[2] = (ksum[0] & ksum[1] & ksum[2] & ksum[3] & 0xff00u) | ((ksum[0] | ksum[1] | ksum[2] | ksum[3]) & 0xffu);
 }
 
 // ---- emit --------------------------------------------------------------------------------------------------
@@ -227,13 +247,15 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
     if (i == 0) seg_count[0] = 0u;
     if (i >= P) return;
     const uint32_t g = order[i];
-    if (tiles[g] == 0) return;
+    uint32_t off = offsets[i];
+    // (requested together, one latency behind `order`: the culled Gaussians sit at the end of the depth order)
+    const uint32_t ntiles = tiles[g];
     const float px = rec[(size_t)g * REC + R_X], py = rec[(size_t)g * REC + R_Y];
     const float r = (float)radii[g];
+    if (ntiles == 0) return;
     // same rectangle as the preprocess stage (auxiliary.h:53-63); plain divisions, nothing to contract
     const int x0 = min(gx, max(0, (int)((px - r) / TILE))), y0 = min(gy, max(0, (int)((py - r) / TILE)));
     const int x1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE))), y1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
-    uint32_t off = offsets[i];
     // for the backward's gradient rows: first instance index (emit order) and tile rectangle of this Gaussian
     rec[(size_t)g * REC + R_IBASE] = __builtin_bit_cast(float, off);
     rec[(size_t)g * REC + R_RECT] = __builtin_bit_cast(float, (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20));
@@ -437,11 +459,12 @@ void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, co
 }
 
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
-                         uint32_t* total_out, hipStream_t s) {
+                         uint32_t* total_out, const uint32_t* key_top, int n_key_top, hipStream_t s) {
     const int nb = scan_blocks(n);
-    hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp);
+    uint32_t* block_key = scan_tmp + nb + 1;
+    hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp, key_top, n_key_top, block_key);
     hipLaunchKernelGGL(offsets_write_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp, offsets, nb,
-                       total_out);
+                       total_out, block_key);
 }
 
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,

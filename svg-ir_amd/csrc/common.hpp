@@ -58,9 +58,10 @@ struct GeomLayout {
     uint32_t* key[2];      // [P] depth keys ping/pong
     uint32_t* idx[2];      // [P] Gaussian ids ping/pong (idx[final] = depth-sorted order)
     uint32_t* offsets;     // [P] exclusive scan of tiles in depth-sorted order
-    uint32_t* scan_tmp;    // [scan_blocks(P)+1]
+    uint32_t* scan_tmp;    // [2 * (scan_blocks(P)+1)]: block sums | per-block depth-key summaries
     uint32_t* radix_tbl;   // [256 * sort_blocks(P)]
-    uint32_t* counters;    // [4]: [0] = R
+    uint32_t* counters;    // [4]: [0] = R, [1] = prefilter violation, [2] = top bytes of the visible depth keys {AND << 8 | OR}
+    uint32_t* key_top;     // [ceil(P / 64)] the same per preprocess wave (identity 0xff00 where a wave has no visible Gaussian)
     size_t bytes;
 };
 inline GeomLayout geom_layout(char* base, int P) {
@@ -77,9 +78,10 @@ inline GeomLayout geom_layout(char* base, int P) {
     g.idx[0] = (uint32_t*)take(p * 4);
     g.idx[1] = (uint32_t*)take(p * 4);
     g.offsets = (uint32_t*)take(p * 4);
-    g.scan_tmp = (uint32_t*)take(((size_t)scan_blocks(P) + 1) * 4);
+    g.scan_tmp = (uint32_t*)take(((size_t)scan_blocks(P) + 1) * 8);
     g.radix_tbl = (uint32_t*)take(radix_table_words(P) * 4);
     g.counters = (uint32_t*)take(16);
+    g.key_top = (uint32_t*)take((p + 63) / 64 * 4);
     g.bytes = off;
     return g;
 }
@@ -285,6 +287,7 @@ struct PreArgs {
     float* rec; float* cov3D; uint32_t* clamped; uint32_t* tiles; uint32_t* key; uint32_t* idx; int32_t* radii;
     float* out_weights;              // [P] zeroed here (accumulated with atomics by the composite)
     uint32_t* zero_words; int n_zero_words;   // small table cleared in passing (the depth sort's group totals)
+    int spec_top; uint32_t* key_top;   // speculated common top byte of the visible depth keys (-1: none) -> key of a culled Gaussian; per-wave summary out
     uint32_t* prefilter_violation;   // non-null <=> `prefiltered`: set to 1 when a frustum / back-face cull fires (auxiliary.h:163-167)
 };
 
@@ -352,8 +355,9 @@ void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t
 void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, int total_bits,
                        int bits_per_pass, uint32_t* table, hipStream_t s);
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
+// total_out[2] = the per-wave depth-key summaries `key_top[n_key_top]` folded into one word
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
-                         uint32_t* total_out, hipStream_t s);
+                         uint32_t* total_out, const uint32_t* key_top, int n_key_top, hipStream_t s);
 // also clears ranges[2*gx*gy] + the per-tile-block segment counts behind it, the live-segment counter and the group totals of the tile sort's table (`sort_table`,
 // sized for `cap` elements)
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,

@@ -137,8 +137,11 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     // defaults for a culled Gaussian
     a.radii[idx] = 0;
     a.tiles[idx] = 0;
-    a.key[idx] = 0xFFFFFFFFu;
+    // (behind every visible key; under a speculated common top byte the depth sort skips that byte, so the culled keys carry it too.
+    // Where a culled Gaussian lands in the depth order is immaterial: it emits nothing)
+    a.key[idx] = a.spec_top >= 0 ? (((uint32_t)a.spec_top << 24) | 0x00FFFFFFu) : 0xFFFFFFFFu;
     a.idx[idx] = (uint32_t)idx;
+    if ((threadIdx.x & 63) == 0) a.key_top[idx >> 6] = 0xff00u;   // this wave's summary: none visible so far
 
     const float po[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
     float q[4] = {1.f, 0.f, 0.f, 0.f};
@@ -289,7 +292,19 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     a.clamped[idx] = cmask;
     a.radii[idx] = (int)my_radius;
     a.tiles[idx] = (uint32_t)area;
-    a.key[idx] = __float_as_uint(pv[2]);
+    const uint32_t depth_key = __float_as_uint(pv[2]);
+    a.key[idx] = depth_key;
+    {   // AND / OR of the top bytes of this wave's visible keys (the lanes still here), for the host's guess of the next view's common byte
+        const unsigned long long act = __ballot(true);
+        uint32_t av = 0, ov = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((depth_key >> (24 + b)) & 1u);
+            av |= (m == act) ? (1u << b) : 0u;
+            ov |= (m != 0ull) ? (1u << b) : 0u;
+        }
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)act) - 1)) a.key_top[idx >> 6] = (av << 8) | ov;
+    }
 
     float iu = 0.f, iv = 0.f;
     if (SVGSS && a.scales) {

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
 
 RGSS, SVGSS = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -77,6 +77,8 @@ def _load():
     lib.svgir_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.svgir_backward_scratch_bytes_for.restype = C.c_size_t
     lib.svgir_backward_scratch_bytes_for.argtypes = [C.c_int32, C.c_int32, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.svgir_speculation_stats.restype = None
+    lib.svgir_speculation_stats.argtypes = [C.POINTER(C.c_int64)]
     lib.svgir_mark_visible.restype = C.c_int
     lib.svgir_mark_visible.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svgir_set_profiling.argtypes = [C.c_int]
@@ -92,7 +94,7 @@ lib = _load()
 
 EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_binning_bytes",
            "svgir_image_ncontrib_offset", "svgir_image_ranges_offset", "svgir_binning_point_list_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
-           "svgir_backward_scratch_bytes", "svgir_backward_scratch_bytes_for", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
+           "svgir_backward_scratch_bytes", "svgir_backward_scratch_bytes_for", "svgir_speculation_stats", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
            "svgir_shade_backward", "svgir_incident_dirs", "svgir_resample_bilinear", "svgir_unpack_planes",
            "svgir_unpack_forward", "svgir_unpack_backward", "svgir_depth2normal", "svgir_depth2normal_backward", "svgir_pack_rgss_forward",
            "svgir_pack_rgss_backward", "svgir_unpack_rgss_forward", "svgir_unpack_rgss_backward", "svgir_l1_ssim_partials",
@@ -101,6 +103,13 @@ EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_
            "svgir_split_transform", "svgir_bvh_bytes", "svgir_bvh_build",
            "svgir_bvh_trace_visibility", "svgir_pbgi_bvh_bytes", "svgir_pbgi_bvh_build", "svgir_pbgi_bvh_export",
            "svgir_pbgi_trace_radiance")
+
+
+def speculation_stats():
+    """{forwards, re-runs: instance capacity / state slots / depth-key byte, three-pass depth sorts} of this process (include/svgir_raster.h)."""
+    out = (C.c_int64 * 5)()
+    lib.svgir_speculation_stats(out)
+    return dict(zip(("forwards", "rerun_capacity", "rerun_slots", "rerun_depth_key", "three_pass"), [int(v) for v in out]))
 
 
 def last_error():

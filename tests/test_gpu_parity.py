@@ -7,6 +7,7 @@ signal.  The composite kernels evaluate alpha in exactly the operation order of 
 exp, so the alpha >= 1/255 and T < 1e-4 decisions agree with the oracle's; the measured flip share is 0 on every
 BASELINE config (profiles/parity_r02.json), and the tests allow at most FLIP_FRAC isolated outliers, each bounded.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -449,6 +450,34 @@ def test_state_slot_capacity_guess_too_small_reruns(built):
         out, leaves, o, R = _run_both(sc, "svgss", grads)
         _check_forward(out, o, R, "svgss")
         _check_backward(leaves, o, "svgss")
+
+
+def test_depth_key_byte_speculation_reruns_when_a_view_breaks_it(built):
+    """The depth sort drops its fourth 8-bit pass once three consecutive views of a workload had all visible depth keys in one top byte
+    (depths in [2, 8) here: 0x40), csrc/api.hip.  A view of the same workload whose surfels straddle two bytes (half of them pushed
+    beyond depth 8) must be detected and re-run with four passes; `point_list` (exact) and the images pin the order either way."""
+    from gaussian_renderer import _native
+    near = scenes.surface_scene(P=6000, W=160, H=128, seed=17, sh_degree=2, variant="rgss", S=3, VS=0, scale_lo=0.01, scale_hi=0.03)
+    far = dict(near)
+    V = np.asarray(near["viewmatrix"], dtype=np.float64).reshape(4, 4)   # row-vector convention: p_view = [p, 1] @ V
+    m = np.asarray(near["means3D"], dtype=np.float64)
+    z = (np.c_[m, np.ones(len(m))] @ V)[:, 2]
+    assert z.min() > 2.0 and z.max() < 8.0
+    campos = np.asarray(near["campos"], dtype=np.float64)
+    push = (np.arange(len(m)) % 2 == 0)[:, None]
+    far["means3D"] = np.where(push, campos + (m - campos) * 2.6, m).astype(np.float32)   # every second surfel 2.6x as far away (same pixel)
+    z2 = (np.c_[far["means3D"].astype(np.float64), np.ones(len(m))] @ V)[:, 2]
+    assert (z2 > 8.0).sum() > 1000 and (z2 < 8.0).sum() > 1000
+    before = _native.speculation_stats()
+    for sc in (near, near, near, near, near, far, near, near, near, near):
+        grads = scenes.upstream_grads(sc, "rgss", seed=6)
+        out, leaves, o, R = _run_both(sc, "rgss", grads)
+        _check_forward(out, o, R, "rgss")
+        _check_backward(leaves, o, "rgss")
+    after = _native.speculation_stats()
+    if os.environ.get("SVGIR_NO_KEY_SPEC") is None:
+        assert after["three_pass"] - before["three_pass"] >= 3      # views 4-5 and the last one(s) ran the short sort ...
+        assert after["rerun_depth_key"] - before["rerun_depth_key"] == 1   # ... and exactly the straddling view was re-run
 
 
 def test_prefiltered_flag_reports_culled_points(built):
