@@ -104,10 +104,11 @@ typedef struct svgir_outputs {
 
 /* Upstream gradients and gradient outputs of backward (Rasterizer::backward, svgss rasterizer_impl.cu:386-432,
  * rgss :411-449).  The caller need not clear the dL_d* outputs (the reference's glue zero-fills them,
- * rasterize_points.cu:195-211): svgir_backward clears them itself, on an internal side stream while the composite
- * backward -- which accumulates in the scratch, not in these tensors -- runs on the caller's stream, and joins the two
- * before the per-Gaussian kernels write the gradients of the visible Gaussians.  A caller that lays all outputs out in
- * one allocation passes it as clear_base / clear_bytes: one memset instead of one per tensor. */
+ * rasterize_points.cu:195-211): svgir_backward clears them itself before the per-Gaussian kernels write the gradients of
+ * the visible Gaussians.  A caller that lays all outputs out in one allocation (16-byte aligned, a multiple of 16 bytes) passes it as
+ * clear_base / clear_bytes: the waves of the composite backward -- which accumulates in the scratch, not in these tensors -- then zero
+ * it in passing, no memset and no second stream; without the hint the tensors are cleared one by one on an internal side stream that is
+ * joined behind the composite backward. */
 typedef struct svgir_grads {
     const float* dL_dout_color;    /* [3,H,W] */
     const float* dL_dout_normal;   /* [3,H,W] */

@@ -729,7 +729,11 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         }
         ~ClearJoin() { join(); }
     } cleared{s};
-    {
+    // (one allocation behind all gradient tensors, 16-byte granular, and a specialised composite about to run: its waves clear it)
+    const bool clear_in_kernel = !generic && R > 0 && g->clear_base && g->clear_bytes && (((uintptr_t)g->clear_base | g->clear_bytes) & 15) == 0;
+    ba.clear = clear_in_kernel ? (uint4*)g->clear_base : nullptr;
+    ba.clear_n16 = clear_in_kernel ? g->clear_bytes / 16 : 0;
+    if (!clear_in_kernel) {
         hipStream_t cs = generic ? s : side_stream(s);
         if (!cs) cs = s;
         hipEvent_t ev_fork = nullptr;

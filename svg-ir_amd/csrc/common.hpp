@@ -319,6 +319,7 @@ struct RenderBwdArgs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
     float* grad_rows; uint32_t* row_of; uint32_t rows_cap;   // svgss (VS > 0): compact gradient rows + reverse map; else: packed rows [P][RS]
     const float* pair_stream;               // (experiment builds) see BinLayout
+    uint4* clear; size_t clear_n16;         // the caller's gradient allocation, zeroed in passing by the composite backward's waves (or null)
 };
 
 struct GradReduceArgs {

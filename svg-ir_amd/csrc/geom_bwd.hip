@@ -47,6 +47,11 @@ __constant__ float gC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315391
 __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
+#ifdef GEOM_ABL_NOSH   // (ablation builds only: without the SH rows -- wrong results)
+#define GEOM_SHS ((const float*)nullptr)
+#else
+#define GEOM_SHS a.shs
+#endif
 __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.P || !(a.radii[idx] > 0)) return;
@@ -56,7 +61,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     float V[16], PR[16], campos[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 16; i++) { V[i] = a.view[i]; PR[i] = a.proj[i]; }
-    if (a.shs) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
+    if (GEOM_SHS) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
 
     // ---------------- every input of this Gaussian ----------------
     float in_color[3], in_normal[3], in_depth, in_m2d[2], in_conic[3], in_opacity = 0.f;
@@ -65,11 +70,14 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         // colour3, normal3, depth, feature S | pad | mean2D.xy, conic.xyz, opacity); it is unpacked into the caller's tensors below
         const int P4 = (7 + a.S + 3) / 4 * 4, RS = (P4 + 6 + 3) / 4 * 4;
         const float* row = a.packed + (size_t)idx * RS;
-#pragma unroll
-        for (int c = 0; c < 3; c++) { in_color[c] = row[c]; in_normal[c] = row[3 + c]; in_conic[c] = row[P4 + 2 + c]; }
-        in_depth = row[6];
-        in_m2d[0] = row[P4]; in_m2d[1] = row[P4 + 1];
-        in_opacity = row[P4 + 5];
+        // (rows are 16-byte aligned multiples of four floats: the head {colour3, normal3, depth, .} and the tail {mean2D.xy, conic.xyz,
+        // opacity, . .} are four 128-bit loads -- the lanes of a wave are a row apart, so it is the number of instructions that costs)
+        const float4 h0 = reinterpret_cast<const float4*>(row)[0], h1 = reinterpret_cast<const float4*>(row)[1];
+        const float4 t0 = reinterpret_cast<const float4*>(row + P4)[0], t1 = reinterpret_cast<const float4*>(row + P4)[1];
+        in_color[0] = h0.x; in_color[1] = h0.y; in_color[2] = h0.z; in_normal[0] = h0.w; in_normal[1] = h1.x; in_normal[2] = h1.y;
+        in_depth = h1.z;
+        in_m2d[0] = t0.x; in_m2d[1] = t0.y; in_conic[0] = t0.z; in_conic[1] = t0.w; in_conic[2] = t1.x;
+        in_opacity = t1.y;
     } else {
 #pragma unroll
         for (int c = 0; c < 3; c++) { in_color[c] = a.dL_dcolor[3 * idx + c]; in_normal[c] = a.dL_dnormal[3 * idx + c]; }
@@ -84,12 +92,12 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     // The 48-float coefficient row of a Gaussian (M = 16) is contiguous and 16-byte aligned: it is read and its
     // gradient row written with 12 float4 accesses per lane instead of 48 dword accesses (the lanes of a wave are
     // 192 bytes apart, so the number of memory transactions is what this stage costs).
-    const bool vec = a.shs && a.M == 16 && ((((size_t)a.shs) | ((size_t)a.dL_dsh)) & 15) == 0;
+    const bool vec = GEOM_SHS && a.M == 16 && ((((size_t)GEOM_SHS) | ((size_t)a.dL_dsh)) & 15) == 0;
     const int nk = (a.D + 1) * (a.D + 1);
     float sh[48];
     uint32_t cm = 0;
-    if (a.shs) {
-        const float* shp = a.shs + (size_t)idx * a.M * 3;
+    if (GEOM_SHS) {
+        const float* shp = GEOM_SHS + (size_t)idx * a.M * 3;
         cm = a.clamped[idx];
         if (vec) {
 #pragma unroll
@@ -224,7 +232,7 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
     }
 
     // ---------------- colour -> SH, view direction -> mean ----------------
-    if (a.shs) {
+    if (GEOM_SHS) {
         const float kC0 = 0.28209479177387814f, kC1 = 0.4886025119029199f;
         const float dor[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
         const float len = sqrtf(dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2]);

@@ -101,6 +101,13 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     // depend on the count: common.hpp seg_item_of)
     cu32* dsc0 = (cu32*)(uintptr_t)(a.seg_desc + min(seg_item_of(blockIdx.x), (uint32_t)a.seg_cap));
     uint32_t d_sm = dsc0[0], d_r0 = dsc0[1], d_len = dsc0[2], d_count = dsc0[3], d_ndump = dsc0[4], d_sb = dsc0[6];
+    // The caller's gradient tensors start from zero and are first touched by the kernels BEHIND this one: every wave of the grid clears
+    // its share here -- stores the wave never waits for, in a kernel that is bound by latency, not by bandwidth -- instead of a memset
+    // on a side stream that has to be forked from and joined with the caller's stream.
+    if (a.clear) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < a.clear_n16; i += (size_t)gridDim.x * 64) a.clear[i] = z;
+    }
     const uint32_t nlive = min(a.seg_count[0], (uint32_t)a.seg_cap);
     const uint32_t nwork = seg_work_ids(nlive);
     if (blockIdx.x >= nwork) return;
