@@ -100,19 +100,43 @@ void record_top(const CapKey& k, uint32_t summary) {   // {AND << 8 | OR}; AND =
     if (e->top_streak > 0 && e->top_byte == av) e->top_streak = std::min(e->top_streak + 1, 1 << 20);
     else { e->top_byte = av; e->top_streak = 1; }
 }
-// Pinned landing slots for the 4-byte instance-count read-back (a pageable destination would make the "async" copy a
-// blocking staged one).  A small ring: concurrent forwards on different threads/streams get different slots.
-uint32_t* g_pinned = nullptr;
+// Pinned landing slots for the instance count (+ prefilter violation + depth-key summary): the scan's last block stores them there,
+// tagged, with system-scope stores -- no copy operation and no event on the stream -- and the host spins on the tag.  A small ring:
+// concurrent forwards on different threads / streams get different slots.
+unsigned long long* g_pinned = nullptr;
 std::atomic<unsigned> g_pinned_next{0};
+std::atomic<uint32_t> g_pinned_tag{0};
 constexpr unsigned kPinnedSlots = 64;
 std::once_flag g_pinned_once;
-uint32_t* pinned_slot() {
+unsigned long long* pinned_slot(uint32_t* tag) {
     std::call_once(g_pinned_once, [] {
         void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, kPinnedSlots * 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) g_pinned = (uint32_t*)ptr;
+        if (hipHostMalloc(&ptr, kPinnedSlots * 2 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
+            g_pinned = (unsigned long long*)ptr;
+            for (unsigned i = 0; i < 2 * kPinnedSlots; i++) g_pinned[i] = 0ull;
+        }
     });
-    return g_pinned ? g_pinned + 4 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
-}   // instance count of the previous forward: sizes the speculative binning blob
+    uint32_t t = ++g_pinned_tag;
+    if (t == 0) t = ++g_pinned_tag;   // (never 0: the slots start as 0)
+    *tag = t;
+    return g_pinned ? g_pinned + 2 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
+}
+// waits for the two tagged words (typically tens of microseconds away); false after ~2 s (a forward that failed on the device)
+bool pinned_wait(volatile unsigned long long* at, uint32_t tag, uint32_t* w0, uint32_t* w1) {
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long long spin = 0;; spin++) {
+        const unsigned long long v0 = at[0], v1 = at[1];
+        if ((uint32_t)(v0 >> 32) == tag && (uint32_t)(v1 >> 32) == tag) { *w0 = (uint32_t)v0; *w1 = (uint32_t)v1; return true; }
+        if ((spin & 255) == 255) {
+            struct timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            if (el > 2.0) return false;
+            if (el > 5e-3) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+        }
+    }
+}
 // Per-view counts that exist only behind the cull -- the surviving (sub-tile, instance) pairs (= gradient rows the svgss backward needs)
 // and the state slots the composite forward may dump into -- reach the host as tagged 8-byte stores of order_desc_kernel into pinned
 // memory (no copy operation, no event on the stream) and are kept per IMAGE BLOB together with the capacities the forward laid the
@@ -474,16 +498,12 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
     if (int rc = check("depth sort")) return rc;
     tm.mark("sort_depth");
 
-    launch_offsets_scan(G.tiles, depth_order, G.offsets, G.scan_tmp, P, G.counters, G.key_top, (P + 63) / 64, s);
+    uint32_t R_tag = 0;
+    unsigned long long* R_slot = pinned_slot(&R_tag);
+    launch_offsets_scan(G.tiles, depth_order, G.offsets, G.scan_tmp, P, G.counters, G.key_top, (P + 63) / 64, pa.prefilter_violation,
+                        R_slot, R_tag, s);
     if (int rc = check("offsets scan")) return rc;
     tm.mark("scan");
-    uint32_t R_pageable[4] = {0, 0, 0, 0};
-    uint32_t* R_slot = pinned_slot();
-    if (!R_slot) R_slot = R_pageable;
-    HIP_OK(hipMemcpyAsync(R_slot, G.counters, 12, hipMemcpyDeviceToHost, s));   // R, prefilter violation, depth-key summary
-    hipEvent_t evR;
-    HIP_OK(hipEventCreateWithFlags(&evR, hipEventDisableTiming));
-    HIP_OK(hipEventRecord(evR, s));
 
     const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
     const TileSortPlan plan = tile_sort_plan(T);
@@ -567,22 +587,32 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         // (a failed speculative allocation is not an error: the guess may be far larger than this view needs; fall
         // through to the exact-size path below)
         if (bblob) {
-            if (int rc = run_binning_and_render(bblob, cap, cap_slots, true)) { (void)hipEventDestroy(evR); return rc; }
+            if (int rc = run_binning_and_render(bblob, cap, cap_slots, true)) return rc;
         } else {
             cap = 0;
         }
     }
-    HIP_OK(hipEventSynchronize(evR));   // waits for the count only; the speculative stages keep running
-    (void)hipEventDestroy(evR);
-    const uint32_t R_host = *(volatile uint32_t*)R_slot;
-    if (p->prefiltered && ((volatile uint32_t*)R_slot)[1] != 0u) {
+    // the instance count (only: the speculative stages keep running)
+    uint32_t R_host = 0, R_aux = 0;
+    if (R_slot) {
+        if (!pinned_wait(R_slot, R_tag, &R_host, &R_aux)) {
+            const hipError_t e = hipStreamSynchronize(s);
+            return fail(SVGIR_ERR_HIP, "the instance count did not arrive: %s", hipGetErrorString(e == hipSuccess ? hipGetLastError() : e));
+        }
+    } else {   // no pinned memory: a blocking copy
+        uint32_t w[3] = {0, 0, 0};
+        HIP_OK(hipMemcpyAsync(w, G.counters, 12, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        R_host = w[0]; R_aux = ((p->prefiltered && w[1]) ? 1u << 16 : 0u) | (w[2] & 0xffffu);
+    }
+    if (p->prefiltered && (R_aux >> 16) != 0u) {
         (void)hipStreamSynchronize(s);
         return fail(SVGIR_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");   // auxiliary.h:163-167
     }
     if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
     const int R = (int)R_host;
     {   // the visible depth keys' top bytes: history for the next view; and did this view's speculation hold?
-        const uint32_t summary = ((volatile uint32_t*)R_slot)[2];
+        const uint32_t summary = R_aux & 0xffffu;
         if (key_spec) { record_top(ckey, summary); g_spec_stats[0]++; }
         if (spec_top >= 0) g_spec_stats[4]++;
         const int av = (int)((summary >> 8) & 0xffu), ov = (int)(summary & 0xffu);

@@ -191,17 +191,12 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ block_sums,
                                                               uint32_t* __restrict__ offsets, int nblocks,
                                                               uint32_t* __restrict__ total_out,
-                                                              const uint32_t* __restrict__ block_key) {
+                                                              const uint32_t* __restrict__ block_key,
+                                                              const uint32_t* __restrict__ violation,
+                                                              unsigned long long* __restrict__ host_out, uint32_t host_tag) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t psum[4];
     __shared__ uint32_t ksum[4];
-    if (blockIdx.x == 0) {   // (block 0 has no preceding block sums to add up) fold the blocks' depth-key summaries: {AND << 8 | OR}
-        uint32_t kv = 0xff00u;
-        for (int j = threadIdx.x; j < nblocks; j += BLOCK) { const uint32_t v = block_key[j]; kv = (kv & v & 0xff00u) | ((kv | v) & 0xffu); }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kv, d); kv = (kv & o & 0xff00u) | ((kv | o) & 0xffu); }
-        if ((threadIdx.x & 63) == 0) ksum[threadIdx.x >> 6] = kv;
-    }
     uint32_t v[8];
     const int base = blockIdx.x * SCAN_BLOCK_ELEMS + threadIdx.x * 8;
     uint32_t oi[8];   // two rounds of independent loads instead of 8 dependent pairs
@@ -212,11 +207,18 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? v[i] : 0u;
     // sum of the preceding blocks' totals (the block sums are few: every block adds them up itself, no scan kernel)
-    uint32_t pre = 0;
+    const bool last = blockIdx.x == (unsigned)(nblocks - 1);
+    uint32_t pre = 0, kv = 0xff00u;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) pre += block_sums[b];
+    if (last)   // the last block walks all the blocks anyway: it also folds their depth-key summaries {AND << 8 | OR}
+        for (int b = threadIdx.x; b < nblocks; b += BLOCK) { const uint32_t x = block_key[b]; kv = (kv & x & 0xff00u) | ((kv | x) & 0xffu); }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
-    if ((threadIdx.x & 63) == 0) psum[threadIdx.x >> 6] = pre;
+    for (int d = 32; d >= 1; d >>= 1) {
+        pre += __shfl_xor(pre, d);
+        const uint32_t o = (uint32_t)__shfl_xor((int)kv, d);
+        kv = (kv & o & 0xff00u) | ((kv | o) & 0xffu);
+    }
+    if ((threadIdx.x & 63) == 0) { psum[threadIdx.x >> 6] = pre; ksum[threadIdx.x >> 6] = kv; }
     uint32_t total;
     uint32_t run = block_exclusive_scan_2048(v, wsum, total);   // contains a __syncthreads()
     const uint32_t before = psum[0] + psum[1] + psum[2] + psum[3];
@@ -226,9 +228,19 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
         if (base + i < n) offsets[base + i] = run;
         run += v[i];
     }
-    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) total_out[0] = before + total;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        total_out[2] = (ksum[0] & ksum[1] & ksum[2] & ksum[3] & 0xff00u) | ((ksum[0] | ksum[1] | ksum[2] | ksum[3]) & 0xffu);
+    if (last && threadIdx.x == 0) {
+        const uint32_t R = before + total;
+        const uint32_t summary = (ksum[0] & ksum[1] & ksum[2] & ksum[3] & 0xff00u) | ((ksum[0] | ksum[1] | ksum[2] | ksum[3]) & 0xffu);
+        total_out[0] = R;
+        total_out[2] = summary;
+        // the host's copy: tagged 8-byte stores into pinned host memory -- no copy operation and no event on the stream; the host
+        // recognises the values of THIS forward by the tag (api.hip): {R} and {prefilter violation << 16 | summary}
+        if (host_out) {
+            const uint32_t viol = violation ? (violation[0] != 0u ? 1u : 0u) : 0u;
+            __hip_atomic_store(host_out, ((unsigned long long)host_tag << 32) | R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_out + 1, ((unsigned long long)host_tag << 32) | (viol << 16) | summary, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---- emit --------------------------------------------------------------------------------------------------
@@ -459,12 +471,13 @@ void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, co
 }
 
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
-                         uint32_t* total_out, const uint32_t* key_top, int n_key_top, hipStream_t s) {
+                         uint32_t* total_out, const uint32_t* key_top, int n_key_top, const uint32_t* violation,
+                         unsigned long long* host_out, uint32_t host_tag, hipStream_t s) {
     const int nb = scan_blocks(n);
     uint32_t* block_key = scan_tmp + nb + 1;
     hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp, key_top, n_key_top, block_key);
     hipLaunchKernelGGL(offsets_write_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp, offsets, nb,
-                       total_out, block_key);
+                       total_out, block_key, violation, host_out, host_tag);
 }
 
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,

@@ -356,9 +356,11 @@ void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t
 void launch_radix_sort(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, int total_bits,
                        int bits_per_pass, uint32_t* table, hipStream_t s);
 // offsets[i] = exclusive prefix sum of tiles[order[i]]; total -> *total_out
-// total_out[2] = the per-wave depth-key summaries `key_top[n_key_top]` folded into one word
+// total_out[2] = the per-wave depth-key summaries `key_top[n_key_top]` folded into one word; host_out (pinned host memory, or null):
+// {host_tag << 32 | total}, {host_tag << 32 | (*violation != 0) << 16 | that word} stored by the last block
 void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t* offsets, uint32_t* scan_tmp, int n,
-                         uint32_t* total_out, const uint32_t* key_top, int n_key_top, hipStream_t s);
+                         uint32_t* total_out, const uint32_t* key_top, int n_key_top, const uint32_t* violation,
+                         unsigned long long* host_out, uint32_t host_tag, hipStream_t s);
 // also clears ranges[2*gx*gy] + the per-tile-block segment counts behind it, the live-segment counter and the group totals of the tile sort's table (`sort_table`,
 // sized for `cap` elements)
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
