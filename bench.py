@@ -324,6 +324,10 @@ def timed(wl, args, world, dev, dry=None):
     step = dry or wl.step
     gatherer = vp.MetricsGatherer(3, dev)   # async: the collective of step i overlaps with step i+1
     R = 0
+    # (untimed, like the warm-up: the library sizes its speculative launches -- instance capacity, state slots, depth-sort passes --
+    # from the last three views of a workload; with W < 4 the first timed steps would still be the unprimed ones)
+    for _ in range(0 if dry else max(0, 4 - args.warmup)):
+        step()
     for _ in range(args.warmup):
         R, color, gm = step()
         gatherer.submit(metrics(R, color, gm))

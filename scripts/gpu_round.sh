@@ -36,4 +36,5 @@ if [ -f build/variants/dev/libsvgir_raster.so ]; then
 fi
 bash scripts/pmc_tracer.sh ${TAG}_pmct > gpurun_out/${TAG}_tracer_pmc.txt 2>&1; tail -6 gpurun_out/${TAG}_tracer_pmc.txt
 rm -rf gpurun_out/${TAG}_pmct_a gpurun_out/${TAG}_pmct_b gpurun_out/${TAG}_*_rd gpurun_out/${TAG}_*_wr gpurun_out/${TAG}_*_iss
+timeout 600 python scripts/blob_sizes.py cfg2 cfg3_train cfg3_eval cfg5 cfg5_dense 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_blob_sizes.txt; cat gpurun_out/${TAG}_blob_sizes.txt
 python scripts/parity_report.py r04 cfg1 cfg2 cfg3_train cfg3_eval cfg4 cfg5 cfg5_dense > gpurun_out/${TAG}_parity.log 2>&1; tail -30 gpurun_out/${TAG}_parity.log
