@@ -34,7 +34,8 @@ std::atomic<bool> g_prof{false};
 // over-allocate each other's blobs.  A small fixed table, least-recently-used replacement.
 struct CapKey { int dev, W, H, P, S, VS, variant; };
 struct CapEntry { CapKey key; int hist[8]; long long hist_slots[8]; unsigned next, next_slots; unsigned long long stamp; bool used;
-                  int top_byte, top_streak; };   // common top byte of the visible depth keys of the last `top_streak` views (0: none / not common)
+                  int top_byte, top_streak;
+                  const void* last_view; };   // image blob of the workload's latest forward: its slot total is read when the next one starts   // common top byte of the visible depth keys of the last `top_streak` views (0: none / not common)
 std::mutex g_cap_mu;
 CapEntry g_cap[16];
 unsigned long long g_cap_clock = 0;
@@ -142,7 +143,8 @@ bool pinned_wait(volatile unsigned long long* at, uint32_t tag, uint32_t* w0, ui
 // memory (no copy operation, no event on the stream) and are kept per IMAGE BLOB together with the capacities the forward laid the
 // binning blob out for: the backward and svgir_backward_scratch_bytes_for() find them there.  A host wait right behind the cull costs
 // nothing: the composite is still queued (measured with a full event synchronisation there: 0.4353 vs 0.4361 ms per cfg2 step).
-struct ViewEntry { const void* key = nullptr; uint32_t tag = 0; int cap_R = 0; long long cap_slots = -1; unsigned long long stamp = 0; };
+struct ViewEntry { const void* key = nullptr; uint32_t tag = 0; int cap_R = 0; long long cap_slots = -1; unsigned long long stamp = 0;
+                   bool recorded = false; };   // its slot total has entered the workload's history
 constexpr int kViewEntries = 1024;   // forwards whose backward may still come (least recently used entry replaced)
 std::mutex g_view_mu;
 ViewEntry g_view[kViewEntries];
@@ -164,7 +166,7 @@ unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_s
         if (g_view[i].stamp < g_view[slot].stamp) slot = i;
     }
     ViewEntry& e = g_view[slot];
-    e.key = image_blob; e.stamp = ++g_view_clock; e.cap_R = cap_R; e.cap_slots = cap_slots;
+    e.key = image_blob; e.stamp = ++g_view_clock; e.cap_R = cap_R; e.cap_slots = cap_slots; e.recorded = false;
     e.tag = ++g_view_tag ? g_view_tag : ++g_view_tag;   // (never 0: the slots start as 0)
     *tag = e.tag;
     return g_view_pinned + 2 * slot;
@@ -172,7 +174,7 @@ unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_s
 // the entry of the forward that owns `image_blob` (capacities; counts when `wait`): false = unknown blob.  The counts are in host memory
 // as soon as the forward's order kernel has run; the wait only ever spins when the host is ahead of the GPU and gives up after ~2 s
 // (a forward that failed on the device never writes them): pairs / slots stay -1 then.
-bool view_lookup(const void* image_blob, bool wait, int* cap_R, long long* cap_slots, long long* pairs, long long* slots) {
+bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_slots, long long* pairs, long long* slots) {
     volatile unsigned long long* at = nullptr;
     uint32_t tag = 0;
     {
@@ -200,6 +202,7 @@ bool view_lookup(const void* image_blob, bool wait, int* cap_R, long long* cap_s
             if (slots) *slots = (long long)(uint32_t)v1;
             return true;
         }
+        if (wait == 2) break;   // (peek: one look)
         if ((spin & 255) == 255) {
             struct timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -209,6 +212,24 @@ bool view_lookup(const void* image_blob, bool wait, int* cap_R, long long* cap_s
         }
     }
     return true;
+}
+// A view's state-slot total enters its workload's history once, through whoever sees it first: the workload's next forward (mode 2:
+// a look, no wait -- the forward itself never waits for the cull) or the view's own backward (mode 1: the value is there by then).
+void note_view_slots(const CapKey& k, const void* image_blob, int mode) {
+    long long slots = -1;
+    if (!image_blob || !view_lookup(image_blob, mode, nullptr, nullptr, nullptr, &slots) || slots < 0) return;
+    {
+        std::lock_guard<std::mutex> lk(g_view_mu);
+        bool found = false;
+        for (int i = 0; i < kViewEntries; i++)
+            if (g_view[i].key == image_blob) {
+                if (g_view[i].recorded) return;
+                g_view[i].recorded = true; found = true;
+                break;
+            }
+        if (!found) return;
+    }
+    record_slots(k, slots);
 }
 // Side stream of the backward: the gradient tensors are cleared there while the composite backward (which only writes the
 // scratch) runs on the caller's stream.  One per device, created on first use; fork / join through events.
@@ -534,6 +555,7 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         ra.bg = p->background;
         ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_total = I.sub_total; ra.sub_order = I.sub_order;
         ra.sub_pair_base = I.sub_pair_base; ra.sub_slot_base = I.sub_slot_base; ra.slot_cap = (uint32_t)std::min<size_t>(B.slot_cap, 0xffffffffu);
+        ra.dump_only = 0;
         ra.sub_count = I.sub_count;
         ra.sub_ndump = I.sub_ndump; ra.seg_list = B.seg_list; ra.seg_desc = B.seg_desc; ra.seg_count = I.counters; ra.seg_block = I.seg_block; ra.seg_state = B.seg_state;
         ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;
@@ -579,6 +601,11 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
     int cap = 0;
     long long cap_slots = -1;
     char* bblob = nullptr;
+    {   // the previous view of this workload: its slot total, if the backward has not recorded it already (forward-only loops)
+        const void* prev = nullptr;
+        { std::lock_guard<std::mutex> lk(g_cap_mu); if (const CapEntry* e = cap_entry(ckey, false)) prev = e->last_view; }
+        note_view_slots(ckey, prev, 2);
+    }
     if (const int guess = guess_R(ckey)) {
         cap = binning_capacity((long long)guess + guess / 8 + 1024);
         const long long gs = guess_slots(ckey);
@@ -624,29 +651,24 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         }
     }
     record_R(ckey, R);
-    // the view's state-slot count (behind the cull; the composite is still queued, so this wait is free): did the guess hold?
-    long long slots = -1;
-    bool slots_fit = true;
-    if (bblob && R <= cap) {
-        (void)view_lookup(iblob, true, nullptr, nullptr, nullptr, &slots);
-        if (slots >= 0 && cap_slots >= 0 && slots > cap_slots) slots_fit = false;
-    }
-    if (!bblob || R > cap || !slots_fit) {
-        // first view, or the scene grew past a guess: (re)do the dependent stages -- exact instance capacity; exact slot count when this
-        // view's cull has already produced it (complete lists: R fitted), else the worst case
+    // (whether the state-slot guess held is the backward's business -- svgir_backward re-dumps the states of a view that exceeded it; the
+    // forward does not wait for the cull.  Measured on the host-bound training step, bench.py --workload train_step: 2.11 ms with
+    // the wait and a re-run here)
+    if (!bblob || R > cap) {
+        // first view, or the scene grew past a guess: (re)do the dependent stages -- exact instance capacity, worst-case state slots
         const bool redo = bblob != nullptr;
-        const bool lists_complete = redo && R <= cap && slots >= 0;
-        if (redo) g_spec_stats[R > cap ? 1 : 2]++;
-        if (redo) HIP_OK(hipStreamSynchronize(s));
+        if (redo) { HIP_OK(hipStreamSynchronize(s)); g_spec_stats[1]++; }
         cap = binning_capacity(R);
-        cap_slots = lists_complete ? slots : -1;
+        cap_slots = -1;
         bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
         if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
         if (redo && o->out_weights) HIP_OK(hipMemsetAsync(o->out_weights, 0, (size_t)P * 4, s));   // accumulated by atomics
         if (int rc = run_binning_and_render(bblob, cap, cap_slots, !redo)) return rc;
-        (void)view_lookup(iblob, true, nullptr, nullptr, nullptr, &slots);   // (for the next view's guess)
     }
-    if (slots >= 0) record_slots(ckey, slots);
+    {
+        std::lock_guard<std::mutex> lk(g_cap_mu);
+        cap_entry(ckey, true)->last_view = iblob;
+    }
 
 #if defined(SVGIR_EXP_SYNC_AFTER_CULL)
     if (sync_after_cull) { (void)hipEventSynchronize(sync_after_cull); (void)hipEventDestroy(sync_after_cull); }
@@ -719,12 +741,45 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     const int fin = tile_sort_plan(T).passes & 1;
     StageTimer tm(s);
 
+    // The forward dumped its blend states into slots sized from the workload's previous views and never waited to learn whether this
+    // view fits (that wait stalls a host-bound training loop).  By now the view's slot total is in host memory: it enters the
+    // workload's history, and if it exceeds the capacity the states are dumped AGAIN, all of them, into a stream-ordered temporary -- a
+    // replay of the composite forward that writes nothing else (one extra forward composite on the rare view that outgrows its guess).
+    float* seg_state = B.seg_state;
+    void* redump = nullptr;
+    {
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
+        note_view_slots(ckey, image_blob, 1);
+        long long slots = -1;
+        const bool seen = cap_slots >= 0 && R > 0 && view_lookup(image_blob, 1, nullptr, nullptr, nullptr, &slots);
+        static const bool trace = getenv("SVGIR_TRACE_SPEC") != nullptr;
+        if (trace) fprintf(stderr, "[svgir] backward: R=%d capacity=%d state slots: capacity %lld, view %lld%s\n", R, cap, cap_slots, slots, (seen && slots > cap_slots) ? " -> re-dump" : "");
+        if (seen && slots > cap_slots) {
+            if (!render_specialised(p->S, svgss ? p->VS : 0, svgss)) return fail(SVGIR_ERR_INVALID, "state slots without a specialised composite");
+            HIP_OK(hipMallocAsync(&redump, align_up((size_t)slots * nstate * 64 * 4), s));
+            seg_state = (float*)redump;
+            g_spec_stats[2]++;
+            RenderArgs ra{};
+            ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = svgss ? p->VS : 0;
+            ra.ranges = I.ranges; ra.point_list = B.val[fin]; ra.rec = G.rec; ra.features = p->features; ra.vfeatures = p->vfeatures;
+            ra.bg = p->background; ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_total = I.sub_total; ra.sub_order = I.sub_order;
+            ra.sub_pair_base = I.sub_pair_base; ra.sub_slot_base = I.sub_slot_base; ra.slot_cap = (uint32_t)std::min<long long>(slots, 0xffffffffll);
+            ra.sub_count = I.sub_count; ra.sub_ndump = I.sub_ndump; ra.seg_block = I.seg_block; ra.seg_state = seg_state;
+            ra.dump_only = 1;
+            if (launch_render_fwd(ra, svgss, s) < 0) { (void)hipFreeAsync(redump, s); return fail(SVGIR_ERR_INVALID, "state re-dump: no specialised composite"); }
+            tm.mark("state_redump");
+        }
+    }
+    struct FreeAsync { void* p; hipStream_t s; ~FreeAsync() { if (p) (void)hipFreeAsync(p, s); } } free_redump{redump, s};
+
     RenderBwdArgs ba;
     ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.S = p->S; ba.VS = svgss ? p->VS : 0;
     ba.ranges = I.ranges; ba.point_list = B.val[fin]; ba.rec = G.rec; ba.features = p->features; ba.vfeatures = p->vfeatures;
     ba.bg = p->background;
     ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count;
-    ba.sub_ndump = I.sub_ndump; ba.seg_list = B.seg_list; ba.seg_desc = B.seg_desc; ba.seg_count = I.counters; ba.seg_state = B.seg_state;
+    ba.sub_ndump = I.sub_ndump; ba.seg_list = B.seg_list; ba.seg_desc = B.seg_desc; ba.seg_count = I.counters; ba.seg_state = seg_state;
     ba.seg_cap = (int)B.seg_cap;
     ba.pair_stream = B.pair_stream;
     ba.backward_geometry = p->backward_geometry;

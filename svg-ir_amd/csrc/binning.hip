@@ -296,80 +296,62 @@ __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t
     if (i == R - 1) ranges[2 * cur + 1] = (uint32_t)R;
 }
 
-// One-block counting sort of n work items by descending size: order[] = item ids, largest first.  1024 size buckets, one
-// per count below 1023 (exact order there; everything longer shares the first bucket -- those waves start first anyway).
+// One workgroup behind the cull: (a) counting sort of the n work items by descending size: order[] = item ids, largest first -- 1024
+// size buckets, one per count below 1023 (exact order there; everything longer shares the first bucket -- those waves start first
+// anyway); (b) exclusive prefix sums, in index order, of the counts (the first gradient row of every sub-tile) and of seg_slots(count)
+// (its first dumped-state slot), and their totals (device + tagged host copy).  Every wave owns a contiguous chunk of the items and walks
+// it 64 at a time; the counts are read ONCE (PIT rounds in registers) and serve the histogram, the wave totals, the prefixes and the
+// scatter: one global latency and three barriers from the first load to the last store.
 __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __restrict__ counts, int n,
                                                           uint32_t* __restrict__ order, uint32_t* __restrict__ prefix,
                                                           uint32_t* __restrict__ slot_prefix, uint32_t* __restrict__ total,
                                                           unsigned long long* __restrict__ host_total, uint32_t host_tag) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long wsum2[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     hist[t] = 0;
-    __syncthreads();
-    // Items of size 0 (most of an image is usually empty) all land in the last bucket: they are counted with one
-    // atomic per wave instead of one per item, and placed in index order at the very end.
-    constexpr int KEEP = 12;   // counts cached in registers between the two passes (n <= 12288 = an 880 x 880 image)
-    uint32_t cache[KEEP];
+    const int chunk = ((n + 15) / 16 + 63) / 64 * 64;   // items per wave
+    const int c0 = wave * chunk, c1 = min(n, c0 + chunk);
+    constexpr int PIT = 12;   // chunk rounds held in registers (n <= 12288 = an 880 x 880 image; beyond that the rounds re-read the counts)
+    const bool in_regs = chunk <= PIT * 64;
+    uint32_t cv[PIT];
 #pragma unroll
-    for (int q = 0; q < KEEP; q++) {
-        const int i = q * 1024 + t;
-        cache[q] = i < n ? counts[i] : 1u;
-    }
-    auto count_of = [&](int q, int i) -> uint32_t { return i < n ? counts[i] : 1u; };
-    for (int i0 = 0, q = 0; i0 < n; i0 += 1024, q++) {
-        const int i = i0 + t;
-        uint32_t len = 1u;
-        if (q < KEEP) {
-#pragma unroll
-            for (int qq = 0; qq < KEEP; qq++) len = qq == q ? cache[qq] : len;
-        } else {
-            len = count_of(q, i);
-        }
-        const unsigned long long zero = __ballot(i < n && len == 0u);
-        if (i < n && len != 0u) atomicAdd(&hist[1023u - min(1023u, len)], 1u);
+    for (int r = 0; r < PIT; r++) cv[r] = (in_regs && c0 + r * 64 + lane < c1) ? counts[c0 + r * 64 + lane] : 0u;   // all loads in flight together
+    auto both = [](uint32_t c) { return (unsigned long long)c | ((unsigned long long)seg_slots(c) << 32); };   // low word: counts, high word: slots
+    __syncthreads();   // (hist is zero; the loads are still in flight)
+    // ---- pass 1: size histogram + wave totals.  Items of size 0 (most of an image is usually empty) all land in the last bucket: they
+    // are counted with one atomic per wave and round instead of one per item
+    unsigned long long wtot = 0;
+    auto count1 = [&](int i0, uint32_t len) {
+        const bool valid = i0 + lane < c1;
+        const unsigned long long zero = __ballot(valid && len == 0u);
+        if (valid && len != 0u) atomicAdd(&hist[1023u - min(1023u, len)], 1u);
         if (lane == 0 && zero) atomicAdd(&hist[1023], (uint32_t)__popcll(zero));
+        wtot += both(valid ? len : 0u);
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < PIT; r++)
+            if (c0 + r * 64 < c1) count1(c0 + r * 64, cv[r]);   // (uniform)
+    } else {
+        for (int i0 = c0; i0 < c1; i0 += 64) count1(i0, i0 + lane < c1 ? counts[i0 + lane] : 0u);
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wtot += (unsigned long long)__shfl_xor((long long)wtot, d);
+    if (lane == 0) wsum2[wave] = wtot;
     __syncthreads();
-    // exclusive scan of hist over the 1024 threads
-    const uint32_t v = hist[t];
-    uint32_t incl = v;
+    // ---- exclusive scan of hist over the 1024 threads -> bucket cursors
+    const uint32_t hv = hist[t];
+    uint32_t incl = hv;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(incl, d);
         if (lane >= d) incl += o;
     }
     if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; w++) woff += wsum[w];
-    __syncthreads();
-    hist[t] = woff + incl - v;  // becomes the bucket cursor
-    __syncthreads();
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int i0 = 0, q = 0; i0 < n; i0 += 1024, q++) {
-        const int i = i0 + t;
-        uint32_t len = 1u;
-        if (q < KEEP) {
-#pragma unroll
-            for (int qq = 0; qq < KEEP; qq++) len = qq == q ? cache[qq] : len;
-        } else {
-            len = count_of(q, i);
-        }
-        const bool z = i < n && len == 0u;
-        const unsigned long long zero = __ballot(z);
-        if (i < n && len != 0u) order[atomicAdd(&hist[1023u - min(1023u, len)], 1u)] = (uint32_t)i;
-        uint32_t zbase = 0;
-        if (lane == 0 && zero) zbase = atomicAdd(&hist[1023], (uint32_t)__popcll(zero));
-        zbase = (uint32_t)__shfl((int)zbase, 0);
-        if (z) order[zbase + (uint32_t)__popcll(zero & lt_mask)] = (uint32_t)i;
-    }
-    if (!prefix && !slot_prefix && !total && !host_total) return;
-    // exclusive prefix sums in index order of the counts (the first gradient row of every sub-tile) and of seg_slots(count) (its first
-    // dumped-state slot), and their totals.  Every wave owns a contiguous chunk of the items and walks it 64 at a time (coalesced loads
-    // and stores, wave scans on DPP): first its total, then -- behind ONE barrier -- the running prefixes.
-    const int chunk = ((n + 15) / 16 + 63) / 64 * 64;   // items per wave
-    const int c0 = wave * chunk, c1 = min(n, c0 + chunk);
+    // ---- prefixes in index order (between the two barriers of the bucket scan: they only need wsum2)
     // inclusive wave scans on the VALU (DPP row shifts + row broadcasts; a __shfl_up scan is 6 LDS permutes per word)
     auto scan32 = [](uint32_t v) {
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
@@ -383,31 +365,13 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
     auto wave_incl = [&](unsigned long long v) {   // (two independent 32-bit scans: neither half overflows into the other)
         return (unsigned long long)scan32((uint32_t)v) | ((unsigned long long)scan32((uint32_t)(v >> 32)) << 32);
     };
-    auto both = [](uint32_t c) { return (unsigned long long)c | ((unsigned long long)seg_slots(c) << 32); };   // low word: counts, high word: slots
-    constexpr int PIT = 12;   // chunk rounds held in registers (n <= 12288; beyond that the rounds re-read the counts)
-    const bool in_regs = chunk <= PIT * 64;
-    uint32_t cv[PIT];
-#pragma unroll
-    for (int r = 0; r < PIT; r++) cv[r] = (in_regs && c0 + r * 64 + lane < c1) ? counts[c0 + r * 64 + lane] : 0u;   // all loads in flight together
-    unsigned long long wtot = 0;
-    if (in_regs) {
-#pragma unroll
-        for (int r = 0; r < PIT; r++) wtot += both(cv[r]);
-    } else {
-        for (int i0 = c0; i0 < c1; i0 += 64) wtot += both(i0 + lane < c1 ? counts[i0 + lane] : 0u);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wtot += (unsigned long long)__shfl_xor((long long)wtot, d);
-    __shared__ unsigned long long wsum2[16];
-    if (lane == 0) wsum2[wave] = wtot;
-    __syncthreads();
     unsigned long long run = 0, all = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) { const unsigned long long x = wsum2[w]; run += w < wave ? x : 0ull; all += x; }
     if (prefix || slot_prefix) {
         auto round = [&](int i0, uint32_t c) {
             const int i = i0 + lane;
-            const unsigned long long v = both(c), inc = wave_incl(v);
+            const unsigned long long v = both(i < c1 ? c : 0u), inc = wave_incl(v);
             if (i < c1) {
                 if (prefix) prefix[i] = (uint32_t)(run + inc - v);
                 if (slot_prefix) slot_prefix[i] = (uint32_t)((run + inc - v) >> 32);
@@ -431,6 +395,29 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
             __hip_atomic_store(host_total, ((unsigned long long)host_tag << 32) | (all & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_total + 1, ((unsigned long long)host_tag << 32) | (all >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    hist[t] = woff + incl - hv;   // first output position of bucket t
+    __syncthreads();
+    // ---- pass 2: scatter (items of equal size in arrival order; the zero-size items at the very end)
+    auto place = [&](int i0, uint32_t len) {
+        const int i = i0 + lane;
+        const bool valid = i < c1, z = valid && len == 0u;
+        const unsigned long long zero = __ballot(z);
+        if (valid && len != 0u) order[atomicAdd(&hist[1023u - min(1023u, len)], 1u)] = (uint32_t)i;
+        uint32_t zbase = 0;
+        if (lane == 0 && zero) zbase = atomicAdd(&hist[1023], (uint32_t)__popcll(zero));
+        zbase = (uint32_t)__shfl((int)zbase, 0);
+        if (z) order[zbase + (uint32_t)__popcll(zero & lt_mask)] = (uint32_t)i;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < PIT; r++)
+            if (c0 + r * 64 < c1) place(c0 + r * 64, cv[r]);   // (uniform)
+    } else {
+        for (int i0 = c0; i0 < c1; i0 += 64) place(i0, i0 + lane < c1 ? counts[i0 + lane] : 0u);
     }
 }
 

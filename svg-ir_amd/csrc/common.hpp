@@ -300,6 +300,7 @@ struct RenderArgs {
     uint2* sub_list; uint32_t* sub_total; uint32_t* sub_order; uint32_t* sub_count;
     uint32_t* sub_ndump; uint32_t* seg_list; SegDesc* seg_desc; uint32_t* seg_count; uint32_t* seg_block; float* seg_state;
     uint32_t* sub_pair_base; uint32_t* sub_slot_base; uint32_t slot_cap;
+    int dump_only;   // composite forward: replay for the state dumps alone (svgir_backward, a view that exceeded its slot capacity): no output is written
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null

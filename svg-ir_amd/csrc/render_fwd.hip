@@ -294,7 +294,7 @@ render_fwd_kernel(const RenderArgs a) {
         auto flush_weights = [&](int bprev) {
             if (lane < nflush) {
                 const float wsum = sW[(bprev & 1) * CH + lane];
-                if (wsum != 0.f) atomic_add_f32(&a.out_weights[sQ[(bprev & 1) * CH + lane].x], wsum);
+                if (wsum != 0.f && !a.dump_only) atomic_add_f32(&a.out_weights[sQ[(bprev & 1) * CH + lane].x], wsum);
             }
         };
         int b = 0;
@@ -443,7 +443,7 @@ render_fwd_kernel(const RenderArgs a) {
     }
     // the live segments -- those that hold at least one consumed candidate -- are listed in tile order by seg_build_kernel
     // from these counts; the per-block totals it needs are summed here (fire-and-forget atomics, 4 T / 1024 counters)
-    if (lane == 0) {
+    if (lane == 0 && !a.dump_only) {
         a.sub_count[sid] = head; a.sub_ndump[sid] = ndump;
         const uint32_t nseg = head != 0 ? min((head + (uint32_t)SEG - 1u) / (uint32_t)SEG, ndump + 1u) : 0u;
         if (nseg != 0) {   // nseg - 1 full segments + the last one, by its length class
@@ -456,7 +456,7 @@ render_fwd_kernel(const RenderArgs a) {
     if (head != 0 && ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
     else gather_acc();
 
-    if (inside) {
+    if (inside && !a.dump_only) {
         const size_t N_ = (size_t)a.W * a.H;
         const size_t pid = (size_t)a.W * py + px;
         T = fminf((float)(1 - 0.000001), T);

@@ -437,19 +437,30 @@ def test_speculative_capacity_small_large_small(built):
 def test_state_slot_capacity_guess_too_small_reruns(built):
     """The composite forward dumps its blend state every 64 candidates of a sub-tile; the slots it may use are allocated from the
     pair statistics of the workload's recent views (csrc/api.hip).  A view whose lists are suddenly much longer -- the same surfels,
-    the same instance count, but all of them on top of each other -- exceeds that guess and must take the re-run path; before and
-    after it, views with short lists run inside their (tiny / over-sized) allocations.  All three match the oracle, forward and
-    backward."""
-    spread = scenes.surface_scene(P=20000, W=256, H=256, seed=91, sh_degree=1, variant="svgss", S=4, VS=52, scale_lo=0.004, scale_hi=0.006)
+    the same instance count, but all of them on top of each other -- exceeds that guess: the forward (which does not wait for the cull)
+    drops the dumps that do not fit, and the view's backward replays the composite forward for the states alone; before and after it,
+    views with short lists run inside their (tiny / over-sized) allocations.  All three match the oracle, forward and backward."""
+    spread = scenes.surface_scene(P=20000, W=512, H=512, seed=91, sh_degree=1, variant="svgss", S=4, VS=52, scale_lo=0.004, scale_hi=0.006)   # short lists: few state slots
     stacked = dict(spread)
     rng = np.random.default_rng(92)
-    stacked["means3D"] = (0.03 * rng.normal(size=spread["means3D"].shape)).astype(np.float32)
+    stacked["means3D"] = (0.004 * rng.normal(size=spread["means3D"].shape)).astype(np.float32)
     stacked["opacities"] = (spread["opacities"] * 0.02).astype(np.float32)   # translucent: the lists are consumed to the end
+    # (fewer instances than the spread views, so that the instance capacity holds: every second surfel goes behind the camera)
+    campos = np.asarray(spread["campos"], dtype=np.float64)
+    behind = campos + 2.0 * (campos - 0.0) / np.linalg.norm(campos)
+    stacked["means3D"][1::2] = (behind + 0.01 * rng.normal(size=stacked["means3D"][1::2].shape)).astype(np.float32)
+    from gaussian_renderer import _native
+    before = _native.speculation_stats()
+    Rs = []
     for sc in (spread, spread, stacked, spread):
         grads = scenes.upstream_grads(sc, "svgss", seed=5)
         out, leaves, o, R = _run_both(sc, "svgss", grads)
         _check_forward(out, o, R, "svgss")
         _check_backward(leaves, o, "svgss")
+        Rs.append(R)
+    after = _native.speculation_stats()
+    assert after["rerun_capacity"] == before["rerun_capacity"]      # (it is the slot guess that fails, not the instance capacity)
+    assert after["rerun_slots"] == before["rerun_slots"] + 1        # the stacked view's states were dumped again by its backward
 
 
 def test_depth_key_byte_speculation_reruns_when_a_view_breaks_it(built):
