@@ -165,9 +165,10 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o,
                   void* stream);
 
 /* What the speculative launches of svgir_forward did so far in this process (monitoring / tests; ABI 11):
- * out5 = {forwards, views re-run because the instance capacity guessed from the previous views was too small, ... because the state-slot
- * capacity was, ... because a visible depth key did not carry the top byte the last views' keys shared (the depth sort then runs three
- * 8-bit passes instead of four), views whose depth sort ran three passes}.  The reference has no counterpart: its forward waits for the
+ * out5 = {forwards, views re-run because the instance capacity guessed from the previous views was too small, views whose blend states
+ * were dumped again by their backward because the state-slot capacity was, views re-run because a visible depth key did not carry the
+ * top byte the last views' keys shared (the depth sort then runs three 8-bit passes instead of four), views whose depth sort ran three
+ * passes}.  The reference has no counterpart: its forward waits for the
  * instance count (rasterizer_impl.cu:307-312) and always sorts 64-bit keys. */
 void svgir_speculation_stats(int64_t* out5);
 
