@@ -3,8 +3,19 @@
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-TAG=g9 TESTS=1 WORKLOADS="cfg2 cfg3_train" bash scripts/gpu_iter.sh
-timeout 600 python scripts/stress.py 5 30 2>&1 | tail -2
-timeout 600 python bench.py --workload train_step --no-cpu-baseline 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train_step', d['ms_per_step'], d.get('phase_ms'))"
+
+for V in orig f10 orig f10; do
+  if [ $V = product ]; then unset SVGIR_RASTER_LIB; else export SVGIR_RASTER_LIB=$PWD/build/variants/$V/libsvgir_raster.so; fi
+  for W in cfg3_eval cfg3_train; do
+    timeout 300 python bench.py --workload $W --steps 20 --warmup 5 --repeats 5 --no-cpu-baseline --no-shaded --no-concurrent > gpurun_out/s_$W.json 2> gpurun_out/s_$W.err
+    python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/s_$W.json").read().strip().splitlines()[-1])
+    st=d.get("stage_ms") or {}
+    print("$V $W ms/step %.4f"%d["ms_per_step"], {k:round(v,4) for k,v in st.items() if "shade" in k})
+except Exception as e:
+    print("$V $W FAILED", e); print(open("gpurun_out/s_$W.err").read()[-1500:])
+PY
+  done
+done
