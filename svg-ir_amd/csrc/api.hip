@@ -533,9 +533,6 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
     // Everything from here on depends on the instance count R that the GPU is still computing.  The stages are
     // launched for an instance CAPACITY `cap` and read R on the device (min(cap, R)); the binning blob is laid out
     // for `cap`.  `timed`: stage marks are only recorded for the launch sequence that counts.
-#if defined(SVGIR_EXP_SYNC_AFTER_CULL)
-    hipEvent_t sync_after_cull = nullptr;
-#endif
     auto run_binning_and_render = [&](char* bblob, int cap, long long cap_slots, bool timed) -> int {
         const BinLayout B = bin_layout(bblob, cap, T, nstate, cap_slots);
         launch_emit(P, depth_order, G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
@@ -574,14 +571,6 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, I.sub_slot_base, I.counters, vslot, vtag, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
-#if defined(SVGIR_EXP_SYNC_AFTER_CULL)
-        {   // experiment: what a second host read-back behind the cull would cost (blob sizing from the pair count, DESIGN.md 7 open 6)
-            hipEvent_t evc;
-            HIP_OK(hipEventCreateWithFlags(&evc, hipEventDisableTiming));
-            HIP_OK(hipEventRecord(evc, s));
-            sync_after_cull = evc;
-        }
-#endif
 #if defined(BWDP_STREAM)
         if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
         launch_pair_stream(ra, s);
@@ -670,9 +659,6 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         cap_entry(ckey, true)->last_view = iblob;
     }
 
-#if defined(SVGIR_EXP_SYNC_AFTER_CULL)
-    if (sync_after_cull) { (void)hipEventSynchronize(sync_after_cull); (void)hipEventDestroy(sync_after_cull); }
-#endif
     if (!svgss && p->computer_pseudo_normal) {
         launch_image_ops(W, H, p->viewmatrix, focal_x, focal_y, p->cx, p->cy, o->out_opacity, o->out_depth,
                          o->out_pseudo_normal, o->out_surface_xyz, s);
