@@ -154,8 +154,8 @@ size_t svgir_image_ncontrib_offset(int32_t W, int32_t H);
  * rgss :209-407).  Calls geom(), image() and binning().  From the second call on, binning() is called -- and the
  * count-dependent stages (emit, tile sort, ranges, composite) are launched -- speculatively for a capacity derived
  * from the previous call's instance count, while the GPU still computes the count; the stages read the count on the
- * device.  The one 4-byte device->host read of the count then only confirms the guess (no GPU idle time); if the
- * guess was too small, binning() is called again and those stages are re-run (only the LAST pointer it returned is
+ * device.  The count reaches the host as a tagged store into pinned memory (no copy, no event) and then only confirms the guess (no
+ * GPU idle time); if the guess was too small, binning() is called again and those stages are re-run (only the LAST pointer it returned is
  * used).
  * Returns num_rendered (R >= 0) or a negative svgir_status. */
 int svgir_forward(const svgir_params* p, const svgir_outputs* o,
