@@ -463,6 +463,29 @@ def test_state_slot_capacity_guess_too_small_reruns(built):
     assert after["rerun_slots"] == before["rerun_slots"] + 1        # the stacked view's states were dumped again by its backward
 
 
+def test_forward_only_loops_learn_their_slot_capacity(built):
+    """Without a backward (evaluation renders) nobody reads a view's state-slot total on its behalf: the workload's NEXT forward looks at
+    it (no wait) before it sizes its own blob.  The first view's binning blob is the worst case, later ones are compact (an odd multiple
+    of 128 bytes, csrc/common.hpp bin_layout) and smaller, and the images stay equal to the first view's."""
+    dev = _dev()
+    sc = scenes.surface_scene(P=12000, W=192, H=160, seed=23, sh_degree=1, variant="svgss", S=4, VS=52, scale_lo=0.01, scale_hi=0.03)
+    sct = runner.to_torch(sc, dev)
+    sizes, first = [], None
+    for it in range(5):
+        raw = runner.forward_raw(sct, "svgss")
+        torch.cuda.synchronize()
+        sizes.append(int(raw["blobs"][1].numel()))
+        color = raw["color"]
+        if first is None:
+            first = color.clone()
+        else:
+            assert torch.equal(color, first)
+        del raw
+    assert sizes[0] % 256 == 0                                  # worst-case layout
+    assert all(b % 256 == 128 for b in sizes[2:]), sizes        # compact from the third view on at the latest
+    assert max(sizes[2:]) < sizes[0], sizes
+
+
 def test_depth_key_byte_speculation_reruns_when_a_view_breaks_it(built):
     """The depth sort drops its fourth 8-bit pass once three consecutive views of a workload had all visible depth keys in one top byte
     (depths in [2, 8) here: 0x40), csrc/api.hip.  A view of the same workload whose surfels straddle two bytes (half of them pushed
