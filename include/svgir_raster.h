@@ -419,7 +419,10 @@ int svgir_bvh_trace_visibility(int32_t P, char* bvh, int64_t num_rays, const flo
  *       T <= 0.001, no hit, or the hit is the primitive whose index equals the ROW of the ray.  Outputs: radiance [N,S,3]
  *       clamped to [0,10], visibility [N,S] (T, or 0 once T < 0.2), hit_indices [N,S] int32 (first hit or -1), uvs [N,S,2].
  *       rotations [P,4] (r,x,y,z), normals [P,3], opacity [P], cov3D_inverse [P,6] (xx xy xz yy yz zz).
- *       oracle/pbgi_oracle.cpp lists the reference's traversal quirks that are reproduced. */
+ *       oracle/pbgi_oracle.cpp lists the reference's traversal quirks that are reproduced.
+ *       The blob is NOT read-only during a trace: the per-call leaf records, the row order of the call and its ray queue live in it.
+ *       Calls that share one blob (build, trace) must therefore be ordered on ONE stream (or by events); concurrent traces from several
+ *       streams / threads need one blob each (a build is 6 launches). */
 size_t svgir_pbgi_bvh_bytes(int32_t P);
 int svgir_pbgi_bvh_build(int32_t P, const float* centers, const float* scales, char* bvh, void* stream);
 int svgir_pbgi_bvh_export(int32_t P, char* bvh, int32_t* info, float* aabb, int32_t* sorted, void* stream);

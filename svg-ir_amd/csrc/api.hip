@@ -102,38 +102,80 @@ void record_top(const CapKey& k, uint32_t summary) {   // {AND << 8 | OR}; AND =
     else { e->top_byte = av; e->top_streak = 1; }
 }
 // Pinned landing slots for the instance count (+ prefilter violation + depth-key summary): the scan's last block stores them there,
-// tagged, with system-scope stores -- no copy operation and no event on the stream -- and the host spins on the tag.  A small ring:
-// concurrent forwards on different threads / streams get different slots.
+// tagged, with system-scope stores -- no copy operation and no event on the stream -- and the host spins on the tag.  A slot belongs to
+// ONE forward from its launch until that forward has read the count (a free list, not a ring: any number of forwards may be in flight
+// across threads / streams; the ones that find no free slot read the count with a blocking copy like the reference does,
+// rasterizer_impl.cu:307-312).
 unsigned long long* g_pinned = nullptr;
-std::atomic<unsigned> g_pinned_next{0};
 std::atomic<uint32_t> g_pinned_tag{0};
-constexpr unsigned kPinnedSlots = 64;
+constexpr unsigned kPinnedSlots = 256;
 std::once_flag g_pinned_once;
-unsigned long long* pinned_slot(uint32_t* tag) {
-    std::call_once(g_pinned_once, [] {
-        void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, kPinnedSlots * 2 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
-            g_pinned = (unsigned long long*)ptr;
-            for (unsigned i = 0; i < 2 * kPinnedSlots; i++) g_pinned[i] = 0ull;
-        }
-    });
-    uint32_t t = ++g_pinned_tag;
-    if (t == 0) t = ++g_pinned_tag;   // (never 0: the slots start as 0)
-    *tag = t;
-    return g_pinned ? g_pinned + 2 * (g_pinned_next.fetch_add(1) % kPinnedSlots) : nullptr;
+std::mutex g_pinned_mu;
+uint64_t g_pinned_busy[kPinnedSlots / 64];   // bit set: the slot is owned by a forward in flight
+struct PinnedSlot {
+    unsigned long long* at = nullptr; uint32_t tag = 0; int index = -1;
+    PinnedSlot() {
+        std::call_once(g_pinned_once, [] {
+            void* ptr = nullptr;
+            // (explicitly host-coherent: the device's system-scope stores must become visible to the polling host thread)
+            if (hipHostMalloc(&ptr, kPinnedSlots * 2 * sizeof(unsigned long long), hipHostMallocCoherent) == hipSuccess) {
+                g_pinned = (unsigned long long*)ptr;
+                for (unsigned i = 0; i < 2 * kPinnedSlots; i++) g_pinned[i] = 0ull;
+            } else {
+                (void)hipGetLastError();
+            }
+        });
+        uint32_t t = ++g_pinned_tag;
+        if (t == 0) t = ++g_pinned_tag;   // (never 0: the slots start as 0)
+        tag = t;
+        if (!g_pinned) return;
+        // (SVGIR_PINNED_SLOTS: fewer slots, for tests of the no-free-slot path)
+        static const unsigned usable = [] { const char* e = getenv("SVGIR_PINNED_SLOTS"); return e ? (unsigned)std::min<long>(std::max<long>(atol(e), 0), kPinnedSlots) : kPinnedSlots; }();
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        for (unsigned i = 0; i < usable; i++)
+            if (!(g_pinned_busy[i / 64] >> (i % 64) & 1ull)) {
+                g_pinned_busy[i / 64] |= 1ull << (i % 64);
+                index = (int)i;
+                at = g_pinned + 2 * index;
+                return;
+            }
+    }
+    ~PinnedSlot() {
+        if (index < 0) return;
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        g_pinned_busy[index / 64] &= ~(1ull << (index % 64));
+    }
+    PinnedSlot(const PinnedSlot&) = delete;
+    PinnedSlot& operator=(const PinnedSlot&) = delete;
+};
+// How long a host thread polls pinned memory for a tagged word before it stops polling and blocks on the stream instead (the value is
+// typically tens of microseconds away; a longer wait means the stream holds a backlog -- tracer updates, a shared GPU, a profiler that
+// serialises kernels -- and then blocking is the right way to wait).  SVGIR_SPIN_MS overrides it (tests use 0: always the blocking path).
+double spin_budget_s() {
+    static const double v = [] {
+        const char* e = getenv("SVGIR_SPIN_MS");
+        return e ? std::max(0.0, atof(e)) * 1e-3 : 0.05;
+    }();
+    return v;
 }
-// waits for the two tagged words (typically tens of microseconds away); false after ~2 s (a forward that failed on the device)
-bool pinned_wait(volatile unsigned long long* at, uint32_t tag, uint32_t* w0, uint32_t* w1) {
+inline bool tagged_pair(volatile unsigned long long* at, uint32_t tag, uint32_t* w0, uint32_t* w1) {
+    const unsigned long long v0 = at[0], v1 = at[1];
+    if ((uint32_t)(v0 >> 32) != tag || (uint32_t)(v1 >> 32) != tag) return false;
+    *w0 = (uint32_t)v0; *w1 = (uint32_t)v1;
+    return true;
+}
+// polls for the two tagged words; false when the spin budget ran out (NOT an error: the caller then blocks on the stream and looks again)
+bool pinned_spin(volatile unsigned long long* at, uint32_t tag, uint32_t* w0, uint32_t* w1) {
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    const double budget = spin_budget_s();
     for (long long spin = 0;; spin++) {
-        const unsigned long long v0 = at[0], v1 = at[1];
-        if ((uint32_t)(v0 >> 32) == tag && (uint32_t)(v1 >> 32) == tag) { *w0 = (uint32_t)v0; *w1 = (uint32_t)v1; return true; }
-        if ((spin & 255) == 255) {
+        if (tagged_pair(at, tag, w0, w1)) return true;
+        if ((spin & 255) == 255 || budget == 0.0) {
             struct timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
             const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-            if (el > 2.0) return false;
+            if (el >= budget) return false;
             if (el > 5e-3) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
         }
     }
@@ -156,7 +198,7 @@ unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_s
     std::lock_guard<std::mutex> lk(g_view_mu);
     if (!g_view_pinned) {
         void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, kViewEntries * 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&ptr, kViewEntries * 2 * sizeof(unsigned long long), hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         g_view_pinned = (unsigned long long*)ptr;
         for (int i = 0; i < 2 * kViewEntries; i++) g_view_pinned[i] = 0ull;
     }
@@ -171,10 +213,27 @@ unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_s
     *tag = e.tag;
     return g_view_pinned + 2 * slot;
 }
+// The same four numbers live in the image blob itself (ImageLayout::counters, written by order_desc_kernel): a blob the host table no
+// longer knows -- more than kViewEntries forwards ago, or a binder that moved / cloned the saved buffer -- is still self-describing, like
+// the reference's blobs; the table is the fast path (no device read, no synchronisation).
+constexpr uint32_t kBlobMagic = 0x53564931u;   // "SVI1" in counters[3]: order_desc_kernel of this library version wrote the words behind it
+struct ViewCounts { int cap_R = 0; long long cap_slots = -1, pairs = -1, slots = -1; };
+// blocking read of the blob's own copy; the forward that wrote it must be complete on the device (the callers synchronise first)
+bool view_from_blob(const uint32_t* counters_dev, ViewCounts* out) {
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!counters_dev || hipMemcpy(w, counters_dev, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (w[3] != kBlobMagic) return false;
+    out->pairs = (long long)w[1]; out->slots = (long long)w[2]; out->cap_R = (int)w[4];
+    out->cap_slots = (long long)((unsigned long long)w[5] | ((unsigned long long)w[6] << 32));
+    return true;
+}
 // the entry of the forward that owns `image_blob` (capacities; counts when `wait`): false = unknown blob.  The counts are in host memory
-// as soon as the forward's order kernel has run; the wait only ever spins when the host is ahead of the GPU and gives up after ~2 s
-// (a forward that failed on the device never writes them): pairs / slots stay -1 then.
-bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_slots, long long* pairs, long long* slots) {
+// as soon as the forward's order kernel has run.  wait = 1: poll for spin_budget_s(), then BLOCK -- on `*sync_stream` when the caller has
+// the stream the forward ran on (or one ordered behind it), else on the device -- and look again: a backlog in front of the forward is
+// not an error.  pairs / slots stay -1 only if the forward never wrote them (it failed on the device) or the entry was recycled.
+// wait = 2: one look.
+bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_slots, long long* pairs, long long* slots,
+                 const hipStream_t* sync_stream = nullptr) {
     volatile unsigned long long* at = nullptr;
     uint32_t tag = 0;
     {
@@ -191,33 +250,24 @@ bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_sl
     if (slots) *slots = -1;
     if (!at) return false;
     if (!wait) return true;
-    // (a pure spin on host memory: the value is typically 100-200 us away -- the rest of the binning -- and a sleep's granularity of
-    // ~60 us would hand the GPU an idle gap; after 5 ms the waits become sleeps, after ~2 s the lookup gives up)
-    struct timespec t0;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (long long spin = 0;; spin++) {
-        const unsigned long long v0 = at[0], v1 = at[1];
-        if ((uint32_t)(v0 >> 32) == tag && (uint32_t)(v1 >> 32) == tag) {
-            if (pairs) *pairs = (long long)(uint32_t)v0;
-            if (slots) *slots = (long long)(uint32_t)v1;
-            return true;
-        }
-        if (wait == 2) break;   // (peek: one look)
-        if ((spin & 255) == 255) {
-            struct timespec t1;
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-            if (el > 2.0) break;
-            if (el > 5e-3) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
-        }
+    uint32_t w0 = 0, w1 = 0;
+    bool got = wait == 2 ? tagged_pair(at, tag, &w0, &w1) : pinned_spin(at, tag, &w0, &w1);
+    if (!got && wait == 1) {
+        const hipError_t e = sync_stream ? hipStreamSynchronize(*sync_stream) : hipDeviceSynchronize();
+        if (e != hipSuccess) (void)hipGetLastError();
+        got = tagged_pair(at, tag, &w0, &w1);
+    }
+    if (got) {
+        if (pairs) *pairs = (long long)w0;
+        if (slots) *slots = (long long)w1;
     }
     return true;
 }
 // A view's state-slot total enters its workload's history once, through whoever sees it first: the workload's next forward (mode 2:
 // a look, no wait -- the forward itself never waits for the cull) or the view's own backward (mode 1: the value is there by then).
-void note_view_slots(const CapKey& k, const void* image_blob, int mode) {
+void note_view_slots(const CapKey& k, const void* image_blob, int mode, const hipStream_t* sync_stream = nullptr) {
     long long slots = -1;
-    if (!image_blob || !view_lookup(image_blob, mode, nullptr, nullptr, nullptr, &slots) || slots < 0) return;
+    if (!image_blob || !view_lookup(image_blob, mode, nullptr, nullptr, nullptr, &slots, sync_stream) || slots < 0) return;
     {
         std::lock_guard<std::mutex> lk(g_view_mu);
         bool found = false;
@@ -403,7 +453,12 @@ size_t svgir_binning_point_list_offset(size_t binning_bytes, const char* image_b
     const int nstate = seg_nstate(S, VS);
     int cap = 0;
     if (bin_bytes_compact(binning_bytes)) {   // laid out for a state-slot capacity of the forward's choosing: the view's entry knows
-        if (!image_blob || !view_lookup(image_blob, false, &cap, nullptr, nullptr, nullptr)) return (size_t)-1;
+        if (!image_blob) return (size_t)-1;
+        if (!view_lookup(image_blob, false, &cap, nullptr, nullptr, nullptr)) {   // not in the host table: the blob's own copy
+            ViewCounts vc;
+            if (hipDeviceSynchronize() != hipSuccess || !view_from_blob(image_layout(const_cast<char*>(image_blob), W, H).counters, &vc)) return (size_t)-1;
+            cap = vc.cap_R;
+        }
     } else {
         cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
     }
@@ -519,8 +574,9 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
     if (int rc = check("depth sort")) return rc;
     tm.mark("sort_depth");
 
-    uint32_t R_tag = 0;
-    unsigned long long* R_slot = pinned_slot(&R_tag);
+    const PinnedSlot R_pin;   // (released when this forward returns)
+    unsigned long long* const R_slot = R_pin.at;
+    const uint32_t R_tag = R_pin.tag;
     launch_offsets_scan(G.tiles, depth_order, G.offsets, G.scan_tmp, P, G.counters, G.key_top, (P + 63) / 64, pa.prefilter_violation,
                         R_slot, R_tag, s);
     if (int rc = check("offsets scan")) return rc;
@@ -568,7 +624,8 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         uint32_t vtag = 0;
         unsigned long long* vslot = view_note(iblob, cap, cap_slots, &vtag);
         const bool row_path = svgss && p->VS > 0 && render_specialised(p->S, p->VS, true);   // (only the svgss backward writes gradient rows)
-        launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, I.sub_slot_base, I.counters, vslot, vtag, s);
+        launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, I.sub_slot_base, I.counters, vslot, vtag,
+                          (uint32_t)cap, cap_slots, kBlobMagic, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
 #if defined(BWDP_STREAM)
@@ -610,16 +667,20 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
     }
     // the instance count (only: the speculative stages keep running)
     uint32_t R_host = 0, R_aux = 0;
-    if (R_slot) {
-        if (!pinned_wait(R_slot, R_tag, &R_host, &R_aux)) {
-            const hipError_t e = hipStreamSynchronize(s);
-            return fail(SVGIR_ERR_HIP, "the instance count did not arrive: %s", hipGetErrorString(e == hipSuccess ? hipGetLastError() : e));
+    bool have_R = R_slot && pinned_spin(R_slot, R_tag, &R_host, &R_aux);
+    if (!have_R) {
+        // The count is further away than the spin budget -- a backlog in front of this forward on the stream (the reference's call order
+        // puts update_visibility / update_radiace, seconds of work, right before a render), a shared GPU, a serialising profiler -- or no
+        // landing slot was free.  Like the reference (rasterizer_impl.cu:307-312: a cudaMemcpy without a deadline): block, then look again;
+        // a slow stream is not an error.
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "the forward failed on the device: %s", hipGetErrorString(e));
+        have_R = R_slot && tagged_pair(R_slot, R_tag, &R_host, &R_aux);
+        if (!have_R) {   // the counters' device copy (same three words)
+            uint32_t w[3] = {0, 0, 0};
+            HIP_OK(hipMemcpy(w, G.counters, 12, hipMemcpyDeviceToHost));
+            R_host = w[0]; R_aux = ((p->prefiltered && w[1]) ? 1u << 16 : 0u) | (w[2] & 0xffffu);
         }
-    } else {   // no pinned memory: a blocking copy
-        uint32_t w[3] = {0, 0, 0};
-        HIP_OK(hipMemcpyAsync(w, G.counters, 12, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        R_host = w[0]; R_aux = ((p->prefiltered && w[1]) ? 1u << 16 : 0u) | (w[2] & 0xffffu);
     }
     if (p->prefiltered && (R_aux >> 16) != 0u) {
         (void)hipStreamSynchronize(s);
@@ -689,7 +750,15 @@ size_t svgir_backward_scratch_bytes_for(int32_t variant, int32_t P, size_t binni
     // view when its count is known, else four per instance
     int cap = 0;
     long long pairs = -1;
-    const bool known = image_blob && view_lookup(image_blob, true, &cap, nullptr, &pairs, nullptr);
+    bool known = image_blob && view_lookup(image_blob, true, &cap, nullptr, &pairs, nullptr);
+    if (image_blob && (!known || pairs < 0)) {   // not in the host table (or its counts never arrived): the blob's own copy, blocking
+        ViewCounts vc;
+        if (hipDeviceSynchronize() == hipSuccess && view_from_blob(image_layout(const_cast<char*>(image_blob), W, H).counters, &vc)) {
+            known = true; cap = vc.cap_R; pairs = vc.pairs;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (!bin_bytes_compact(binning_bytes)) cap = binning_capacity_from_bytes(binning_bytes, T, seg_nstate(S, VS));
     else if (!known) cap = binning_capacity((long long)(binning_bytes / 48));   // (no view given: an upper bound -- every instance owns 48 B of the blob)
     const size_t rows = pairs >= 0 ? (size_t)std::min<long long>(pairs, (long long)4 * cap) : (size_t)4 * cap;
@@ -715,9 +784,15 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     int cap = 0;
     long long cap_slots = -1;
     if (bin_bytes_compact(binning_bytes)) {   // laid out by the forward for a state-slot capacity of its choosing: the view's entry knows
-        if (!view_lookup(image_blob, false, &cap, &cap_slots, nullptr, nullptr) || cap_slots < 0)
-            return fail(SVGIR_ERR_INVALID, "the binning blob (%zu bytes) was laid out by a forward this library no longer knows "
-                                           "(more than 1024 forwards ago, or the image blob was copied)", binning_bytes);
+        if (!view_lookup(image_blob, false, &cap, &cap_slots, nullptr, nullptr) || cap_slots < 0) {
+            // not in the host table (an old forward, or a binder that moved the saved buffer): the image blob carries its own copy
+            ViewCounts vc;
+            HIP_OK(hipStreamSynchronize(s));
+            if (!view_from_blob(I.counters, &vc) || vc.cap_slots < 0)
+                return fail(SVGIR_ERR_INVALID, "the binning blob (%zu bytes) has a compact layout, but the image blob does not describe it "
+                                               "(not the image blob of the same svgir_forward?)", binning_bytes);
+            cap = vc.cap_R; cap_slots = vc.cap_slots;
+        }
     } else {
         cap = binning_capacity_from_bytes(binning_bytes, T, nstate);
     }
@@ -737,9 +812,18 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
-        note_view_slots(ckey, image_blob, 1);
+        note_view_slots(ckey, image_blob, 1, &s);
         long long slots = -1;
-        const bool seen = cap_slots >= 0 && R > 0 && view_lookup(image_blob, 1, nullptr, nullptr, nullptr, &slots);
+        bool seen = cap_slots >= 0 && R > 0 && view_lookup(image_blob, 1, nullptr, nullptr, nullptr, &slots, &s) && slots >= 0;
+        if (cap_slots >= 0 && R > 0 && !seen) {
+            // The slot total is not in host memory even after blocking on the stream (the table entry was recycled, or the blob came
+            // from elsewhere): read the blob's own copy.  The backward never runs on state slots it has not verified.
+            ViewCounts vc;
+            HIP_OK(hipStreamSynchronize(s));
+            if (!view_from_blob(I.counters, &vc))
+                return fail(SVGIR_ERR_INVALID, "the image blob does not carry this view's state-slot total (forward failed, or a foreign blob)");
+            slots = vc.slots; seen = true;
+        }
         static const bool trace = getenv("SVGIR_TRACE_SPEC") != nullptr;
         if (trace) fprintf(stderr, "[svgir] backward: R=%d capacity=%d state slots: capacity %lld, view %lld%s\n", R, cap, cap_slots, slots, (seen && slots > cap_slots) ? " -> re-dump" : "");
         if (seen && slots > cap_slots) {

@@ -305,7 +305,8 @@ __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t
 __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __restrict__ counts, int n,
                                                           uint32_t* __restrict__ order, uint32_t* __restrict__ prefix,
                                                           uint32_t* __restrict__ slot_prefix, uint32_t* __restrict__ total,
-                                                          unsigned long long* __restrict__ host_total, uint32_t host_tag) {
+                                                          unsigned long long* __restrict__ host_total, uint32_t host_tag,
+                                                          uint32_t cap_R, long long cap_slots, uint32_t magic) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     __shared__ unsigned long long wsum2[16];
@@ -388,7 +389,11 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
         }
     }
     if (t == 0) {
-        if (total) { total[1] = (uint32_t)all; total[2] = (uint32_t)(all >> 32); }
+        if (total) {
+            total[1] = (uint32_t)all; total[2] = (uint32_t)(all >> 32);
+            // the capacities the forward laid the binning blob out for: the image blob describes its view by itself (api.hip view_from_blob)
+            total[3] = magic; total[4] = cap_R; total[5] = (uint32_t)(unsigned long long)cap_slots; total[6] = (uint32_t)((unsigned long long)cap_slots >> 32);
+        }
         // the host's copy: {sum, tag of this forward} as 8-byte stores into pinned host memory -- no copy operation and no event on the
         // stream; the host recognises the values by their tag (api.hip view_lookup)
         if (host_total) {
@@ -424,8 +429,9 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
 }  // namespace
 
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* slot_prefix, uint32_t* totals,
-                       unsigned long long* host_totals, uint32_t host_tag, hipStream_t s) {
-    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order, prefix, slot_prefix, totals, host_totals, host_tag);
+                       unsigned long long* host_totals, uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, hipStream_t s) {
+    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order, prefix, slot_prefix, totals, host_totals, host_tag,
+                       cap_R, cap_slots, magic);
 }
 
 template <int ITEMS>

@@ -101,8 +101,9 @@ struct ImageLayout {
     uint32_t* sub_ndump; // [4*T] #segment-boundary states the forward dumped for the sub-tile (see SEG)
     uint32_t* sub_pair_base; // [4*T] exclusive prefix of sub_total over the sub-tiles: first gradient row of a sub-tile's candidates
     uint32_t* sub_slot_base; // [4*T] exclusive prefix of seg_slots(sub_total): first dumped-state slot of a sub-tile (BinLayout::seg_state)
-    uint32_t* counters;  // [4]: [0] = number of live backward segments (entries of BinLayout::seg_list); [1] = sum of sub_total (pairs);
-                         // [2] = sum of seg_slots(sub_total) (state slots)
+    uint32_t* counters;  // [8]: [0] = number of live backward segments (entries of BinLayout::seg_list); [1] = sum of sub_total (pairs);
+                         // [2] = sum of seg_slots(sub_total) (state slots); [3] = magic, [4] = instance capacity, [5..6] = state-slot
+                         // capacity (int64; -1: worst case) the forward laid the binning blob out for (api.hip view_from_blob)
     size_t ncontrib_off;
     size_t bytes;
 };
@@ -124,7 +125,7 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.sub_ndump = (uint32_t*)take(T * 4 * 4);
     im.sub_pair_base = (uint32_t*)take(T * 4 * 4);
     im.sub_slot_base = (uint32_t*)take(T * 4 * 4);
-    im.counters = (uint32_t*)take(16);
+    im.counters = (uint32_t*)take(32);
     im.bytes = off;
     return im;
 }
@@ -371,8 +372,9 @@ void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint
 // order[] = item ids sorted by descending counts[] (longest-processing-time-first dispatch of the composite waves); also
 // prefix[i] = exclusive prefix sum of counts[], slot_prefix[i] = the same of seg_slots(counts[]), totals[1] / totals[2] = the two sums,
 // host_totals[0] / [1] = host_tag << 32 | sum in pinned host memory (any of them may be null)
+// totals[3..6] = {magic, cap_R, cap_slots lo, hi}: the capacities of the launch sequence, kept in the image blob
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* slot_prefix, uint32_t* totals,
-                       unsigned long long* host_totals, uint32_t host_tag, hipStream_t s);
+                       unsigned long long* host_totals, uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
 // tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump; also zeroes

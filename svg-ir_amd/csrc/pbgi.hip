@@ -489,7 +489,8 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
     auto push = [&](int id, float en) {
         if (count < PBGI_LDS_DEPTH) { s_id[count * PBGI_WAVE] = id; s_en[count * PBGI_WAVE] = en; }
         else if (count < PBGI_STACK) { deep_id[count - PBGI_LDS_DEPTH] = id; deep_en[count - PBGI_LDS_DEPTH] = en; }
-        count++;   // (count never reaches PBGI_STACK: see its definition)
+        else return;   // a full stack drops the entry, as the reference does (it cannot happen: see PBGI_STACK) -- never an out-of-bounds pop
+        count++;
     };
     for (;;) {
         if (__any(!walking)) {

@@ -1067,6 +1067,7 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
         !p->env || !p->env_work || (vfeatures && !p->viewmatrix))
         return SVGIR_ERR_INVALID;
     if (!p->incident_dirs && !(p->lattice_normals && p->lattice_work)) return SVGIR_ERR_INVALID;
+    if (((uintptr_t)p->env_work & 15) || (p->lattice_work && ((uintptr_t)p->lattice_work & 15))) return SVGIR_ERR_INVALID;   // read as float4
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);

@@ -1,0 +1,159 @@
+"""The forward's host wait for the instance count must not turn a slow stream into an error.
+
+The reference blocks on a `cudaMemcpy` with no deadline (rasterizer_impl.cu:307-312), and its call order puts seconds of tracer
+work (`update_visibility` / `update_radiace`, scene/gaussian_model.py:435-522) on the stream right before a render.  Here the count
+arrives as a tagged store into pinned host memory the host polls -- for a bounded time; after that it blocks on the stream and looks
+again.  These tests put a backlog well beyond that bound (and beyond round 4's 2 s failure) in front of a forward + backward, run
+every forward through the blocking path (SVGIR_SPIN_MS=0), and keep more forwards in flight than there are landing slots."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from svgir_harness import runner, scenes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scene(variant):
+    kw = dict(P=6000, W=176, H=144, seed=17, sh_degree=2, variant=variant, scale_lo=0.01, scale_hi=0.06)
+    kw.update(dict(S=4, VS=52) if variant == "svgss" else dict(S=5, VS=0))
+    return scenes.surface_scene(**kw)
+
+
+def _fwd_bwd(sct, variant, grads):
+    res, leaves = runner.render(sct, variant, requires_grad=True)
+    runner.backward(res, grads, variant)
+    return res, {k: v.grad for k, v in leaves.items() if v.grad is not None}
+
+
+def _sleep_cycles_for(seconds):
+    """torch.cuda._sleep spins for a number of device clock ticks whose rate differs between parts: calibrate."""
+    n = 10_000_000
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.cuda._sleep(n)
+    torch.cuda.synchronize()
+    dt = max(time.perf_counter() - t0, 1e-5)
+    return int(n * seconds / dt)
+
+
+@pytest.mark.parametrize("variant", ["svgss", "rgss"])
+def test_forward_and_backward_behind_a_three_second_backlog(built, variant):
+    dev = torch.device(DEV)
+    sc = _scene(variant)
+    grads = scenes.upstream_grads(sc, variant, seed=3)
+    sct = runner.to_torch(sc, dev)
+    for _ in range(3):   # (warm: the speculative launch sequence is what a training loop runs)
+        ref, ref_g = _fwd_bwd(sct, variant, grads)
+    torch.cuda.synchronize()
+    ref = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in ref.items()}
+    ref_g = {k: v.clone() for k, v in ref_g.items()}
+    chunk = _sleep_cycles_for(0.25)
+    t0 = time.perf_counter()
+    for _ in range(12):   # ~3 s of work queued in front of the forward
+        torch.cuda._sleep(chunk)
+    assert time.perf_counter() - t0 < 1.0, "the sleeps must be queued, not executed synchronously"
+    res, g = _fwd_bwd(sct, variant, grads)   # round 4: RuntimeError 'the instance count did not arrive'
+    # ... and a backlog between a forward and its backward (the per-view totals of the cull are waited for there)
+    res2, leaves2 = runner.render(sct, variant, requires_grad=True)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        torch.cuda._sleep(chunk)
+    runner.backward(res2, grads, variant)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 > 2.5
+    assert res["num_rendered"] == ref["num_rendered"] == res2["num_rendered"]
+    for k, v in ref.items():
+        if torch.is_tensor(v) and k != "weights":
+            assert torch.equal(res[k], v), k
+    for k, v in ref_g.items():
+        for got in (g[k], leaves2[k].grad):
+            if variant == "svgss":
+                assert torch.equal(got, v), k
+            else:
+                assert torch.allclose(got, v, rtol=2e-4, atol=1e-6 * max(1.0, float(v.abs().max()))), k
+
+
+_SCRIPT = r"""
+import sys, threading
+sys.path.insert(0, sys.argv[1] + "/svg-ir_amd"); sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from svgir_harness import cameras, runner, scenes
+dev = torch.device("cuda:0")
+base = scenes.surface_scene(P=4000, W=160, H=128, seed=23, sh_degree=1, variant="svgss", S=4, VS=52, scale_lo=0.01, scale_hi=0.06)
+views = []
+for i in range(6):
+    v = dict(base); v.update(cameras.make_camera(base["W"], base["H"], cameras.orbit_eye(4.0, 20.0 + 50.0 * i, 15.0))); views.append(v)
+grads = [scenes.upstream_grads(v, "svgss", seed=40 + i) for i, v in enumerate(views)]
+def run(i, rounds, out):
+    st = torch.cuda.Stream(dev)
+    with torch.cuda.stream(st):
+        sct = runner.to_torch(views[i], dev)
+        for _ in range(rounds):
+            res, leaves = runner.render(sct, "svgss", requires_grad=True)
+            runner.backward(res, grads[i], "svgss")
+        st.synchronize()
+    out[i] = (res["num_rendered"], res["color"].cpu().numpy(), leaves["means3D"].grad.cpu().numpy(), leaves["vfeatures"].grad.cpu().numpy())
+alone, both = {}, {}
+for i in range(6): run(i, 2, alone)
+th = [threading.Thread(target=run, args=(i, 10, both)) for i in range(6)]
+[t.start() for t in th]; [t.join() for t in th]
+for i in range(6):
+    assert both[i][0] == alone[i][0], (i, both[i][0], alone[i][0])
+    for a, b in zip(both[i][1:], alone[i][1:]): assert np.array_equal(a, b), i
+print("OK", [alone[i][0] for i in range(6)])
+"""
+
+
+@pytest.mark.parametrize("env", [{"SVGIR_SPIN_MS": "0"}, {"SVGIR_PINNED_SLOTS": "2"}, {"SVGIR_PINNED_SLOTS": "0", "SVGIR_SPIN_MS": "0"}])
+def test_more_forwards_in_flight_than_landing_slots(built, env):
+    """Six host threads x ten forward + backward rounds with two (or no) landing slots for the instance count, and / or with every
+    wait on the blocking path: the forwards that find no free slot read the count with a blocking copy; results as alone."""
+    e = dict(os.environ); e.update(env)
+    out = subprocess.run([sys.executable, "-c", _SCRIPT, ROOT], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_backward_with_a_moved_image_blob(built):
+    """The blobs are self-describing (like the reference's): a binder that clones / moves the saved image buffer, or a backward that
+    comes more than 1024 forwards after its forward, still finds the capacities the binning blob was laid out for -- in the image
+    blob itself (ImageLayout::counters) -- instead of failing on a miss in the library's host table."""
+    from gaussian_renderer.svgss_rasterization import _C
+    dev = torch.device(DEV)
+    sc = _scene("svgss")
+    sct = runner.to_torch(sc, dev)
+    st = runner.settings(sct, "svgss")
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+    g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in scenes.upstream_grads(sc, "svgss", seed=9).items()}
+
+    def fwd():
+        return _C.rasterize_gaussians(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], empty, sct["opacities"], sct["scales"],
+                                      sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
+                                      st.patch_bbox, st.tanfovx, st.tanfovy, st.image_height, st.image_width, sct["shs"], st.sh_degree,
+                                      st.campos, False, False, st.config)
+
+    def bwd(out, ib):
+        R, radii, gb, bb = out[0], out[8], out[9], out[10]
+        return _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], radii, empty, sct["scales"],
+                                               sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
+                                               st.patch_bbox, st.tanfovx, st.tanfovy, g["color"], g["normal"], g["depth"], g["opacity"],
+                                               g["feature"], g["vfeature"], sct["shs"], st.sh_degree, st.campos, gb, R, bb, ib, False,
+                                               st.config)
+
+    for _ in range(3):
+        out = fwd()
+    assert out[10].numel() % 256 == 128, "the fourth view of a workload gets a compact binning blob"
+    ref = bwd(out, out[11])
+    moved = out[11].clone()
+    out[11].fill_(0)   # (the original is gone: nothing can be read from it)
+    got = bwd(out, moved)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
