@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 11
+#define SVGIR_ABI_VERSION 12
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -38,6 +38,8 @@ enum svgir_status {
  * matching backward has run.  Replaces the reference's std::function<char*(size_t)> resize lambdas
  * (rasterize_points.cu:27-33). */
 typedef char* (*svgir_alloc_fn)(size_t bytes, void* ctx);
+
+typedef struct svgir_fused_shade svgir_fused_shade;   /* below, behind the shading entry points */
 
 /* Inputs of one view.  Field-for-field the arguments of Rasterizer::forward
  * (svgss rasterizer_impl.cu:209-242, rgss :209-241). */
@@ -84,6 +86,9 @@ typedef struct svgir_params {
                                        binning of the same view.  Must stay alive until svgir_forward returns; ignored by
                                        svgir_backward.  (ABI 9: replaces the thread-local svgir_forward_wait_features of
                                        ABI 8 -- no state survives between calls.) */
+    const svgir_fused_shade* shade; /* optional (svgss, ABI 12): the per-splat shading of this view, run INSIDE svgir_forward /
+                                       svgir_backward for the surfels the view's composite actually reads (see svgir_fused_shade);
+                                       `features` / `vfeatures` are then OUTPUT buffers of svgir_forward.  NULL: the caller shaded. */
 } svgir_params;
 
 /* Outputs of forward.  Every buffer is written completely: the caller need not clear any of them (the reference's glue
@@ -134,6 +139,16 @@ typedef struct svgir_grads {
     float* dL_dcampos;    /* [3]  svgss */
     void* clear_base;     /* optional: a region that contains every dL_d* output above and nothing the library must */
     size_t clear_bytes;   /*           preserve (NULL / 0: the outputs are cleared one by one) */
+    /* Fused shading (svgir_params.shade != NULL; ABI 12): gradients of the shading inputs, layouts as svgir_shade_backward's outputs,
+     * every one written completely (rows of surfels that received no blend weight in this view are zero).  NOT part of clear_base. */
+    float* dL_dbase_color;      /* [P,12] */
+    float* dL_droughness;       /* [P,4] */
+    float* dL_dshade_normals;   /* [P,4,3] */
+    float* dL_dradiance;        /* [P,Ns,3] */
+    float* dL_denv;             /* [env_h,env_w,3] */
+    float* env_grad_work;       /* scratch, env_h*env_w*3 floats */
+    const float* dL_dreduced;   /* optional [P,70]: upstream gradient of svgir_fused_shade.reduced (needs all_surfels != 0) */
+    const float* out_weights;   /* the forward's out_weights [P] (selects the surfels whose shading is differentiated) */
 } svgir_grads;
 
 int svgir_abi_version(void);
@@ -193,7 +208,8 @@ size_t svgir_backward_scratch_bytes(int32_t variant, int32_t P, size_t binning_b
 /* The same for ONE view: `image_blob` is the image blob of the svgir_forward whose backward is about to run.  svgss with vfeatures
  * then gets one gradient row per (sub-tile, instance) pair that survived that view's cull (1.2 per instance on the BASELINE scenes)
  * instead of four per instance: the forward reads the pair count back asynchronously behind its cull, and this call returns at once
- * unless that copy is still in flight.  An unknown blob (NULL, or one the library has not seen in its last 1024 forwards) gets the
+ * unless that count is still on its way (then it waits: polling, and beyond 50 ms blocking on the device).  A blob the library has not
+ * seen in its last 1024 forwards is read itself (the image blob carries the view's counts and capacities); NULL gets the
  * worst case; svgir_backward accepts either size for the view it belongs to.  (ABI 10) */
 size_t svgir_backward_scratch_bytes_for(int32_t variant, int32_t P, size_t binning_bytes, const char* image_blob, int32_t W, int32_t H,
                                         int32_t S, int32_t VS);
@@ -257,6 +273,12 @@ typedef struct svgir_shade_params {
     const float* lattice_normals;   /* [P,3] unit */
     const float* lattice_offsets;   /* [P] radians or NULL */
     float* lattice_work;
+    /* Shade a SUBSET of the P surfels (ABI 12; both NULL: all of them).  `subset` [P] is a permutation of 0..P-1 in device memory whose
+     * first *subset_count entries (a device uint32) are the surfels to shade; the output rows of the others (reduced / features /
+     * vfeatures; the backward's dL_dbase_color, dL_droughness, dL_dnormals, dL_dradiance) are ZERO-filled by the same call, so every
+     * output is still written completely.  Rows of shaded surfels are bit-identical to an all-P call. */
+    const uint32_t* subset;
+    const uint32_t* subset_count;
 } svgir_shade_params;
 
 #define SVGIR_SHADE_REDUCED 70
@@ -274,6 +296,26 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
                          const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
                          float* env_grad_work, void* stream);
+
+/* Shading fused into the rasterizer calls (svgir_params.shade; ABI 12).  The only consumers of the shading's outputs are the packed
+ * `features` / `vfeatures` rows the svgss composite blends (gaussian_renderer/svgss.py:143-182), and it reads the rows of the surfels
+ * that survive the view's culls only -- 44 % of the surfels pass the preprocess culls on the BASELINE scenes, ~30 % survive the per-tile
+ * cull as well, and 13-29 % ever receive a blend weight -- while the reference (and svgir_shade_forward on its own) shades all P.
+ *   svgir_forward : runs preprocess / sorts / per-tile cull first, then shades exactly the surfels that are a candidate of at least one
+ *       8x8 sub-tile, writes their `features` [P,S] / `vfeatures` [P,VS] rows (S, VS = 4, 52 when sp.training, else 7, 64) and zero-fills
+ *       the others, then composites.  sp.P must equal svgir_params.P; sp.subset / sp.subset_count are ignored (the library's own list,
+ *       kept in the geometry blob, is used).
+ *   svgir_backward: after the rasterizer's backward has produced dL_dfeatures / dL_dvfeatures, differentiates the shading of the
+ *       surfels with out_weights > 0 (all others have exactly-zero feature gradients) into svgir_grads.dL_dbase_color ...; the rest of
+ *       those rows is zero-filled.  Pass the SAME struct (same `features` / `vfeatures` contents) as to the forward.
+ * all_surfels != 0 shades / differentiates all P surfels (needed when `reduced` feeds a loss of its own, e.g. the reference's
+ * lambda_light term, svgss.py:359-364).  Results are bit-identical to the unfused sequence (svgir_shade_forward -> svgir_forward,
+ * svgir_backward -> svgir_shade_backward) except dL_denv, whose float atomics are summed in a different order. */
+struct svgir_fused_shade {
+    svgir_shade_params sp;
+    float* reduced;        /* [P,70] or NULL; rows of unshaded surfels are zero */
+    int32_t all_surfels;
+};
 
 /* Materialises the incident-direction lattice: dirs [P,Ns,3] and / or areas [P,Ns,1] (either may be NULL), the return
  * values of the reference's fibonacci_sphere_sampling(normals, Ns, random_rotate) with `offsets` [P] standing for its

@@ -429,6 +429,15 @@ int validate(const svgir_params* p, bool fwd) {
         if (p->VS != 0) return fail(SVGIR_ERR_INVALID, "rgss has no vfeatures");
         if (p->S > 33) return fail(SVGIR_ERR_INVALID, "rgss supports S<=33 (Q9)");
     }
+    if (p->shade) {   // fused shading: the packed rows are produced inside the call
+        const svgir_shade_params& sp = p->shade->sp;
+        if (p->variant != SVGIR_SVGSS) return fail(SVGIR_ERR_INVALID, "fused shading belongs to the svgss variant");
+        if (sp.P != p->P) return fail(SVGIR_ERR_INVALID, "fused shading: sp.P = %d but P = %d", sp.P, p->P);
+        if (p->S != (sp.training ? 4 : 7) || p->VS != (sp.training ? 52 : 64))
+            return fail(SVGIR_ERR_INVALID, "fused shading packs S = %d, VS = %d (training = %d), not S = %d, VS = %d", sp.training ? 4 : 7,
+                        sp.training ? 52 : 64, sp.training, p->S, p->VS);
+        if (!sp.viewmatrix) return fail(SVGIR_ERR_INVALID, "fused shading needs sp.viewmatrix (packed view-space normals)");
+    }
     return 0;
 }
 
@@ -551,6 +560,8 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
     pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
     pa.radii = o->radii;
     pa.out_weights = o->out_weights;
+    const bool shade_subset = p->shade && !p->shade->all_surfels;   // shade the view's working set only (subset.hip)
+    pa.needed = shade_subset ? G.needed : nullptr;
     pa.zero_words = radix_gtot(G.radix_tbl, P); pa.n_zero_words = (int)radix_gtot_words(P);
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -619,6 +630,7 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         ra.zero_a = clear_stencil ? o->out_pseudo_normal : nullptr;
         ra.zero_b = clear_stencil ? o->out_surface_xyz : nullptr;
         ra.pair_stream = B.pair_stream;
+        ra.needed = shade_subset ? G.needed : nullptr;
         launch_cull(ra, s);
         // dispatch order of the sub-tiles, first gradient row / first state slot of each, and the two totals (device + tagged host copy)
         uint32_t vtag = 0;
@@ -628,6 +640,21 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
                           (uint32_t)cap, cap_slots, kBlobMagic, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
+        if (p->shade) {
+            // The per-splat shading of this view, for the surfels its composite is about to read: everything that is a candidate of at
+            // least one 8x8 sub-tile (the reference shades all P before it knows the view, svgss.py:116-141).  Rows of the others: zero.
+            svgir_shade_params sp = p->shade->sp;
+            sp.subset = nullptr; sp.subset_count = nullptr;
+            if (shade_subset) {
+                uint32_t* cnt = G.shade_work + partition_work_words(P) - 1;
+                launch_partition(P, G.needed, nullptr, G.shade_list, G.shade_work, cnt, s);
+                sp.subset = G.shade_list; sp.subset_count = cnt;
+            }
+            if (svgir_shade_forward(&sp, p->shade->reduced, const_cast<float*>(p->features), const_cast<float*>(p->vfeatures), s) != 0)
+                return fail(SVGIR_ERR_INVALID, "fused shading: svgir_shade_forward rejected its parameters");
+            if (int rc = check("shade")) return rc;
+            if (timed) tm.mark("shade");
+        }
 #if defined(BWDP_STREAM)
         if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
         launch_pair_stream(ra, s);
@@ -957,6 +984,27 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         ra.dL_dfeature = g->dL_dfeatures; ra.dL_dvfeature = g->dL_dvfeatures; ra.dL_dnormal = g->dL_dnormal; ra.dL_ddepth = g->dL_ddepth;
         launch_grad_reduce(ra, s);
         tm.mark("grad_reduce");
+    }
+    if (p->shade) {
+        // dL_dfeatures / dL_dvfeatures are complete: the shading's backward, for the surfels that received a blend weight (the rows of all
+        // others are exactly zero: no pixel blended them)
+        if (!g->dL_dbase_color || !g->dL_droughness || !g->dL_dshade_normals || !g->dL_dradiance || !g->dL_denv || !g->env_grad_work)
+            return fail(SVGIR_ERR_INVALID, "fused shading: the gradient outputs of the shading inputs must be provided");
+        if (generic) return fail(SVGIR_ERR_INVALID, "fused shading without a specialised composite");
+        const bool all = p->shade->all_surfels != 0;
+        if (g->dL_dreduced && !all) return fail(SVGIR_ERR_INVALID, "fused shading: dL_dreduced needs all_surfels");
+        if (!all && !g->out_weights) return fail(SVGIR_ERR_INVALID, "fused shading: out_weights (the forward's) must be provided");
+        svgir_shade_params sp = p->shade->sp;
+        sp.subset = nullptr; sp.subset_count = nullptr;
+        if (!all) {
+            uint32_t* cnt = G.shade_work + partition_work_words(P) - 1;
+            launch_partition(P, nullptr, g->out_weights, G.shade_list, G.shade_work, cnt, s);
+            sp.subset = G.shade_list; sp.subset_count = cnt;
+        }
+        if (svgir_shade_backward(&sp, g->dL_dreduced, g->dL_dfeatures, g->dL_dvfeatures, g->dL_dbase_color, g->dL_droughness,
+                                 g->dL_dshade_normals, g->dL_dradiance, g->dL_denv, g->env_grad_work, s) != 0)
+            return fail(SVGIR_ERR_INVALID, "fused shading: svgir_shade_backward rejected its parameters");
+        tm.mark("shade_bwd");
     }
 
     GeomBwdArgs ga;

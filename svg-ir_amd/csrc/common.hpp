@@ -62,6 +62,10 @@ struct GeomLayout {
     uint32_t* radix_tbl;   // [256 * sort_blocks(P)]
     uint32_t* counters;    // [4]: [0] = R, [1] = prefilter violation, [2] = top bytes of the visible depth keys {AND << 8 | OR}
     uint32_t* key_top;     // [ceil(P / 64)] the same per preprocess wave (identity 0xff00 where a wave has no visible Gaussian)
+    // working set of the view for the fused shading (svgir_params.shade; subset.hip):
+    uint8_t* needed;       // [P] 1 <=> candidate of at least one 8x8 sub-tile (cleared by preprocess, set by the cull kernel)
+    uint32_t* shade_list;  // [P] partition of 0..P-1: selected surfels in front (forward: `needed`; backward: out_weights > 0)
+    uint32_t* shade_work;  // [partition_work_words(P)] scan scratch; its LAST word = number of selected surfels
     size_t bytes;
 };
 inline GeomLayout geom_layout(char* base, int P) {
@@ -82,6 +86,9 @@ inline GeomLayout geom_layout(char* base, int P) {
     g.radix_tbl = (uint32_t*)take(radix_table_words(P) * 4);
     g.counters = (uint32_t*)take(16);
     g.key_top = (uint32_t*)take((p + 63) / 64 * 4);
+    g.needed = (uint8_t*)take(p);
+    g.shade_list = (uint32_t*)take(p * 4);
+    g.shade_work = (uint32_t*)take(((p + BLOCK * 8 - 1) / (BLOCK * 8) + 2) * 4);
     g.bytes = off;
     return g;
 }
@@ -287,6 +294,7 @@ struct PreArgs {
     CfgRef cfg;
     float* rec; float* cov3D; uint32_t* clamped; uint32_t* tiles; uint32_t* key; uint32_t* idx; int32_t* radii;
     float* out_weights;              // [P] zeroed here (accumulated with atomics by the composite)
+    uint8_t* needed;                 // [P] zeroed here (set by the cull kernel for every surfel that survives it in some sub-tile)
     uint32_t* zero_words; int n_zero_words;   // small table cleared in passing (the depth sort's group totals)
     int spec_top; uint32_t* key_top;   // speculated common top byte of the visible depth keys (-1: none) -> key of a culled Gaussian; per-wave summary out
     uint32_t* prefilter_violation;   // non-null <=> `prefiltered`: set to 1 when a frustum / back-face cull fires (auxiliary.h:163-167)
@@ -305,6 +313,7 @@ struct RenderArgs {
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
+    uint8_t* needed;          // [P] or null: the cull kernel marks every Gaussian that survives in at least one sub-tile
     float* pair_stream;       // (experiment builds) see BinLayout
 };
 
@@ -394,6 +403,13 @@ void launch_geom_bwd(const GeomBwdArgs& a, hipStream_t s);
 void launch_image_ops(int W, int H, const float* view, float focal_x, float focal_y, float cx, float cy,
                       const float* opacity, const float* depth, float* pseudo_normal, float* surface_xyz,
                       hipStream_t s);
+
+// ---- working set of a view (subset.hip): list[0 .. *count_dev) = the surfels with flags[i] != 0 (or, flags == nullptr, positive[i] > 0)
+// in index order, list[P-1-j] = the j-th other one; work: partition_work_words(P) uint32 of scratch
+size_t partition_work_words(int P);
+void launch_partition(int P, const uint8_t* flags, const float* positive, uint32_t* list, uint32_t* work, uint32_t* count_dev, hipStream_t s);
+// zeroes row list[P-1-j], j < P - *count_dev, of up to 6 row-major fp32 tensors (null tensors are skipped)
+void launch_zero_rows(int P, const uint32_t* list, const uint32_t* count_dev, float* const* tensors, const int* row_floats, int n, hipStream_t s);
 
 #if defined(__HIPCC__)
 // ---- device helpers ----------------------------------------------------------------------------------------

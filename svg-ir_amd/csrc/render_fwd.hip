@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
                 m[w] = cull_test(sc, x0, y0, x0 + 7.f, y0 + 7.f);
             }
         }
+        if (a.needed && (m[0] || m[1] || m[2] || m[3])) a.needed[gid] = 1;   // the view's composite reads this surfel's packed rows
         unsigned long long mask[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {

@@ -307,9 +307,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
     float* sS = smem + (size_t)wave * (64 * SREC + 80 + 32);
     float* sOut = sS + 64 * SREC;
     float* sIn = sOut + 80;   // base_color[12] | normals[12] | roughness[4] of this Gaussian, for the packing in the epilogue
-    const size_t g = (size_t)blockIdx.x * 4 + wave;
-    const bool valid = g < (size_t)p.P;
-    const size_t gg = valid ? g : 0;
+    // work item -> surfel: all P of them, or the front of the caller's partition (svgir_shade_params.subset)
+    const size_t wi = (size_t)blockIdx.x * 4 + wave;
+    const size_t nwork = p.subset ? (size_t)min(*p.subset_count, (uint32_t)p.P) : (size_t)p.P;
+    if ((size_t)blockIdx.x * 4 >= nwork) return;   // (whole workgroup past the end of the list)
+    const bool valid = wi < nwork;
+    const size_t g = valid ? (p.subset ? (size_t)p.subset[wi] : wi) : 0;
+    const size_t gg = g;
     const float inv_ns = 1.f / (float)Ns;
 
     float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
@@ -444,14 +448,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
     const svgir_shade_params& p = a.p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Ns = p.Ns;
-    float* sOut = smem + (size_t)wave * (FQ_SURF * (FQ_ROW + FQ_IN));
+    float* sOut = smem + (size_t)wave * (FQ_SURF * (FQ_ROW + FQ_IN) + FQ_SURF);
     float* sIn = sOut + FQ_SURF * FQ_ROW;
+    uint32_t* sId = reinterpret_cast<uint32_t*>(sIn + FQ_SURF * FQ_IN);   // surfel of each of the wave's work items (subset launches)
     const int q = lane >> 2, k = lane & 3;
-    const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * FQ_SURF;       // first surfel of the wave
-    if (g0 >= (size_t)p.P) return;
-    const int nsurf = (int)min((size_t)FQ_SURF, (size_t)p.P - g0);
+    // work items -> surfels: all P of them, or the front of the caller's partition (svgir_shade_params.subset)
+    const size_t nwork = p.subset ? (size_t)min(*p.subset_count, (uint32_t)p.P) : (size_t)p.P;
+    const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * FQ_SURF;       // first work item of the wave
+    if (g0 >= nwork) return;
+    const int nsurf = (int)min((size_t)FQ_SURF, nwork - g0);
     const bool valid = q < nsurf;
-    const size_t gg = g0 + (valid ? q : 0);
+    const size_t wi = g0 + (valid ? q : 0);
+    const size_t gg = p.subset ? (size_t)p.subset[wi] : wi;
+    if (p.subset && k == 0) sId[q] = (uint32_t)gg;
     const float inv_ns = 1.f / (float)Ns;
 
     float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
@@ -592,18 +601,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
         }
     }
     wave_lds_sync();
-    // ---- epilogue: the rows of the wave's surfels are contiguous in every output: consecutive lanes write consecutive floats ----
+    // ---- epilogue: the rows of the wave's surfels are contiguous in every output (all-P launches; a subset's rows are scattered,
+    // each still written by consecutive lanes): consecutive lanes write consecutive floats ----
+    const bool scat = p.subset != nullptr;
+    auto row_of = [&](int qq) -> size_t { return scat ? (size_t)sId[qq] : g0 + (size_t)qq; };
     if (a.reduced) {
-        float* out = a.reduced + g0 * NRED;
-        for (int i = lane; i < nsurf * NRED; i += 64) { const int qq = i / NRED, e = i - qq * NRED; out[i] = sOut[qq * FQ_ROW + e]; }
+        for (int i = lane; i < nsurf * NRED; i += 64) { const int qq = i / NRED, e = i - qq * NRED; a.reduced[row_of(qq) * NRED + e] = sOut[qq * FQ_ROW + e]; }
     }
     if (a.features) {
         if (p.training) {
-            if (lane < nsurf * 4) { const int qq = lane >> 2, e = lane & 3; a.features[g0 * 4 + lane] = sOut[qq * FQ_ROW + (e == 0 ? 69 : 63 + (e - 1))]; }
+            if (lane < nsurf * 4) { const int qq = lane >> 2, e = lane & 3; a.features[row_of(qq) * 4 + e] = sOut[qq * FQ_ROW + (e == 0 ? 69 : 63 + (e - 1))]; }
         } else {
             for (int i = lane; i < nsurf * 7; i += 64) {
                 const int qq = i / 7, e = i - qq * 7;
-                a.features[g0 * 7 + i] = sOut[qq * FQ_ROW + (e < 3 ? 60 + e : (e < 6 ? 63 + (e - 3) : 69))];
+                a.features[row_of(qq) * 7 + e] = sOut[qq * FQ_ROW + (e < 3 ? 60 + e : (e < 6 ? 63 + (e - 3) : 69))];
             }
         }
     }
@@ -623,11 +634,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
             return so[48 + (e - 52)];
         };
         if (p.training) {
-            float* out = a.vfeatures + g0 * 52;
-            for (int i = lane; i < nsurf * 52; i += 64) { const int qq = i / 52; out[i] = pack(qq, i - qq * 52, true); }
+            for (int i = lane; i < nsurf * 52; i += 64) { const int qq = i / 52, e = i - qq * 52; a.vfeatures[row_of(qq) * 52 + e] = pack(qq, e, true); }
         } else {
-            float* out = a.vfeatures + g0 * 64;
-            for (int i = lane; i < nsurf * 64; i += 64) out[i] = pack(i >> 6, i & 63, false);
+            for (int i = lane; i < nsurf * 64; i += 64) a.vfeatures[row_of(i >> 6) * 64 + (i & 63)] = pack(i >> 6, i & 63, false);
         }
     }
 }
@@ -761,7 +770,11 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     __syncthreads();
     const float inv_ns = 1.f / (float)Ns;
     const int k = lane & 3, sg = lane >> 2;
-    const int P = p.P;
+    // work items: all P surfels, or the front of the caller's partition (svgir_shade_params.subset); `g` counts work items, sid(g) is
+    // the surfel
+    const int P = p.subset ? (int)min(*p.subset_count, (uint32_t)p.P) : p.P;
+    const uint32_t* __restrict__ sub = p.subset;
+    auto sid = [&](int w) -> size_t { return sub ? (size_t)sub[w] : (size_t)w; };
     const int gstep = (int)gridDim.x * BWAVES;
     int g = (int)blockIdx.x * BWAVES + wave;   // wave-uniform
 
@@ -770,7 +783,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     DEV_TRACE_DECL();
     [[maybe_unused]] unsigned dev_n = 0;
     RawSample raw;
-    if (g < P) raw = load_raw(p, (size_t)g, 0, lane, min(64, Ns));
+    if (g < P) raw = load_raw(p, sid(g), 0, lane, min(64, Ns));
     // The per-(Gaussian, corner) constants -- unit view vector, corner frame, and the upstream gradients folded into the
     // coefficients of the four light sums -- are ~130 scattered loads and ~400 instructions per corner.  With lane = (sample
     // group, corner) all 64 lanes would repeat them for ONE Gaussian; instead the wave prepares its next KB_G Gaussians at once,
@@ -780,7 +793,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     if (lane < 4 * KB_G) {
         const int gj = gb + (lane >> 2) * gstep;
         if (gj < P) {
-        const size_t gg = (size_t)gj;
+        const size_t gg = sid(gj);
         float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
         {
             const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
@@ -855,7 +868,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     for (int jb = 0; jb < KB_G; jb++) {
         g = gb + jb * gstep;
         if (g >= P) break;
-        const size_t gg = (size_t)g;
+        const size_t gg = sid(g);
         float V[3], kAd[3], kAl[3], kBd[3], kBl[3], qd[3], ql[3], gmig[3], dir_b[3], dir_n[3], dir_r, grad_const;
         GaussConst c;
         {
@@ -886,7 +899,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 const bool more = s0 + 64 < Ns;
                 const int gn = more ? g : g + gstep;
                 const int sn = more ? s0 + 64 : 0;
-                if (gn < P) raw = load_raw(p, (size_t)gn, sn, lane, min(64, Ns - sn));
+                if (gn < P) raw = load_raw(p, more ? gg : sid(gn), sn, lane, min(64, Ns - sn));
             }
             wave_lds_sync();
             DEV_TRACE_MARK(1);   // staging of a chunk (+ issue of the prefetches)
@@ -1068,6 +1081,7 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
         return SVGIR_ERR_INVALID;
     if (!p->incident_dirs && !(p->lattice_normals && p->lattice_work)) return SVGIR_ERR_INVALID;
     if (((uintptr_t)p->env_work & 15) || (p->lattice_work && ((uintptr_t)p->lattice_work & 15))) return SVGIR_ERR_INVALID;   // read as float4
+    if ((p->subset != nullptr) != (p->subset_count != nullptr)) return SVGIR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
@@ -1078,6 +1092,11 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     stage_mark(tm, "shade_env_table");
     ShadeArgs a;
     a.p = *p; a.reduced = reduced; a.features = features; a.vfeatures = vfeatures;
+    if (p->subset) {   // the rows of the surfels outside the subset: zero (every output is written completely)
+        float* const t[3] = {reduced, features, vfeatures};
+        const int w[3] = {NRED, p->training ? 4 : 7, p->training ? 52 : 64};
+        launch_zero_rows(p->P, p->subset, p->subset_count, t, w, 3, s);
+    }
 #ifndef SHADE_FWD_QUAD
 #define SHADE_FWD_QUAD 1
 #endif
@@ -1088,7 +1107,7 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     // those are amortised anyway and the one-wave-per-surfel kernel streams the samples better (lane = sample: 768 contiguous bytes
     // per load; 771 us against 1 001 us at Ns = 384)
     if (SHADE_FWD_QUAD && p->Ns <= SHADE_FWD_QUAD_MAX_NS) {
-        const size_t lds = (size_t)4 * FQ_SURF * (FQ_ROW + FQ_IN) * 4;
+        const size_t lds = (size_t)4 * (FQ_SURF * (FQ_ROW + FQ_IN) + FQ_SURF) * 4;
         hipLaunchKernelGGL(shade_fwd_quad_kernel, dim3((p->P + 4 * FQ_SURF - 1) / (4 * FQ_SURF)), dim3(BLOCK), lds, s, a);
     } else {
         const size_t lds = (size_t)4 * (64 * SREC + 80 + 32) * 4;
@@ -1108,6 +1127,8 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
         !env_grad_work || !p->env_work)
         return SVGIR_ERR_INVALID;
     if (!p->incident_dirs && !(p->lattice_normals && p->lattice_work)) return SVGIR_ERR_INVALID;
+    if (((uintptr_t)p->env_work & 15) || (p->lattice_work && ((uintptr_t)p->lattice_work & 15))) return SVGIR_ERR_INVALID;   // read as float4
+    if ((p->subset != nullptr) != (p->subset_count != nullptr)) return SVGIR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
@@ -1116,6 +1137,11 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     hipLaunchKernelGGL(env_table_kernel, dim3((ntex / 3 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, (float4*)p->env_work, ntex / 3,
                        p->env_softplus);
     if (hipMemsetAsync(env_grad_work, 0, (size_t)ntex * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
+    if (p->subset) {   // the rows of the surfels outside the subset: zero (every output is written completely)
+        float* const t[4] = {dL_dbase_color, dL_droughness, dL_dnormals, dL_dradiance};
+        const int w[4] = {12, 4, 12, 3 * p->Ns};
+        launch_zero_rows(p->P, p->subset, p->subset_count, t, w, 4, s);
+    }
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
 
 RGSS, SVGSS = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("cx", C.c_float),
         ("cy", C.c_float),
         ("prefiltered", C.c_int32), ("computer_pseudo_normal", C.c_int32), ("backward_geometry", C.c_int32),
-        ("debug", C.c_int32), ("features_ready", C.c_void_p),
+        ("debug", C.c_int32), ("features_ready", C.c_void_p), ("shade", C.c_void_p),
     ]
 
 
@@ -45,7 +45,26 @@ class Grads(C.Structure):
         "dL_dout_color", "dL_dout_normal", "dL_dout_depth", "dL_dout_opacity", "dL_dout_feature", "dL_dout_vfeature",
         "dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dfeatures", "dL_dvfeatures", "dL_dnormal",
         "dL_ddepth", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dviewmat",
-        "dL_dprojmat", "dL_dcampos", "clear_base")] + [("clear_bytes", C.c_size_t)]
+        "dL_dprojmat", "dL_dcampos", "clear_base")] + [("clear_bytes", C.c_size_t)] + [(n, C.c_void_p) for n in (
+        "dL_dbase_color", "dL_droughness", "dL_dshade_normals", "dL_dradiance", "dL_denv", "env_grad_work", "dL_dreduced",
+        "out_weights")]
+
+
+class ShadeParams(C.Structure):
+    """svgir_shade_params (include/svgir_raster.h)."""
+    _fields_ = [("P", C.c_int32), ("Ns", C.c_int32), ("env_h", C.c_int32), ("env_w", C.c_int32),
+                ("env_softplus", C.c_int32), ("training", C.c_int32), ("env_scale", C.c_float),
+                ("base_color", C.c_void_p), ("roughness", C.c_void_p), ("normals", C.c_void_p),
+                ("viewdirs", C.c_void_p), ("radiance", C.c_void_p), ("visibility", C.c_void_p),
+                ("incident_dirs", C.c_void_p), ("incident_areas", C.c_void_p), ("env", C.c_void_p),
+                ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p), ("env_transform", C.c_void_p),
+                ("lattice_normals", C.c_void_p), ("lattice_offsets", C.c_void_p), ("lattice_work", C.c_void_p),
+                ("subset", C.c_void_p), ("subset_count", C.c_void_p)]
+
+
+class FusedShade(C.Structure):
+    """svgir_fused_shade: the shading of a view run inside svgir_forward / svgir_backward for the view's working set."""
+    _fields_ = [("sp", ShadeParams), ("reduced", C.c_void_p), ("all_surfels", C.c_int32)]
 
 
 def _load():

@@ -20,14 +20,7 @@ from . import _native as N
 NRED = 70
 
 
-class ShadeParams(C.Structure):
-    _fields_ = [("P", C.c_int32), ("Ns", C.c_int32), ("env_h", C.c_int32), ("env_w", C.c_int32),
-                ("env_softplus", C.c_int32), ("training", C.c_int32), ("env_scale", C.c_float),
-                ("base_color", C.c_void_p), ("roughness", C.c_void_p), ("normals", C.c_void_p),
-                ("viewdirs", C.c_void_p), ("radiance", C.c_void_p), ("visibility", C.c_void_p),
-                ("incident_dirs", C.c_void_p), ("incident_areas", C.c_void_p), ("env", C.c_void_p),
-                ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p), ("env_transform", C.c_void_p),
-                ("lattice_normals", C.c_void_p), ("lattice_offsets", C.c_void_p), ("lattice_work", C.c_void_p)]
+ShadeParams = N.ShadeParams
 
 
 N.lib.svgir_shade_forward.restype = C.c_int
@@ -248,3 +241,113 @@ def shade_and_pack(base_color, roughness, normals, viewdirs, radiance, direct_li
     env, softplus, scale, transform = _env_of(direct_light_env_light)
     return _ShadePack.apply(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix,
                             softplus, scale, bool(is_training), transform)
+
+
+# ---- shading fused into the rasterizer calls: "shade only what the view reads" ---------------------------------------------------
+
+def _fused_struct(p, reduced, all_surfels):
+    fs = N.FusedShade()
+    C.memmove(C.byref(fs, N.FusedShade.sp.offset), C.byref(p), C.sizeof(ShadeParams))
+    fs.reduced = N.ptr(reduced)
+    fs.all_surfels = int(bool(all_surfels))
+    return fs
+
+
+class _ShadedRasterize(torch.autograd.Function):
+    """svgss.py:116-182 as ONE pair of library calls: svgir_forward runs its preprocess / sorts / per-tile cull, shades exactly the
+    surfels that are a candidate of some 8x8 sub-tile of THIS view (packing included) and composites; svgir_backward differentiates
+    the composite, then the shading of the surfels that received a blend weight.  Same results as shade_and_pack(...) followed by
+    GaussianRasterizer(...) -- bit for bit, except dL/d(env), whose float atomics are summed in another order."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, base_color, roughness, normals, viewdirs, radiance,
+                visibility, dirs, areas, env, raster_settings, softplus, scale, training, env_transform, all_surfels, want_reduced):
+        from .svgss_rasterization import _C
+        st = raster_settings
+        sp, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env,
+                                             softplus, scale, viewmatrix=st.viewmatrix, training=training,
+                                             env_transform=env_transform)
+        if P != means3D.shape[0]:
+            raise RuntimeError("render_shaded: the material tensors and means3D disagree on the number of surfels")
+        S, VS = (4, 52) if training else (7, 64)
+        feats, vfeats = N.out_tensor((P, S), torch.float32, dev), N.out_tensor((P, VS), torch.float32, dev)
+        red = N.out_tensor((P, NRED), torch.float32, dev) if want_reduced else None
+        fs = _fused_struct(sp, red, all_surfels)
+        empty = torch.empty(0, dtype=torch.float32, device=dev)
+        out = _C.rasterize_gaussians(st.bg, means3D, feats, vfeats, empty, opacities, scales, rotations, st.scale_modifier, empty,
+                                     st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy,
+                                     st.image_height, st.image_width, sh, st.sh_degree, st.campos, st.prefiltered, st.debug, st.config,
+                                     shade=fs)
+        (R, color, normal, depth, opacity, feature, vfeature, weights, radii, gb, bb, ib) = out
+        lat = dirs if isinstance(dirs, FibonacciLattice) else None
+        ctx.save_for_backward(means3D, sh, scales, rotations, base_color, roughness, normals, viewdirs, radiance, visibility,
+                              None if lat else dirs, areas, env, feats, vfeats, weights, radii, gb, bb, ib)
+        ctx.cfg = (st, R, softplus, scale, training, env_transform, lat, all_surfels)
+        ctx.mark_non_differentiable(weights, radii)
+        ctx.set_materialize_grads(False)
+        if red is None:
+            red = empty
+        return R, color, normal, opacity, depth, feature, vfeature, weights, radii, red
+
+    @staticmethod
+    def backward(ctx, _gR, g_color, g_normal, g_opacity, g_depth, g_feature, g_vfeature, _gw, _gr, g_red):
+        from .svgss_rasterization import _C
+        (means3D, sh, scales, rotations, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, feats,
+         vfeats, weights, radii, gb, bb, ib) = ctx.saved_tensors
+        st, R, softplus, scale, training, env_transform, lat, all_surfels = ctx.cfg
+        dev = means3D.device
+        H, W = st.image_height, st.image_width
+        sp, keep, _, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility,
+                                                   lat if lat is not None else dirs, areas, env, softplus, scale,
+                                                   viewmatrix=st.viewmatrix, training=training, env_transform=env_transform)
+        if g_red is not None and not all_surfels:
+            raise RuntimeError("render_shaded: a loss on `reduced` needs all_surfels=True (rows of unshaded surfels are zero)")
+        def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss
+            return g if g is not None else torch.zeros((ch, H, W), dtype=torch.float32, device=dev)
+
+        empty = torch.empty(0, dtype=torch.float32, device=dev)
+        args = (st.bg, means3D, feats, vfeats, radii, empty, scales, rotations, st.scale_modifier, empty, st.viewmatrix, st.projmatrix,
+                st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy, _g(g_color, 3), _g(g_normal, 3), _g(g_depth, 1), _g(g_opacity, 1),
+                _g(g_feature, feats.shape[1]), _g(g_vfeature, vfeats.shape[1] // 4), sh, st.sh_degree, st.campos, gb, R, bb, ib,
+                st.debug, st.config)
+        if not any(ctx.needs_input_grad[i] for i in (6, 7, 8, 10, 14)):   # frozen materials (evaluation): the rasterizer's backward alone
+            res = _C.rasterize_gaussians_backward(*args)
+            return (res[3], res[0], res[7], res[2], res[8], res[9]) + (None,) * 16
+        fs = _fused_struct(sp, None, all_surfels)
+        d_base, d_rough, d_norm, d_rad, d_env = (N.out_tensor(keep[i].shape, torch.float32, dev) for i in (0, 1, 2, 4, 8))
+        gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+        sg = dict(dL_dbase_color=d_base, dL_droughness=d_rough, dL_dshade_normals=d_norm, dL_dradiance=d_rad, dL_denv=d_env,
+                  env_grad_work=gwork, dL_dreduced=None if g_red is None else N.f32c(g_red, dev), out_weights=weights)
+        if P == 0:
+            for t in (d_base, d_rough, d_norm, d_rad, d_env):
+                t.zero_()
+
+        res = _C.rasterize_gaussians_backward(*args, shade=fs, shade_grads=sg)
+        (g_means2D, _gc, g_opac, g_means3D, _gf, _gvf, _gcov, g_sh, g_scales, g_rot, _gv, _gp, _gcp) = res
+        return (g_means3D, g_means2D, g_sh, g_opac, g_scales, g_rot, d_base.reshape(base_color.shape),
+                d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None, d_rad.reshape(radiance.shape), None, None,
+                None, d_env.reshape(env.shape), None, None, None, None, None, None, None)
+
+
+def fused_shade(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light, visibility, dirs, areas, viewmatrix,
+                is_training, reduced=None, all_surfels=False):
+    """(`_native.FusedShade`, keep-alive list) for the `shade=` keyword of `_C.rasterize_gaussians{,_backward}`: the binding-level
+    form of render_shaded (no autograd)."""
+    env, softplus, scale, transform = _env_of(direct_light_env_light)
+    sp, keep, *_ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
+                           viewmatrix=viewmatrix, training=bool(is_training), env_transform=transform)
+    return _fused_struct(sp, reduced, all_surfels), keep + [reduced]
+
+
+def render_shaded(raster_settings, means3D, means2D, opacities, shs, scales, rotations, base_color, roughness, normals, viewdirs,
+                  radiance, direct_light_env_light, visibility, dirs, areas, is_training, all_surfels=False, want_reduced=False):
+    """Shading + packing + svgss rasterization of one view (the reference's svgss.py:116-182) with the shading restricted to the
+    surfels the view reads.  Returns the rasterizer's 9-tuple (num_rendered, color, normal, opacity, depth, feature, vfeature,
+    weights, radii) and `reduced` [P,70] (rows of unshaded surfels zero; an empty tensor unless want_reduced).
+    all_surfels=True shades every surfel (needed when a loss reads `reduced` directly: the reference's lambda_light term,
+    svgss.py:359-364)."""
+    env, softplus, scale, transform = _env_of(direct_light_env_light)
+    out = _ShadedRasterize.apply(means3D, means2D, shs, opacities, scales, rotations, base_color, roughness, normals, viewdirs,
+                                 radiance, visibility, dirs, areas, env, raster_settings, softplus, scale, bool(is_training),
+                                 transform, bool(all_surfels), bool(want_reduced))
+    return out[:9], out[9]

@@ -32,10 +32,12 @@ class _CBinding:
     def rasterize_gaussians(background, means3D, features, vfeatures, colors, opacity, scales, rotations,
                             scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx,
                             tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, config, *,
-                            features_ready=None):
+                            features_ready=None, shade=None):
         """`features_ready` (extension, keyword only): a torch.cuda.Event recorded on the stream that is still producing
         `features` / `vfeatures` (the shading kernels on a side stream); only the composite kernel waits for it, so the
-        shading of a view overlaps its binning.  The caller keeps the tensors alive across streams (`record_stream`)."""
+        shading of a view overlaps its binning.  The caller keeps the tensors alive across streams (`record_stream`).
+        `shade` (extension, keyword only): a `_native.FusedShade` -- the library shades the surfels this view's composite reads
+        and WRITES `features` / `vfeatures` (pass uninitialised [P,S] / [P,VS] buffers; gaussian_renderer/shading.py)."""
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:65-67
         dev = means3D.device
@@ -85,6 +87,8 @@ class _CBinding:
             o.out_weights, o.radii = out_weights.data_ptr(), radii.data_ptr()
             if features_ready is not None:   # (a struct field of this call: nothing survives if anything below raises)
                 p.features_ready = features_ready.cuda_event
+            if shade is not None:
+                p.shade = C.addressof(shade)
             rendered = N.guarded(dev, "forward", N.lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
                                                    blobs.fn("image"), None, N.stream_ptr(dev))
         # note: C++ order is (..., depth, opac, ...) -- the Python wrapper re-orders (svgss_rasterization.py:175,183)
@@ -96,7 +100,9 @@ class _CBinding:
                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox,
                                      tan_fovx, tan_fovy, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac,
                                      dL_dout_feature, dL_dout_vfeature, sh, degree, campos, geomBuffer, R,
-                                     binningBuffer, imageBuffer, debug, config):
+                                     binningBuffer, imageBuffer, debug, config, *, shade=None, shade_grads=None):
+        """`shade` / `shade_grads` (extension, keyword only): the `_native.FusedShade` of the forward and a dict of the shading's
+        gradient outputs + `out_weights` (+ optional `dL_dreduced`), written by svgir_backward (gaussian_renderer/shading.py)."""
         dev = means3D.device
         P = means3D.size(0)
         S = features.size(1) if features.dim() == 2 else 0
@@ -134,6 +140,10 @@ class _CBinding:
             if N.CLEAR_HINT:
                 g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
             g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
+            if shade is not None:
+                p.shade = C.addressof(shade)
+                for k, t in shade_grads.items():
+                    setattr(g, k, N.ptr(t))
             rad = radii.contiguous()
             # scratch for the gradient accumulation: one row per (instance, sub-tile) pair that survived this view's cull (the
             # forward read the count back behind its cull), summed per Gaussian

@@ -187,14 +187,21 @@ def unpack(rendered, bg_color, is_training):
     return res
 
 
-def render_svgss_view(sc, mat, light, is_training):
+def render_svgss_view(sc, mat, light, is_training, fused=False):
     """sc: runner.to_torch() scene (geometry + camera); mat: dict with base_color [P,12], roughness [P,4], normals
     [P,4,3], viewdirs [P,3], radiance / dirs [P,Ns,3], visibility / areas [P,Ns,1]; light: DirectLightMap-like (.env).
-    Returns (results dict, means2D gradient carrier)."""
+    Returns (results dict, means2D gradient carrier).  fused=True: the shading runs inside the rasterizer calls, for the surfels
+    the view reads only (shading.render_shaded); same results."""
+    means2D = torch.zeros_like(sc["means3D"], requires_grad=torch.is_grad_enabled())
+    if fused:
+        rendered, _ = shading.render_shaded(runner.settings(sc, "svgss"), sc["means3D"], means2D, sc["opacities"], sc["shs"],
+                                            sc["scales"], sc["rotations"], mat["base_color"], mat["roughness"], mat["normals"],
+                                            mat["viewdirs"], mat["radiance"], light, mat["visibility"], mat["dirs"], mat["areas"],
+                                            is_training)
+        return unpack(rendered, sc["bg"], is_training), means2D
     feats, vfeats, _ = shading.shade_and_pack(mat["base_color"], mat["roughness"], mat["normals"], mat["viewdirs"],
                                               mat["radiance"], light, mat["visibility"], mat["dirs"], mat["areas"],
                                               sc["viewmatrix"], is_training)
-    means2D = torch.zeros_like(sc["means3D"], requires_grad=torch.is_grad_enabled())
     rast = GaussianRasterizer(runner.settings(sc, "svgss"))
     rendered = rast(means3D=sc["means3D"], means2D=means2D, opacities=sc["opacities"], shs=sc["shs"],
                     scales=sc["scales"], rotations=sc["rotations"], features=feats, vfeatures=vfeats)

@@ -41,14 +41,14 @@ class TrainStep:
 
     LAMBDA_DSSIM = 0.2   # arguments/__init__.py: lambda_dssim
 
-    def __init__(self, dev, seed=5, name="cfg3_train", Ns=64):
+    def __init__(self, dev, seed=5, name="cfg3_train", Ns=64, fused=True, scene=None):
         from gaussian_renderer import shading
         from gaussian_renderer.svgss_rasterization import GaussianRasterizer
         from . import losses, optim, render_view
         self.shading, self.render_view, self.losses, self.optim = shading, render_view, losses, optim
         self.GaussianRasterizer = GaussianRasterizer
-        self.dev, self.name, self.Ns = dev, name, Ns
-        sc = self.sc = scenes.make(name)
+        self.dev, self.name, self.Ns, self.fused = dev, name, Ns, fused
+        sc = self.sc = scenes.make(name) if scene is None else scene
         sct = self.sct = runner.to_torch(sc, dev)
         self.P, self.W, self.H = int(sc["means3D"].shape[0]), sc["W"], sc["H"]
         self.S, self.VS = 4, 52
@@ -89,13 +89,19 @@ class TrainStep:
         viewdirs = torch.nn.functional.normalize(campos[None, :] - p["xyz"].detach(), dim=-1)
         offs = torch.rand(self.P, device=self.dev) * (2 * math.pi)          # sample_incident_rays(training): random azimuths
         lattice = self.shading.FibonacciLattice(self.geo_n, self.Ns, offs)
-        feats, vfeats, _ = self.shading.shade_and_pack(p["base_color"], p["roughness"], p["normal"], viewdirs, p["radiance"],
-                                                      self.light, self.visibility, lattice, None, st.viewmatrix, True)
-        self._mark("shade_fwd")
+        self.last_offsets = offs
         means2D = torch.zeros_like(p["xyz"], requires_grad=True)
-        rast = self.GaussianRasterizer(st)
-        rendered = rast(means3D=p["xyz"], means2D=means2D, opacities=p["opacity"], shs=p["shs"], scales=p["scaling"],
-                        rotations=p["rotation"], features=feats, vfeatures=vfeats)
+        if self.fused:   # the shading runs inside the rasterizer calls, for the surfels this view reads (include/svgir_raster.h: svgir_fused_shade)
+            rendered, _ = self.shading.render_shaded(st, p["xyz"], means2D, p["opacity"], p["shs"], p["scaling"], p["rotation"],
+                                                     p["base_color"], p["roughness"], p["normal"], viewdirs, p["radiance"], self.light,
+                                                     self.visibility, lattice, None, True)
+        else:
+            feats, vfeats, _ = self.shading.shade_and_pack(p["base_color"], p["roughness"], p["normal"], viewdirs, p["radiance"],
+                                                          self.light, self.visibility, lattice, None, st.viewmatrix, True)
+            self._mark("shade_fwd")
+            rast = self.GaussianRasterizer(st)
+            rendered = rast(means3D=p["xyz"], means2D=means2D, opacities=p["opacity"], shs=p["shs"], scales=p["scaling"],
+                            rotations=p["rotation"], features=feats, vfeatures=vfeats)
         self._mark("raster_fwd")
         res = self.render_view.unpack(rendered, st.bg, True)
         l1, ssim = self.losses.l1_ssim(res["pbr"], self.gt)

@@ -20,7 +20,7 @@ def test_library_exports_every_symbol_of_the_header(built):
     lib = C.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.svgir_abi_version() == _native.ABI_VERSION == 11
+    assert lib.svgir_abi_version() == _native.ABI_VERSION == 12
 
 
 def test_struct_layouts_match_header_field_order(built):
@@ -29,7 +29,8 @@ def test_struct_layouts_match_header_field_order(built):
     hdr = open(os.path.join(ROOT, "include", "svgir_raster.h")).read()
 
     def fields(struct):
-        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        m = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S) or re.search(r"\nstruct %s \{(.*?)\};" % struct, hdr, re.S)
+        body = m.group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         out = []
         for decl in body.split(";"):
@@ -45,6 +46,7 @@ def test_struct_layouts_match_header_field_order(built):
     assert fields("svgir_grads") == [f[0] for f in _native.Grads._fields_]
     from gaussian_renderer import shading
     assert fields("svgir_shade_params") == [f[0] for f in shading.ShadeParams._fields_]
+    assert fields("svgir_fused_shade") == [f[0] for f in _native.FusedShade._fields_]
     from svgir_harness import optim
     assert fields("svgir_adam_tensor") == [f[0] for f in optim._AdamTensor._fields_]
     assert fields("svgir_row_tensor") == [f[0] for f in optim._RowTensor._fields_]

@@ -100,7 +100,7 @@ def run(i, rounds, out):
             res, leaves = runner.render(sct, "svgss", requires_grad=True)
             runner.backward(res, grads[i], "svgss")
         st.synchronize()
-    out[i] = (res["num_rendered"], res["color"].cpu().numpy(), leaves["means3D"].grad.cpu().numpy(), leaves["vfeatures"].grad.cpu().numpy())
+    out[i] = (res["num_rendered"], res["color"].detach().cpu().numpy(), leaves["means3D"].grad.cpu().numpy(), leaves["vfeatures"].grad.cpu().numpy())
 alone, both = {}, {}
 for i in range(6): run(i, 2, alone)
 th = [threading.Thread(target=run, args=(i, 10, both)) for i in range(6)]
