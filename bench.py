@@ -132,6 +132,8 @@ def parse():
     ap.add_argument("--no-concurrent", action="store_true", help="skip the supplementary two-views-on-two-streams record")
     ap.add_argument("--no-overlap", action="store_true", help="svgss workloads: run the shading forward on the rasterizer's stream "
                     "instead of a side stream that overlaps the binning (svgir_params.features_ready)")
+    ap.add_argument("--unfused", action="store_true", help="svgss workloads: shade ALL surfels with svgir_shade_forward / _backward around "
+                    "the rasterizer calls (rounds 1-4) instead of the view's working set inside them (svgir_params.shade)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-oracle steps (0 = as many as fit ~12 s)")
     ap.add_argument("--no-shade", action="store_true", help="svgss workloads: skip the SV-BRDF shading stage")
     ap.add_argument("--streamed-dirs", action="store_true", help="shading reads [P,Ns,3] incident directions from HBM "
@@ -248,14 +250,50 @@ class Workload:
             self.light = shade_inputs.Light(self.leaves["env"])
             # the shading forward does not depend on the binning of the view (and vice versa): it runs on a side stream and only
             # the composite kernel waits for it (include/svgir_raster.h: svgir_params.features_ready)
-            self.side = None if getattr(args, "no_overlap", False) else torch.cuda.Stream(dev)
+            self.fused = not getattr(args, "unfused", False)
+            self.side = None if (getattr(args, "no_overlap", False) or self.fused) else torch.cuda.Stream(dev)
             self.feat_ev = torch.cuda.Event() if self.side is not None else None
+            if self.fused:   # outputs the library writes: the packed rows, and (training) the gradients of the shading's inputs
+                self.f_buf = torch.empty((self.P, self.S), dtype=torch.float32, device=dev)
+                self.vf_buf = torch.empty((self.P, self.VS), dtype=torch.float32, device=dev)
+                self.sgrads = None
+                if self.training:   # (the per-surfel gradient tensors are carved out of the rasterizer's gradient allocation per step)
+                    self.senv = (torch.empty_like(sd["env"]), torch.empty(sd["env"].numel(), device=dev))
+                    self.sshapes = dict(dL_dbase_color=sd["base_color"].shape, dL_droughness=sd["roughness"].shape,
+                                        dL_dshade_normals=sd["normals"].shape, dL_dradiance=sd["radiance"].shape)
+
+    def shading_light(self):
+        from svgir_harness import shade_inputs
+        return shade_inputs.Light(self.leaves["env"].detach())
 
     def step(self):
         """One forward (+ backward) through the binding layer; returns (R, colour image, a gradient tensor)."""
         import torch
         st, sct, gt, _C, empty = self.st, self.sct, self.gt, self._C, self.empty
-        if self.variant == "svgss":
+        if self.variant == "svgss" and self.shade and self.fused:
+            # the shading runs inside the two library calls, for the surfels this view reads (svgir_fused_shade)
+            lv, sd = self.leaves, self.sd
+            fs, keep = self.shading.fused_shade(lv["base_color"].detach(), lv["roughness"].detach(), lv["normals"].detach(), sd["viewdirs"],
+                                                lv["radiance"].detach(), self.shading_light(), sd["visibility"], self.dirs, self.areas,
+                                                st.viewmatrix, self.training)
+            out = _C.rasterize_gaussians(st.bg, sct["means3D"], self.f_buf, self.vf_buf, empty, sct["opacities"], sct["scales"],
+                                         sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
+                                         st.patch_bbox, st.tanfovx, st.tanfovy, st.image_height, st.image_width, sct["shs"],
+                                         st.sh_degree, st.campos, False, False, st.config, shade=fs)
+            (R, color, normal, depth, opac, feat, vfeat, weights, radii, gb, bb, ib) = out
+            if not self.train:
+                return R, color, weights
+            kw = {}
+            if self.training:
+                self.sgrads = dict(dL_denv=self.senv[0], env_grad_work=self.senv[1], dL_dreduced=None, out_weights=weights,
+                                   _shapes=dict(self.sshapes))
+                kw = dict(shade=fs, shade_grads=self.sgrads)
+            g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], self.f_buf, self.vf_buf, radii, empty, sct["scales"],
+                                                sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
+                                                st.patch_bbox, st.tanfovx, st.tanfovy, gt["color"], gt["normal"], gt["depth"],
+                                                gt["opacity"], gt["feature"], gt["vfeature"], sct["shs"], st.sh_degree, st.campos,
+                                                gb, R, bb, ib, False, st.config, **kw)
+        elif self.variant == "svgss":
             feats_in, vfeats_in = sct["features"], sct["vfeatures"]
             if self.shade:
                 for v in self.leaves.values():
@@ -480,17 +518,35 @@ def roofline_of(wl, R, stage, workload):
     return out
 
 
-def shading_record(wl, stage):
+def shading_counts(wl):
+    """(surfels the shading forward shades, surfels its backward differentiates) for one view of a fused svgss Workload: the
+    candidates of at least one 8x8 sub-tile, and the surfels with out_weights > 0."""
+    import torch
+    if not getattr(wl, "fused", False):
+        return wl.P, wl.P
+    _, _, third = wl.step()
+    torch.cuda.synchronize()
+    nf = int((wl.vf_buf.abs().sum(1) > 0).sum())
+    w = wl.sgrads["out_weights"] if wl.sgrads is not None else third   # (forward-only workloads return the weights)
+    return nf, int((w > 0).sum())
+
+
+def shading_record(wl, stage, counts=None):
     sf_per_sample = 32 if not isinstance(wl.dirs, wl.shading.FibonacciLattice) else 16
-    sf = wl.P * wl.Ns * sf_per_sample + wl.P * (31 + 70 + (0 if wl.training else wl.S + wl.VS) + (0 if sf_per_sample == 32 else 4)) * 4
-    rec = {"config": f"rendering_equation4 + packing, Ns={wl.Ns} incident samples/surfel, env 32x64, incident directions "
+    # surfels the kernels actually shade: all P (--unfused), or the view's working set (fused); the byte model charges those
+    nf, nb = counts if counts is not None else shading_counts(wl)
+    Pf = nf
+    sf = Pf * wl.Ns * sf_per_sample + Pf * (31 + 70 + (0 if wl.training else wl.S + wl.VS) + (0 if sf_per_sample == 32 else 4)) * 4
+    rec = {"surfels": wl.P, "surfels_shaded_fwd": nf, "surfels_shaded_bwd": nb if wl.training else None,
+           "mode": "fused into svgir_forward / svgir_backward: the view's working set" if getattr(wl, "fused", False) else "all surfels (svgir_shade_forward / _backward around the rasterizer)",
+           "config": f"rendering_equation4 + packing, Ns={wl.Ns} incident samples/surfel, env 32x64, incident directions "
                      f"{'streamed from HBM' if sf_per_sample == 32 else 'generated in the kernels (Fibonacci lattice)'}, "
                      f"{'forward+backward' if wl.training else 'forward only (eval)'}",
            "fwd": {"avg_launch_ms": stage["shade_fwd"][0], "algorithmic_bytes_per_launch": sf, "bytes_per_sample": sf_per_sample,
                    "achieved": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
                    "frac": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     if wl.training and "shade_bwd" in stage:
-        sb = wl.P * wl.Ns * (sf_per_sample + 12) + wl.P * (31 + 70 + 28) * 4   # + dL_dradiance per sample, per-surfel gradients
+        sb = nb * wl.Ns * (sf_per_sample + 12) + nb * (31 + 70 + 28) * 4 + (wl.P - nb) * (wl.Ns * 12 + 28 * 4)   # + dL_dradiance per sample, per-surfel gradients (zero rows for the rest)
         rec["bwd"] = {"avg_launch_ms": stage["shade_bwd"][0], "algorithmic_bytes_per_launch": sb,
                       "achieved": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
                       "frac": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -618,6 +674,12 @@ def bench_train_step(args, dev):
     w = _W()
     w.P, w.W, w.H, w.S, w.VS, w.variant, w.Ns, w.training = ts.P, ts.W, ts.H, ts.S, ts.VS, "svgss", ts.Ns, True
     w.shading, w.dirs = ts.shading, ts.shading.FibonacciLattice(ts.geo_n, ts.Ns, None)
+    w.fused = ts.fused
+    counts = (ts.P, ts.P)
+    if ts.fused:   # (the same scene and camera as the cfg3_train workload: its working-set sizes)
+        w3 = Workload("cfg3_train", dev, 0, 1, args)
+        counts = shading_counts(w3)
+        del w3
     n_adam = ts.n_param_elems
     res = {
         "metric": "Gaussian-surfels/sec, whole stage-2 training iteration @800x800 (shade + rasterize + unpack + L1/SSIM + backward + Adam)",
@@ -633,7 +695,7 @@ def bench_train_step(args, dev):
         "phase_ms": {k: round(v, 4) for k, v in phases.items()},
         "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
         "roofline": roofline_of(w, R, stage, "cfg3_train"),
-        "shading": {k: v for k, v in shading_record(w, stage).items() if k != "config"},
+        "shading": {k: v for k, v in shading_record(w, stage, counts).items() if k != "config"},
         "optimizer": {"kernel": "adam_kernel (multi-tensor, NaN scrub)", "algorithmic_bytes_per_launch": 28 * n_adam,
                       "note": "28 B per parameter element (param, grad, two moments read; param, two moments written)"},
     }
@@ -835,8 +897,9 @@ def main():
             "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
         }
         if wl.shade:
-            res["config"]["shading"] = shading_record(wl, stage)["config"]
-            res["shading"] = {k: v for k, v in shading_record(wl, stage).items() if k != "config"}
+            srec = shading_record(wl, stage)
+            res["config"]["shading"] = srec["config"]
+            res["shading"] = {k: v for k, v in srec.items() if k != "config"}
     # the "shaded + blended" number of north_star: cfg3_train with the shading stage, same measurement, extra keys
     if world == 1 and args.workload is None and not args.no_shaded:
         wl.sct = wl.gt = None

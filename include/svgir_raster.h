@@ -140,7 +140,9 @@ typedef struct svgir_grads {
     void* clear_base;     /* optional: a region that contains every dL_d* output above and nothing the library must */
     size_t clear_bytes;   /*           preserve (NULL / 0: the outputs are cleared one by one) */
     /* Fused shading (svgir_params.shade != NULL; ABI 12): gradients of the shading inputs, layouts as svgir_shade_backward's outputs,
-     * every one written completely (rows of surfels that received no blend weight in this view are zero).  NOT part of clear_base. */
+     * every one written completely (rows of surfels that received no blend weight in this view are zero).  The four per-surfel tensors
+     * MAY lie inside clear_base (all four or none): their zero rows then come from the composite backward's clearing sweep instead of a
+     * zero-fill launch; dL_denv and env_grad_work must lie outside. */
     float* dL_dbase_color;      /* [P,12] */
     float* dL_droughness;       /* [P,4] */
     float* dL_dshade_normals;   /* [P,4,3] */
@@ -302,7 +304,8 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
  * that survive the view's culls only -- 44 % of the surfels pass the preprocess culls on the BASELINE scenes, ~30 % survive the per-tile
  * cull as well, and 13-29 % ever receive a blend weight -- while the reference (and svgir_shade_forward on its own) shades all P.
  *   svgir_forward : runs preprocess / sorts / per-tile cull first, then shades exactly the surfels that are a candidate of at least one
- *       8x8 sub-tile, writes their `features` [P,S] / `vfeatures` [P,VS] rows (S, VS = 4, 52 when sp.training, else 7, 64) and zero-fills
+ *       8x8 sub-tile -- or, when sp.Ns >= 128 (evaluation sample counts: shading a surfel costs far more than compositing it), the
+ *       surfels a geometry-only pre-pass of the composite finds to receive a blend weight -- writes their `features` [P,S] / `vfeatures` [P,VS] rows (S, VS = 4, 52 when sp.training, else 7, 64) and zero-fills
  *       the others, then composites.  sp.P must equal svgir_params.P; sp.subset / sp.subset_count are ignored (the library's own list,
  *       kept in the geometry blob, is used).
  *   svgir_backward: after the rasterizer's backward has produced dL_dfeatures / dL_dvfeatures, differentiates the shading of the

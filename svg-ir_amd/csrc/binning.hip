@@ -223,11 +223,18 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
     uint32_t run = block_exclusive_scan_2048(v, wsum, total);   // contains a __syncthreads()
     const uint32_t before = psum[0] + psum[1] + psum[2] + psum[3];
     run += before;
+    uint32_t span = 0;   // 1 + position (in depth order) of this thread's last Gaussian that touches a tile
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (base + i < n) offsets[base + i] = run;
         run += v[i];
+        if (v[i] != 0u) span = (uint32_t)(base + i + 1);
     }
+    // total_out[3] = the visible span of the depth order: order[0 .. span) holds every Gaussian with tiles > 0 (they sort in front of
+    // the culled ones) -- the working set of the fused shading (api.hip).  One atomic per wave that holds a visible Gaussian.
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) span = max(span, (uint32_t)__shfl_xor((int)span, d));
+    if ((threadIdx.x & 63) == 0 && span != 0u) atomicMax(total_out + 3, span);
     if (last && threadIdx.x == 0) {
         const uint32_t R = before + total;
         const uint32_t summary = (ksum[0] & ksum[1] & ksum[2] & ksum[3] & 0xff00u) | ((ksum[0] | ksum[1] | ksum[2] | ksum[3]) & 0xffu);

@@ -60,11 +60,12 @@ struct GeomLayout {
     uint32_t* offsets;     // [P] exclusive scan of tiles in depth-sorted order
     uint32_t* scan_tmp;    // [2 * (scan_blocks(P)+1)]: block sums | per-block depth-key summaries
     uint32_t* radix_tbl;   // [256 * sort_blocks(P)]
-    uint32_t* counters;    // [4]: [0] = R, [1] = prefilter violation, [2] = top bytes of the visible depth keys {AND << 8 | OR}
+    uint32_t* counters;    // [4]: [0] = R, [1] = prefilter violation, [2] = top bytes of the visible depth keys {AND << 8 | OR},
+                           // [3] = visible span of the depth order (1 + position of the last Gaussian with tiles > 0)
     uint32_t* key_top;     // [ceil(P / 64)] the same per preprocess wave (identity 0xff00 where a wave has no visible Gaussian)
     // working set of the view for the fused shading (svgir_params.shade; subset.hip):
-    uint8_t* needed;       // [P] 1 <=> candidate of at least one 8x8 sub-tile (cleared by preprocess, set by the cull kernel)
-    uint32_t* shade_list;  // [P] partition of 0..P-1: selected surfels in front (forward: `needed`; backward: out_weights > 0)
+    uint8_t* needed;       // [P] 1 <=> receives a blend weight (cleared by preprocess, set by the contribution pre-pass of the composite)
+    uint32_t* shade_list;  // [P] partition of 0..P-1: selected surfels in front (forward with pre-pass: `needed`; backward: out_weights > 0)
     uint32_t* shade_work;  // [partition_work_words(P)] scan scratch; its LAST word = number of selected surfels
     size_t bytes;
 };
@@ -294,7 +295,8 @@ struct PreArgs {
     CfgRef cfg;
     float* rec; float* cov3D; uint32_t* clamped; uint32_t* tiles; uint32_t* key; uint32_t* idx; int32_t* radii;
     float* out_weights;              // [P] zeroed here (accumulated with atomics by the composite)
-    uint8_t* needed;                 // [P] zeroed here (set by the cull kernel for every surfel that survives it in some sub-tile)
+    uint8_t* needed;                 // [P] or null: zeroed here (set by the contribution pre-pass of the fused shading)
+    uint32_t* span;                  // GeomLayout::counters + 3, zeroed here
     uint32_t* zero_words; int n_zero_words;   // small table cleared in passing (the depth sort's group totals)
     int spec_top; uint32_t* key_top;   // speculated common top byte of the visible depth keys (-1: none) -> key of a culled Gaussian; per-wave summary out
     uint32_t* prefilter_violation;   // non-null <=> `prefiltered`: set to 1 when a frustum / back-face cull fires (auxiliary.h:163-167)
@@ -309,11 +311,13 @@ struct RenderArgs {
     uint2* sub_list; uint32_t* sub_total; uint32_t* sub_order; uint32_t* sub_count;
     uint32_t* sub_ndump; uint32_t* seg_list; SegDesc* seg_desc; uint32_t* seg_count; uint32_t* seg_block; float* seg_state;
     uint32_t* sub_pair_base; uint32_t* sub_slot_base; uint32_t slot_cap;
-    int dump_only;   // composite forward: replay for the state dumps alone (svgir_backward, a view that exceeded its slot capacity): no output is written
+    int dump_only;   // composite forward: 1 = replay for the state dumps alone (svgir_backward, a view that exceeded its slot capacity): no output
+                     // is written; 2 = contribution pre-pass of the fused shading (S = VS = 0): nothing is written but needed[id] = 1 for
+                     // every surfel that receives a blend weight
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
-    uint8_t* needed;          // [P] or null: the cull kernel marks every Gaussian that survives in at least one sub-tile
+    uint8_t* needed;          // [P] or null: contribution pre-pass (dump_only == 2) marks every Gaussian that receives a blend weight
     float* pair_stream;       // (experiment builds) see BinLayout
 };
 
@@ -410,6 +414,12 @@ size_t partition_work_words(int P);
 void launch_partition(int P, const uint8_t* flags, const float* positive, uint32_t* list, uint32_t* work, uint32_t* count_dev, hipStream_t s);
 // zeroes row list[P-1-j], j < P - *count_dev, of up to 6 row-major fp32 tensors (null tensors are skipped)
 void launch_zero_rows(int P, const uint32_t* list, const uint32_t* count_dev, float* const* tensors, const int* row_floats, int n, hipStream_t s);
+
+// svgir_shade_backward with one more switch: rows_precleared = the four per-surfel gradient tensors are already zero (svgir_backward
+// lets the composite backward's waves clear them in passing), so the rows outside the subset need no zero-fill launch
+int shade_backward_impl(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures, const float* dL_dvfeatures,
+                        float* dL_dbase_color, float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
+                        float* env_grad_work, bool rows_precleared, void* stream);
 
 #if defined(__HIPCC__)
 // ---- device helpers ----------------------------------------------------------------------------------------

@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     const bool surface = cfg_flag(a.cfg, 0), pix_depth = cfg_flag(a.cfg, 2);
     if (a.out_weights) a.out_weights[idx] = 0.f;
     if (a.needed) a.needed[idx] = 0;
+    if (idx == 0 && a.span) *a.span = 0u;   // (accumulated with atomicMax by the offsets scan)
     // defaults for a culled Gaussian
     a.radii[idx] = 0;
     a.tiles[idx] = 0;

@@ -105,7 +105,6 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
                 m[w] = cull_test(sc, x0, y0, x0 + 7.f, y0 + 7.f);
             }
         }
-        if (a.needed && (m[0] || m[1] || m[2] || m[3])) a.needed[gid] = 1;   // the view's composite reads this surfel's packed rows
         unsigned long long mask[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -257,6 +256,7 @@ render_fwd_kernel(const RenderArgs a) {
     const uint32_t dump_base = a.sub_slot_base[sid];   // first state slot of this sub-tile (compact: common.hpp SEG)
     uint32_t ndump = 0;
     auto dump_state = [&](uint32_t j) {
+        if (a.dump_only == 2) return;   // (contribution pre-pass: no state is kept)
         gather_acc();
         if (dump_base + j >= a.slot_cap) return;   // (only in a speculative launch whose capacity guess was too small: the forward re-runs)
         float* d = a.seg_state + ((size_t)(dump_base + j) * NST) * 64 + lane;
@@ -296,6 +296,8 @@ render_fwd_kernel(const RenderArgs a) {
             if (lane < nflush) {
                 const float wsum = sW[(bprev & 1) * CH + lane];
                 if (wsum != 0.f && !a.dump_only) atomic_add_f32(&a.out_weights[sQ[(bprev & 1) * CH + lane].x], wsum);
+                // contribution pre-pass (dump_only == 2): the surfel received a blend weight from this sub-tile -> its packed rows will be read
+                if (wsum != 0.f && a.dump_only == 2) a.needed[sQ[(bprev & 1) * CH + lane].x] = 1;
             }
         };
         int b = 0;

@@ -54,14 +54,8 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-// f(env) as one float4 per texel {f(r), f(g), f(b), 0}: a bilinear tap is ONE 16-byte gather instead of three dwords
-__global__ void __launch_bounds__(BLOCK) env_table_kernel(const float* __restrict__ env, float4* __restrict__ tab, int ntexel,
-                                                          int softplus) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= ntexel) return;
-    const float r = env[3 * i], g = env[3 * i + 1], b = env[3 * i + 2];
-    tab[i] = softplus ? make_float4(softplus_f(r), softplus_f(g), softplus_f(b), 0.f) : make_float4(r, g, b, 0.f);
-}
+// (the f(env) table -- one float4 per texel {f(r), f(g), f(b), 0}: a bilinear tap is ONE 16-byte gather instead of three dwords -- is
+// built by shade_prologue_kernel below)
 
 // Lat-long bilinear lookup (grid_sample, align_corners=True, zero padding) of direction d.
 struct EnvTap { int idx[4]; float w[4]; };
@@ -108,6 +102,34 @@ __global__ void __launch_bounds__(BLOCK) lattice_table_kernel(int Ns, float4* __
     float sn, cs;
     sincosf(t, &sn, &cs);
     tab[i] = make_float4(sn, cs, z, rad);
+}
+
+// One launch in front of a shading kernel: the f(env) table, the lattice table (when the directions are generated in-kernel) and, for
+// the backward, the clear of the env-gradient accumulator -- three tiny jobs that used to be three launches (~4 us of stream time each).
+__global__ void __launch_bounds__(BLOCK) shade_prologue_kernel(const float* __restrict__ env, float4* __restrict__ env_tab, int ntexel, int softplus,
+                                                               int Ns, float4* __restrict__ lat_tab, float* __restrict__ zero, int nzero) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < ntexel) {
+        const float r = env[3 * i], g = env[3 * i + 1], b = env[3 * i + 2];
+        env_tab[i] = softplus ? make_float4(softplus_f(r), softplus_f(g), softplus_f(b), 0.f) : make_float4(r, g, b, 0.f);
+    }
+    for (int j = i; j < nzero; j += gridDim.x * BLOCK) zero[j] = 0.f;
+    if (lat_tab && i < Ns) {
+#pragma clang fp contract(off)
+        const float fi = (float)i;
+        const float z = fmaxf(1.f - 2.f * fi / (float)(2 * Ns - 1), 0.17364817766693033f);   // sin(10 deg)
+        const float rad = sqrtf(1.f - z * z);
+        const float t = kLatticeDelta * fi;
+        float sn, cs;
+        sincosf(t, &sn, &cs);
+        lat_tab[i] = make_float4(sn, cs, z, rad);
+    }
+}
+static void launch_shade_prologue(const svgir_shade_params* p, float* zero, int nzero, hipStream_t s) {
+    const int ntexel = p->env_h * p->env_w;
+    const int n = std::max(ntexel, p->incident_dirs ? 0 : p->Ns);
+    hipLaunchKernelGGL(shade_prologue_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, (float4*)p->env_work, ntexel, p->env_softplus,
+                       p->Ns, p->incident_dirs ? (float4*)nullptr : (float4*)p->lattice_work, zero, nzero);
 }
 
 struct LatticeFrame { float R[9]; float so, co, off; };   // rotation taking +z to the surfel's normal; offset angle
@@ -294,6 +316,20 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
     }
 }
 
+// Subset launches: the packed rows of the surfels OUTSIDE the subset are zero-filled by the same kernel -- every wave takes a strided share
+// of the partition's back (svgir_shade_params.subset) before its own work; stores nobody waits for.
+__device__ __forceinline__ void zero_rest_rows(const ShadeArgs& a, size_t wave_id, size_t nwaves, size_t nsel, int lane) {
+    const svgir_shade_params& p = a.p;
+    const size_t nrest = (size_t)p.P - nsel;
+    const int nf = p.training ? 4 : 7, nvf = p.training ? 52 : 64;
+    for (size_t j = wave_id; j < nrest; j += nwaves) {
+        const size_t g = p.subset[(size_t)p.P - 1 - j];
+        if (a.reduced) { a.reduced[g * NRED + lane] = 0.f; if (lane + 64 < NRED) a.reduced[g * NRED + 64 + lane] = 0.f; }
+        if (a.features && lane < nf) a.features[g * nf + lane] = 0.f;
+        if (a.vfeatures && lane < nvf) a.vfeatures[g * nvf + lane] = 0.f;
+    }
+}
+
 #ifndef SHADE_FWPE
 #define SHADE_FWPE 5   // 96 VGPRs without spills; the default heuristic settles on 107 (4 waves per SIMD): 285 -> 252 us at P = 200k, Ns = 64
 #endif
@@ -310,6 +346,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
     // work item -> surfel: all P of them, or the front of the caller's partition (svgir_shade_params.subset)
     const size_t wi = (size_t)blockIdx.x * 4 + wave;
     const size_t nwork = p.subset ? (size_t)min(*p.subset_count, (uint32_t)p.P) : (size_t)p.P;
+    if (p.subset) zero_rest_rows(a, wi, (size_t)gridDim.x * 4, nwork, lane);
     if ((size_t)blockIdx.x * 4 >= nwork) return;   // (whole workgroup past the end of the list)
     const bool valid = wi < nwork;
     const size_t g = valid ? (p.subset ? (size_t)p.subset[wi] : wi) : 0;
@@ -455,6 +492,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
     // work items -> surfels: all P of them, or the front of the caller's partition (svgir_shade_params.subset)
     const size_t nwork = p.subset ? (size_t)min(*p.subset_count, (uint32_t)p.P) : (size_t)p.P;
     const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * FQ_SURF;       // first work item of the wave
+    if (p.subset) zero_rest_rows(a, (size_t)blockIdx.x * 4 + wave, (size_t)gridDim.x * 4, nwork, lane);
     if (g0 >= nwork) return;
     const int nsurf = (int)min((size_t)FQ_SURF, nwork - g0);
     const bool valid = q < nsurf;
@@ -1085,18 +1123,11 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
-    if (!p->incident_dirs)
-        hipLaunchKernelGGL(lattice_table_kernel, dim3((p->Ns + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->Ns, (float4*)p->lattice_work);
-    hipLaunchKernelGGL(env_table_kernel, dim3((ntex / 3 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, (float4*)p->env_work, ntex / 3,
-                       p->env_softplus);
+    launch_shade_prologue(p, nullptr, 0, s);
     stage_mark(tm, "shade_env_table");
     ShadeArgs a;
     a.p = *p; a.reduced = reduced; a.features = features; a.vfeatures = vfeatures;
-    if (p->subset) {   // the rows of the surfels outside the subset: zero (every output is written completely)
-        float* const t[3] = {reduced, features, vfeatures};
-        const int w[3] = {NRED, p->training ? 4 : 7, p->training ? 52 : 64};
-        launch_zero_rows(p->P, p->subset, p->subset_count, t, w, 3, s);
-    }
+    // (subset launches: the rows of the surfels outside the subset are zero-filled by the shading kernel's own waves)
 #ifndef SHADE_FWD_QUAD
 #define SHADE_FWD_QUAD 1
 #endif
@@ -1121,6 +1152,16 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
                          const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
                          float* env_grad_work, void* stream) {
+    return svgir::shade_backward_impl(p, dL_dreduced, dL_dfeatures, dL_dvfeatures, dL_dbase_color, dL_droughness, dL_dnormals, dL_dradiance,
+                                      dL_denv, env_grad_work, false, stream);
+}
+
+}  // extern "C"
+
+int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
+                               const float* dL_dvfeatures, float* dL_dbase_color,
+                               float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
+                               float* env_grad_work, bool rows_precleared, void* stream) {
     if (!p || p->P < 0 || p->Ns <= 0 || p->env_h <= 0 || p->env_w <= 0) return SVGIR_ERR_INVALID;
     if (p->P == 0) return 0;
     if ((!dL_dreduced && !dL_dfeatures && !dL_dvfeatures) || (dL_dvfeatures && !p->viewmatrix) || !dL_dbase_color || !dL_droughness || !dL_dnormals || !dL_dradiance || !dL_denv ||
@@ -1132,12 +1173,8 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
-    if (!p->incident_dirs)
-        hipLaunchKernelGGL(lattice_table_kernel, dim3((p->Ns + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->Ns, (float4*)p->lattice_work);
-    hipLaunchKernelGGL(env_table_kernel, dim3((ntex / 3 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, (float4*)p->env_work, ntex / 3,
-                       p->env_softplus);
-    if (hipMemsetAsync(env_grad_work, 0, (size_t)ntex * 4, s) != hipSuccess) return SVGIR_ERR_HIP;
-    if (p->subset) {   // the rows of the surfels outside the subset: zero (every output is written completely)
+    launch_shade_prologue(p, env_grad_work, ntex, s);
+    if (p->subset && !rows_precleared) {   // the rows of the surfels outside the subset: zero (every output is written completely)
         float* const t[4] = {dL_dbase_color, dL_droughness, dL_dnormals, dL_dradiance};
         const int w[4] = {12, 4, 12, 3 * p->Ns};
         launch_zero_rows(p->P, p->subset, p->subset_count, t, w, 4, s);
@@ -1170,6 +1207,8 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
     stage_mark(tm, "shade_env_grad");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
+
+extern "C" {
 
 int svgir_incident_dirs(int32_t P, int32_t Ns, const float* normals, const float* offsets, float* lattice_work,
                         float* dirs, float* areas, void* stream) {

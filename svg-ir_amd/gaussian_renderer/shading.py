@@ -314,15 +314,17 @@ class _ShadedRasterize(torch.autograd.Function):
             res = _C.rasterize_gaussians_backward(*args)
             return (res[3], res[0], res[7], res[2], res[8], res[9]) + (None,) * 16
         fs = _fused_struct(sp, None, all_surfels)
-        d_base, d_rough, d_norm, d_rad, d_env = (N.out_tensor(keep[i].shape, torch.float32, dev) for i in (0, 1, 2, 4, 8))
+        d_env = N.out_tensor(keep[8].shape, torch.float32, dev)
         gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
-        sg = dict(dL_dbase_color=d_base, dL_droughness=d_rough, dL_dshade_normals=d_norm, dL_dradiance=d_rad, dL_denv=d_env,
-                  env_grad_work=gwork, dL_dreduced=None if g_red is None else N.f32c(g_red, dev), out_weights=weights)
+        # (the four per-surfel gradient tensors are carved out of the rasterizer's gradient allocation by the binding: the composite
+        # backward clears that region in passing, the shading backward then writes the rows of the surfels that were blended)
+        sg = dict(dL_denv=d_env, env_grad_work=gwork, dL_dreduced=None if g_red is None else N.f32c(g_red, dev), out_weights=weights,
+                  _shapes=dict(dL_dbase_color=keep[0].shape, dL_droughness=keep[1].shape, dL_dshade_normals=keep[2].shape,
+                               dL_dradiance=keep[4].shape))
         if P == 0:
-            for t in (d_base, d_rough, d_norm, d_rad, d_env):
-                t.zero_()
-
+            d_env.zero_()
         res = _C.rasterize_gaussians_backward(*args, shade=fs, shade_grads=sg)
+        d_base, d_rough, d_norm, d_rad = sg["dL_dbase_color"], sg["dL_droughness"], sg["dL_dshade_normals"], sg["dL_dradiance"]
         (g_means2D, _gc, g_opac, g_means3D, _gf, _gvf, _gcov, g_sh, g_scales, g_rot, _gv, _gp, _gcp) = res
         return (g_means3D, g_means2D, g_sh, g_opac, g_scales, g_rot, d_base.reshape(base_color.shape),
                 d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None, d_rad.reshape(radiance.shape), None, None,

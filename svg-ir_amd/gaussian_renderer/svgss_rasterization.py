@@ -109,10 +109,15 @@ class _CBinding:
         VS = vfeatures.size(1) if vfeatures.dim() == 2 else 0
         H, W = dL_dout_color.size(1), dL_dout_color.size(2)
         M = sh.size(1) if sh.numel() != 0 else 0
+        # (fused shading: per-surfel gradient tensors the caller asks for by shape -- shade_grads["_shapes"] -- live in the same
+        # allocation, so the composite backward's clearing sweep zeroes them too; svgir_backward then writes the differentiated rows)
+        extra = list((shade_grads or {}).pop("_shapes", {}).items()) if shade is not None else []
+        views, gblob = N.grad_blob(dev, [(P, 3), (P, 3), (P, S), (P, VS), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6),
+                                         (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)] + [tuple(sh) for _, sh in extra], zero=(P == 0))
         (dL_dmeans3D, dL_dmeans2D, dL_dfeatures, dL_dvfeatures, dL_dcolors, dL_dnormal, dL_ddepth, dL_dconic,
-         dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos), gblob = \
-            N.grad_blob(dev, [(P, 3), (P, 3), (P, S), (P, VS), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6),
-                                    (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)], zero=(P == 0))
+         dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos) = views[:16]
+        for (name, _), v in zip(extra, views[16:]):
+            shade_grads[name] = v
         if P != 0:
             keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, vfeatures, scales, rotations,
                                               cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint, patchbbox,
