@@ -9,7 +9,7 @@ OUT=$ROOT/build/variants/$NAME
 mkdir -p "$OUT"
 FLAGS=$(make -s -C "$ROOT/svg-ir_amd/csrc" print-hipflags)
 pids=()
-for f in api preprocess binning render_fwd render_bwd render_bwd_plain render_generic geom_bwd grad_reduce image_ops shade epilogue loss optim bvh pbgi; do
+for f in api preprocess binning render_fwd render_bwd render_bwd_plain render_generic geom_bwd grad_reduce image_ops shade subset epilogue loss optim bvh pbgi; do
   [ -f "$ROOT/svg-ir_amd/csrc/$f.hip" ] || continue
   /opt/rocm/bin/hipcc $FLAGS "$@" -c "$ROOT/svg-ir_amd/csrc/$f.hip" -o "$OUT/$f.o" &
   pids+=($!)

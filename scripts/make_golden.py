@@ -58,6 +58,9 @@ def main():
     import torch.utils.cpp_extension as cpp
     cpp.load = lambda *a, **k: _Stub("_C")
     rng = np.random.default_rng(1234)
+    if "--shading-only" in sys.argv:   # (regenerates tests/golden/shading.npz alone; the other archives stay byte-identical)
+        shading_fixtures()
+        return
 
     # ---- SH evaluation (utils/sh_utils.py:71-128 as used at gaussian_renderer/svgss.py:92-96) ----
     from utils.sh_utils import eval_sh
@@ -148,11 +151,17 @@ def shading_fixtures():
             return light_rgbs.reshape(*shape) * 2.0
 
     out = {}
-    for tag, n, Ns, seed in (("a", 48, 8, 0), ("b", 33, 64, 1)):
+    # (a, b: the round-1 fixtures, unchanged draws; c: 200 surfels x 64 samples with a third of the corners at the glossy end of the
+    # reference's roughness range, 0.09 .. 0.15, where fp32 is ill-conditioned)
+    for tag, n, Ns, seed in (("a", 48, 8, 0), ("b", 33, 64, 1), ("c", 200, 64, 2)):
         g = torch.Generator().manual_seed(seed)
         rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
         base = (torch.sigmoid(rnd(n, 12)) * 0.77 + 0.03).requires_grad_(True)
-        rough = (torch.sigmoid(rnd(n, 4)) * 0.9 + 0.09).requires_grad_(True)
+        rough = torch.sigmoid(rnd(n, 4)) * 0.9 + 0.09
+        if tag == "c":
+            glossy = torch.rand(n, 4, generator=g, dtype=torch.float64) < 0.33
+            rough = torch.where(glossy, 0.09 + 0.06 * torch.rand(n, 4, generator=g, dtype=torch.float64), rough)
+        rough = rough.requires_grad_(True)
         nrm0 = F.normalize(rnd(n, 1, 3), dim=-1)
         normals = (nrm0 + 0.1 * rnd(n, 4, 3)).requires_grad_(True)
         viewdirs = F.normalize(nrm0[:, 0] + 0.6 * rnd(n, 3), dim=-1)
@@ -183,6 +192,26 @@ def shading_fixtures():
         out[pre + "mean_vis"] = ex["incident_visibility"].mean(-2).detach().numpy()
         for k, gv in zip(("base", "rough", "normals", "radiance", "env"), grads):
             out[pre + "g_" + k] = gv.numpy()
+        # The SAME reference function on the SAME inputs in fp32 -- the precision the reference actually trains and renders in
+        # (everything on its hot path is torch.float32): forward values and autograd gradients, keys "f32_*".  Their distance from
+        # the fp64 values above is the error the reference's own arithmetic carries (glossy corners: the GGX denominator cancels in
+        # fp32); the tests budget the HIP kernels against it instead of against a flat tolerance.
+        f32 = lambda t: t.detach().float()  # noqa: E731
+        b32, r32, n32, ra32, e32 = (f32(t).requires_grad_(True) for t in (base, rough, normals, radiance, env))
+        light32 = EnvStandIn(e32)
+        pbr32, ex32 = rendering_equation4(b32, r32, n32, f32(viewdirs), ra32, light32, visibility_precompute=f32(vis),
+                                          incident_dirs_precompute=f32(dirs), incident_areas_precompute=f32(areas))
+        loss32 = (pbr32 * f32(w_pbr)).sum() + sum((ex32[k] * f32(wts[k])).sum() for k in wts) \
+            + (ex32["incident_lights"].mean(-2) * f32(w_inc)).sum() + (ex32["global_incident_lights"].mean(-2) * f32(w_glob)).sum()
+        grads32 = torch.autograd.grad(loss32, [b32, r32, n32, ra32, e32])
+        assert pbr32.dtype == torch.float32 and all(g_.dtype == torch.float32 for g_ in grads32)
+        out[pre + "f32_pbr"] = pbr32.detach().numpy()
+        for k in ("diffuse_light", "specular", "direct", "indirect"):
+            out[pre + "f32_" + k] = ex32[k].detach().numpy()
+        out[pre + "f32_mean_incident"] = ex32["incident_lights"].mean(-2).detach().numpy()
+        out[pre + "f32_mean_global"] = ex32["global_incident_lights"].mean(-2).detach().numpy()
+        for k, gv in zip(("base", "rough", "normals", "radiance", "env"), grads32):
+            out[pre + "f32_g_" + k] = gv.numpy()
     np.savez_compressed(os.path.join(OUT, "shading.npz"), **out)
     print("wrote shading.npz", len(out), "arrays")
 

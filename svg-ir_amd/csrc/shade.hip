@@ -52,6 +52,21 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of
     return v;
 }
 
+#ifndef SHADE_PRECISE
+#define SHADE_PRECISE 2
+#endif
+// 1 / max(sqrt(x2), 1e-12) for the normalisations.  At the glossy end of the reference's roughness range (0.09: alpha^2 = 6.6e-5) the GGX
+// denominator N.H^2 (alpha^2 - 1) + 1 amplifies an error of N.H 15 000 times, so the unit vectors must be as good as the reference's
+// (torch: correctly rounded sqrt and division): the hardware's 1-ulp rsq gets one Newton step.
+__device__ __forceinline__ float inv_norm(float x2) {
+    const float y = fminf(__builtin_amdgcn_rsqf(x2), 1e12f);
+#if SHADE_PRECISE >= 1
+    return x2 > 1e-24f ? y * fmaf(-0.5f * x2 * y, y, 1.5f) : y;
+#else
+    return y;
+#endif
+}
+
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 // (the f(env) table -- one float4 per texel {f(r), f(g), f(b), 0}: a bilinear tap is ONE 16-byte gather instead of three dwords -- is
@@ -167,7 +182,7 @@ __device__ __forceinline__ void lattice_dir(const LatticeFrame& f, const float4 
     }
     const float x = sn * t.w, y = cs * t.w, z = t.z;
     float v[3] = {f.R[0] * x + f.R[1] * y + f.R[2] * z, f.R[3] * x + f.R[4] * y + f.R[5] * z, f.R[6] * x + f.R[7] * y + f.R[8] * z};
-    const float il = fminf(__builtin_amdgcn_rsqf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+    const float il = inv_norm(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);   // = 1 / max(|.|, 1e-12)
     d[0] = v[0] * il; d[1] = v[1] * il; d[2] = v[2] * il;
 }
 
@@ -209,6 +224,24 @@ struct GaussConst {  // per-(Gaussian, corner) constants of a phase-2 lane
     float sgn, inv_len, NoV_raw;  // for the backward
 };
 
+// The GGX denominator term  nom0 = clamp(N.H, 1e-6, 1)^2 (alpha^2 - 1) + 1  (svgss.py:612-617) for unit N (flipped to the viewer) and
+// unit H.  Evaluated literally, 1 - N.H^2 cancels when N is near H -- exactly where a glossy lobe (alpha^2 down to 6.6e-5) has its
+// weight -- and one ulp of N.H moves nom0 by 2e-3.  With  1 - N.H^2 = |H - (N.H) N|^2  (the part of H perpendicular to N: three FMAs
+// whose results are small and carry ~1e-7 ABSOLUTE error, i.e. ~1e-5 of their own size at the lobe's width; an error of N.H itself
+// enters squared)  nom0 = alpha^2 + |H - (N.H) N|^2 (1 - alpha^2)  is good to ~1e-5 where the literal form -- the reference's own fp32
+// code included -- is good to ~2e-3; the lower clamp (N.H < 1e-6: H behind the surface) keeps the reference's value.
+__device__ __forceinline__ float ggx_nom0(const float* N, const float* H, float a2) {
+    const float noh = N[0] * H[0] + N[1] * H[1] + N[2] * H[2];
+#if SHADE_PRECISE >= 2
+    const float px = fmaf(-noh, N[0], H[0]), py = fmaf(-noh, N[1], H[1]), pz = fmaf(-noh, N[2], H[2]);
+    const float s2 = fminf(px * px + py * py + pz * pz, 1.f);
+    return noh >= 1e-6f ? fmaf(s2, 1.f - a2, a2) : 1e-12f * (a2 - 1.f) + 1.f;
+#else
+    const float NoH = fminf(1.f, fmaxf(1e-6f, noh));
+    return NoH * NoH * (a2 - 1.f) + 1.f;
+#endif
+}
+
 struct CornerIn { float v[3], n[3], r, base[3]; };   // what the constants of one (Gaussian, corner) are made from
 __device__ __forceinline__ CornerIn load_corner_in(const svgir_shade_params& p, size_t g, int k) {
     CornerIn ci;
@@ -221,7 +254,11 @@ __device__ __forceinline__ void corner_consts(const CornerIn& ci, const float* V
     const float* n = ci.n;
     c.nraw[0] = n[0]; c.nraw[1] = n[1]; c.nraw[2] = n[2];
     const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+#if SHADE_PRECISE >= 1
+    c.inv_len = 1.0f / len;
+#else
     c.inv_len = __builtin_amdgcn_rcpf(len);
+#endif
     float Nn[3] = {n[0] * c.inv_len, n[1] * c.inv_len, n[2] * c.inv_len};
     const float nov = V[0] * Nn[0] + V[1] * Nn[1] + V[2] * Nn[2];
     c.sgn = nov > 0.f ? 1.f : (nov < 0.f ? -1.f : 0.f);
@@ -273,10 +310,10 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         else lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[s], s, p.lattice_offsets != nullptr, d);
         const float rad[3] = {p.radiance[o * 3], p.radiance[o * 3 + 1], p.radiance[o * 3 + 2]};
         const float vis = p.visibility[o], area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
-        const float il = fminf(__builtin_amdgcn_rsqf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+        const float il = inv_norm(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // = 1 / max(|.|, 1e-12)
         const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
         float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
-        const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+        const float ih = inv_norm(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]);   // = 1 / max(|.|, 1e-12)
         H[0] *= ih; H[1] *= ih; H[2] *= ih;
         const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
         const float frac0 = 0.04f + (1.f - 0.04f) * __builtin_amdgcn_exp2f((-5.55473f * VoH - 6.98316f) * VoH);
@@ -355,7 +392,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
 
     float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
     {
-        const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+        const float iv = inv_norm(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);   // = 1 / max(|.|, 1e-12)
         V[0] *= iv; V[1] *= iv; V[2] *= iv;
     }
     DEV_TRACE_DECL();
@@ -386,8 +423,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
         const float* r = sS + s * SREC;
         const float ndi = fmaxf(c.nraw[0] * r[0] + c.nraw[1] * r[1] + c.nraw[2] * r[2], 0.f);
         const float NoL = fminf(1.f, fmaxf(1e-6f, c.Nh[0] * r[3] + c.Nh[1] * r[4] + c.Nh[2] * r[5]));
-        const float NoH = fminf(1.f, fmaxf(1e-6f, c.Nh[0] * r[6] + c.Nh[1] * r[7] + c.Nh[2] * r[8]));
-        const float nom0 = NoH * NoH * (c.a2 - 1.f) + 1.f;
+        const float nom0 = ggx_nom0(c.Nh, r + 6, c.a2);
         const float nom = fminf(4.f * kPi, fmaxf(1e-6f, 4.f * kPi * nom0 * nom0 * c.nom1 * (NoL * (1.f - c.kk) + c.kk)));
         const float fs = r[9] * c.a2 * __builtin_amdgcn_rcpf(nom);
         const float ge = r[16] * ndi;
@@ -503,14 +539,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
 
     float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
     {
-        const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+        const float iv = inv_norm(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);   // = 1 / max(|.|, 1e-12)
         V[0] *= iv; V[1] *= iv; V[2] *= iv;
     }
     GaussConst c;
     {
         const CornerIn ci = load_corner_in(p, gg, k);
         corner_consts(ci, V, c);
-        if (a.vfeatures) {   // the quad holds exactly the surfel's 28 packing inputs
+        {   // the quad holds exactly the surfel's 28 packing inputs (also the epilogue's source of the diffuse albedo)
             float* si = sIn + q * FQ_IN;
 #pragma unroll
             for (int j = 0; j < 3; j++) { si[j * 4 + k] = ci.base[j]; si[12 + k * 3 + j] = ci.n[j]; }
@@ -550,10 +586,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
         {
             float d[3] = {x.d[0], x.d[1], x.d[2]};
             if (lattice) lattice_dir(lf, ltab[min(s, Ns - 1)], min(s, Ns - 1), has_off, d);
-            const float il = fminf(__builtin_amdgcn_rsqf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+            const float il = inv_norm(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // = 1 / max(|.|, 1e-12)
             const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
             float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
-            const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+            const float ih = inv_norm(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]);   // = 1 / max(|.|, 1e-12)
             const float VoH = fminf(1.f, fmaxf(1e-6f, (V[0] * H[0] + V[1] * H[1] + V[2] * H[2]) * ih));
             f.frac0 = 0.04f + (1.f - 0.04f) * __builtin_amdgcn_exp2f((-5.55473f * VoH - 6.98316f) * VoH);
             EnvTap t;
@@ -595,8 +631,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
             const float ndi = fmaxf(c.nraw[0] * r.d[0] + c.nraw[1] * r.d[1] + c.nraw[2] * r.d[2], 0.f);
             const float nl = (c.Nh[0] * r.d[0] + c.Nh[1] * r.d[1] + c.Nh[2] * r.d[2]) * r.il;     // Nh . L
             const float NoL = fminf(1.f, fmaxf(1e-6f, nl));
-            const float NoH = fminf(1.f, fmaxf(1e-6f, (nl + c.NoV_raw) * 0.5f * r.ih));           // Nh . H,  H = (L + V) / 2 * ih
+            const float nohr = (nl + c.NoV_raw) * 0.5f * r.ih;                                      // Nh . H,  H = (L + V) / 2 * ih
+#if SHADE_PRECISE >= 2
+            // 1 - (Nh . H)^2 = |H - (Nh . H) Nh|^2 with 2 H / ih = d il + V (see ggx_nom0)
+            const float nohu = nl + c.NoV_raw;
+            const float px = fmaf(-nohu, c.Nh[0], fmaf(r.d[0], r.il, V[0])), py = fmaf(-nohu, c.Nh[1], fmaf(r.d[1], r.il, V[1])),
+                        pz = fmaf(-nohu, c.Nh[2], fmaf(r.d[2], r.il, V[2]));
+            const float hs = 0.5f * r.ih;
+            const float s2 = fminf((px * px + py * py + pz * pz) * (hs * hs), 1.f);
+            const float nom0 = nohr >= 1e-6f ? fmaf(s2, -a2m1, c.a2) : 1e-12f * a2m1 + 1.f;
+#else
+            const float NoH = fminf(1.f, fmaxf(1e-6f, nohr));
             const float nom0 = NoH * NoH * a2m1 + 1.f;
+#endif
             const float nom = fminf(4.f * kPi, fmaxf(1e-6f, 4.f * kPi * nom0 * nom0 * c.nom1 * (NoL * omk + c.kk)));
             const float fs = r.frac0 * c.a2 * __builtin_amdgcn_rcpf(nom);
 #pragma unroll
@@ -633,7 +680,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             const float ad = Ad[ch], al = Al[ch], bd = Bd[ch], bl = Bl[ch];
-            const float v1 = ad + al, v2 = bd + bl, v3 = c.fd[ch] * ad + bd, v4 = c.fd[ch] * al + bl, v0 = v3 + v4;
+            const float fd = sIn[q * FQ_IN + ch * 4 + k] * kInvPi;   // (= c.fd[ch], not held across the sample loop)
+            const float v1 = ad + al, v2 = bd + bl, v3 = fd * ad + bd, v4 = fd * al + bl, v0 = v3 + v4;
             so[0 + ch * 4 + k] = v0 * inv_ns; so[12 + ch * 4 + k] = v1 * inv_ns; so[24 + ch * 4 + k] = v2 * inv_ns;
             so[36 + ch * 4 + k] = v3 * inv_ns; so[48 + ch * 4 + k] = v4 * inv_ns;
         }
@@ -687,6 +735,8 @@ struct ShadeBwdArgs {
     const float* g_red;          // may be null when g_feat / g_vfeat carry the upstream gradient
     const float *g_feat, *g_vfeat;  // optional: gradients w.r.t. the packed features [P,S] / vfeatures [P,VS]
     float *d_base, *d_rough, *d_normals, *d_radiance, *d_envtab;  // d_envtab: gradient w.r.t. the f(env) table
+    int zero_rest;   // subset launches: the waves also zero-fill the gradient rows of the surfels OUTSIDE the subset (a few rows per processed
+                     // surfel: stores nobody waits for, in a kernel that is bound by instruction issue)
 };
 
 // ---- backward sample record (BREC = 20 floats = five float4, written and read with 128-bit LDS instructions):
@@ -714,10 +764,10 @@ constexpr int KB_G = SHADE_KB_G, KREC = 52;   // Gaussians prepared per batch; f
 __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const RawSample& x, int lane, const float* V,
                                               float* __restrict__ sS) {
     const float* d = x.d;
-    const float il = fminf(__builtin_amdgcn_rsqf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+    const float il = inv_norm(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // = 1 / max(|.|, 1e-12)
     const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
     float H[3] = {(L[0] + V[0]) * 0.5f, (L[1] + V[1]) * 0.5f, (L[2] + V[2]) * 0.5f};
-    const float ih = fminf(__builtin_amdgcn_rsqf(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+    const float ih = inv_norm(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]);   // = 1 / max(|.|, 1e-12)
     H[0] *= ih; H[1] *= ih; H[2] *= ih;
     const float VoH = fminf(1.f, fmaxf(1e-6f, V[0] * H[0] + V[1] * H[1] + V[2] * H[2]));
     const float frac0 = 0.04f + (1.f - 0.04f) * __builtin_amdgcn_exp2f((-5.55473f * VoH - 6.98316f) * VoH);
@@ -818,6 +868,19 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 
     const bool tr = p.training != 0;
     const int nvf = tr ? 52 : 64, nf = tr ? 4 : 7;
+    // zero rows of the partition's back (see ShadeBwdArgs::zero_rest): this wave's share is every gstep-th of them
+    const uint32_t nrest = (sub && a.zero_rest) ? (uint32_t)(p.P - P) : 0u;
+    uint32_t zj = (uint32_t)g;
+    const int zquota = (int)((nrest / (uint32_t)gstep + 1u) / (uint32_t)max(1, P / gstep) + 1u);   // rows per processed surfel
+    auto zero_rows = [&](int n) {
+        for (int i = 0; i < n && zj < nrest; i++, zj += (uint32_t)gstep) {
+            const size_t gz = (size_t)sub[(uint32_t)p.P - 1u - zj];
+            if (lane < 12) { a.d_base[gz * 12 + lane] = 0.f; a.d_normals[gz * 12 + lane] = 0.f; }
+            if (lane < 4) a.d_rough[gz * 4 + lane] = 0.f;
+            float* row = a.d_radiance + gz * (size_t)(3 * Ns);
+            for (int e = lane; e < 3 * Ns; e += 64) row[e] = 0.f;
+        }
+    };
     DEV_TRACE_DECL();
     [[maybe_unused]] unsigned dev_n = 0;
     RawSample raw;
@@ -834,7 +897,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         const size_t gg = sid(gj);
         float V[3] = {p.viewdirs[gg * 3], p.viewdirs[gg * 3 + 1], p.viewdirs[gg * 3 + 2]};
         {
-            const float iv = fminf(__builtin_amdgcn_rsqf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]), 1e12f);   // = 1 / max(|.|, 1e-12)
+            const float iv = inv_norm(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);   // = 1 / max(|.|, 1e-12)
             V[0] *= iv; V[1] *= iv; V[2] *= iv;
         }
         GaussConst c;
@@ -907,6 +970,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         g = gb + jb * gstep;
         if (g >= P) break;
         const size_t gg = sid(g);
+        zero_rows(zquota);
         float V[3], kAd[3], kAl[3], kBd[3], kBl[3], qd[3], ql[3], gmig[3], dir_b[3], dir_n[3], dir_r, grad_const;
         GaussConst c;
         {
@@ -958,7 +1022,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                 const float NoLr = c.Nh[0] * Lv[0] + c.Nh[1] * Lv[1] + c.Nh[2] * Lv[2];
                 const float NoHr = c.Nh[0] * r[4] + c.Nh[1] * r[5] + c.Nh[2] * r[6];
                 const float NoL = fminf(1.f, fmaxf(1e-6f, NoLr)), NoH = fminf(1.f, fmaxf(1e-6f, NoHr));
-                const float nom0 = NoH * NoH * (c.a2 - 1.f) + 1.f;
+                const float nom0 = ggx_nom0(c.Nh, r + 4, c.a2);   // (the VALUE; its derivative below is the literal form's)
                 const float nom2 = NoL * (1.f - c.kk) + c.kk;
                 const float nomr = 4.f * kPi * nom0 * nom0 * c.nom1 * nom2;
                 const float nom = fminf(4.f * kPi, fmaxf(1e-6f, nomr));
@@ -1071,6 +1135,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         DEV_TRACE_MARK(3);   // row stores + per-Gaussian chain rule and stores
     }
     }
+    zero_rows(0x7fffffff);   // (what is left of this wave's share: waves with few or no surfels of their own)
     DEV_TRACE_END(0, dev_n, (unsigned)Ns, 0u);
     __syncthreads();
     if (env_in_lds) {
@@ -1174,14 +1239,11 @@ int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dred
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
     launch_shade_prologue(p, env_grad_work, ntex, s);
-    if (p->subset && !rows_precleared) {   // the rows of the surfels outside the subset: zero (every output is written completely)
-        float* const t[4] = {dL_dbase_color, dL_droughness, dL_dnormals, dL_dradiance};
-        const int w[4] = {12, 4, 12, 3 * p->Ns};
-        launch_zero_rows(p->P, p->subset, p->subset_count, t, w, 4, s);
-    }
+
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
+    a.zero_rest = (p->subset && !rows_precleared) ? 1 : 0;   // (every output is written completely: rows outside the subset are zero)
     const size_t per_wave = (size_t)(64 * BREC + 4 * KB_G * KREC) * 4;
     size_t lds = BWAVES * per_wave;
     int env_in_lds = 0;

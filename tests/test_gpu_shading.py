@@ -1,10 +1,13 @@
 """GPU parity of the fused shading kernels (csrc/shade.hip) against the shading oracle and the reference-generated
 fixtures (tests/golden/shading.npz).
 
-Tolerance: 1e-4 relative to the tensor scale (fp32 kernel vs fp64 oracle) for roughness >= 0.3.  For glossy corners
-(the reference's range goes down to roughness 0.09, alpha^2 = 6.6e-5) the GGX denominator NoH^2 (a2 - 1) + 1 cancels
-catastrophically in fp32 -- in the reference's own fp32 PyTorch code just as here -- so those cases are compared at
-2e-3 (forward) / 5e-3 (gradients), which is the size of the fp32-vs-fp64 gap of the oracle itself."""
+Tolerance: 1e-4 relative to the tensor scale (fp32 kernel vs fp64 oracle) for roughness >= 0.3 on the synthetic cases.  The fixture
+cases -- the reference's own `rendering_equation4` run on CPU in fp64 AND in fp32 (scripts/make_golden.py), roughness over the
+reference's whole range 0.09 .. 0.99, fixture `c` with a third of the corners at 0.09 .. 0.15 where the GGX denominator
+NoH^2 (a2 - 1) + 1 cancels in fp32 -- are budgeted against what the reference's own fp32 arithmetic loses: per tensor,
+err(HIP vs reference fp64) <= 1.5 x err(reference fp32 vs reference fp64) + 1e-4 (errors = max abs / tensor scale), forward and
+gradients.  (Rounds 1-4 used flat 2e-3 / 5e-3 here and only asserted that the reference's fp32 was that far off too; measured, it is
+8e-6 .. 3.5e-4.)"""
 import os
 
 import numpy as np
@@ -30,6 +33,19 @@ def _close(name, a, b, tol=1e-4):
     assert err <= tol * scale + 1e-7, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
 
 
+def _err(a, b):
+    a = a.detach().double().cpu().reshape(-1)
+    b = (b if torch.is_tensor(b) else torch.from_numpy(np.asarray(b))).detach().double().cpu().reshape(-1)
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _within_budget(name, hip, ref64, ref32, factor=1.5, floor=1e-4):
+    """err(HIP vs reference fp64) <= factor * err(reference fp32 vs reference fp64) + floor; returns the budget used."""
+    e_hip, e_ref = _err(hip, ref64), _err(ref32, ref64)
+    assert e_hip <= factor * e_ref + floor, f"{name}: HIP err {e_hip:.3e} > {factor} x reference-fp32 err {e_ref:.3e} + {floor:.0e}"
+    return factor * e_ref + floor
+
+
 def _fixture(tag):
     g = np.load(GOLD)
     pre = "shade_" + tag + "_"
@@ -50,29 +66,31 @@ def _random_case(n, Ns, seed, He=32, We=64, rough_lo=0.09):
         radiance=(0.2 * rnd(n, Ns, 3)).abs(), env=3.0 * torch.rand(1, He, We, 3, generator=g, dtype=torch.float64))
 
 
-@pytest.mark.parametrize("case", ["fix_a", "fix_b", "rand64", "rand384", "glossy64"])
+@pytest.mark.parametrize("case", ["fix_a", "fix_b", "fix_c", "rand64", "rand384"])
 def test_shading_forward_and_packing(built, case):
     from gaussian_renderer import shading
     dev = torch.device("cuda:0")
-    if case.startswith("fix"):
-        d = _fixture(case[-1])
-    else:
-        d = _random_case(500, 384 if case == "rand384" else 64, 7, rough_lo=0.09 if case == "glossy64" else 0.3)
-    ftol = 1e-4 if case in ("rand64", "rand384") else 2e-3
+    fix = case.startswith("fix")
+    d = _fixture(case[-1]) if fix else _random_case(500, 384 if case == "rand384" else 64, 7, rough_lo=0.3)
+    ftol = 1e-4
     ref = so.shade(d["base"], d["rough"], d["normals"], d["viewdirs"], d["radiance"], d["vis"], d["dirs"], d["areas"], d["env"])
     f32 = {k: v.float().to(dev) for k, v in d.items() if k in ("base", "rough", "normals", "viewdirs", "radiance", "vis", "dirs", "areas", "env")}
     with torch.no_grad():
         pbr, ex = shading.rendering_equation4(f32["base"], f32["rough"], f32["normals"], f32["viewdirs"], f32["radiance"],
                                               _Light(f32["env"]), visibility_precompute=f32["vis"],
                                               incident_dirs_precompute=f32["dirs"], incident_areas_precompute=f32["areas"])
-    _close("pbr", pbr, ref["pbr"], tol=ftol)
-    for k in ("diffuse_light", "specular", "direct", "indirect"):
-        _close(k, ex[k], ref[k], tol=ftol)
-    _close("mean_incident", ex["incident_lights"].mean(-2), ref["mean_incident"])
-    _close("mean_global", ex["global_incident_lights"].mean(-2), ref["mean_global"])
-    if case.startswith("fix"):   # and directly against the reference's own outputs
-        _close("pbr_vs_reference", pbr, d["pbr"], tol=ftol)
-        _close("direct_vs_reference", ex["direct"], d["direct"], tol=ftol)
+    if fix:   # against the reference's own outputs, within what its own fp32 arithmetic loses (see the module docstring)
+        got = dict(pbr=pbr, mean_incident=ex["incident_lights"].mean(-2), mean_global=ex["global_incident_lights"].mean(-2),
+                   **{k: ex[k] for k in ("diffuse_light", "specular", "direct", "indirect")})
+        ftol = max(_within_budget(k, v, d[k], d["f32_" + k]) for k, v in got.items())
+        for k, v in got.items():   # (and the oracle restates the reference: fp64 vs fp64)
+            assert _err(ref[k], d[k]) < 1e-9, k
+    else:
+        _close("pbr", pbr, ref["pbr"], tol=ftol)
+        for k in ("diffuse_light", "specular", "direct", "indirect"):
+            _close(k, ex[k], ref[k], tol=ftol)
+        _close("mean_incident", ex["incident_lights"].mean(-2), ref["mean_incident"])
+        _close("mean_global", ex["global_incident_lights"].mean(-2), ref["mean_global"])
     view = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))[0]
     vm = torch.eye(4, dtype=torch.float64)
     vm[:3, :3] = view
@@ -86,12 +104,32 @@ def test_shading_forward_and_packing(built, case):
         _close("vfeatures", vf, vr, tol=ftol)
 
 
-@pytest.mark.parametrize("case", ["fix_a", "fix_b", "rand64"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_shading_backward_within_the_reference_fp32_budget(built, tag):
+    """Gradients of the fixture's loss (the reference's autograd in fp64 = g_*, in fp32 = f32_g_*) through the HIP kernels."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _fixture(tag)
+    names = ("base", "rough", "normals", "radiance", "env")
+    lg = {k: d[k].float().to(dev).requires_grad_(True) for k in names}
+    c = {k: d[k].float().to(dev) for k in ("viewdirs", "vis", "dirs", "areas")}
+    pbr, ex = shading.rendering_equation4(lg["base"], lg["rough"], lg["normals"], c["viewdirs"], lg["radiance"], _Light(lg["env"]),
+                                          visibility_precompute=c["vis"], incident_dirs_precompute=c["dirs"],
+                                          incident_areas_precompute=c["areas"])
+    w = lambda k: d[k].float().to(dev)  # noqa: E731
+    loss = (pbr * w("w_pbr")).sum() + sum((ex[k] * w("w_" + k)).sum() for k in ("diffuse_light", "specular", "direct", "indirect")) \
+        + (ex["incident_lights"].mean(-2) * w("w_inc")).sum() + (ex["global_incident_lights"].mean(-2) * w("w_glob")).sum()
+    loss.backward()
+    for k in names:
+        _within_budget("grad_" + k, lg[k].grad, d["g_" + k], d["f32_g_" + k])
+
+
+@pytest.mark.parametrize("case", ["rand64"])
 def test_shading_backward(built, case):
     from gaussian_renderer import shading
     dev = torch.device("cuda:0")
-    d = _fixture(case[-1]) if case.startswith("fix") else _random_case(300, 64, 11, rough_lo=0.3)
-    gtol = 5e-3 if case.startswith("fix") else 3e-4
+    d = _random_case(300, 64, 11, rough_lo=0.3)
+    gtol = 3e-4
     names = ("base", "rough", "normals", "radiance", "env")
     lo = {k: d[k].clone().requires_grad_(True) for k in names}
     ref = so.shade(lo["base"], lo["rough"], lo["normals"], d["viewdirs"], lo["radiance"], d["vis"], d["dirs"], d["areas"], lo["env"])
