@@ -82,12 +82,14 @@ class TrainStep:
             e.record()
             self.marks.append((name, e))
 
-    def step(self):
+    def step(self, offsets=None, keep_grads=False):
+        """One iteration.  `offsets` [P]: the random azimuths of this iteration's incident lattices (drawn here when None);
+        keep_grads: leave the parameters' .grad in place behind the optimizer step (tests)."""
         p, st = self.params, self.st
         self._mark("begin")
         campos = st.campos
         viewdirs = torch.nn.functional.normalize(campos[None, :] - p["xyz"].detach(), dim=-1)
-        offs = torch.rand(self.P, device=self.dev) * (2 * math.pi)          # sample_incident_rays(training): random azimuths
+        offs = torch.rand(self.P, device=self.dev) * (2 * math.pi) if offsets is None else offsets   # sample_incident_rays(training): random azimuths
         lattice = self.shading.FibonacciLattice(self.geo_n, self.Ns, offs)
         self.last_offsets = offs
         means2D = torch.zeros_like(p["xyz"], requires_grad=True)
@@ -111,7 +113,8 @@ class TrainStep:
         self._mark("backward")
         self.optim.add_densification_stats(means2D.grad, res["visibility_filter"], res["weights"], self.weights_accum,
                                            self.xyz_gradient_accum, self.denom)
-        self.optimizer.step(nan_values=self.nan_values, zero_grad=True)
+        self.last = dict(means2D_grad=means2D.grad, visibility_filter=res["visibility_filter"], weights=res["weights"])
+        self.optimizer.step(nan_values=self.nan_values, zero_grad=not keep_grads)
         self._mark("stats_adam")
         return int(rendered[0]), res["pbr"], loss
 

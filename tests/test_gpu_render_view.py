@@ -31,7 +31,6 @@ def test_svgss_view_end_to_end(built, is_training):
                               scale_hi=0.07)
     P = sc["means3D"].shape[0]
     d = shade_inputs.make(P, 32, seed=4)
-    d["roughness"] = d["roughness"].clamp_min(0.3)
     # ---- GPU ----
     sct = runner.to_torch(sc, dev)
     mat = {k: v.to(dev) for k, v in d.items() if k != "env"}
