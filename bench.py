@@ -167,6 +167,25 @@ def visible_gpu_count():
     return n
 
 
+def pin_rank_to_cores(local, world):
+    """One process per GPU: rank r keeps to its own slice of the host cores (the host side of a view is a Python thread that launches
+    ~25 kernels and polls pinned memory for the instance count for up to 50 ms; eight such ranks that share cores -- or migrate across
+    NUMA nodes -- delay each other's launches).  Cores = the affinity mask this process inherited (a container's cpuset), split evenly
+    in order; SVGIR_NO_AFFINITY=1 leaves the scheduler alone.  Returns the sorted list of cores, [] when nothing was pinned."""
+    if world <= 1 or os.environ.get("SVGIR_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return []
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // world
+    if per < 1:
+        return []
+    mine = cores[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return []
+    return mine
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without torchrun: start N fresh rank processes.  Nothing in this process touches the
     GPU or the HIP runtime (no torch import): the children are plain child processes, never an exec of a GPU process."""
@@ -833,6 +852,7 @@ def main():
     import numpy as np
     import torch
     from svgir_harness import view_parallel as vp
+    cores = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
     rank, world, local = vp.init_from_env(backend="gloo" if args.dry_run else None)
     if world != max(1, args.gpus):
         print(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
@@ -847,13 +867,15 @@ def main():
             return 100 + rank, tok * 2.0, tok + 1.0
 
         regions, R, stage, table = timed(None, args, world, dev, dry=dry_step)
+        core_tab = vp.gather_rows(torch.tensor([float(len(cores)), float(cores[0]) if cores else -1.0, float(cores[-1]) if cores else -1.0]))
         if rank == 0:
             med = float(np.median(regions))
             print(json.dumps({"metric": "dry-run (no GPU work)", "value": world * args.steps / med, "unit": "steps/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "repeats": len(regions), "ms_per_step": med / args.steps * 1e3,
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": name + " (dry run)", "views_per_step": world},
-                              "per_rank_R": [int(r[2]) for r in table]}))
+                              "per_rank_R": [int(r[2]) for r in table],
+                              "per_rank_cpus": [list(range(int(c[1]), int(c[2]) + 1)) if c[0] > 0 else [] for c in core_tab]}))
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -891,6 +913,7 @@ def main():
                                    f"(BASELINE.json configs[1] = cfg2 at N=1; configs[3] = cfg4, view r on rank r, at N>1)",
                        "num_rendered": int(R), "views_per_step": world, "parallelism": f"view-parallel x{world}",
                        "per_rank_num_rendered": [int(r[2]) for r in table],
+                       "per_rank_cpus": "pinned: cores split evenly over the ranks (bench.py pin_rank_to_cores)" if cores else "not pinned",
                        "per_rank_device": [{"rank": i, "ordinal": int(r[0]), "pci": "%04x:%02x:%02x" % (int(r[1]) & 0xffff, int(r[2]) & 0xff, int(r[3]) & 0xff)}
                                            for i, r in enumerate(ids)]},
             "roofline": roofline_of(wl, R, stage, name),

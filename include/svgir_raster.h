@@ -86,6 +86,9 @@ typedef struct svgir_params {
                                        binning of the same view.  Must stay alive until svgir_forward returns; ignored by
                                        svgir_backward.  (ABI 9: replaces the thread-local svgir_forward_wait_features of
                                        ABI 8 -- no state survives between calls.) */
+    int32_t forward_only;           /* != 0 (ABI 12): no backward will follow (evaluation loops).  The composite keeps no blend states for
+                                       the backward's depth segments -- nothing is dumped, the binning blob holds no state slots.  A
+                                       svgir_backward on such a forward still works: it replays the composite once to produce them. */
     const svgir_fused_shade* shade; /* optional (svgss, ABI 12): the per-splat shading of this view, run INSIDE svgir_forward /
                                        svgir_backward for the surfels the view's composite actually reads (see svgir_fused_shade);
                                        `features` / `vfeatures` are then OUTPUT buffers of svgir_forward.  NULL: the caller shaded. */
@@ -180,6 +183,22 @@ int svgir_forward(const svgir_params* p, const svgir_outputs* o,
                   svgir_alloc_fn binning, void* binning_ctx,
                   svgir_alloc_fn image, void* image_ctx,
                   void* stream);
+
+/* Several views in flight from ONE host thread (ABI 12).  Every view is begun -- validated, its blobs allocated, ALL of its kernels
+ * launched on its stream, the count-dependent ones speculatively -- before the first view's instance count is awaited.  Views on distinct
+ * streams overlap on the GPU (a single 800 x 800 view leaves the SIMDs under-occupied: two views in flight render 1.3x the surfels per
+ * second); the results are bit-identical to `count` svgir_forward calls.  num_rendered receives each view's R or its negative status;
+ * the return value is 0 or the first error.  The reference has no counterpart (its forward blocks on a cudaMemcpy per view,
+ * rasterizer_impl.cu:307-312; eval_relighting_tensoIR.py:303-378 renders its views one after the other). */
+typedef struct svgir_view_call {
+    const svgir_params* params; const svgir_outputs* outputs;
+    svgir_alloc_fn geom; void* geom_ctx;
+    svgir_alloc_fn binning; void* binning_ctx;
+    svgir_alloc_fn image; void* image_ctx;
+    void* stream;
+    int32_t num_rendered;   /* out */
+} svgir_view_call;
+int svgir_forward_batch(svgir_view_call* views, int32_t count);
 
 /* What the speculative launches of svgir_forward did so far in this process (monitoring / tests; ABI 11):
  * out5 = {forwards, views re-run because the instance capacity guessed from the previous views was too small, views whose blend states

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -503,48 +504,33 @@ int svgir_last_timings(const char** names, float* avg_ms, int* counts, int cap) 
     return n;
 }
 
-static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
-                        svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream, bool key_spec);
+// One svgir_forward, in two halves: begin() validates, allocates and launches EVERYTHING -- the count-dependent stages speculatively, for
+// capacities guessed from the workload's recent views -- without waiting for the GPU; finish() waits for the instance count (it only
+// confirms the guess, or re-runs the dependent stages) and returns it.  svgir_forward is begin() + finish(); svgir_forward_batch begins all
+// its views before it finishes the first, so that ONE host thread keeps several views in flight (on as many streams).
+struct ForwardCall {
+    const svgir_params* p; const svgir_outputs* o;
+    svgir_alloc_fn geom, binning, image; void *geom_ctx, *binning_ctx, *image_ctx;
+    hipStream_t s; bool key_spec;
+    // set by begin()
+    int P = 0, W = 0, H = 0, gx = 0, gy = 0, T = 0, nstate = 0, fin = 0, spec_top = -1, cap = 0;
+    size_t N = 0;
+    bool svgss = false, shade_subset = false, prepass = false, done = false;
+    CfgRef cfg{}; float focal_x = 0.f, focal_y = 0.f;
+    char *gblob = nullptr, *iblob = nullptr, *bblob = nullptr;
+    GeomLayout G{}; ImageLayout I{}; TileSortPlan plan{};
+    CapKey ckey{}; const uint32_t* depth_order = nullptr; long long cap_slots = -1;
+    hipEvent_t features_ready = nullptr;
+    PinnedSlot R_pin; unsigned long long* R_slot = nullptr; uint32_t R_tag = 0;
+    const uint32_t* prefilter_violation = nullptr;
+    StageTimer tm;
 
-int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
-                  svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream) {
-    return forward_impl(p, o, geom, geom_ctx, binning, binning_ctx, image, image_ctx, stream, true);
-}
+    ForwardCall(const svgir_params* p_, const svgir_outputs* o_, svgir_alloc_fn geom_, void* geom_ctx_, svgir_alloc_fn binning_,
+                void* binning_ctx_, svgir_alloc_fn image_, void* image_ctx_, void* stream, bool key_spec_)
+        : p(p_), o(o_), geom(geom_), binning(binning_), image(image_), geom_ctx(geom_ctx_), binning_ctx(binning_ctx_), image_ctx(image_ctx_),
+          s((hipStream_t)stream), key_spec(key_spec_), tm((hipStream_t)stream) {}
 
-static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
-                        svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream, bool key_spec) {
-    if (int rc = validate(p, true)) return rc;
-    // features / vfeatures may still be in production on another stream (the shading kernels do not depend on the binning and
-    // the binning does not read them): only the composite kernel waits for the caller's event
-    const hipEvent_t features_ready = (hipEvent_t)p->features_ready;
-    if (!o || !geom || !binning || !image) return fail(SVGIR_ERR_INVALID, "outputs / allocators must be provided");
-    hipStream_t s = (hipStream_t)stream;
-    const int P = p->P, W = p->W, H = p->H;
-    const size_t N = (size_t)W * H;
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
-    const bool svgss = p->variant == SVGIR_SVGSS;
-    const CfgRef cfg = cfg_ref(p);
-    if (P == 0) {  // rasterize_points.cu:100: nothing runs, outputs stay zero
-        HIP_OK(hipMemsetAsync(o->out_color, 0, 3 * N * 4, s));
-        HIP_OK(hipMemsetAsync(o->out_normal, 0, 3 * N * 4, s));
-        HIP_OK(hipMemsetAsync(o->out_depth, 0, N * 4, s));
-        HIP_OK(hipMemsetAsync(o->out_opacity, 0, N * 4, s));
-        if (p->S) HIP_OK(hipMemsetAsync(o->out_feature, 0, (size_t)p->S * N * 4, s));
-        if (svgss && p->VS) HIP_OK(hipMemsetAsync(o->out_vfeature, 0, (size_t)(p->VS / 4) * N * 4, s));
-        if (!svgss && o->out_pseudo_normal) HIP_OK(hipMemsetAsync(o->out_pseudo_normal, 0, 3 * N * 4, s));
-        if (!svgss && o->out_surface_xyz) HIP_OK(hipMemsetAsync(o->out_surface_xyz, 0, 3 * N * 4, s));
-        return 0;
-    }
-    const float focal_y = H / (2.0f * p->tan_fovy), focal_x = W / (2.0f * p->tan_fovx);
-
-    char* gblob = geom(geom_layout(nullptr, P).bytes, geom_ctx);
-    char* iblob = image(image_layout(nullptr, W, H).bytes, image_ctx);
-    if (!gblob || !iblob) return fail(SVGIR_ERR_ALLOC, "geometry/image blob allocation failed");
-    const GeomLayout G = geom_layout(gblob, P);
-    const ImageLayout I = image_layout(iblob, W, H);
-
-    StageTimer tm(s);
-    auto check = [&](const char* what) -> int {
+    int check(const char* what) {
         if (!p->debug) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
@@ -554,66 +540,12 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         return 0;
-    };
-
-    PreArgs pa;
-    pa.P = P; pa.D = p->D; pa.M = p->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
-    pa.means3D = p->means3D; pa.shs = p->colors_precomp ? nullptr : p->shs; pa.colors_precomp = p->colors_precomp;
-    pa.opacities = p->opacities; pa.scales = p->scales; pa.rotations = p->rotations; pa.cov3D_precomp = p->cov3D_precomp;
-    pa.view = p->viewmatrix; pa.proj = p->projmatrix; pa.campos = p->cam_pos; pa.patchbbox = p->patchbbox;
-    pa.scale_modifier = p->scale_modifier; pa.tanx = p->tan_fovx; pa.tany = p->tan_fovy;
-    pa.focal_x = focal_x; pa.focal_y = focal_y; pa.cfg = cfg;
-    pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
-    pa.radii = o->radii;
-    pa.out_weights = o->out_weights;
-    const bool shade_subset = p->shade && !p->shade->all_surfels;   // shade the view's working set only (subset.hip)
-    // With many incident samples per surfel (evaluation: 384) shading a surfel costs far more than compositing it, and a geometry-only
-    // pass of the composite (the alpha / transmittance chain of the very same arithmetic: no channels, no outputs) first finds the surfels
-    // that actually receive a blend weight -- 29 % at cfg3, 13 % at cfg5 -- for ~40 % of the full composite's time.  Otherwise the
-    // working set is every surfel that touches a tile (44 % on the BASELINE scenes: the preprocess culls), which costs nothing to find:
-    // the depth order holds them in front, and the offsets scan reports where they end.
-    const bool prepass = shade_subset && shade_prepass(p->shade->sp.Ns);
-    pa.needed = prepass ? G.needed : nullptr;
-    pa.span = G.counters + 3;
-    pa.zero_words = radix_gtot(G.radix_tbl, P); pa.n_zero_words = (int)radix_gtot_words(P);
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
-    static const bool key_spec_env = getenv("SVGIR_NO_KEY_SPEC") == nullptr;
-    const int spec_top = (key_spec && key_spec_env) ? guess_top(ckey) : -1;
-    pa.spec_top = spec_top; pa.key_top = G.key_top;
-    pa.prefilter_violation = nullptr;
-    if (p->prefiltered) {   // the violation flag sits next to the instance counter and is read back with it
-        HIP_OK(hipMemsetAsync(G.counters, 0, 16, s));
-        pa.prefilter_violation = G.counters + 1;
     }
-    launch_preprocess(pa, svgss, s);
-    if (int rc = check("preprocess")) return rc;
-    tm.mark("preprocess");
 
-    // depth sort of the P Gaussians: 4 x 8-bit stable passes (ends in slot 0), or 3 when the top byte is speculated to be common (slot 1)
-    const int depth_bits = spec_top >= 0 ? 24 : 32;
-    const uint32_t* depth_order = G.idx[(depth_bits / 8) & 1];
-    launch_radix_sort(G.key, G.idx, P, nullptr, depth_bits, 8, G.radix_tbl, s);
-    if (int rc = check("depth sort")) return rc;
-    tm.mark("sort_depth");
-
-    const PinnedSlot R_pin;   // (released when this forward returns)
-    unsigned long long* const R_slot = R_pin.at;
-    const uint32_t R_tag = R_pin.tag;
-    launch_offsets_scan(G.tiles, depth_order, G.offsets, G.scan_tmp, P, G.counters, G.key_top, (P + 63) / 64, pa.prefilter_violation,
-                        R_slot, R_tag, s);
-    if (int rc = check("offsets scan")) return rc;
-    tm.mark("scan");
-
-    const int nstate = seg_nstate(p->S, svgss ? p->VS : 0);
-    const TileSortPlan plan = tile_sort_plan(T);
-    const int fin = plan.passes & 1;
-
-    // Everything from here on depends on the instance count R that the GPU is still computing.  The stages are
-    // launched for an instance CAPACITY `cap` and read R on the device (min(cap, R)); the binning blob is laid out
-    // for `cap`.  `timed`: stage marks are only recorded for the launch sequence that counts.
-    auto run_binning_and_render = [&](char* bblob, int cap, long long cap_slots, bool timed) -> int {
+    // Everything behind the offsets scan depends on the instance count R that the GPU is still computing.  The stages are launched for an
+    // instance CAPACITY `cap` and read R on the device (min(cap, R)); the binning blob is laid out for `cap`.  `timed`: stage marks are
+    // only recorded for the launch sequence that counts.
+    int run_binning_and_render(char* bblob, int cap, long long cap_slots, bool timed) {
         const BinLayout B = bin_layout(bblob, cap, T, nstate, cap_slots);
         launch_emit(P, depth_order, G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
                     I.counters, B.radix_tbl, s);
@@ -688,96 +620,225 @@ static int forward_impl(const svgir_params* p, const svgir_outputs* o, svgir_all
         if (timed) tm.mark("render");
         // (the list of live backward segments is built by svgir_backward, next to its clears: a forward-only call never pays for it)
         return 0;
-    };
-
-    // Speculative launch: capacities from this workload's recent views (+12.5 %) -- instances (binning arrays) and state slots
-    // (seg_state) -- no host round trip in between.  The first view of a workload gets the exact instance capacity and the worst-case
-    // slot count (4 full lists per tile); later ones typically a third of that.
-    int cap = 0;
-    long long cap_slots = -1;
-    char* bblob = nullptr;
-    {   // the previous view of this workload: its slot total, if the backward has not recorded it already (forward-only loops)
-        const void* prev = nullptr;
-        { std::lock_guard<std::mutex> lk(g_cap_mu); if (const CapEntry* e = cap_entry(ckey, false)) prev = e->last_view; }
-        note_view_slots(ckey, prev, 2);
-    }
-    if (const int guess = guess_R(ckey)) {
-        cap = binning_capacity((long long)guess + guess / 8 + 1024);
-        const long long gs = guess_slots(ckey);
-        cap_slots = gs < 0 ? -1 : std::min<long long>(gs + gs / 8 + 64, (long long)seg_capacity(cap, T));
-        bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
-        // (a failed speculative allocation is not an error: the guess may be far larger than this view needs; fall
-        // through to the exact-size path below)
-        if (bblob) {
-            if (int rc = run_binning_and_render(bblob, cap, cap_slots, true)) return rc;
-        } else {
-            cap = 0;
-        }
-    }
-    // the instance count (only: the speculative stages keep running)
-    uint32_t R_host = 0, R_aux = 0;
-    bool have_R = R_slot && pinned_spin(R_slot, R_tag, &R_host, &R_aux);
-    if (!have_R) {
-        // The count is further away than the spin budget -- a backlog in front of this forward on the stream (the reference's call order
-        // puts update_visibility / update_radiace, seconds of work, right before a render), a shared GPU, a serialising profiler -- or no
-        // landing slot was free.  Like the reference (rasterizer_impl.cu:307-312: a cudaMemcpy without a deadline): block, then look again;
-        // a slow stream is not an error.
-        const hipError_t e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "the forward failed on the device: %s", hipGetErrorString(e));
-        have_R = R_slot && tagged_pair(R_slot, R_tag, &R_host, &R_aux);
-        if (!have_R) {   // the counters' device copy (same three words)
-            uint32_t w[3] = {0, 0, 0};
-            HIP_OK(hipMemcpy(w, G.counters, 12, hipMemcpyDeviceToHost));
-            R_host = w[0]; R_aux = ((p->prefiltered && w[1]) ? 1u << 16 : 0u) | (w[2] & 0xffffu);
-        }
-    }
-    if (p->prefiltered && (R_aux >> 16) != 0u) {
-        (void)hipStreamSynchronize(s);
-        return fail(SVGIR_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");   // auxiliary.h:163-167
-    }
-    if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
-    const int R = (int)R_host;
-    {   // the visible depth keys' top bytes: history for the next view; and did this view's speculation hold?
-        const uint32_t summary = R_aux & 0xffffu;
-        if (key_spec) { record_top(ckey, summary); g_spec_stats[0]++; }
-        if (spec_top >= 0) g_spec_stats[4]++;
-        const int av = (int)((summary >> 8) & 0xffu), ov = (int)(summary & 0xffu);
-        if (spec_top >= 0 && !(av == 0xff && ov == 0) && (av != spec_top || ov != spec_top)) {
-            // a visible key outside the speculated byte: the three-pass order is wrong -- run the whole view again, four passes
-            HIP_OK(hipStreamSynchronize(s));
-            g_spec_stats[3]++;
-            return forward_impl(p, o, geom, geom_ctx, binning, binning_ctx, image, image_ctx, stream, false);
-        }
-    }
-    record_R(ckey, R);
-    // (whether the state-slot guess held is the backward's business -- svgir_backward re-dumps the states of a view that exceeded it; the
-    // forward does not wait for the cull.  Measured on the host-bound training step, bench.py --workload train_step: 2.11 ms with
-    // the wait and a re-run here)
-    if (!bblob || R > cap) {
-        // first view, or the scene grew past a guess: (re)do the dependent stages -- exact instance capacity, worst-case state slots
-        const bool redo = bblob != nullptr;
-        if (redo) { HIP_OK(hipStreamSynchronize(s)); g_spec_stats[1]++; }
-        cap = binning_capacity(R);
-        cap_slots = -1;
-        bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
-        if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
-        if (redo && o->out_weights) HIP_OK(hipMemsetAsync(o->out_weights, 0, (size_t)P * 4, s));   // accumulated by atomics
-        if (int rc = run_binning_and_render(bblob, cap, cap_slots, !redo)) return rc;
-    }
-    {
-        std::lock_guard<std::mutex> lk(g_cap_mu);
-        cap_entry(ckey, true)->last_view = iblob;
     }
 
-    if (!svgss && p->computer_pseudo_normal) {
-        launch_image_ops(W, H, p->viewmatrix, focal_x, focal_y, p->cx, p->cy, o->out_opacity, o->out_depth,
-                         o->out_pseudo_normal, o->out_surface_xyz, s);
-        if (int rc = check("image ops")) return rc;
-        tm.mark("image");
+    // returns a negative status, or 0 (launched; finish() must follow), or 1 (nothing to finish: P == 0)
+    int begin() {
+        if (int rc = validate(p, true)) return rc;
+        // features / vfeatures may still be in production on another stream (the shading kernels do not depend on the binning and
+        // the binning does not read them): only the composite kernel waits for the caller's event
+        features_ready = (hipEvent_t)p->features_ready;
+        if (!o || !geom || !binning || !image) return fail(SVGIR_ERR_INVALID, "outputs / allocators must be provided");
+        P = p->P; W = p->W; H = p->H;
+        N = (size_t)W * H;
+        gx = (W + TILE - 1) / TILE; gy = (H + TILE - 1) / TILE; T = gx * gy;
+        svgss = p->variant == SVGIR_SVGSS;
+        cfg = cfg_ref(p);
+        if (P == 0) {  // rasterize_points.cu:100: nothing runs, outputs stay zero
+            HIP_OK(hipMemsetAsync(o->out_color, 0, 3 * N * 4, s));
+            HIP_OK(hipMemsetAsync(o->out_normal, 0, 3 * N * 4, s));
+            HIP_OK(hipMemsetAsync(o->out_depth, 0, N * 4, s));
+            HIP_OK(hipMemsetAsync(o->out_opacity, 0, N * 4, s));
+            if (p->S) HIP_OK(hipMemsetAsync(o->out_feature, 0, (size_t)p->S * N * 4, s));
+            if (svgss && p->VS) HIP_OK(hipMemsetAsync(o->out_vfeature, 0, (size_t)(p->VS / 4) * N * 4, s));
+            if (!svgss && o->out_pseudo_normal) HIP_OK(hipMemsetAsync(o->out_pseudo_normal, 0, 3 * N * 4, s));
+            if (!svgss && o->out_surface_xyz) HIP_OK(hipMemsetAsync(o->out_surface_xyz, 0, 3 * N * 4, s));
+            done = true;
+            return 1;
+        }
+        focal_y = H / (2.0f * p->tan_fovy); focal_x = W / (2.0f * p->tan_fovx);
+        gblob = geom(geom_layout(nullptr, P).bytes, geom_ctx);
+        iblob = image(image_layout(nullptr, W, H).bytes, image_ctx);
+        if (!gblob || !iblob) return fail(SVGIR_ERR_ALLOC, "geometry/image blob allocation failed");
+        G = geom_layout(gblob, P);
+        I = image_layout(iblob, W, H);
+
+        PreArgs pa;
+        pa.P = P; pa.D = p->D; pa.M = p->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
+        pa.means3D = p->means3D; pa.shs = p->colors_precomp ? nullptr : p->shs; pa.colors_precomp = p->colors_precomp;
+        pa.opacities = p->opacities; pa.scales = p->scales; pa.rotations = p->rotations; pa.cov3D_precomp = p->cov3D_precomp;
+        pa.view = p->viewmatrix; pa.proj = p->projmatrix; pa.campos = p->cam_pos; pa.patchbbox = p->patchbbox;
+        pa.scale_modifier = p->scale_modifier; pa.tanx = p->tan_fovx; pa.tany = p->tan_fovy;
+        pa.focal_x = focal_x; pa.focal_y = focal_y; pa.cfg = cfg;
+        pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
+        pa.radii = o->radii;
+        pa.out_weights = o->out_weights;
+        shade_subset = p->shade && !p->shade->all_surfels;   // shade the view's working set only (subset.hip)
+        // With many incident samples per surfel (evaluation: 384) shading a surfel costs far more than compositing it, and a geometry-only
+        // pass of the composite (the alpha / transmittance chain of the very same arithmetic: no channels, no outputs) first finds the surfels
+        // that actually receive a blend weight -- 29 % at cfg3, 13 % at cfg5 -- for ~40 % of the full composite's time.  Otherwise the
+        // working set is every surfel that touches a tile (44 % on the BASELINE scenes: the preprocess culls), which costs nothing to find:
+        // the depth order holds them in front, and the offsets scan reports where they end.
+        prepass = shade_subset && shade_prepass(p->shade->sp.Ns);
+        pa.needed = prepass ? G.needed : nullptr;
+        pa.span = G.counters + 3;
+        pa.zero_words = radix_gtot(G.radix_tbl, P); pa.n_zero_words = (int)radix_gtot_words(P);
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        ckey = CapKey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
+        static const bool key_spec_env = getenv("SVGIR_NO_KEY_SPEC") == nullptr;
+        spec_top = (key_spec && key_spec_env) ? guess_top(ckey) : -1;
+        pa.spec_top = spec_top; pa.key_top = G.key_top;
+        pa.prefilter_violation = nullptr;
+        if (p->prefiltered) {   // the violation flag sits next to the instance counter and is read back with it
+            HIP_OK(hipMemsetAsync(G.counters, 0, 16, s));
+            pa.prefilter_violation = G.counters + 1;
+        }
+        launch_preprocess(pa, svgss, s);
+        if (int rc = check("preprocess")) return rc;
+        tm.mark("preprocess");
+
+        // depth sort of the P Gaussians: 4 x 8-bit stable passes (ends in slot 0), or 3 when the top byte is speculated to be common (slot 1)
+        const int depth_bits = spec_top >= 0 ? 24 : 32;
+        depth_order = G.idx[(depth_bits / 8) & 1];
+        launch_radix_sort(G.key, G.idx, P, nullptr, depth_bits, 8, G.radix_tbl, s);
+        if (int rc = check("depth sort")) return rc;
+        tm.mark("sort_depth");
+
+        R_slot = R_pin.at; R_tag = R_pin.tag;   // (the slot is released when this call object dies)
+        launch_offsets_scan(G.tiles, depth_order, G.offsets, G.scan_tmp, P, G.counters, G.key_top, (P + 63) / 64, pa.prefilter_violation,
+                            R_slot, R_tag, s);
+        if (int rc = check("offsets scan")) return rc;
+        tm.mark("scan");
+
+        prefilter_violation = pa.prefilter_violation;
+        nstate = seg_nstate(p->S, svgss ? p->VS : 0);
+        plan = tile_sort_plan(T);
+        fin = plan.passes & 1;
+
+        // Speculative launch: capacities from this workload's recent views (+12.5 %) -- instances (binning arrays) and state slots
+        // (seg_state) -- no host round trip in between.  The first view of a workload gets the exact instance capacity and the worst-case
+        // slot count (4 full lists per tile); later ones typically a third of that.
+        cap = 0; cap_slots = -1; bblob = nullptr;
+        {   // the previous view of this workload: its slot total, if the backward has not recorded it already (forward-only loops)
+            const void* prev = nullptr;
+            { std::lock_guard<std::mutex> lk(g_cap_mu); if (const CapEntry* e = cap_entry(ckey, false)) prev = e->last_view; }
+            note_view_slots(ckey, prev, 2);
+        }
+        if (const int guess = guess_R(ckey)) {
+            cap = binning_capacity((long long)guess + guess / 8 + 1024);
+            const long long gs = guess_slots(ckey);
+            cap_slots = p->forward_only ? 0 : (gs < 0 ? -1 : std::min<long long>(gs + gs / 8 + 64, (long long)seg_capacity(cap, T)));
+            bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
+            // (a failed speculative allocation is not an error: the guess may be far larger than this view needs; fall
+            // through to the exact-size path below)
+            if (bblob) {
+                if (int rc = run_binning_and_render(bblob, cap, cap_slots, true)) return rc;
+            } else {
+                cap = 0;
+            }
+        }
+        return 0;
     }
-    return R;
+
+    // waits for the instance count, confirms (or repairs) the speculation; returns R or a negative status
+    int finish() {
+        if (done) return 0;
+        done = true;
+        // the instance count (only: the speculative stages keep running)
+        uint32_t R_host = 0, R_aux = 0;
+        bool have_R = R_slot && pinned_spin(R_slot, R_tag, &R_host, &R_aux);
+        if (!have_R) {
+            // The count is further away than the spin budget -- a backlog in front of this forward on the stream (the reference's call order
+            // puts update_visibility / update_radiace, seconds of work, right before a render), a shared GPU, a serialising profiler -- or no
+            // landing slot was free.  Like the reference (rasterizer_impl.cu:307-312: a cudaMemcpy without a deadline): block, then look again;
+            // a slow stream is not an error.
+            const hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return fail(SVGIR_ERR_HIP, "the forward failed on the device: %s", hipGetErrorString(e));
+            have_R = R_slot && tagged_pair(R_slot, R_tag, &R_host, &R_aux);
+            if (!have_R) {   // the counters' device copy (same three words)
+                uint32_t w[3] = {0, 0, 0};
+                HIP_OK(hipMemcpy(w, G.counters, 12, hipMemcpyDeviceToHost));
+                R_host = w[0]; R_aux = ((p->prefiltered && w[1]) ? 1u << 16 : 0u) | (w[2] & 0xffffu);
+            }
+        }
+        if (p->prefiltered && (R_aux >> 16) != 0u) {
+            (void)hipStreamSynchronize(s);
+            return fail(SVGIR_ERR_INVALID, "Point is filtered although prefiltered is set. This shouldn't happen!");   // auxiliary.h:163-167
+        }
+        if (R_host > 0x7ffff000u) return fail(SVGIR_ERR_INVALID, "instance count %u overflows int32", R_host);
+        const int R = (int)R_host;
+        {   // the visible depth keys' top bytes: history for the next view; and did this view's speculation hold?
+            const uint32_t summary = R_aux & 0xffffu;
+            if (key_spec) { record_top(ckey, summary); g_spec_stats[0]++; }
+            if (spec_top >= 0) g_spec_stats[4]++;
+            const int av = (int)((summary >> 8) & 0xffu), ov = (int)(summary & 0xffu);
+            if (spec_top >= 0 && !(av == 0xff && ov == 0) && (av != spec_top || ov != spec_top)) {
+                // a visible key outside the speculated byte: the three-pass order is wrong -- run the whole view again, four passes
+                HIP_OK(hipStreamSynchronize(s));
+                g_spec_stats[3]++;
+                ForwardCall again(p, o, geom, geom_ctx, binning, binning_ctx, image, image_ctx, (void*)s, false);
+                if (int rc = again.begin()) return rc < 0 ? rc : 0;
+                return again.finish();
+            }
+        }
+        record_R(ckey, R);
+        // (whether the state-slot guess held is the backward's business -- svgir_backward re-dumps the states of a view that exceeded it; the
+        // forward does not wait for the cull.  Measured on the host-bound training step, bench.py --workload train_step: 2.11 ms with
+        // the wait and a re-run here)
+        if (!bblob || R > cap) {
+            // first view, or the scene grew past a guess: (re)do the dependent stages -- exact instance capacity, worst-case state slots
+            const bool redo = bblob != nullptr;
+            if (redo) { HIP_OK(hipStreamSynchronize(s)); g_spec_stats[1]++; }
+            cap = binning_capacity(R);
+            cap_slots = p->forward_only ? 0 : -1;
+            bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
+            if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
+            if (redo && o->out_weights) HIP_OK(hipMemsetAsync(o->out_weights, 0, (size_t)P * 4, s));   // accumulated by atomics
+            if (int rc = run_binning_and_render(bblob, cap, cap_slots, !redo)) return rc;
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_cap_mu);
+            cap_entry(ckey, true)->last_view = iblob;
+        }
+
+        if (!svgss && p->computer_pseudo_normal) {
+            launch_image_ops(W, H, p->viewmatrix, focal_x, focal_y, p->cx, p->cy, o->out_opacity, o->out_depth,
+                             o->out_pseudo_normal, o->out_surface_xyz, s);
+            if (int rc = check("image ops")) return rc;
+            tm.mark("image");
+        }
+        return R;
+    }
+};
+
+}  // extern "C"  (the call object is C++)
+
+extern "C" {
+
+int svgir_forward(const svgir_params* p, const svgir_outputs* o, svgir_alloc_fn geom, void* geom_ctx,
+                  svgir_alloc_fn binning, void* binning_ctx, svgir_alloc_fn image, void* image_ctx, void* stream) {
+    ForwardCall c(p, o, geom, geom_ctx, binning, binning_ctx, image, image_ctx, stream, true);
+    const int rc = c.begin();
+    if (rc != 0) return rc < 0 ? rc : 0;
+    return c.finish();
 }
 
+// Several views in flight from ONE host thread: every view is begun (validated, allocated, all of its kernels launched on ITS stream)
+// before the first is finished (its instance count awaited).  On distinct streams the views overlap on the GPU -- one view leaves the
+// SIMDs under-occupied -- and the host never idles between them.
+int svgir_forward_batch(svgir_view_call* views, int32_t count) {
+    if (count < 0 || (count > 0 && !views)) return fail(SVGIR_ERR_INVALID, "views is NULL");
+    std::vector<std::unique_ptr<ForwardCall>> calls;
+    calls.reserve((size_t)count);
+    int first_err = 0;
+    for (int v = 0; v < count; v++) {
+        svgir_view_call& c = views[v];
+        calls.emplace_back(new ForwardCall(c.params, c.outputs, c.geom, c.geom_ctx, c.binning, c.binning_ctx, c.image, c.image_ctx, c.stream, true));
+        const int rc = calls.back()->begin();
+        c.num_rendered = rc < 0 ? rc : 0;
+        if (rc < 0 && !first_err) first_err = rc;
+    }
+    const std::string begin_err = first_err ? g_err : std::string();
+    for (int v = 0; v < count; v++) {
+        if (views[v].num_rendered < 0) continue;
+        const int rc = calls[(size_t)v]->finish();
+        views[v].num_rendered = rc;
+        if (rc < 0 && !first_err) first_err = rc;
+    }
+    if (!begin_err.empty()) g_err = begin_err;
+    return first_err;
+}
 void svgir_speculation_stats(int64_t* out5) {
     if (out5) for (int i = 0; i < 5; i++) out5[i] = (int64_t)g_spec_stats[i].load();
 }

@@ -255,10 +255,14 @@ render_fwd_kernel(const RenderArgs a) {
     constexpr int NST = 8 + S + VC;
     const uint32_t dump_base = a.sub_slot_base[sid];   // first state slot of this sub-tile (compact: common.hpp SEG)
     uint32_t ndump = 0;
-    auto dump_state = [&](uint32_t j) {
-        if (a.dump_only == 2) return;   // (contribution pre-pass: no state is kept)
+    auto dump_state = [&](uint32_t j, bool last) {
+        if (a.dump_only == 2) return;   // (contribution pre-pass: no state is kept, nothing is written)
+        // no slot: a speculative launch whose capacity guess was too small (the view's backward dumps the states again), or a
+        // forward_only view (slot capacity 0) -- then the accumulators are only gathered for the epilogue (`last`)
+        const bool slot = dump_base + j < a.slot_cap;
+        if (!slot && !last) return;
         gather_acc();
-        if (dump_base + j >= a.slot_cap) return;   // (only in a speculative launch whose capacity guess was too small: the forward re-runs)
+        if (!slot) return;
         float* d = a.seg_state + ((size_t)(dump_base + j) * NST) * 64 + lane;
         d[0] = T; d[64] = chan(0); d[128] = chan(1); d[192] = chan(2);
         // (the normal channels are blended unconditionally; without `surface` they do not exist for the consumers)
@@ -439,7 +443,7 @@ render_fwd_kernel(const RenderArgs a) {
             head += (uint32_t)m;
             DEV_TRACE_MARK(2);   // blending
             // batches are CH-aligned and CH divides SEG: segment boundaries are batch ends
-            if (!wave_done && (head & (uint32_t)(SEG - 1)) == 0u) dump_state(ndump++);
+            if (!wave_done && (head & (uint32_t)(SEG - 1)) == 0u) dump_state(ndump++, false);
         }
         wave_lds_sync();
         flush_weights(b - 1);
@@ -456,7 +460,7 @@ render_fwd_kernel(const RenderArgs a) {
             if (lc != 0) atomicAdd(cnt + lc, 1u);
         }
     }
-    if (head != 0 && ndump != 0) dump_state(ndump);   // final state (only needed by segments that do not start from the end)
+    if (head != 0 && ndump != 0) dump_state(ndump, true);   // final state (only needed by segments that do not start from the end)
     else gather_acc();
 
     if (inside && !a.dump_only) {

@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("cx", C.c_float),
         ("cy", C.c_float),
         ("prefiltered", C.c_int32), ("computer_pseudo_normal", C.c_int32), ("backward_geometry", C.c_int32),
-        ("debug", C.c_int32), ("features_ready", C.c_void_p), ("shade", C.c_void_p),
+        ("debug", C.c_int32), ("features_ready", C.c_void_p), ("forward_only", C.c_int32), ("shade", C.c_void_p),
     ]
 
 
@@ -48,6 +48,13 @@ class Grads(C.Structure):
         "dL_dprojmat", "dL_dcampos", "clear_base")] + [("clear_bytes", C.c_size_t)] + [(n, C.c_void_p) for n in (
         "dL_dbase_color", "dL_droughness", "dL_dshade_normals", "dL_dradiance", "dL_denv", "env_grad_work", "dL_dreduced",
         "out_weights")]
+
+
+class ViewCall(C.Structure):
+    """svgir_view_call: one view of svgir_forward_batch."""
+    _fields_ = [("params", C.POINTER(Params)), ("outputs", C.POINTER(Outputs)), ("geom", ALLOC_FN), ("geom_ctx", C.c_void_p),
+                ("binning", ALLOC_FN), ("binning_ctx", C.c_void_p), ("image", ALLOC_FN), ("image_ctx", C.c_void_p),
+                ("stream", C.c_void_p), ("num_rendered", C.c_int32)]
 
 
 class ShadeParams(C.Structure):
@@ -89,6 +96,8 @@ def _load():
     lib.svgir_forward.restype = C.c_int
     lib.svgir_forward.argtypes = [C.POINTER(Params), C.POINTER(Outputs), ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
                                   ALLOC_FN, C.c_void_p, C.c_void_p]
+    lib.svgir_forward_batch.restype = C.c_int
+    lib.svgir_forward_batch.argtypes = [C.POINTER(ViewCall), C.c_int32]
     lib.svgir_backward.restype = C.c_int
     lib.svgir_backward.argtypes = [C.POINTER(Params), C.POINTER(Grads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -112,7 +121,7 @@ def _load():
 lib = _load()
 
 EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_binning_bytes",
-           "svgir_image_ncontrib_offset", "svgir_image_ranges_offset", "svgir_binning_point_list_offset", "svgir_forward", "svgir_backward", "svgir_mark_visible",
+           "svgir_image_ncontrib_offset", "svgir_image_ranges_offset", "svgir_binning_point_list_offset", "svgir_forward", "svgir_forward_batch", "svgir_backward", "svgir_mark_visible",
            "svgir_backward_scratch_bytes", "svgir_backward_scratch_bytes_for", "svgir_speculation_stats", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
            "svgir_shade_backward", "svgir_incident_dirs", "svgir_resample_bilinear", "svgir_unpack_planes",
            "svgir_unpack_forward", "svgir_unpack_backward", "svgir_depth2normal", "svgir_depth2normal_backward", "svgir_pack_rgss_forward",
@@ -178,18 +187,23 @@ class BlobAllocator:
     would fall through the caching allocator to hipMalloc.  The closures therefore capture a plain dict, and `take()`
     hands the tensors over and drops the thunks."""
 
-    def __init__(self, device):
+    def __init__(self, device, stream=None):
         self.device = device
+        self.stream = stream    # the stream the forward runs on when it is not the caller's current one (svgir_forward_batch)
         self.tensors = {}
         self._fns = []
 
     def fn(self, name):
-        tensors, device = self.tensors, self.device
+        tensors, device, stream = self.tensors, self.device, self.stream
 
         def alloc(nbytes, _ctx):
             t0 = time.perf_counter()
             tensors[name] = None          # a speculative blob that turned out too small is released first
-            t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            if stream is None:
+                t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            else:   # (the caching allocator ties a block to the stream that is current when it is allocated)
+                with torch.cuda.stream(stream):
+                    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             tensors[name] = t
             dt = time.perf_counter() - t0
             ALLOC_STATS["calls"] += 1
@@ -212,6 +226,61 @@ class BlobAllocator:
         self._fns = []
         self.tensors = {}
         return out
+
+
+def run_forward(steps):
+    """Drives one `_forward_steps` generator of a binding (it yields (device, Params, Outputs, BlobAllocator) where the C call belongs
+    and returns the binding's tuple): ONE svgir_forward on the current stream."""
+    try:
+        dev, p, o, blobs = next(steps)
+    except StopIteration as e:   # (P == 0: nothing to launch)
+        return e.value
+    rendered = guarded(dev, "forward", lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None, blobs.fn("image"), None,
+                       stream_ptr(dev))
+    try:
+        steps.send(rendered)
+    except StopIteration as e:
+        return e.value
+    raise RuntimeError("binding generator did not finish")
+
+
+def run_forward_batch(make_steps, device, streams):
+    """svgir_forward_batch: `make_steps[v]()` creates the `_forward_steps` generator of view v (called with streams[v] current, so the
+    view's outputs and blobs belong to that stream); all views are launched before the first one's instance count is awaited -- one host
+    thread, len(streams) views in flight.  Returns the bindings' tuples in order."""
+    n = len(make_steps)
+    gens, reqs, out = [None] * n, [None] * n, [None] * n
+    for v in range(n):
+        with torch.cuda.stream(streams[v]):
+            g = make_steps[v]()
+            try:
+                reqs[v] = next(g)
+                gens[v] = g
+            except StopIteration as e:
+                out[v] = e.value
+    live = [v for v in range(n) if gens[v] is not None]
+    if live:
+        calls = (ViewCall * len(live))()
+        for i, v in enumerate(live):
+            dev, p, o, blobs = reqs[v]
+            blobs.stream = streams[v]
+            c = calls[i]
+            c.params, c.outputs = C.pointer(p), C.pointer(o)
+            c.geom, c.binning, c.image = blobs.fn("geom"), blobs.fn("binning"), blobs.fn("image")
+            c.stream = streams[v].cuda_stream
+        with torch.cuda.device(device):
+            rc = lib.svgir_forward_batch(calls, len(live))
+        for i, v in enumerate(live):
+            if calls[i].num_rendered < 0:
+                raise RuntimeError(f"svgir forward_batch failed for view {v} ({calls[i].num_rendered}): {last_error()}")
+        check(rc, "forward_batch")
+        for i, v in enumerate(live):
+            with torch.cuda.stream(streams[v]):
+                try:
+                    gens[v].send(int(calls[i].num_rendered))
+                except StopIteration as e:
+                    out[v] = e.value
+    return out
 
 
 CLEAR_HINT = True   # pass the gradient blob as svgir_grads.clear_base (tests switch it off to cover the per-tensor clears)

@@ -27,9 +27,22 @@ class _CBinding:
     """Same three entry points as the reference's pybind module (rgss-rasterization/ext.cpp:15-19)."""
 
     @staticmethod
-    def rasterize_gaussians(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
-                            cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height,
-                            image_width, sh, degree, campos, prefiltered, computer_pseudo_normal, debug):
+    def rasterize_gaussians(*args, **kw):
+        """The reference's `_C.rasterize_gaussians` (23 positional arguments, rasterize_points.h:18-43); keyword-only extension:
+        `forward_only` (no backward will follow: the composite keeps no blend states)."""
+        return N.run_forward(_CBinding._forward_steps(*args, **kw))
+
+    @staticmethod
+    def rasterize_gaussians_batch(calls, device, streams):
+        """Extension: `calls` = [(args, kwargs)] of rasterize_gaussians, one view each, launched with ONE svgir_forward_batch --
+        view v on streams[v], all views in flight before the first instance count is awaited (one host thread).  Returns the
+        list of 14-tuples.  The caller orders `streams` against the producers / consumers of the tensors."""
+        return N.run_forward_batch([(lambda a=a, k=k: _CBinding._forward_steps(*a, **k)) for a, k in calls], device, streams)
+
+    @staticmethod
+    def _forward_steps(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
+                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height,
+                       image_width, sh, degree, campos, prefiltered, computer_pseudo_normal, debug, *, forward_only=False):
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:62-64
         dev = means3D.device
@@ -77,8 +90,8 @@ class _CBinding:
             o.out_feature = N.ptr(out_feature)
             o.out_pseudo_normal, o.out_surface_xyz = out_pseudo_normal.data_ptr(), out_surface_xyz.data_ptr()
             o.out_weights, o.radii = out_weights.data_ptr(), radii.data_ptr()
-            rendered = N.guarded(dev, "forward", N.lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
-                                                   blobs.fn("image"), None, N.stream_ptr(dev))
+            p.forward_only = int(bool(forward_only))
+            rendered = yield (dev, p, o, blobs)          # <- svgir_forward / svgir_forward_batch (gaussian_renderer/_native.py)
             img = blobs.get("image")
             off = N.lib.svgir_image_ncontrib_offset(W, H)
             n_contrib = img[off:off + 4 * H * W].view(torch.int32).view(H, W)  # view into the blob (Q10)
@@ -177,16 +190,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             raster_settings.image_height, raster_settings.image_width, sh, raster_settings.sh_degree,
             raster_settings.campos, raster_settings.prefiltered, raster_settings.computer_pseudo_normal,
             raster_settings.debug)
+        fwd_only = not any(ctx.needs_input_grad)   # (evaluation / no_grad: the composite keeps no blend states for a backward)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                out = _C.rasterize_gaussians(*args)
+                out = _C.rasterize_gaussians(*args, forward_only=fwd_only)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            out = _C.rasterize_gaussians(*args)
+            out = _C.rasterize_gaussians(*args, forward_only=fwd_only)
         (num_rendered, num_contrib, color, normal, opacity, depth, feature, pseudo_normal, surface_xyz, weights, radii,
          geomBuffer, binningBuffer, imgBuffer) = out
         ctx.raster_settings = raster_settings

@@ -277,7 +277,7 @@ class _ShadedRasterize(torch.autograd.Function):
         out = _C.rasterize_gaussians(st.bg, means3D, feats, vfeats, empty, opacities, scales, rotations, st.scale_modifier, empty,
                                      st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy,
                                      st.image_height, st.image_width, sh, st.sh_degree, st.campos, st.prefiltered, st.debug, st.config,
-                                     shade=fs)
+                                     shade=fs, forward_only=not any(ctx.needs_input_grad))
         (R, color, normal, depth, opacity, feature, vfeature, weights, radii, gb, bb, ib) = out
         lat = dirs if isinstance(dirs, FibonacciLattice) else None
         ctx.save_for_backward(means3D, sh, scales, rotations, base_color, roughness, normals, viewdirs, radiance, visibility,

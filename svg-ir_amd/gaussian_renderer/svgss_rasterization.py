@@ -29,15 +29,29 @@ class _CBinding:
     """Same three entry points as the reference's pybind module (svgss_rasterization/ext.cpp:15-19)."""
 
     @staticmethod
-    def rasterize_gaussians(background, means3D, features, vfeatures, colors, opacity, scales, rotations,
-                            scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx,
-                            tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, config, *,
-                            features_ready=None, shade=None):
+    def rasterize_gaussians(*args, **kw):
+        """The reference's `_C.rasterize_gaussians` (24 positional arguments, rasterize_points.h:18-46); keyword-only extensions:
+        `features_ready`, `shade`, `forward_only` (see `_forward_steps`)."""
+        return N.run_forward(_CBinding._forward_steps(*args, **kw))
+
+    @staticmethod
+    def rasterize_gaussians_batch(calls, device, streams):
+        """Extension: `calls` = [(args, kwargs)] of rasterize_gaussians, one view each, launched with ONE svgir_forward_batch --
+        view v on streams[v], all views in flight before the first instance count is awaited (one host thread).  Returns the
+        list of 12-tuples.  The caller orders `streams` against the producers / consumers of the tensors."""
+        return N.run_forward_batch([(lambda a=a, k=k: _CBinding._forward_steps(*a, **k)) for a, k in calls], device, streams)
+
+    @staticmethod
+    def _forward_steps(background, means3D, features, vfeatures, colors, opacity, scales, rotations,
+                       scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx,
+                       tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, config, *,
+                       features_ready=None, shade=None, forward_only=False):
         """`features_ready` (extension, keyword only): a torch.cuda.Event recorded on the stream that is still producing
         `features` / `vfeatures` (the shading kernels on a side stream); only the composite kernel waits for it, so the
         shading of a view overlaps its binning.  The caller keeps the tensors alive across streams (`record_stream`).
         `shade` (extension, keyword only): a `_native.FusedShade` -- the library shades the surfels this view's composite reads
-        and WRITES `features` / `vfeatures` (pass uninitialised [P,S] / [P,VS] buffers; gaussian_renderer/shading.py)."""
+        and WRITES `features` / `vfeatures` (pass uninitialised [P,S] / [P,VS] buffers; gaussian_renderer/shading.py).
+        `forward_only` (extension, keyword only): no backward will follow -- the composite keeps no blend states."""
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:65-67
         dev = means3D.device
@@ -89,8 +103,8 @@ class _CBinding:
                 p.features_ready = features_ready.cuda_event
             if shade is not None:
                 p.shade = C.addressof(shade)
-            rendered = N.guarded(dev, "forward", N.lib.svgir_forward, p, o, blobs.fn("geom"), None, blobs.fn("binning"), None,
-                                                   blobs.fn("image"), None, N.stream_ptr(dev))
+            p.forward_only = int(bool(forward_only))   # evaluation: no blend states are kept for a backward
+            rendered = yield (dev, p, o, blobs)          # <- svgir_forward / svgir_forward_batch (gaussian_renderer/_native.py)
         # note: C++ order is (..., depth, opac, ...) -- the Python wrapper re-orders (svgss_rasterization.py:175,183)
         return (rendered, out_color, out_normal, out_depth, out_opac, out_feature, out_vfeature, out_weights, radii,
                 *blobs.take("geom", "binning", "image"))
@@ -209,16 +223,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             raster_settings.patch_bbox, raster_settings.tanfovx, raster_settings.tanfovy,
             raster_settings.image_height, raster_settings.image_width, sh, raster_settings.sh_degree, campos,
             raster_settings.prefiltered, raster_settings.debug, raster_settings.config)
+        fwd_only = not any(ctx.needs_input_grad)   # (evaluation / no_grad: the composite keeps no blend states for a backward)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
             try:
-                out = _C.rasterize_gaussians(*args)
+                out = _C.rasterize_gaussians(*args, forward_only=fwd_only)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            out = _C.rasterize_gaussians(*args)
+            out = _C.rasterize_gaussians(*args, forward_only=fwd_only)
         (num_rendered, color, normal, depth, opacity, feature, vfeature, weights, radii, geomBuffer, binningBuffer,
          imgBuffer) = out
         ctx.raster_settings = raster_settings

@@ -126,26 +126,65 @@ def barrier():
         dist.barrier()
 
 
-def run_views(render_view, num_views, rank, world, device, metrics_dim):
-    """Renders this rank's share of `num_views` with render_view(v) -> 1-D fp32 tensor[metrics_dim]; returns the
-    [num_views, metrics_dim] table assembled from all ranks (rows of views no rank owns stay NaN)."""
+def run_views(render_view, num_views, rank, world, device, metrics_dim, render_batch=None, batch=4):
+    """Renders this rank's share of `num_views` and returns the [num_views, metrics_dim] table assembled from all ranks (rows of
+    views no rank owns stay NaN).  render_view(v) -> 1-D fp32 tensor[metrics_dim]; or render_batch([v, ...]) -> list of such
+    tensors for up to `batch` views at a time (one host thread keeping several views in flight: render_views_in_flight /
+    svgir_forward_batch).  No collective and no host synchronisation while the views render: every rank keeps its rows on the
+    device and ONE all_gather at the end assembles the table (the reference's evaluation loop is sequential on one GPU,
+    eval_relighting_tensoIR.py:303-378)."""
     mine = shard_views(num_views, rank, world)
-    rounds = (num_views + world - 1) // world
-    table = torch.full((num_views, metrics_dim), float("nan"), dtype=torch.float32, device=device)
-    for r in range(rounds):
-        v = r * world + rank
-        if v < num_views:
-            assert v in mine
-            m = render_view(v).to(device=device, dtype=torch.float32).reshape(-1)
-            payload = torch.cat([torch.tensor([float(v)], device=device), m])
-        else:
-            payload = torch.cat([torch.tensor([-1.0], device=device), torch.zeros(metrics_dim, device=device)])
-        allm = gather_metrics(payload)
-        for row in allm:
-            vi = int(row[0].item())
-            if vi >= 0:
-                table[vi] = row[1:]
-    return table
+    n_max = (num_views + world - 1) // world           # rows every rank contributes (padded: view id -1)
+    local = torch.zeros((n_max, 1 + metrics_dim), dtype=torch.float32, device=device)
+    local[:, 0] = -1.0
+    if render_batch is not None:
+        done = 0
+        for c0 in range(0, len(mine), max(1, batch)):
+            chunk = mine[c0:c0 + max(1, batch)]
+            ms = render_batch(chunk)
+            assert len(ms) == len(chunk)
+            for v, m in zip(chunk, ms):
+                local[done, 0] = float(v)
+                local[done, 1:] = m.to(device=device, dtype=torch.float32).reshape(-1)
+                done += 1
+    else:
+        for i, v in enumerate(mine):
+            local[i, 0] = float(v)
+            local[i, 1:] = render_view(v).to(device=device, dtype=torch.float32).reshape(-1)
+    allr = gather_rows(local.reshape(-1)).reshape(-1, 1 + metrics_dim)     # the one collective
+    table = torch.full((num_views + 1, metrics_dim), float("nan"), dtype=torch.float32, device=device)
+    ids = allr[:, 0].to(torch.int64)
+    ids = torch.where(ids >= 0, ids, torch.full_like(ids, num_views))         # padding rows land in the spare last row
+    table[ids] = allr[:, 1:]
+    return table[:num_views]
+
+
+def render_views_in_flight(make_call, finish, views, device, rasterize_batch, in_flight=4, streams=None):
+    """Renders `views` on ONE GPU from ONE host thread with up to `in_flight` of them in flight (svgir_forward_batch): for each
+    group, make_call(v) -> (args, kwargs) of the binding's rasterize_gaussians is evaluated with the view's stream current,
+    `rasterize_batch` (= `_C.rasterize_gaussians_batch` of either binding) launches the whole group before it waits for the first
+    view's instance count, and finish(v, result_tuple) -> anything runs on the view's stream again.  Returns finish's results in
+    the order of `views`.  The worker streams first wait for the caller's current stream and are joined into it at the end."""
+    views = list(views)
+    cur = torch.cuda.current_stream(device)
+    if streams is None:
+        streams = [torch.cuda.Stream(device) for _ in range(max(1, min(in_flight, len(views))))]
+    for s in streams:
+        s.wait_stream(cur)
+    out = []
+    for c0 in range(0, len(views), len(streams)):
+        chunk = views[c0:c0 + len(streams)]
+        calls = []
+        for i, v in enumerate(chunk):
+            with torch.cuda.stream(streams[i]):
+                calls.append(make_call(v))
+        res = rasterize_batch(calls, device, streams[:len(chunk)])
+        for i, v in enumerate(chunk):
+            with torch.cuda.stream(streams[i]):
+                out.append(finish(v, res[i]))
+    for s in streams:
+        cur.wait_stream(s)
+    return out
 
 
 def render_in_flight(render_view, views, device, in_flight=2):

@@ -122,3 +122,129 @@ def test_shading_on_a_side_stream_overlapping_the_binning(built):
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(got, ref))
         assert torch.allclose(got_w, ref_w, rtol=1e-5, atol=1e-6)
+
+
+def _call_args(sct, st, variant, empty):
+    if variant == "svgss":
+        return (st.bg, sct["means3D"], sct["features"], sct["vfeatures"], empty, sct["opacities"], sct["scales"], sct["rotations"],
+                st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy,
+                st.image_height, st.image_width, sct["shs"], st.sh_degree, st.campos, False, False, st.config)
+    return (st.bg, sct["means3D"], sct["features"], empty, sct["opacities"], sct["scales"], sct["rotations"], st.scale_modifier, empty,
+            st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.cx, st.cy, st.image_height, st.image_width, sct["shs"],
+            st.sh_degree, st.campos, False, False, False)
+
+
+@pytest.mark.parametrize("variant", ["svgss", "rgss"])
+def test_forward_batch_from_one_thread_matches_single_calls(built, variant):
+    """svgir_forward_batch: five views of one scene launched from ONE host thread on four streams -- every view's kernels are
+    in the queue before the first view's instance count is awaited -- give bit for bit what five svgir_forward calls give, and the
+    blobs they leave behind drive the backward like any other."""
+    from svgir_harness import view_parallel as vp
+    if variant == "svgss":
+        from gaussian_renderer.svgss_rasterization import _C
+    else:
+        from gaussian_renderer.rgss_rasterization import _C
+    dev = torch.device(DEV)
+    base, _ = _views(variant)
+    scs = []
+    for i in range(5):
+        v = dict(base)
+        v.update(cameras.make_camera(base["W"], base["H"], cameras.orbit_eye(4.0, 15.0 + 60.0 * i, 10.0 + 5.0 * i)))
+        scs.append(runner.to_torch(v, dev))
+    sts = [runner.settings(s, variant) for s in scs]
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+    nimg = 7 if variant == "svgss" else 9      # leading tensors of the tuple that are images (+ n_contrib for rgss)
+    for rounds in range(3):   # (the third round runs the speculative launch sequence for every view)
+        single = [_C.rasterize_gaussians(*_call_args(scs[i], sts[i], variant, empty)) for i in range(5)]
+        torch.cuda.synchronize()
+        got = vp.render_views_in_flight(lambda i: (_call_args(scs[i], sts[i], variant, empty), {}), lambda i, res: res, range(5), dev,
+                                        _C.rasterize_gaussians_batch, in_flight=4)
+        torch.cuda.synchronize()
+        assert len({s[0] for s in single}) > 1            # really different views
+        for a, b in zip(single, got):
+            assert a[0] == b[0]
+            for j in range(1, nimg):
+                assert torch.equal(a[j], b[j]), j
+            assert torch.equal(a[-4], b[-4])              # radii
+    # a backward on the blobs of a batched forward
+    i = 3
+    g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in scenes.upstream_grads(base, variant, seed=2).items()}
+    sct, st = scs[i], sts[i]
+
+    def bwd(out):
+        if variant == "svgss":
+            return _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], out[8], empty, sct["scales"],
+                                                   sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
+                                                   st.patch_bbox, st.tanfovx, st.tanfovy, g["color"], g["normal"], g["depth"], g["opacity"],
+                                                   g["feature"], g["vfeature"], sct["shs"], st.sh_degree, st.campos, out[9], out[0], out[10],
+                                                   out[11], False, st.config)
+        return _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], out[10], empty, sct["scales"], sct["rotations"],
+                                               st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, g["color"],
+                                               g["normal"], g["opacity"], g["depth"], g["feature"], sct["shs"], st.sh_degree, st.campos,
+                                               out[11], out[0], out[12], out[13], True, False)
+
+    ga, ga2, gb = bwd(single[i]), bwd(single[i]), bwd(got[i])
+    torch.cuda.synchronize()
+    for a, a2, b in zip(ga, ga2, gb):
+        if variant == "svgss":
+            assert torch.equal(a, b)
+        else:   # rgss sums its packed rows with float atomics: the same call twice differs by `noise`
+            noise = float((a - a2).abs().max())
+            assert float((a - b).abs().max()) <= 4.0 * noise + 1e-6 * float(a.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("variant", ["svgss", "rgss"])
+def test_forward_only_keeps_no_states_and_a_backward_still_works(built, variant):
+    """svgir_params.forward_only (evaluation loops): same images from a smaller binning blob (no state slots); a backward that
+    comes anyway replays the composite for its states and gives the usual gradients."""
+    if variant == "svgss":
+        from gaussian_renderer.svgss_rasterization import _C
+    else:
+        from gaussian_renderer.rgss_rasterization import _C
+    dev = torch.device(DEV)
+    kw = dict(P=20000, W=256, H=192, seed=33, sh_degree=1, variant=variant, scale_lo=0.03, scale_hi=0.12)   # long lists: states are dumped
+    kw.update(dict(S=4, VS=52) if variant == "svgss" else dict(S=5, VS=0))
+    sc = scenes.surface_scene(**kw)
+    sct = runner.to_torch(sc, dev)
+    st = runner.settings(sct, variant)
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+    args = _call_args(sct, st, variant, empty)
+    for _ in range(3):
+        a = _C.rasterize_gaussians(*args)
+        b = _C.rasterize_gaussians(*args, forward_only=True)
+    torch.cuda.synchronize()
+    nimg = 7 if variant == "svgss" else 9
+    assert a[0] == b[0]
+    for j in range(1, nimg):
+        assert torch.equal(a[j], b[j]), j
+    assert b[-2].numel() < a[-2].numel(), "no state slots in the binding blob of a forward-only view"
+    g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in scenes.upstream_grads(sc, variant, seed=4).items()}
+
+    def bwd(out):
+        if variant == "svgss":
+            return _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], sct["vfeatures"], out[8], empty, sct["scales"],
+                                                   sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
+                                                   st.patch_bbox, st.tanfovx, st.tanfovy, g["color"], g["normal"], g["depth"], g["opacity"],
+                                                   g["feature"], g["vfeature"], sct["shs"], st.sh_degree, st.campos, out[9], out[0], out[10],
+                                                   out[11], False, st.config)
+        return _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], out[10], empty, sct["scales"], sct["rotations"],
+                                               st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, g["color"],
+                                               g["normal"], g["opacity"], g["depth"], g["feature"], sct["shs"], st.sh_degree, st.campos,
+                                               out[11], out[0], out[12], out[13], True, False)
+
+    ga, ga2 = bwd(a), bwd(a)
+    before = N_stats()
+    gb = bwd(b)
+    torch.cuda.synchronize()
+    assert N_stats()["rerun_slots"] == before["rerun_slots"] + 1, "the forward-only view's states were dumped by its backward"
+    for x, x2, y in zip(ga, ga2, gb):
+        if variant == "svgss":
+            assert torch.equal(x, y)
+        else:   # rgss sums its packed rows with float atomics: the same call twice differs by `noise`
+            noise = float((x - x2).abs().max())
+            assert float((x - y).abs().max()) <= 4.0 * noise + 1e-6 * float(x.abs().max()) + 1e-12
+
+
+def N_stats():
+    from gaussian_renderer import _native
+    return _native.speculation_stats()

@@ -108,3 +108,75 @@ def test_bench_self_launches_ranks_dry_run():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "GPU(s) are visible" in out.stderr
+
+
+def _worker8(rank, world, port, q):
+    for p in (os.path.join(ROOT, "svg-ir_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from svgir_harness import view_parallel as vp
+    vp.init_from_env(backend="gloo")
+    dev = torch.device("cpu")
+    calls = []
+
+    def metrics(v):
+        return torch.tensor([float(v), float(v * v % 97), float(rank)])
+
+    def render_view(v):
+        calls.append(v)
+        return metrics(v)
+
+    def render_batch(vs):
+        calls.append(tuple(vs))
+        return [metrics(v) for v in vs]
+
+    t1 = vp.run_views(render_view, 200, rank, world, dev, 3)
+    assert calls == vp.shard_views(200, rank, world) and len(calls) == 25       # a 200-frame TensoIR test set: 25 views per rank
+    calls.clear()
+    t2 = vp.run_views(None, 200, rank, world, dev, 3, render_batch=render_batch, batch=4)
+    assert [v for c in calls for v in c] == vp.shard_views(200, rank, world) and max(len(c) for c in calls) == 4 and len(calls) == 7
+    t3 = vp.run_views(render_view, 13, rank, world, dev, 3)                      # fewer views than 2 x world: ragged shares
+    vp.barrier()
+    q.put((rank, t1.numpy(), t2.numpy(), t3.numpy()))
+
+
+def test_view_parallel_world8_gloo_200_views():
+    """8-GPU readiness that does not need the node: eight ranks (gloo), the 200 views of a TensoIR test set, 25 per rank, one
+    all_gather at the end (no per-round collective, no host synchronisation inside the loop), per-view and batched drivers."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29820 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    v = np.arange(200, dtype=np.float32)
+    exp = np.stack([v, (v * v) % 97, v % 8], axis=1)
+    for rank, t1, t2, t3 in res:
+        assert np.array_equal(t1, exp) and np.array_equal(t2, exp), rank
+        assert np.array_equal(t3, exp[:13]), rank
+
+
+def test_bench_dry_run_world8():
+    """`python bench.py --gpus 8 --dry-run`: the launcher starts eight ranks, every region carries the barrier + metrics
+    all_gather, rank 0 prints ONE line with n_gpus = 8 and the aggregate over the eight ranks."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1",
+                          "--repeats", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["per_rank_R"] == [100 + r for r in range(8)]
+    assert d["config"]["workload"].startswith("cfg4") and len(d["per_rank_cpus"]) == 8
+    # disjoint core sets (or all unpinned where the machine has fewer cores than ranks x 1)
+    cpus = [set(c) for c in d["per_rank_cpus"] if c]
+    assert all(a.isdisjoint(b) for i, a in enumerate(cpus) for b in cpus[i + 1:])
