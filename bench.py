@@ -615,6 +615,56 @@ def two_streams(name, dev, args):
                     "supplementary, the headline value is one view per step" % rounds}
 
 
+def one_thread_batch(name, dev, args, V=4):
+    """Supplementary record: V views of the workload in flight from ONE host thread -- `svgir_forward_batch` launches the forwards of
+    all V views (one stream each) before it waits for the first view's instance count, the V backwards follow on the views' streams.
+    No second thread, no Python GIL hand-over between views (the `two_streams` record needs two threads for two views)."""
+    import time
+    import torch
+    wls = [Workload(name, dev, r, max(2, V), args) for r in range(V)]   # the same replicated scene from V cameras
+    streams = [torch.cuda.Stream(dev) for _ in range(V)]
+    w0 = wls[0]
+    if w0.variant != "rgss":
+        return None
+    _C, empty = w0._C, w0.empty
+
+    def fwd_args(w):
+        st, sct = w.st, w.sct
+        return ((st.bg, sct["means3D"], sct["features"], empty, sct["opacities"], sct["scales"], sct["rotations"], st.scale_modifier, empty,
+                 st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.cx, st.cy, st.image_height, st.image_width, sct["shs"],
+                 st.sh_degree, st.campos, False, False, False), {})
+
+    def bwd(w, out):
+        st, sct, gt = w.st, w.sct, w.gt
+        (R, ncontrib, color, normal, opac, depth, feat, pn, sx, weights, radii, gb, bb, ib) = out
+        return _C.rasterize_gaussians_backward(st.bg, sct["means3D"], sct["features"], radii, empty, sct["scales"], sct["rotations"],
+                                               st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, gt["color"],
+                                               gt["normal"], gt["opacity"], gt["depth"], gt["feature"], sct["shs"], st.sh_degree, st.campos,
+                                               gb, R, bb, ib, True, False)
+
+    def round_():
+        outs = _C.rasterize_gaussians_batch([fwd_args(w) for w in wls], dev, streams)
+        for w, s, out in zip(wls, streams, outs):
+            with torch.cuda.stream(s):
+                bwd(w, out)
+
+    rounds = max(10, args.steps)
+    for _ in range(4):
+        round_()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            round_()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    ms_view = best / rounds / V * 1e3
+    return {"views_in_flight": V, "host_threads": 1, "ms_per_view": ms_view, "value": w0.P / (ms_view * 1e-3), "unit": "surfels/s",
+            "note": "svgir_forward_batch: %d views of the same workload launched from ONE host thread on %d HIP streams, forward + backward, "
+                    "wall clock over %d rounds, best of 5; supplementary, the headline value is one view per step" % (V, V, rounds)}
+
+
 def cpu_baseline(wl, args):
     """The CPU oracle on the host cores: `-O3 -march=native` build (compiled here, on the machine that
     runs it) when the compiler is available, else the parity build."""
@@ -941,6 +991,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(wl, args)
     if rank == 0 and world == 1 and not args.no_concurrent:   # (last: it creates streams of its own)
+        torch.cuda.empty_cache()
+        # (HIP streams share a few hardware queues, dealt in creation order: each record creates its streams right before it runs)
+        ob = one_thread_batch(name, dev, args)
+        if ob:
+            res["one_thread_batch"] = ob
         torch.cuda.empty_cache()
         res["two_streams"] = two_streams(name, dev, args)
     if rank == 0:
