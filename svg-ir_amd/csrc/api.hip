@@ -34,14 +34,17 @@ std::atomic<bool> g_prof{false};
 // preview next to a 1600x1600 render, several scenes, several devices) neither re-run each other's dependent stages nor
 // over-allocate each other's blobs.  A small fixed table, least-recently-used replacement.
 struct CapKey { int dev, W, H, P, S, VS, variant; };
-struct CapEntry { CapKey key; int hist[8]; long long hist_slots[8]; unsigned next, next_slots; unsigned long long stamp; bool used;
-                  int top_byte, top_streak;
-                  const void* last_view; };   // image blob of the workload's latest forward: its slot total is read when the next one starts   // common top byte of the visible depth keys of the last `top_streak` views (0: none / not common)
+// (P is NOT part of a workload's identity: densification / pruning changes it every few hundred iterations,
+// scene/gaussian_model.py:1229-1253, and the history must survive that -- every sample remembers the Gaussian count it was taken at and
+// is scaled to the caller's: instances and state slots grow with the surfel count on a fixed view)
+struct CapEntry { CapKey key; int hist[8]; int hist_P[8]; long long hist_slots[8]; int hist_slots_P[8]; unsigned next, next_slots; unsigned long long stamp; bool used;
+                  int top_byte, top_streak;   // common top byte of the visible depth keys of the last `top_streak` views (0: none / not common)
+                  const void* last_view; int last_view_P; };   // image blob of the workload's latest forward: its slot total is read when the next one starts
 std::mutex g_cap_mu;
 CapEntry g_cap[16];
 unsigned long long g_cap_clock = 0;
 bool same_key(const CapKey& a, const CapKey& b) {
-    return a.dev == b.dev && a.W == b.W && a.H == b.H && a.P == b.P && a.S == b.S && a.VS == b.VS && a.variant == b.variant;
+    return a.dev == b.dev && a.W == b.W && a.H == b.H && a.S == b.S && a.VS == b.VS && a.variant == b.variant;
 }
 CapEntry* cap_entry(const CapKey& k, bool create) {
     CapEntry* lru = &g_cap[0];
@@ -55,30 +58,36 @@ CapEntry* cap_entry(const CapKey& k, bool create) {
     lru->key = k; lru->used = true; lru->stamp = ++g_cap_clock;
     return lru;
 }
+inline long long scale_to(long long v, int from_P, int to_P) {   // a count measured at from_P Gaussians, expected at to_P
+    if (from_P <= 0 || from_P == to_P) return v;
+    return (long long)((double)v * (double)to_P / (double)from_P) + 1;
+}
 int guess_R(const CapKey& k) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     const CapEntry* e = cap_entry(k, false);
-    int m = 0;
-    if (e) for (int r : e->hist) m = std::max(m, r);
-    return m;
+    long long m = 0;
+    if (e) for (unsigned i = 0; i < std::min(e->next, 8u); i++) m = std::max(m, scale_to(e->hist[i], e->hist_P[i], k.P));
+    return (int)std::min<long long>(m, 0x7ffff000LL);
 }
 void record_R(const CapKey& k, int R) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     CapEntry* e = cap_entry(k, true);
-    e->hist[e->next++ % 8] = R;
+    e->hist[e->next % 8] = R; e->hist_P[e->next % 8] = k.P;
+    e->next++;
 }
 // state slots (common.hpp seg_slots summed over the sub-tiles) of recent views of the workload: -1 = none seen yet
 long long guess_slots(const CapKey& k) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     const CapEntry* e = cap_entry(k, false);
     long long m = -1;
-    if (e && e->next_slots) for (unsigned i = 0; i < std::min(e->next_slots, 8u); i++) m = std::max(m, e->hist_slots[i]);
+    if (e && e->next_slots) for (unsigned i = 0; i < std::min(e->next_slots, 8u); i++) m = std::max(m, scale_to(e->hist_slots[i], e->hist_slots_P[i], k.P));
     return m;
 }
 void record_slots(const CapKey& k, long long slots) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     CapEntry* e = cap_entry(k, true);
-    e->hist_slots[e->next_slots++ % 8] = slots;
+    e->hist_slots[e->next_slots % 8] = slots; e->hist_slots_P[e->next_slots % 8] = k.P;
+    e->next_slots++;
 }
 // Depth-key speculation.  The depth keys are positive floats; in a bounded scene they share their top byte (sign + 7 exponent bits: all
 // depths in [2, 8), or [8, 32) ...), and then the fourth 8-bit pass of the depth sort orders nothing.  The preprocess reports AND / OR of
@@ -545,7 +554,7 @@ struct ForwardCall {
     // Everything behind the offsets scan depends on the instance count R that the GPU is still computing.  The stages are launched for an
     // instance CAPACITY `cap` and read R on the device (min(cap, R)); the binning blob is laid out for `cap`.  `timed`: stage marks are
     // only recorded for the launch sequence that counts.
-    int run_binning_and_render(char* bblob, int cap, long long cap_slots, bool timed) {
+    int run_binning_and_render(char* bblob, int cap, long long cap_slots, bool timed, bool cull_only = false) {
         const BinLayout B = bin_layout(bblob, cap, T, nstate, cap_slots);
         launch_emit(P, depth_order, G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
                     I.counters, B.radix_tbl, s);
@@ -585,6 +594,7 @@ struct ForwardCall {
                           (uint32_t)cap, cap_slots, kBlobMagic, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
+        if (cull_only) return 0;   // (the sizing phase of a workload's first view: see finish())
         if (prepass) {
             RenderArgs rp = ra;
             rp.S = 0; rp.VS = 0; rp.features = nullptr; rp.vfeatures = nullptr; rp.dump_only = 2; rp.needed = G.needed;
@@ -712,8 +722,9 @@ struct ForwardCall {
         cap = 0; cap_slots = -1; bblob = nullptr;
         {   // the previous view of this workload: its slot total, if the backward has not recorded it already (forward-only loops)
             const void* prev = nullptr;
-            { std::lock_guard<std::mutex> lk(g_cap_mu); if (const CapEntry* e = cap_entry(ckey, false)) prev = e->last_view; }
-            note_view_slots(ckey, prev, 2);
+            CapKey pkey = ckey;
+            { std::lock_guard<std::mutex> lk(g_cap_mu); if (const CapEntry* e = cap_entry(ckey, false)) { prev = e->last_view; pkey.P = e->last_view_P; } }
+            note_view_slots(pkey, prev, 2);
         }
         if (const int guess = guess_R(ckey)) {
             cap = binning_capacity((long long)guess + guess / 8 + 1024);
@@ -782,6 +793,23 @@ struct ForwardCall {
             if (redo) { HIP_OK(hipStreamSynchronize(s)); g_spec_stats[1]++; }
             cap = binning_capacity(R);
             cap_slots = p->forward_only ? 0 : -1;
+            if (cap_slots < 0 && R > 0) {
+                // No history to size the state slots from (a workload's first view, or one that outgrew its guess): instead of the worst
+                // case over the cull -- four full lists per tile, 3-4x what a view needs, 35 GB at cfg5_dense -- the binning and the
+                // cull run once into a stream-ordered temporary WITHOUT state slots, the view's own slot total comes back (the same tagged
+                // store the backward reads), and the blob the caller keeps is laid out for exactly that.  ~0.2 ms, once per workload.
+                void* tmp = nullptr;
+                if (hipMallocAsync(&tmp, bin_layout(nullptr, cap, T, nstate, 0).bytes, s) == hipSuccess) {
+                    const int rc = run_binning_and_render((char*)tmp, cap, 0, false, true);
+                    long long slots = -1;
+                    if (rc == 0) (void)view_lookup(iblob, 1, nullptr, nullptr, nullptr, &slots, &s);
+                    (void)hipFreeAsync(tmp, s);
+                    if (rc) return rc;
+                    if (slots >= 0) cap_slots = std::min<long long>(slots, (long long)seg_capacity(cap, T));
+                } else {
+                    (void)hipGetLastError();   // (no temporary: the worst-case layout, as before)
+                }
+            }
             bblob = binning(bin_layout(nullptr, cap, T, nstate, cap_slots).bytes, binning_ctx);
             if (!bblob) return fail(SVGIR_ERR_ALLOC, "binning blob allocation failed");
             if (redo && o->out_weights) HIP_OK(hipMemsetAsync(o->out_weights, 0, (size_t)P * 4, s));   // accumulated by atomics
@@ -789,7 +817,8 @@ struct ForwardCall {
         }
         {
             std::lock_guard<std::mutex> lk(g_cap_mu);
-            cap_entry(ckey, true)->last_view = iblob;
+            CapEntry* e = cap_entry(ckey, true);
+            e->last_view = iblob; e->last_view_P = P;
         }
 
         if (!svgss && p->computer_pseudo_normal) {
