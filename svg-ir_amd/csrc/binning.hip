@@ -121,6 +121,51 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
         if (valid && in_round == 0) wcnt[wave][d] = prior + (uint32_t)__popcll(same);
     }
     __syncthreads();
+    if (ITEMS >= 16) {
+        // Large inputs (bandwidth, not launch latency, sets the time): the block's keys are first put in digit order in LDS, then
+        // written out -- consecutive lanes write consecutive addresses of a digit's run (a block of 4096 keys holds runs of ~32 per 7-bit
+        // digit) instead of 64 lanes writing to 64 different runs.
+        __shared__ uint32_t sK[BLOCK * (ITEMS >= 16 ? ITEMS : 1)], sV[BLOCK * (ITEMS >= 16 ? ITEMS : 1)];
+        __shared__ uint32_t bstart[256], gcur[256];
+        const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
+        const uint32_t bc = c0 + c1 + c2 + c3;            // keys of digit t in this block
+        uint32_t incl = bc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        __syncthreads();                                   // (wtot was read by every thread above)
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) woff += w < wave ? wtot[w] : 0u;
+        const uint32_t bs = woff + incl - bc;              // first slot of digit t in the block's staging order
+        bstart[t] = bs; gcur[t] = cursor;
+        wcnt[0][t] = bs; wcnt[1][t] = bs + c0; wcnt[2][t] = bs + c0 + c1; wcnt[3][t] = bs + c0 + c1 + c2;   // the waves' staging cursors
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+            if (base + c * 64 + lane < n) {
+                const uint32_t lp = wcnt[wave][(ks[c] >> bit_lo) & mask] + rk[c];
+                sK[lp] = ks[c]; sV[lp] = vs[c];
+            }
+        }
+        __syncthreads();
+        const int nblk = min(BLOCK * ITEMS, n - (int)blockIdx.x * (BLOCK * ITEMS));
+#pragma unroll
+        for (int c = 0; c < ITEMS; c++) {
+            const int i = c * BLOCK + t;
+            if (i < nblk) {
+                const uint32_t k = sK[i], d = (k >> bit_lo) & mask;
+                const uint32_t pos = gcur[d] + ((uint32_t)i - bstart[d]);
+                kout[pos] = k;
+                vout[pos] = sV[i];
+            }
+        }
+        return;
+    }
     {   // digit t: the waves' cursors = block cursor + counts of the waves in front
         const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t];
         __syncthreads();
