@@ -499,11 +499,17 @@ def roofline_of(wl, R, stage, workload):
         if tj.get("kernel_source_hash") == kernel_source_hash() and (same_lib or library_is_current()):
             if not same_lib:   # another build of the SAME sources (e.g. rebuilt on the measuring machine)
                 out["traffic_note"] = "library rebuilt from the kernel sources profiles/traffic_%s.json was measured with" % workload
-            tr = 0
+            tr = trf = 0
             for kname, kv in tj.get("kernels", {}).items():
                 if kname.startswith("render_bwd") or kname.startswith("grad_reduce_kernel"):
                     tr += kv["read_bytes"] + kv["write_bytes"]
-            out["traffic"] = tr or None
+                if kname.startswith("cull_kernel") or kname.startswith("render_fwd"):
+                    trf += kv["read_bytes"] + kv["write_bytes"]
+            if "render_bwd" in stage:
+                out["traffic"] = tr or None
+                out["fwd_composite"]["traffic"] = trf or None
+            else:
+                out["traffic"] = trf or None
         else:
             out["traffic_note"] = "profiles/traffic_%s.json was measured with different kernel sources / another library build" % workload
     try:
@@ -534,6 +540,12 @@ def roofline_of(wl, R, stage, workload):
         if irf and irf.get("issue_frac") is not None:
             out["fwd_composite"]["issue_frac"] = irf["issue_frac"]
             out["fwd_composite"]["bound"] = "issue" if irf["issue_frac"] > out["fwd_composite"]["frac"] else "hbm"
+    # where the step's time goes: the stage with the largest share (the composite backward on the training / rgss configurations; the
+    # shading forward can lead at the evaluation sample counts) -- `kernel` above stays the composite, BASELINE's roofline metric
+    core = {k: v[0] for k, v in stage.items() if k not in ("shade", "shade_env_table", "shade_bwd_prologue", "shade_env_grad")}
+    if core:
+        top = max(core, key=core.get)
+        out["dominant_stage_by_time"] = {"stage": top, "ms": core[top], "share_of_stage_sum": core[top] / sum(core.values())}
     return out
 
 

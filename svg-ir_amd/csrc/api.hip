@@ -614,7 +614,7 @@ struct ForwardCall {
             } else if (shade_subset) {   // (a permutation of 0..P-1 whose first counters[3] entries hold every surfel that touches a tile)
                 sp.subset = depth_order; sp.subset_count = G.counters + 3;
             }
-            if (svgir_shade_forward(&sp, p->shade->reduced, const_cast<float*>(p->features), const_cast<float*>(p->vfeatures), s) != 0)
+            if (shade_forward_impl(&sp, p->shade->reduced, const_cast<float*>(p->features), const_cast<float*>(p->vfeatures), true, s) != 0)
                 return fail(SVGIR_ERR_INVALID, "fused shading: svgir_shade_forward rejected its parameters");
             if (int rc = check("shade")) return rc;
             if (timed) tm.mark("shade");
@@ -682,6 +682,7 @@ struct ForwardCall {
         prepass = shade_subset && shade_prepass(p->shade->sp.Ns);
         pa.needed = prepass ? G.needed : nullptr;
         pa.span = G.counters + 3;
+        if (p->shade) pa.tabs = shade_tables(&p->shade->sp, nullptr, 0);   // (the preprocess launch carries the shading kernels' tables)
         pa.zero_words = radix_gtot(G.radix_tbl, P); pa.n_zero_words = (int)radix_gtot_words(P);
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
@@ -1070,6 +1071,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
             sc_clear = ba.grad_rows; sc_bytes = align_up((size_t)P * rg.RS * 4);
         }
     }
+    ShadeTables shade_tabs;   // (env == nullptr: the shading backward launches its own prologue)
     if (R > 0) {
         // live backward segments, longest first (common.hpp SEG), from the forward's per-sub-tile counts: built here -- a forward-only
         // call never pays for it -- together with the scratch clear
@@ -1077,7 +1079,9 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         sa.W = W; sa.H = H; sa.gx = gx; sa.gy = gy; sa.S = p->S; sa.VS = ba.VS;
         sa.ranges = I.ranges; sa.sub_count = I.sub_count; sa.sub_ndump = I.sub_ndump; sa.seg_list = B.seg_list; sa.seg_desc = B.seg_desc;
         sa.seg_count = I.counters; sa.seg_block = I.seg_block; sa.sub_pair_base = I.sub_pair_base; sa.sub_slot_base = I.sub_slot_base;
-        launch_seg_build(sa, sc_clear, sc_bytes, s);
+        // (fused shading: the same launch builds the tables and zeroes the env-gradient accumulator of the shading backward below)
+        if (p->shade && g->env_grad_work) shade_tabs = shade_tables(&p->shade->sp, g->env_grad_work, p->shade->sp.env_h * p->shade->sp.env_w * 3);
+        launch_seg_build(sa, sc_clear, sc_bytes, shade_tabs, s);
     } else if (sc_clear && !rows) {
         HIP_OK(hipMemsetAsync(sc_clear, 0, sc_bytes, s));   // (nothing rendered: geom_bwd still unpacks the -- zero -- packed rows)
     }
@@ -1123,7 +1127,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         const bool precleared = in_clear(g->dL_dbase_color, 12 * Pz) && in_clear(g->dL_droughness, 4 * Pz) &&
                                 in_clear(g->dL_dshade_normals, 12 * Pz) && in_clear(g->dL_dradiance, 3 * Pz * (size_t)sp.Ns);
         if (shade_backward_impl(&sp, g->dL_dreduced, g->dL_dfeatures, g->dL_dvfeatures, g->dL_dbase_color, g->dL_droughness,
-                                g->dL_dshade_normals, g->dL_dradiance, g->dL_denv, g->env_grad_work, precleared, s) != 0)
+                                g->dL_dshade_normals, g->dL_dradiance, g->dL_denv, g->env_grad_work, precleared, shade_tabs.env != nullptr, s) != 0)
             return fail(SVGIR_ERR_INVALID, "fused shading: svgir_shade_backward rejected its parameters");
         tm.mark("shade_bwd");
     }

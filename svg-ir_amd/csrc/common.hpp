@@ -286,6 +286,17 @@ __device__ __forceinline__ bool cfg_flag(const CfgRef& c, int i) {
 }
 #endif
 
+// the two small tables of the shading kernels (shade_tables.hpp), built in passing by kernels of the fused path
+struct ShadeTables {
+    const float* env = nullptr; float4* env_tab = nullptr; int ntexel = 0, softplus = 0;   // env == nullptr: nothing to do
+    int Ns = 0; float4* lat_tab = nullptr;                                                  // lat_tab == nullptr: directions are streamed
+    float* zero = nullptr; int nzero = 0;                                                   // backward: the env-gradient accumulator
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    int entries() const { return env ? (ntexel > (lat_tab ? Ns : 0) ? ntexel : (lat_tab ? Ns : 0)) : 0; }
+};
+
 // ---- kernel argument blocks --------------------------------------------------------------------------------
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
@@ -297,6 +308,7 @@ struct PreArgs {
     float* out_weights;              // [P] zeroed here (accumulated with atomics by the composite)
     uint8_t* needed;                 // [P] or null: zeroed here (set by the contribution pre-pass of the fused shading)
     uint32_t* span;                  // GeomLayout::counters + 3, zeroed here
+    ShadeTables tabs; int pblocks;   // fused shading: workgroups >= pblocks build the shading tables (shade_tables.hpp)
     uint32_t* zero_words; int n_zero_words;   // small table cleared in passing (the depth sort's group totals)
     int spec_top; uint32_t* key_top;   // speculated common top byte of the visible depth keys (-1: none) -> key of a culled Gaussian; per-wave summary out
     uint32_t* prefilter_violation;   // non-null <=> `prefiltered`: set to 1 when a frustum / back-face cull fires (auxiliary.h:163-167)
@@ -392,7 +404,7 @@ void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t*
 void launch_cull(const RenderArgs& a, hipStream_t s);
 // tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump; also zeroes
 // `clear_bytes` bytes at `clear` (a multiple of 16; the backward's scratch clear rides on this launch)
-void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, hipStream_t s);
+void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, hipStream_t s);   // (+ the shading tables of the fused path)
 // (experiment builds, -DBWDP_STREAM) gather-free candidate stream: one 24-float record per (sub-tile, candidate) pair, in list order
 void launch_pair_stream(const RenderArgs& a, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 (nothing launched) if (S,VS) has no specialised kernel
@@ -417,9 +429,13 @@ void launch_zero_rows(int P, const uint32_t* list, const uint32_t* count_dev, fl
 
 // svgir_shade_backward with one more switch: rows_precleared = the four per-surfel gradient tensors are already zero (svgir_backward
 // lets the composite backward's waves clear them in passing), so the rows outside the subset need no zero-fill launch
+// tables_ready = the f(env) / lattice tables (and, backward, the zeroed env-gradient accumulator) were already produced by a kernel in
+// front (shade_tables.hpp): no prologue launch
+ShadeTables shade_tables(const svgir_shade_params* p, float* zero, int nzero);
+int shade_forward_impl(const svgir_shade_params* p, float* reduced, float* features, float* vfeatures, bool tables_ready, void* stream);
 int shade_backward_impl(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures, const float* dL_dvfeatures,
                         float* dL_dbase_color, float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
-                        float* env_grad_work, bool rows_precleared, void* stream);
+                        float* env_grad_work, bool rows_precleared, bool tables_ready, void* stream);
 
 #if defined(__HIPCC__)
 // ---- device helpers ----------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 // Floating-point contraction is OFF in this file: culling decisions, radii and tile rectangles are integer
 // outputs (num_rendered, radii, point_list) and are kept bit-identical to the un-fused arithmetic of the oracle.
 #include "common.hpp"
+#include "shade_tables.hpp"
 
 #pragma clang fp contract(off)
 
@@ -131,6 +132,10 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     if (!a.colors_precomp) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
     if (SVGSS) { pbb[0] = a.patchbbox[0]; pbb[1] = a.patchbbox[1]; pbb[2] = a.patchbbox[2]; pbb[3] = a.patchbbox[3]; }
     for (int j = idx; j < a.n_zero_words; j += gridDim.x * BLOCK) a.zero_words[j] = 0u;
+    if ((int)blockIdx.x >= a.pblocks) {   // fused shading: the workgroups behind the Gaussians' build the shading kernels' tables
+        shade_table_entry(a.tabs, ((int)blockIdx.x - a.pblocks) * BLOCK + (int)threadIdx.x);
+        return;
+    }
     if (idx >= a.P) return;
     const bool surface = cfg_flag(a.cfg, 0), pix_depth = cfg_flag(a.cfg, 2);
     if (a.out_weights) a.out_weights[idx] = 0.f;
@@ -335,8 +340,10 @@ __global__ void __launch_bounds__(BLOCK) mark_visible_kernel(int P, const float*
 
 }  // namespace
 
-void launch_preprocess(const PreArgs& a, bool svgss, hipStream_t s) {
-    const int grid = (a.P + BLOCK - 1) / BLOCK;
+void launch_preprocess(const PreArgs& a_, bool svgss, hipStream_t s) {
+    PreArgs a = a_;
+    a.pblocks = (a.P + BLOCK - 1) / BLOCK;
+    const int grid = a.pblocks + (a.tabs.entries() + BLOCK - 1) / BLOCK;   // (+ the shading tables of the fused path)
     if (svgss) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL(preprocess_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, a);
 }

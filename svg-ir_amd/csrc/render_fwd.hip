@@ -32,6 +32,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "shade_tables.hpp"
 #include "stage.hpp"
 #include "pairstage.hpp"
 #include "dev_trace.hpp"
@@ -492,10 +493,17 @@ render_fwd_kernel(const RenderArgs a) {
 // `ndump` states has min(ceil(count / SEG), ndump + 1) live segments: all full but possibly the last.  The forward has
 // already summed them per workgroup and length class (seg_block), so every workgroup derives its own bases, scans its 256
 // tiles and writes ids + descriptors: class-major, tile order inside a class.  Deterministic.
-__global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int T, int nblk, uint4* __restrict__ clear, size_t clear_n16) {
+__global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int T, int nblk, uint4* __restrict__ clear, size_t clear_n16,
+                                                        const ShadeTables tabs) {
     // piggy-backed: the backward's scratch clear (validity bytes / packed gradient rows), grid-stride over all workgroups -- one
     // launch in front of the composite backward instead of a memset + this kernel
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < clear_n16; i += (size_t)gridDim.x * 256) clear[i] = make_uint4(0u, 0u, 0u, 0u);
+    // ... and, fused shading, the tables + the zeroed env-gradient accumulator the shading backward behind the composite needs
+    if (tabs.env) {
+        const int ne = tabs.entries();
+        for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < ne; i += (int)gridDim.x * 256) shade_table_entry(tabs, i);
+        for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < tabs.nzero; i += (int)gridDim.x * 256) tabs.zero[i] = 0.f;
+    }
     if ((int)blockIdx.x >= nblk) return;   // (workgroups beyond the tile blocks only clear)
     __shared__ uint32_t red_b[SEG_CLASSES][4], red_t[SEG_CLASSES][4], wfull[4];
     __shared__ unsigned long long wpart[4];
@@ -599,11 +607,11 @@ void launch(const RenderArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, hipStream_t s) {
+void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, hipStream_t s) {
     const int T = a.gx * a.gy, nblk = (T + 255) / 256;
     const size_t n16 = clear ? (clear_bytes + 15) / 16 : 0;   // (the scratch regions are 256-byte aligned and padded: common.hpp align_up)
     const int grid = (int)std::max<size_t>((size_t)nblk, std::min<size_t>((n16 + 255) / 256, 2048));
-    hipLaunchKernelGGL(seg_build_kernel, dim3(grid), dim3(256), 0, s, a, T, nblk, (uint4*)clear, n16);
+    hipLaunchKernelGGL(seg_build_kernel, dim3(grid), dim3(256), 0, s, a, T, nblk, (uint4*)clear, n16, tabs);
 }
 
 void launch_pair_stream(const RenderArgs& a, hipStream_t s) {

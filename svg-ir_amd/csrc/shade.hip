@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "shade_tables.hpp"
 
 #include "dev_trace.hpp"
 
@@ -67,7 +68,6 @@ __device__ __forceinline__ float inv_norm(float x2) {
 #endif
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 // (the f(env) table -- one float4 per texel {f(r), f(g), f(b), 0}: a bilinear tap is ONE 16-byte gather instead of three dwords -- is
 // built by shade_prologue_kernel below)
@@ -103,7 +103,6 @@ __device__ __forceinline__ void env_taps(const float* d, int He, int We, EnvTap&
 // registers from 3 (+1) floats per SURFEL.
 // The reference evaluates t_i in fp32 (one ulp is 6e-5 rad at t = 900); the table is built from exactly that rounded
 // product, and the offset is added with the rounding error of the fp32 sum carried to first order.
-constexpr float kLatticeDelta = 2.39996322972865332f;   // fp32(pi * (3 - sqrt(5)))
 constexpr float kTwoPi = 6.28318530717958647692f;
 
 __global__ void __launch_bounds__(BLOCK) lattice_table_kernel(int Ns, float4* __restrict__ tab) {
@@ -120,31 +119,22 @@ __global__ void __launch_bounds__(BLOCK) lattice_table_kernel(int Ns, float4* __
 }
 
 // One launch in front of a shading kernel: the f(env) table, the lattice table (when the directions are generated in-kernel) and, for
-// the backward, the clear of the env-gradient accumulator -- three tiny jobs that used to be three launches (~4 us of stream time each).
-__global__ void __launch_bounds__(BLOCK) shade_prologue_kernel(const float* __restrict__ env, float4* __restrict__ env_tab, int ntexel, int softplus,
-                                                               int Ns, float4* __restrict__ lat_tab, float* __restrict__ zero, int nzero) {
+// the backward, the clear of the env-gradient accumulator -- three tiny jobs that used to be three launches (shade_tables.hpp).
+__global__ void __launch_bounds__(BLOCK) shade_prologue_kernel(const ShadeTables t) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < ntexel) {
-        const float r = env[3 * i], g = env[3 * i + 1], b = env[3 * i + 2];
-        env_tab[i] = softplus ? make_float4(softplus_f(r), softplus_f(g), softplus_f(b), 0.f) : make_float4(r, g, b, 0.f);
-    }
-    for (int j = i; j < nzero; j += gridDim.x * BLOCK) zero[j] = 0.f;
-    if (lat_tab && i < Ns) {
-#pragma clang fp contract(off)
-        const float fi = (float)i;
-        const float z = fmaxf(1.f - 2.f * fi / (float)(2 * Ns - 1), 0.17364817766693033f);   // sin(10 deg)
-        const float rad = sqrtf(1.f - z * z);
-        const float t = kLatticeDelta * fi;
-        float sn, cs;
-        sincosf(t, &sn, &cs);
-        lat_tab[i] = make_float4(sn, cs, z, rad);
-    }
+    shade_table_entry(t, i);
+    for (int j = i; j < t.nzero; j += gridDim.x * BLOCK) t.zero[j] = 0.f;
+}
+static ShadeTables shade_tables_of(const svgir_shade_params* p, float* zero, int nzero) {
+    ShadeTables t;
+    t.env = p->env; t.env_tab = (float4*)p->env_work; t.ntexel = p->env_h * p->env_w; t.softplus = p->env_softplus;
+    t.Ns = p->Ns; t.lat_tab = p->incident_dirs ? (float4*)nullptr : (float4*)p->lattice_work;
+    t.zero = zero; t.nzero = nzero;
+    return t;
 }
 static void launch_shade_prologue(const svgir_shade_params* p, float* zero, int nzero, hipStream_t s) {
-    const int ntexel = p->env_h * p->env_w;
-    const int n = std::max(ntexel, p->incident_dirs ? 0 : p->Ns);
-    hipLaunchKernelGGL(shade_prologue_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, (float4*)p->env_work, ntexel, p->env_softplus,
-                       p->Ns, p->incident_dirs ? (float4*)nullptr : (float4*)p->lattice_work, zero, nzero);
+    const ShadeTables t = shade_tables_of(p, zero, nzero);
+    hipLaunchKernelGGL(shade_prologue_kernel, dim3((t.entries() + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, t);
 }
 
 struct LatticeFrame { float R[9]; float so, co, off; };   // rotation taking +z to the surfel's normal; offset angle
@@ -1177,6 +1167,14 @@ extern "C" int svgir_dev_trace_read_shade(unsigned long long* out, int cap_recor
 extern "C" {
 
 int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* features, float* vfeatures, void* stream) {
+    return svgir::shade_forward_impl(p, reduced, features, vfeatures, false, stream);
+}
+
+}  // extern "C"
+
+svgir::ShadeTables svgir::shade_tables(const svgir_shade_params* p, float* zero, int nzero) { return shade_tables_of(p, zero, nzero); }
+
+int svgir::shade_forward_impl(const svgir_shade_params* p, float* reduced, float* features, float* vfeatures, bool tables_ready, void* stream) {
     if (!p || p->P < 0 || p->Ns <= 0 || p->env_h <= 0 || p->env_w <= 0) return SVGIR_ERR_INVALID;
     if (p->P == 0) return 0;
     if (!p->base_color || !p->roughness || !p->normals || !p->viewdirs || !p->radiance || !p->visibility ||
@@ -1188,7 +1186,7 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
-    launch_shade_prologue(p, nullptr, 0, s);
+    if (!tables_ready) launch_shade_prologue(p, nullptr, 0, s);
     stage_mark(tm, "shade_env_table");
     ShadeArgs a;
     a.p = *p; a.reduced = reduced; a.features = features; a.vfeatures = vfeatures;
@@ -1213,12 +1211,14 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
 
+extern "C" {
+
 int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
                          const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
                          float* env_grad_work, void* stream) {
     return svgir::shade_backward_impl(p, dL_dreduced, dL_dfeatures, dL_dvfeatures, dL_dbase_color, dL_droughness, dL_dnormals, dL_dradiance,
-                                      dL_denv, env_grad_work, false, stream);
+                                      dL_denv, env_grad_work, false, false, stream);
 }
 
 }  // extern "C"
@@ -1226,7 +1226,7 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
 int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
                                const float* dL_dvfeatures, float* dL_dbase_color,
                                float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
-                               float* env_grad_work, bool rows_precleared, void* stream) {
+                               float* env_grad_work, bool rows_precleared, bool tables_ready, void* stream) {
     if (!p || p->P < 0 || p->Ns <= 0 || p->env_h <= 0 || p->env_w <= 0) return SVGIR_ERR_INVALID;
     if (p->P == 0) return 0;
     if ((!dL_dreduced && !dL_dfeatures && !dL_dvfeatures) || (dL_dvfeatures && !p->viewmatrix) || !dL_dbase_color || !dL_droughness || !dL_dnormals || !dL_dradiance || !dL_denv ||
@@ -1238,7 +1238,7 @@ int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dred
     hipStream_t s = (hipStream_t)stream;
     const int ntex = p->env_h * p->env_w * 3;
     StageMarks tm = stage_begin(s);
-    launch_shade_prologue(p, env_grad_work, ntex, s);
+    if (!tables_ready) launch_shade_prologue(p, env_grad_work, ntex, s);
 
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
