@@ -598,7 +598,9 @@ struct ForwardCall {
         if (prepass) {
             RenderArgs rp = ra;
             rp.S = 0; rp.VS = 0; rp.features = nullptr; rp.vfeatures = nullptr; rp.dump_only = 2; rp.needed = G.needed;
-            if (launch_render_fwd(rp, svgss, s) < 0) return fail(SVGIR_ERR_HIP, "contribution pre-pass: no composite kernel");
+            static const bool full = getenv("SVGIR_PREPASS_FULL") != nullptr;   // (A/B: the composite kernel itself in its no-output mode)
+            if (!full) launch_contrib_prepass(rp, s);
+            else if (launch_render_fwd(rp, svgss, s) < 0) return fail(SVGIR_ERR_HIP, "contribution pre-pass: no composite kernel");
             if (int rc = check("prepass")) return rc;
             if (timed) tm.mark("prepass");
         }

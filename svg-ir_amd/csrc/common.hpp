@@ -402,6 +402,8 @@ void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t*
                        unsigned long long* host_totals, uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
+// fused shading: needed[id] = 1 for every surfel that receives a blend weight in this view (the composite's transmittance walk alone)
+void launch_contrib_prepass(const RenderArgs& a, hipStream_t s);
 // tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump; also zeroes
 // `clear_bytes` bytes at `clear` (a multiple of 16; the backward's scratch clear rides on this launch)
 void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, hipStream_t s);   // (+ the shading tables of the fused path)

@@ -488,6 +488,86 @@ render_fwd_kernel(const RenderArgs a) {
     DEV_TRACE_END(0, (unsigned)total, head, blockIdx.x);
 }
 
+// ---- contribution pre-pass of the fused shading -----------------------------------------------------------------------------
+// Which surfels receive a blend weight at all?  The transmittance walk of render_fwd_kernel -- the same alpha (pair_power / exp_nonpos
+// are the element-wise twins of the packed forms, stage.hpp / pairstage.hpp), the same alpha >= 1/255 and T < 1e-4 decisions in the same
+// order, hence the same set bit for bit -- without anything else: no channels, no depth, no weights sum, no state; a candidate costs its
+// 32-byte record header, ~35 instructions and one ballot.  One wave per 8x8 sub-tile in the composite's dispatch order; 64 candidates are
+// staged per batch (lane = candidate: entry -> two 16-byte gathers, one batch ahead) and walked with wave-uniform LDS reads.
+__global__ void __launch_bounds__(64) contrib_prepass_kernel(const RenderArgs a) {
+    // pair-interleaved staging (as pairstage.hpp, geometry only): pair p of a batch = {x0 x1 y0 y1 | a0 a1 c0 c1 | b0 b1 o0 o1}, so that
+    // one ds_read_b128 yields the aligned register pairs of TWO candidates and their alphas are packed fp32 instructions
+    __shared__ __attribute__((aligned(16))) float sQ[2][32][12];
+    __shared__ uint32_t sG[2][64];
+    if ((int)blockIdx.x >= 4 * a.gx * a.gy) return;
+    const uint32_t sid = a.sub_order[blockIdx.x];
+    const int tile = (int)(sid >> 2), sub = (int)(sid & 3u);
+    const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
+    const int len = (int)(r1 - r0);
+    if (len == 0) return;
+    const int total = (int)a.sub_total[sid];
+    if (total == 0) return;
+    const int lane = threadIdx.x;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int px = tx * TILE + (sub & 1) * 8 + (lane & 7), py = ty * TILE + (sub >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const f32x2 pxx = {pxf, pxf}, pyy = {pyf, pyf};
+    const uint2* __restrict__ list = a.sub_list + (size_t)4 * r0 + (size_t)sub * len;
+    const float4* __restrict__ rec4 = reinterpret_cast<const float4*>(a.rec);
+    bool done = !(px < a.W && py < a.H);
+    float T = 1.0f;
+    const int nb = (total + 63) / 64;
+    uint32_t gid = lane < total ? list[lane].x : 0u;
+    float4 A = rec4[(size_t)gid * 6], B = rec4[(size_t)gid * 6 + 1];
+    bool valid = lane < total;
+    for (int b = 0; b < nb; b++) {
+        const int buf = b & 1;
+        {
+            float* q = &sQ[buf][lane >> 1][lane & 1];
+            q[0] = A.x; q[2] = A.y; q[4] = A.z; q[6] = B.x; q[8] = A.w; q[10] = valid ? B.y : 0.f;   // (opacity 0: a padding slot never blends)
+            sG[buf][lane] = gid;
+        }
+        if (b + 1 < nb) {   // the next batch's gathers fly while this one is walked
+            const int i = (b + 1) * 64 + lane;
+            valid = i < total;
+            gid = valid ? list[i].x : 0u;
+            A = rec4[(size_t)gid * 6]; B = rec4[(size_t)gid * 6 + 1];
+        }
+        wave_lds_sync();
+        const int m = min(64, total - b * 64);
+        for (int c = 0; c < m; c += 2) {
+            const f32x4* P = reinterpret_cast<const f32x4*>(&sQ[buf][c >> 1][0]);
+            const f32x4 G0 = P[0], G1 = P[1], G2 = P[2];
+            const f32x2 dx = G0.xy - pxx, dy = G0.zw - pyy;
+            const f32x2 pw = pair_power2(G1.xy, G2.xy, G1.zw, dx, dy);
+            f32x2 a2;
+            {
+#pragma clang fp contract(off)
+                a2 = G2.zw * exp_nonpos2(pw);
+            }
+            const float al[2] = {fminf(0.99f, a2.x), fminf(0.99f, a2.y)};
+            const float pwk[2] = {pw.x, pw.y};
+            bool pass[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const bool live = pwk[k] <= 0.0f && al[k] >= (1.0f / 255.0f) && !done;
+                const float test_T = T * (1.f - al[k]);
+                const bool term = live && test_T < 0.0001f;
+                pass[k] = live && !term;
+                done = done || term;
+                T = pass[k] ? test_T : T;
+            }
+            // (uniform) some pixel blends the candidate: the composite will read its packed rows
+            const bool any0 = __builtin_amdgcn_ballot_w64(pass[0]) != 0ull, any1 = __builtin_amdgcn_ballot_w64(pass[1]) != 0ull;
+            if (any0 || any1) {
+                if (lane < 2 && (lane == 0 ? any0 : any1)) a.needed[sG[buf][c + lane]] = 1;
+            }
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) return;   // (uniform) every pixel is saturated
+        }
+        wave_lds_sync();   // (the buffer written two batches from now is this one)
+    }
+}
+
 // ---- live backward segments, longest first (common.hpp SEG) ------------------------------------------------------
 // One thread per tile (its four sub-tiles), 256 tiles per workgroup.  A sub-tile that consumed `count` candidates and dumped
 // `ndump` states has min(ceil(count / SEG), ndump + 1) live segments: all full but possibly the last.  The forward has
@@ -620,6 +700,10 @@ void launch_pair_stream(const RenderArgs& a, hipStream_t s) {
     else if (a.S == 3) hipLaunchKernelGGL((pair_stream_kernel<3>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
     else if (a.S == 1) hipLaunchKernelGGL((pair_stream_kernel<1>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
     else if (a.S == 0) hipLaunchKernelGGL((pair_stream_kernel<0>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
+}
+
+void launch_contrib_prepass(const RenderArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(contrib_prepass_kernel, dim3(4 * a.gx * a.gy), dim3(64), 0, s, a);
 }
 
 void launch_cull(const RenderArgs& a, hipStream_t s) {
