@@ -302,7 +302,7 @@ class Workload:
             (R, color, normal, depth, opac, feat, vfeat, weights, radii, gb, bb, ib) = out
             if not self.train:
                 return R, color, weights
-            kw = {}
+            kw = dict(out_weights=weights)
             if self.training:
                 self.sgrads = dict(dL_denv=self.senv[0], env_grad_work=self.senv[1], dL_dreduced=None, out_weights=weights,
                                    _shapes=dict(self.sshapes))
@@ -342,7 +342,7 @@ class Workload:
                                                 st.viewmatrix, st.projmatrix, st.prcppoint, st.patch_bbox, st.tanfovx,
                                                 st.tanfovy, gt["color"], gt["normal"], gt["depth"], gt["opacity"],
                                                 gt["feature"], gt["vfeature"], sct["shs"], st.sh_degree, st.campos,
-                                                gb, R, bb, ib, False, st.config)
+                                                gb, R, bb, ib, False, st.config, out_weights=weights)
             if self.shade and self.training:
                 torch.autograd.backward([feats_in, vfeats_in], [g[4], g[5]])
         else:
@@ -355,7 +355,7 @@ class Workload:
                                                 sct["rotations"], st.scale_modifier, empty, st.viewmatrix,
                                                 st.projmatrix, st.tanfovx, st.tanfovy, gt["color"], gt["normal"],
                                                 gt["opacity"], gt["depth"], gt["feature"], sct["shs"], st.sh_degree,
-                                                st.campos, gb, R, bb, ib, True, False)
+                                                st.campos, gb, R, bb, ib, True, False, out_weights=weights)
         return R, color, g[3]
 
 

@@ -406,6 +406,12 @@ CfgRef cfg_ref(const svgir_params* p) {
     return c;
 }
 
+// svgir_grads.out_weights given: below this many Gaussians the two launches of the partition cost more than the per-Gaussian kernels save
+// by walking the blended Gaussians only (the fused shading needs the partition anyway)
+// (measured: cfg3_train, P = 200 k, svgss rows: grad_reduce 85 -> 64 us, geom_bwd 28 -> 24 us against ~10 us for the partition; cfg2,
+// P = 200 k, rgss packed rows: only geom_bwd gains, 31 -> ~25 us: not worth it; cfg5, P = 2 M: 498 -> 345 us and 171 -> 88 us)
+constexpr int kListMinP = 400000, kListMinPRows = 50000;
+
 // fused shading: run the contribution pre-pass?  (SVGIR_PREPASS = 0 / 1 forces it off / on)
 bool shade_prepass(int Ns) {
     static const int forced = [] { const char* e = getenv("SVGIR_PREPASS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
@@ -1088,6 +1094,15 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         HIP_OK(hipMemsetAsync(sc_clear, 0, sc_bytes, s));   // (nothing rendered: geom_bwd still unpacks the -- zero -- packed rows)
     }
     tm.mark("seg_build");
+    // The surfels that received a blend weight (the forward's out_weights > 0): only they own gradient rows, only their per-Gaussian
+    // gradients are non-zero, only their shading is differentiated.  With the weights at hand the per-Gaussian kernels behind the
+    // composite walk that list (13-29 % of the model on the BASELINE scenes) instead of all P.
+    const uint32_t* blended = nullptr; const uint32_t* blended_n = nullptr;
+    if (g->out_weights && !generic && R > 0 && (p->shade || P >= (rows ? kListMinPRows : kListMinP))) {
+        uint32_t* cnt = G.shade_work + partition_work_words(P) - 1;
+        launch_partition(P, nullptr, g->out_weights, G.shade_list, G.shade_work, cnt, s);
+        blended = G.shade_list; blended_n = cnt;
+    }
     if (R > 0) {
         if (generic) launch_render_bwd_generic(ba, svgss, s);
         else (void)launch_render_bwd(ba, svgss, s);
@@ -1096,6 +1111,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     cleared.join();
     if (R > 0 && rows) {
         GradReduceArgs ra;
+        ra.list = blended; ra.list_count = blended_n;
         ra.P = P; ra.S = p->S; ra.VS = ba.VS; ra.radii = radii; ra.tiles = G.tiles; ra.rec = G.rec;
         ra.grad_rows = ba.grad_rows; ra.row_of = ba.row_of;
         ra.dL_dmean2D = g->dL_dmeans2D; ra.dL_dconic = g->dL_dconic; ra.dL_dopacity = g->dL_dopacity; ra.dL_dcolor = g->dL_dcolors;
@@ -1115,9 +1131,12 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         svgir_shade_params sp = p->shade->sp;
         sp.subset = nullptr; sp.subset_count = nullptr;
         if (!all) {
-            uint32_t* cnt = G.shade_work + partition_work_words(P) - 1;
-            launch_partition(P, nullptr, g->out_weights, G.shade_list, G.shade_work, cnt, s);
-            sp.subset = G.shade_list; sp.subset_count = cnt;
+            if (!blended) {   // (R == 0: nothing was blended -- the partition of all-zero weights zero-fills every row)
+                uint32_t* cnt = G.shade_work + partition_work_words(P) - 1;
+                launch_partition(P, nullptr, g->out_weights, G.shade_list, G.shade_work, cnt, s);
+                blended = G.shade_list; blended_n = cnt;
+            }
+            sp.subset = blended; sp.subset_count = blended_n;
         }
         // (a binder that lays the four per-surfel gradient tensors out inside clear_base gets their zero rows from the composite
         // backward's clearing sweep -- stores nobody waits for -- instead of a zero-fill launch in front of the shading backward)
@@ -1135,6 +1154,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     }
 
     GeomBwdArgs ga;
+    ga.list = R > 0 ? blended : nullptr; ga.list_count = blended_n;
     ga.P = P; ga.D = p->D; ga.M = p->M;
     ga.means3D = p->means3D; ga.shs = p->colors_precomp ? nullptr : p->shs; ga.scales = p->scales; ga.rotations = p->rotations;
     ga.cov3D = p->cov3D_precomp ? p->cov3D_precomp : G.cov3D; ga.view = p->viewmatrix; ga.proj = p->projmatrix; ga.campos = p->cam_pos;

@@ -350,6 +350,7 @@ struct RenderBwdArgs {
 };
 
 struct GradReduceArgs {
+    const uint32_t* list; const uint32_t* list_count;   // optional: walk only the Gaussians list[0 .. *list_count) (those that were blended)
     int P, S, VS;
     const int32_t* radii; const uint32_t* tiles; const float* rec;
     const float* grad_rows; const uint32_t* row_of;
@@ -357,6 +358,7 @@ struct GradReduceArgs {
 };
 
 struct GeomBwdArgs {
+    const uint32_t* list; const uint32_t* list_count;   // optional: as GradReduceArgs (all other Gaussians keep their cleared, zero gradients)
     int P, D, M;
     const float *means3D, *shs, *scales, *rotations, *cov3D, *view, *proj, *campos;
     const int32_t* radii; const uint32_t* clamped;

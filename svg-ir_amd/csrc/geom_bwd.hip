@@ -53,8 +53,12 @@ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 #define GEOM_SHS a.shs
 #endif
 __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
-    const int idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    const int w = blockIdx.x * BLOCK + threadIdx.x;
+    // (with a list: only the Gaussians that received a blend weight have non-zero composite gradients; the outputs of the others stay
+    // at the zeros svgir_backward cleared them to)
+    if (w >= (a.list ? (int)min(*a.list_count, (uint32_t)a.P) : a.P)) return;
+    const int idx = a.list ? (int)a.list[w] : w;
+    if (!(a.radii[idx] > 0)) return;
     const bool surface = cfg_flag(a.cfg, 0);
     const bool lrn_cam = a.svgss && a.cfg.len >= 0 && cfg_flag(a.cfg, 3);
     // (the uniform inputs as well: a load the compiler cannot prove untouched by an earlier store is not a scalar load any more)

@@ -23,8 +23,10 @@ constexpr int RB = GRAD_REDUCE_RB;   // gradient rows in flight per wave
 
 __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs a, const GradRowGeom rg) {
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    if (g >= a.P) return;
+    const int w = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    // (with a list: only the Gaussians that received a blend weight own gradient rows; the others keep the caller's zeros)
+    if (w >= (a.list ? (int)min(*a.list_count, (uint32_t)a.P) : a.P)) return;
+    const int g = a.list ? (int)a.list[w] : w;
     // three independent loads first (one memory latency), then the early exits
     const int32_t radius = a.radii[g];
     const uint32_t ntiles = a.tiles[g];

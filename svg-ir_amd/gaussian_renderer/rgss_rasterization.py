@@ -104,7 +104,7 @@ class _CBinding:
     def rasterize_gaussians_backward(background, means3D, features, radii, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                      dL_dout_normal, dL_dout_opacity, dL_dout_depth, dL_dout_feature, sh, degree,
-                                     campos, geomBuffer, R, binningBuffer, imageBuffer, backward_geometry, debug):
+                                     campos, geomBuffer, R, binningBuffer, imageBuffer, backward_geometry, debug, *, out_weights=None):
         dev = means3D.device
         P = means3D.size(0)
         S = features.size(1) if features.dim() == 2 else 0
@@ -137,6 +137,8 @@ class _CBinding:
             g.dL_drotations = dL_drotations.data_ptr()
             if N.CLEAR_HINT:
                 g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
+            if out_weights is not None:   # (extension: the per-Gaussian backward then walks the blended Gaussians only, from ~0.4 M surfels on)
+                g.out_weights = N.ptr(N.f32c(out_weights, dev))
             rad = radii.contiguous()
             # scratch: one packed gradient row per Gaussian (include/svgir_raster.h)
             nscr = N.lib.svgir_backward_scratch_bytes(N.RGSS, P, binningBuffer.numel(), W, H, S, 0)
@@ -206,7 +208,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, features, scales, rotations, cov3Ds_precomp, radii, sh,
-                              geomBuffer, binningBuffer, imgBuffer)
+                              geomBuffer, binningBuffer, imgBuffer, weights)
         ctx.mark_non_differentiable(num_contrib, pseudo_normal, surface_xyz, weights, radii)
         return (num_rendered, num_contrib, color, normal, opacity, depth, feature, pseudo_normal, surface_xyz, weights,
                 radii)
@@ -218,7 +220,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
         (colors_precomp, means3D, features, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
-         imgBuffer) = ctx.saved_tensors
+         imgBuffer, weights) = ctx.saved_tensors
         H, W = raster_settings.image_height, raster_settings.image_width
 
         def _g(g, ch):
@@ -234,13 +236,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                res = _C.rasterize_gaussians_backward(*args)
+                res = _C.rasterize_gaussians_backward(*args, out_weights=weights)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            res = _C.rasterize_gaussians_backward(*args)
+            res = _C.rasterize_gaussians_backward(*args, out_weights=weights)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_features, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations) = res
 

@@ -114,9 +114,11 @@ class _CBinding:
                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox,
                                      tan_fovx, tan_fovy, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac,
                                      dL_dout_feature, dL_dout_vfeature, sh, degree, campos, geomBuffer, R,
-                                     binningBuffer, imageBuffer, debug, config, *, shade=None, shade_grads=None):
+                                     binningBuffer, imageBuffer, debug, config, *, shade=None, shade_grads=None, out_weights=None):
         """`shade` / `shade_grads` (extension, keyword only): the `_native.FusedShade` of the forward and a dict of the shading's
-        gradient outputs + `out_weights` (+ optional `dL_dreduced`), written by svgir_backward (gaussian_renderer/shading.py)."""
+        gradient outputs + `out_weights` (+ optional `dL_dreduced`), written by svgir_backward (gaussian_renderer/shading.py).
+        `out_weights` (extension, keyword only): the forward's weights [P,1] -- the per-Gaussian kernels behind the composite then walk
+        the blended Gaussians only (all others have zero gradients); worth it from a few hundred thousand surfels on."""
         dev = means3D.device
         P = means3D.size(0)
         S = features.size(1) if features.dim() == 2 else 0
@@ -159,6 +161,8 @@ class _CBinding:
             if N.CLEAR_HINT:
                 g.clear_base, g.clear_bytes = gblob.data_ptr(), gblob.numel() * 4
             g.dL_dviewmat, g.dL_dprojmat, g.dL_dcampos = dL_dviewmat.data_ptr(), dL_dprojmat.data_ptr(), dL_dcampos.data_ptr()
+            if out_weights is not None:
+                g.out_weights = N.ptr(N.f32c(out_weights, dev))
             if shade is not None:
                 p.shade = C.addressof(shade)
                 for k, t in shade_grads.items():
@@ -239,7 +243,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, features, vfeatures, scales, rotations, cov3Ds_precomp, radii,
-                              sh, geomBuffer, binningBuffer, imgBuffer)
+                              sh, geomBuffer, binningBuffer, imgBuffer, weights)
         ctx.mark_non_differentiable(weights, radii)
         return num_rendered, color, normal, opacity, depth, feature, vfeature, weights, radii
 
@@ -249,7 +253,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
         (colors_precomp, means3D, features, vfeatures, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
-         binningBuffer, imgBuffer) = ctx.saved_tensors
+         binningBuffer, imgBuffer, weights) = ctx.saved_tensors
         H, W = raster_settings.image_height, raster_settings.image_width
 
         def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss
@@ -267,13 +271,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                res = _C.rasterize_gaussians_backward(*args)
+                res = _C.rasterize_gaussians_backward(*args, out_weights=weights)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            res = _C.rasterize_gaussians_backward(*args)
+            res = _C.rasterize_gaussians_backward(*args, out_weights=weights)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_features, grad_vfeatures,
          grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations, grad_viewmat, grad_projmat, grad_campos) = res
 
