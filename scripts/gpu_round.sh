@@ -9,7 +9,7 @@ if [ "${2:-}" != "quick" ]; then
   python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/${TAG}_tests.log
   cat gpurun_out/${TAG}_tests.log
 fi
-for W in cfg2 cfg3_train; do   # PMC passes first: bench.py reports them as roofline.traffic / roofline.issue_frac (stamped with the kernel-source hash)
+for W in ${PMC_WORKLOADS:-cfg2 cfg3_train cfg3_eval cfg4 cfg5}; do   # PMC passes first: bench.py reports them as roofline.traffic / roofline.issue_frac (stamped with the kernel-source hash)
   scripts/pmc_traffic.sh $W ${TAG}_$W > /dev/null 2>&1 && cp gpurun_out/${TAG}_${W}_traffic.json profiles/traffic_$W.json && cp gpurun_out/${TAG}_${W}_traffic.json gpurun_out/traffic_$W.json
   scripts/pmc_issue.sh $W ${TAG}_$W > /dev/null 2>&1 && cp gpurun_out/${TAG}_${W}_issue.json profiles/issue_$W.json && cp gpurun_out/${TAG}_${W}_issue.json gpurun_out/issue_$W.json
 done
@@ -36,5 +36,6 @@ if [ -f build/variants/dev/libsvgir_raster.so ]; then
 fi
 bash scripts/pmc_tracer.sh ${TAG}_pmct > gpurun_out/${TAG}_tracer_pmc.txt 2>&1; tail -6 gpurun_out/${TAG}_tracer_pmc.txt
 rm -rf gpurun_out/${TAG}_pmct_a gpurun_out/${TAG}_pmct_b gpurun_out/${TAG}_*_rd gpurun_out/${TAG}_*_wr gpurun_out/${TAG}_*_iss
+python scripts/sort_probe.py cfg2 cfg5 cfg5_dense 2>&1 | grep '^cfg' > gpurun_out/${TAG}_sort_probe.txt; cat gpurun_out/${TAG}_sort_probe.txt
 timeout 600 python scripts/blob_sizes.py cfg2 cfg3_train cfg3_eval cfg5 cfg5_dense 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_blob_sizes.txt; cat gpurun_out/${TAG}_blob_sizes.txt
-python scripts/parity_report.py r04 cfg1 cfg2 cfg3_train cfg3_eval cfg4 cfg5 cfg5_dense > gpurun_out/${TAG}_parity.log 2>&1; tail -30 gpurun_out/${TAG}_parity.log
+python scripts/parity_report.py ${PARITY_TAG:-r05} cfg1 cfg2 cfg3_train cfg3_eval cfg4 cfg5 cfg5_dense > gpurun_out/${TAG}_parity.log 2>&1; tail -30 gpurun_out/${TAG}_parity.log

@@ -21,7 +21,7 @@ out = {"workload": sys.argv[2], "kernel_source_hash": bench.kernel_source_hash()
        "method": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_{VALU,SALU,LDS,VMEM,SMEM} (+ MFMA MOPS), wave-level instruction counts per launch "
                  "(averaged over the launches of the run); durations of this profiled run in us", "kernels": {}}
 for k, cs in acc.items():
-    if not any(p in k for p in ("render_", "cull_kernel", "shade_fwd", "shade_bwd", "grad_reduce", "geom_bwd", "preprocess")):
+    if not any(p in k for p in ("render_", "cull_kernel", "contrib_prepass", "shade_fwd", "shade_bwd", "grad_reduce", "geom_bwd", "preprocess")):
         continue
     short = k.replace("svgir::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     c = {n: sum(v) / len(v) for n, v in cs.items()}

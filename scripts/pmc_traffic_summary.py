@@ -26,7 +26,7 @@ def load(d):
 rd, wr = load(sys.argv[1]), load(sys.argv[2])
 out = {"workload": sys.argv[3], "kernel_source_hash": kernel_source_hash(), "library_hash": bench.library_hash(), "method": __doc__.split("usage")[0].strip(), "kernels": {}}
 for k in rd:
-    if not any(p in k for p in ("render_", "cull_kernel", "shade_fwd", "shade_bwd", "grad_reduce")):
+    if not any(p in k for p in ("render_", "cull_kernel", "contrib_prepass", "shade_fwd", "shade_bwd", "grad_reduce")):
         continue
     r, w = rd[k], wr.get(k, {})
     rq, r32 = r.get("TCC_EA0_RDREQ_sum", 0.0), r.get("TCC_EA0_RDREQ_32B_sum", 0.0)
