@@ -118,6 +118,8 @@ typedef struct svgir_outputs {
  * it in passing, no memset and no second stream; without the hint the tensors are cleared one by one on an internal side stream that is
  * joined behind the composite backward. */
 typedef struct svgir_grads {
+    /* upstream gradients: any of the six may be NULL = all zero (an output that took no part in the loss: the training loss of the
+     * reference reads one image, svgss.py:281-289) -- nothing is read for it, and the binder need not allocate and fill a zero image */
     const float* dL_dout_color;    /* [3,H,W] */
     const float* dL_dout_normal;   /* [3,H,W] */
     const float* dL_dout_depth;    /* [1,H,W] */

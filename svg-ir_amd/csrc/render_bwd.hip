@@ -174,12 +174,12 @@ render_bwd_kernel(const RenderBwdArgs a) {
     const uint32_t last_contributor = inside ? (uint32_t)a.n_contrib[pid] : 0u;
     float gC[3], gN[3], gF[SS], gVF[VV], gD = 0.f, gO = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { gC[i] = inside ? a.g_color[i * N_ + pid] : 0.f; gN[i] = inside ? a.g_normal[i * N_ + pid] : 0.f; }
+    for (int i = 0; i < 3; i++) { gC[i] = (inside && a.g_color) ? a.g_color[i * N_ + pid] : 0.f; gN[i] = (inside && a.g_normal) ? a.g_normal[i * N_ + pid] : 0.f; }
 #pragma unroll
-    for (int i = 0; i < SS; i++) gF[i] = (inside && i < S) ? a.g_feature[i * N_ + pid] : 0.f;
+    for (int i = 0; i < SS; i++) gF[i] = (inside && i < S && a.g_feature) ? a.g_feature[i * N_ + pid] : 0.f;
 #pragma unroll
-    for (int i = 0; i < VV; i++) gVF[i] = (inside && i < VC) ? a.g_vfeature[i * N_ + pid] : 0.f;
-    if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
+    for (int i = 0; i < VV; i++) gVF[i] = (inside && i < VC && a.g_vfeature) ? a.g_vfeature[i * N_ + pid] : 0.f;
+    if (inside) { gD = a.g_depth ? a.g_depth[pid] : 0.f; gO = a.g_opacity ? a.g_opacity[pid] : 0.f; }
     constexpr int NST = 8 + S + VC;
     float st_T = 0.f, st_d[NST - 1];   // (final - prefix) of the dumped states, channel by channel (only when kseg < ndump)
 #pragma unroll

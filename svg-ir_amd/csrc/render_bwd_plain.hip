@@ -206,10 +206,10 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     const uint32_t last_contributor = inside ? (uint32_t)a.n_contrib[pid] : 0u;
     float gC[3], gN[3], gF[SS], gD = 0.f, gO = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { gC[i] = inside ? a.g_color[i * N_ + pid] : 0.f; gN[i] = inside ? a.g_normal[i * N_ + pid] : 0.f; }
+    for (int i = 0; i < 3; i++) { gC[i] = (inside && a.g_color) ? a.g_color[i * N_ + pid] : 0.f; gN[i] = (inside && a.g_normal) ? a.g_normal[i * N_ + pid] : 0.f; }
 #pragma unroll
-    for (int i = 0; i < SS; i++) gF[i] = (inside && i < S) ? a.g_feature[i * N_ + pid] : 0.f;
-    if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
+    for (int i = 0; i < SS; i++) gF[i] = (inside && i < S && a.g_feature) ? a.g_feature[i * N_ + pid] : 0.f;
+    if (inside) { gD = a.g_depth ? a.g_depth[pid] : 0.f; gO = a.g_opacity ? a.g_opacity[pid] : 0.f; }
     const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
     const float omt = 1.f - T_final;
     const float gDn = normalize_depth ? gD / omt : gD;  // depth gradient seen by the blended depth

@@ -148,10 +148,10 @@ __global__ void __launch_bounds__(64) render_bwd_generic_kernel(const RenderBwdA
         const float D_final = (inside && normalize_depth) ? a.final_D[pid] : 0.f;
         const uint32_t last_contributor = inside ? (uint32_t)a.n_contrib[pid] : 0u;
         float gC[3], gN[3], gD = 0.f, gO = 0.f;
-        for (int c = 0; c < 3; c++) { gC[c] = inside ? a.g_color[c * N_ + pid] : 0.f; gN[c] = inside ? a.g_normal[c * N_ + pid] : 0.f; }
-        if (inside) { gD = a.g_depth[pid]; gO = a.g_opacity[pid]; }
-        for (int ch = 0; ch < S; ch++) gbuf[ch * 64 + lane] = inside ? a.g_feature[ch * N_ + pid] : 0.f;
-        for (int ch = 0; ch < VC; ch++) gbuf[(S + ch) * 64 + lane] = inside ? a.g_vfeature[ch * N_ + pid] : 0.f;
+        for (int c = 0; c < 3; c++) { gC[c] = (inside && a.g_color) ? a.g_color[c * N_ + pid] : 0.f; gN[c] = (inside && a.g_normal) ? a.g_normal[c * N_ + pid] : 0.f; }
+        if (inside) { gD = a.g_depth ? a.g_depth[pid] : 0.f; gO = a.g_opacity ? a.g_opacity[pid] : 0.f; }
+        for (int ch = 0; ch < S; ch++) gbuf[ch * 64 + lane] = (inside && a.g_feature) ? a.g_feature[ch * N_ + pid] : 0.f;
+        for (int ch = 0; ch < VC; ch++) gbuf[(S + ch) * 64 + lane] = (inside && a.g_vfeature) ? a.g_vfeature[ch * N_ + pid] : 0.f;
         const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
         const float omt = 1.f - T_final;
         const float gDn = normalize_depth ? gD / omt : gD;

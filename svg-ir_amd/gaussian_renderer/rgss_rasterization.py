@@ -108,7 +108,11 @@ class _CBinding:
         dev = means3D.device
         P = means3D.size(0)
         S = features.size(1) if features.dim() == 2 else 0
-        H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+        # (an upstream gradient may be an EMPTY tensor = all zero: an output that took no part in the loss; nothing is read for it)
+        _gs = [t for t in (dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opacity, dL_dout_feature) if t is not None and t.numel()]
+        if not _gs:
+            raise RuntimeError("rasterize_gaussians_backward: every upstream gradient is empty")
+        H, W = _gs[0].size(1), _gs[0].size(2)
         M = sh.size(1) if sh.numel() != 0 else 0
         (dL_dmeans3D, dL_dmeans2D, dL_dfeatures, dL_dcolors, dL_dnormal, dL_ddepth, dL_dconic, dL_dopacity, dL_dcov3D,
          dL_dsh, dL_dscales, dL_drotations), gblob = N.grad_blob(
@@ -223,8 +227,8 @@ class _RasterizeGaussians(torch.autograd.Function):
          imgBuffer, weights) = ctx.saved_tensors
         H, W = raster_settings.image_height, raster_settings.image_width
 
-        def _g(g, ch):
-            return g if g is not None else torch.zeros((ch, H, W), dtype=torch.float32, device=means3D.device)
+        def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss: an empty tensor = all zero for the library
+            return g if g is not None else torch.empty(0, dtype=torch.float32, device=means3D.device)
 
         args = (raster_settings.bg, means3D, features, radii, colors_precomp, scales, rotations,
                 raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,

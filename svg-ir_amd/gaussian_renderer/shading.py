@@ -302,8 +302,8 @@ class _ShadedRasterize(torch.autograd.Function):
                                                    viewmatrix=st.viewmatrix, training=training, env_transform=env_transform)
         if g_red is not None and not all_surfels:
             raise RuntimeError("render_shaded: a loss on `reduced` needs all_surfels=True (rows of unshaded surfels are zero)")
-        def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss
-            return g if g is not None else torch.zeros((ch, H, W), dtype=torch.float32, device=dev)
+        def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss: an empty tensor = all zero for the library
+            return g if g is not None else torch.empty(0, dtype=torch.float32, device=dev)
 
         empty = torch.empty(0, dtype=torch.float32, device=dev)
         args = (st.bg, means3D, feats, vfeats, radii, empty, scales, rotations, st.scale_modifier, empty, st.viewmatrix, st.projmatrix,

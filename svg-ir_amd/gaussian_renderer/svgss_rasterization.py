@@ -123,7 +123,11 @@ class _CBinding:
         P = means3D.size(0)
         S = features.size(1) if features.dim() == 2 else 0
         VS = vfeatures.size(1) if vfeatures.dim() == 2 else 0
-        H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+        # (an upstream gradient may be an EMPTY tensor = all zero: an output that took no part in the loss; nothing is read for it)
+        _gs = [t for t in (dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, dL_dout_feature, dL_dout_vfeature) if t is not None and t.numel()]
+        if not _gs:
+            raise RuntimeError("rasterize_gaussians_backward: every upstream gradient is empty")
+        H, W = _gs[0].size(1), _gs[0].size(2)
         M = sh.size(1) if sh.numel() != 0 else 0
         # (fused shading: per-surfel gradient tensors the caller asks for by shape -- shade_grads["_shapes"] -- live in the same
         # allocation, so the composite backward's clearing sweep zeroes them too; svgir_backward then writes the differentiated rows)
@@ -256,8 +260,8 @@ class _RasterizeGaussians(torch.autograd.Function):
          binningBuffer, imgBuffer, weights) = ctx.saved_tensors
         H, W = raster_settings.image_height, raster_settings.image_width
 
-        def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss
-            return g if g is not None else torch.zeros((ch, H, W), dtype=torch.float32, device=means3D.device)
+        def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss: an empty tensor = all zero for the library
+            return g if g is not None else torch.empty(0, dtype=torch.float32, device=means3D.device)
 
         args = (raster_settings.bg, means3D, features, vfeatures, radii, colors_precomp, scales, rotations,
                 raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,
