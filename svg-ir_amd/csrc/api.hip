@@ -410,7 +410,7 @@ CfgRef cfg_ref(const svgir_params* p) {
 // by walking the blended Gaussians only (the fused shading needs the partition anyway)
 // (measured: cfg3_train, P = 200 k, svgss rows: grad_reduce 85 -> 64 us, geom_bwd 28 -> 24 us against ~10 us for the partition; cfg2,
 // P = 200 k, rgss packed rows: only geom_bwd gains, 31 -> ~25 us: not worth it; cfg5, P = 2 M: 498 -> 345 us and 171 -> 88 us)
-constexpr int kListMinP = 400000, kListMinPRows = 50000;
+constexpr int kListMinP = 400000, kListMinPRows = 50000;   // (round 5, rgss at P = 200 k with the count folded into seg_build: geom_bwd -7 us, scatter launch +5, seg_build +2: no gain)
 
 // fused shading: run the contribution pre-pass?  (SVGIR_PREPASS = 0 / 1 forces it off / on)
 bool shade_prepass(int Ns) {
@@ -1080,6 +1080,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         }
     }
     ShadeTables shade_tabs;   // (env == nullptr: the shading backward launches its own prologue)
+    bool use_list = false;
     if (R > 0) {
         // live backward segments, longest first (common.hpp SEG), from the forward's per-sub-tile counts: built here -- a forward-only
         // call never pays for it -- together with the scratch clear
@@ -1089,7 +1090,9 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         sa.seg_count = I.counters; sa.seg_block = I.seg_block; sa.sub_pair_base = I.sub_pair_base; sa.sub_slot_base = I.sub_slot_base;
         // (fused shading: the same launch builds the tables and zeroes the env-gradient accumulator of the shading backward below)
         if (p->shade && g->env_grad_work) shade_tabs = shade_tables(&p->shade->sp, g->env_grad_work, p->shade->sp.env_h * p->shade->sp.env_w * 3);
-        launch_seg_build(sa, sc_clear, sc_bytes, shade_tabs, s);
+        // (and counts, per chunk, the surfels that received a blend weight: the first half of the partition the per-Gaussian kernels walk)
+        use_list = g->out_weights && !generic && (p->shade || P >= (rows ? kListMinPRows : kListMinP));
+        launch_seg_build(sa, sc_clear, sc_bytes, shade_tabs, use_list ? g->out_weights : nullptr, P, G.shade_work, s);
     } else if (sc_clear && !rows) {
         HIP_OK(hipMemsetAsync(sc_clear, 0, sc_bytes, s));   // (nothing rendered: geom_bwd still unpacks the -- zero -- packed rows)
     }
@@ -1098,9 +1101,9 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     // gradients are non-zero, only their shading is differentiated.  With the weights at hand the per-Gaussian kernels behind the
     // composite walk that list (13-29 % of the model on the BASELINE scenes) instead of all P.
     const uint32_t* blended = nullptr; const uint32_t* blended_n = nullptr;
-    if (g->out_weights && !generic && R > 0 && (p->shade || P >= (rows ? kListMinPRows : kListMinP))) {
+    if (use_list && R > 0) {
         uint32_t* cnt = G.shade_work + partition_work_words(P) - 1;
-        launch_partition(P, nullptr, g->out_weights, G.shade_list, G.shade_work, cnt, s);
+        launch_partition_scatter(P, g->out_weights, G.shade_list, G.shade_work, cnt, s);
         blended = G.shade_list; blended_n = cnt;
     }
     if (R > 0) {

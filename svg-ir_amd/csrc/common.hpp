@@ -408,7 +408,8 @@ void launch_cull(const RenderArgs& a, hipStream_t s);
 void launch_contrib_prepass(const RenderArgs& a, hipStream_t s);
 // tile-ordered list of the live backward segments (seg_list, seg_desc, seg_count) from the forward's sub_count / sub_ndump; also zeroes
 // `clear_bytes` bytes at `clear` (a multiple of 16; the backward's scratch clear rides on this launch)
-void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, hipStream_t s);   // (+ the shading tables of the fused path)
+void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, const float* weights, int P, uint32_t* part_sums,
+                      hipStream_t s);   // (+ the shading tables of the fused path; + per-chunk counts of weights > 0 for launch_partition_scatter)
 // (experiment builds, -DBWDP_STREAM) gather-free candidate stream: one 24-float record per (sub-tile, candidate) pair, in list order
 void launch_pair_stream(const RenderArgs& a, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 (nothing launched) if (S,VS) has no specialised kernel
@@ -426,6 +427,10 @@ void launch_image_ops(int W, int H, const float* view, float focal_x, float foca
 
 // ---- working set of a view (subset.hip): list[0 .. *count_dev) = the surfels with flags[i] != 0 (or, flags == nullptr, positive[i] > 0)
 // in index order, list[P-1-j] = the j-th other one; work: partition_work_words(P) uint32 of scratch
+constexpr int PART_ELEMS = BLOCK * 8;   // surfels per partition workgroup
+// the second half alone: `work` already holds the per-chunk counts of selected surfels (chunk = PART_ELEMS consecutive surfels), e.g.
+// counted in passing by the live-segment kernel of the backward
+void launch_partition_scatter(int P, const float* positive, uint32_t* list, const uint32_t* work, uint32_t* count_dev, hipStream_t s);
 size_t partition_work_words(int P);
 void launch_partition(int P, const uint8_t* flags, const float* positive, uint32_t* list, uint32_t* work, uint32_t* count_dev, hipStream_t s);
 // zeroes row list[P-1-j], j < P - *count_dev, of up to 6 row-major fp32 tensors (null tensors are skipped)

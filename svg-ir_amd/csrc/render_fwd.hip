@@ -574,7 +574,8 @@ __global__ void __launch_bounds__(64) contrib_prepass_kernel(const RenderArgs a)
 // already summed them per workgroup and length class (seg_block), so every workgroup derives its own bases, scans its 256
 // tiles and writes ids + descriptors: class-major, tile order inside a class.  Deterministic.
 __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int T, int nblk, uint4* __restrict__ clear, size_t clear_n16,
-                                                        const ShadeTables tabs) {
+                                                        const ShadeTables tabs, const float* __restrict__ weights, int P,
+                                                        uint32_t* __restrict__ part_sums) {
     // piggy-backed: the backward's scratch clear (validity bytes / packed gradient rows), grid-stride over all workgroups -- one
     // launch in front of the composite backward instead of a memset + this kernel
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < clear_n16; i += (size_t)gridDim.x * 256) clear[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -583,6 +584,24 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
         const int ne = tabs.entries();
         for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < ne; i += (int)gridDim.x * 256) shade_table_entry(tabs, i);
         for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < tabs.nzero; i += (int)gridDim.x * 256) tabs.zero[i] = 0.f;
+    }
+    // ... and the first half of the partition "surfels that received a blend weight" (subset.hip): per chunk of PART_ELEMS surfels the
+    // number with weights > 0 (the scatter half is one small launch behind this one instead of two)
+    if (weights) {
+        __shared__ uint32_t pw[4];
+        const int nch = (P + PART_ELEMS - 1) / PART_ELEMS;
+        for (int ch = (int)blockIdx.x; ch < nch; ch += (int)gridDim.x) {
+            const int base = ch * PART_ELEMS + (int)threadIdx.x * 8;
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) c += (base + i < P && weights[base + i] > 0.f) ? 1u : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+            __syncthreads();   // (pw of the previous chunk has been read)
+            if ((threadIdx.x & 63) == 0) pw[threadIdx.x >> 6] = c;
+            __syncthreads();
+            if (threadIdx.x == 0) part_sums[ch] = pw[0] + pw[1] + pw[2] + pw[3];
+        }
     }
     if ((int)blockIdx.x >= nblk) return;   // (workgroups beyond the tile blocks only clear)
     __shared__ uint32_t red_b[SEG_CLASSES][4], red_t[SEG_CLASSES][4], wfull[4];
@@ -687,11 +706,13 @@ void launch(const RenderArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, hipStream_t s) {
+void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, const float* weights, int P, uint32_t* part_sums,
+                      hipStream_t s) {
     const int T = a.gx * a.gy, nblk = (T + 255) / 256;
     const size_t n16 = clear ? (clear_bytes + 15) / 16 : 0;   // (the scratch regions are 256-byte aligned and padded: common.hpp align_up)
-    const int grid = (int)std::max<size_t>((size_t)nblk, std::min<size_t>((n16 + 255) / 256, 2048));
-    hipLaunchKernelGGL(seg_build_kernel, dim3(grid), dim3(256), 0, s, a, T, nblk, (uint4*)clear, n16, tabs);
+    int grid = (int)std::max<size_t>((size_t)nblk, std::min<size_t>((n16 + 255) / 256, 2048));
+    if (weights) grid = std::max(grid, std::min((P + PART_ELEMS - 1) / PART_ELEMS, 2048));
+    hipLaunchKernelGGL(seg_build_kernel, dim3(grid), dim3(256), 0, s, a, T, nblk, (uint4*)clear, n16, tabs, weights, P, part_sums);
 }
 
 void launch_pair_stream(const RenderArgs& a, hipStream_t s) {

@@ -17,7 +17,6 @@ namespace svgir {
 
 namespace {
 
-constexpr int PART_ELEMS = BLOCK * 8;   // surfels per workgroup
 
 template <bool FLAGS>
 __device__ __forceinline__ bool part_pred(const uint8_t* __restrict__ flags, const float* __restrict__ values, int i) {
@@ -118,6 +117,12 @@ void launch_partition(int P, const uint8_t* flags, const float* positive, uint32
         hipLaunchKernelGGL(part_count_kernel<false>, dim3(nb), dim3(BLOCK), 0, s, flags, positive, P, work);
         hipLaunchKernelGGL(part_scatter_kernel<false>, dim3(nb), dim3(BLOCK), 0, s, flags, positive, P, work, nb, list, count_dev);
     }
+}
+
+void launch_partition_scatter(int P, const float* positive, uint32_t* list, const uint32_t* work, uint32_t* count_dev, hipStream_t s) {
+    if (P <= 0) return;
+    const int nb = (P + PART_ELEMS - 1) / PART_ELEMS;
+    hipLaunchKernelGGL(part_scatter_kernel<false>, dim3(nb), dim3(BLOCK), 0, s, (const uint8_t*)nullptr, positive, P, work, nb, list, count_dev);
 }
 
 void launch_zero_rows(int P, const uint32_t* list, const uint32_t* count_dev, float* const* tensors, const int* row_floats, int n, hipStream_t s) {
