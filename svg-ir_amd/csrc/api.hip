@@ -566,12 +566,18 @@ struct ForwardCall {
                     I.counters, B.radix_tbl, s);
         if (int rc = check("emit")) return rc;
         if (timed) tm.mark("emit");
-        launch_radix_sort(B.key, B.val, cap, G.counters, plan.bits, plan.bits_per_pass, B.radix_tbl, s);
-        if (int rc = check("tile sort")) return rc;
-        if (timed) tm.mark("sort_tile");
-        launch_ranges(cap, G.counters, B.key[fin], I.ranges, T, s);
-        if (int rc = check("ranges")) return rc;
-        if (timed) tm.mark("ranges");
+        if (plan.single) {   // up to 4096 tiles: one counting pass over the whole tile id, which also yields the tile ranges
+            launch_tile_sort12(B.key, B.val, cap, G.counters, B.radix_tbl, I.ranges, T, s);
+            if (int rc = check("tile sort")) return rc;
+            if (timed) tm.mark("sort_tile");
+        } else {
+            launch_radix_sort(B.key, B.val, cap, G.counters, plan.bits, plan.bits_per_pass, B.radix_tbl, s);
+            if (int rc = check("tile sort")) return rc;
+            if (timed) tm.mark("sort_tile");
+            launch_ranges(cap, G.counters, B.key[fin], I.ranges, T, s);
+            if (int rc = check("ranges")) return rc;
+            if (timed) tm.mark("ranges");
+        }
 
         RenderArgs ra;
         ra.W = W; ra.H = H; ra.gx = gx; ra.gy = gy; ra.S = p->S; ra.VS = svgss ? p->VS : 0;

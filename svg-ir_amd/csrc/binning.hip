@@ -182,6 +182,157 @@ __global__ void __launch_bounds__(BLOCK) radix_scatter_kernel(const uint32_t* __
     }
 }
 
+// ---- single-pass tile sort (T <= 4096 tiles) ----------------------------------------------------------------------
+// The tile id has <= 12 bits at 800 x 800 and below: instead of two 6-bit radix passes (four launches) + a ranges kernel, ONE stable
+// counting sort over the whole id -- (1) per-workgroup histograms of TS12_KEYS keys over the tile ids (LDS atomics), (2) per tile
+// the exclusive prefix over the workgroups and the tile's total, (3) scatter: every workgroup scans the totals itself (tile bases = the
+// tiles' RANGES: workgroup 0 writes them out, identifyTileRanges for free), adds its row of prefixes, ranks its keys stably (wave-level
+// matching on the 12 bits against wave-private 16-bit LDS counters) and writes.  Rows hold nbins = T rounded up to 256 counters.
+__global__ void __launch_bounds__(BLOCK) ts12_hist_kernel(const uint32_t* __restrict__ keys, int n_cap, const uint32_t* __restrict__ n_dev,
+                                                          uint32_t* __restrict__ table, int nbins) {
+    __shared__ uint32_t hist[TS12_BINS];
+    const int n = n_dev ? (int)min((uint32_t)n_cap, n_dev[0]) : n_cap;
+    const int t = threadIdx.x;
+    for (int i = t; i < nbins; i += BLOCK) hist[i] = 0u;
+    __syncthreads();
+    const int base = blockIdx.x * TS12_KEYS;
+    uint32_t k[TS12_KEYS / BLOCK];
+#pragma unroll
+    for (int i = 0; i < TS12_KEYS / BLOCK; i++) k[i] = keys[max(0, min(base + i * BLOCK + t, n - 1))];
+#pragma unroll
+    for (int i = 0; i < TS12_KEYS / BLOCK; i++)
+        if (base + i * BLOCK + t < n) atomicAdd(&hist[k[i] & (TS12_BINS - 1)], 1u);
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * nbins;
+    for (int i = t; i < nbins; i += BLOCK) row[i] = hist[i];
+}
+
+// per tile id: exclusive prefix of the workgroups' counts (in place) and the total.  A workgroup = 16 tile ids x 16 row segments: a thread
+// first sums its segment (loads only: all in flight together), the 16 segment sums of a tile meet in LDS, then the thread rewrites its
+// segment as running prefixes -- two short memory round trips instead of one per row.
+__global__ void __launch_bounds__(BLOCK) ts12_colscan_kernel(uint32_t* __restrict__ table, int nb, uint32_t* __restrict__ totals, int nbins) {
+    __shared__ uint32_t psum[16][17];
+    const int col = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int d = blockIdx.x * 16 + col;
+    const int rps = (nb + 15) / 16, r0 = min(nb, seg * rps), r1 = min(nb, r0 + rps);
+    uint32_t* colp = table + d;
+    uint32_t sum = 0;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = colp[(size_t)(r + j) * nbins];
+#pragma unroll
+        for (int j = 0; j < 8; j++) sum += c[j];
+    }
+    for (; r < r1; r++) sum += colp[(size_t)r * nbins];
+    psum[seg][col] = sum;
+    __syncthreads();
+    uint32_t run = 0, all = 0;
+#pragma unroll
+    for (int sg = 0; sg < 16; sg++) { const uint32_t v = psum[sg][col]; run += sg < seg ? v : 0u; all += v; }
+    if (seg == 0) totals[d] = all;
+    r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = colp[(size_t)(r + j) * nbins];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { colp[(size_t)(r + j) * nbins] = run; run += c[j]; }
+    }
+    for (; r < r1; r++) { const uint32_t c = colp[(size_t)r * nbins]; colp[(size_t)r * nbins] = run; run += c; }
+}
+
+__global__ void __launch_bounds__(BLOCK) ts12_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                             uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int n_cap,
+                                                             const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ table,
+                                                             const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranges, int T, int nbins) {
+    __shared__ uint32_t cur[TS12_BINS];          // global position of this workgroup's first key of every tile
+    __shared__ uint16_t wcnt[4][TS12_BINS];      // per-wave tile counters (a workgroup holds 2048 keys)
+    __shared__ uint32_t wtot[4];
+    constexpr int PERMAX = TS12_BINS / BLOCK;    // up to 16 consecutive tiles per thread in the scan
+    constexpr int ROUNDS = TS12_KEYS / BLOCK;    // 8 rounds of 64 keys per wave
+    const int per = nbins / BLOCK;               // (nbins is a multiple of 256)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = n_dev ? (int)min((uint32_t)n_cap, n_dev[0]) : n_cap;
+    const int base = blockIdx.x * TS12_KEYS + wave * (64 * ROUNDS);   // wave w owns the w-th quarter, round-major = key order
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t ks[ROUNDS], vs[ROUNDS];
+    uint16_t rk[ROUNDS];
+#pragma unroll
+    for (int c = 0; c < ROUNDS; c++) {
+        const int e = base + c * 64 + lane;
+        ks[c] = e < n ? kin[e] : 0u;
+        vs[c] = e < n ? vin[e] : 0u;
+    }
+    // ---- tile bases: exclusive scan of the totals (thread t owns tiles per t .. per t + per - 1) ----
+    uint32_t tot[PERMAX], pre[PERMAX];
+    {
+        const uint32_t* tp = totals + t * per;
+        const uint32_t* rp = table + (size_t)blockIdx.x * nbins + t * per;
+#pragma unroll
+        for (int j = 0; j < PERMAX; j++) { tot[j] = j < per ? tp[j] : 0u; pre[j] = j < per ? rp[j] : 0u; }
+    }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < PERMAX; j++) sum += tot[j];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        for (int i = t; i < nbins / 2; i += BLOCK) reinterpret_cast<uint32_t*>(&wcnt[w][0])[i] = 0u;
+    __syncthreads();
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < 4; w++) run += w < wave ? wtot[w] : 0u;
+#pragma unroll
+    for (int j = 0; j < PERMAX; j++) {
+        if (j < per) {
+            const int tile = t * per + j;
+            cur[tile] = run + pre[j];
+            if (blockIdx.x == 0 && tile < T) {   // identifyTileRanges (rasterizer_impl.cu:116-138): [start, end), empty tiles stay (0, 0)
+                ranges[2 * tile] = tot[j] ? run : 0u;
+                ranges[2 * tile + 1] = tot[j] ? run + tot[j] : 0u;
+            }
+            run += tot[j];
+        }
+    }
+    // ---- stable rank of every key among the keys of its WAVE with the same tile id ----
+#pragma unroll
+    for (int c = 0; c < ROUNDS; c++) {
+        const bool valid = base + c * 64 + lane < n;
+        const uint32_t d = ks[c] & (TS12_BINS - 1);
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 12; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t in_round = (uint32_t)__popcll(same & lt_mask);
+        const uint32_t prior = wcnt[wave][d];   // (the DS operations of a wave execute in order: every lane reads before the leader writes)
+        rk[c] = (uint16_t)(prior + in_round);
+        if (valid && in_round == 0) wcnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(same));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ROUNDS; c++) {
+        if (base + c * 64 + lane < n) {
+            const uint32_t d = ks[c] & (TS12_BINS - 1);
+            uint32_t pos = cur[d] + rk[c];
+            if (wave > 0) pos += wcnt[0][d];
+            if (wave > 1) pos += wcnt[1][d];
+            if (wave > 2) pos += wcnt[2][d];
+            kout[pos] = ks[c];
+            vout[pos] = vs[c];
+        }
+    }
+}
+
 // ---- instance offsets: exclusive scan of tiles[order[i]] ---------------------------------------------------
 __device__ __forceinline__ uint32_t block_exclusive_scan_2048(uint32_t (&v)[8], uint32_t* wsum, uint32_t& total) {
     // each thread owns 8 consecutive values; returns the exclusive prefix of the thread's first value
@@ -531,6 +682,17 @@ void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,
                        radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy + (gx * gy + 255) / 256 * SEG_BLOCK_STRIDE, seg_count,
                        radix_gtot(sort_table, cap), (int)radix_gtot_words(cap));
+}
+
+void launch_tile_sort12(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, uint32_t* table, uint32_t* ranges, int T,
+                        hipStream_t s) {
+    if (n <= 0) return;
+    const int nb = (n + TS12_KEYS - 1) / TS12_KEYS;
+    const int nbins = (T + BLOCK - 1) / BLOCK * BLOCK;   // (<= TS12_BINS: tile_sort_plan)
+    uint32_t* totals = table + (size_t)nb * nbins;
+    hipLaunchKernelGGL(ts12_hist_kernel, dim3(nb), dim3(BLOCK), 0, s, key[0], n, n_dev, table, nbins);
+    hipLaunchKernelGGL(ts12_colscan_kernel, dim3(nbins / 16), dim3(BLOCK), 0, s, table, nb, totals, nbins);
+    hipLaunchKernelGGL(ts12_scatter_kernel, dim3(nb), dim3(BLOCK), 0, s, key[0], val[0], key[1], val[1], n, n_dev, table, totals, ranges, T, nbins);
 }
 
 // `ranges` must already be zero (launch_emit clears it)

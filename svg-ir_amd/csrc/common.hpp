@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "../../include/svgir_raster.h"
 
@@ -209,6 +212,28 @@ inline int binning_capacity(long long R) {
     return (int)(c > 0x7ffff000LL ? 0x7ffff000LL : c);
 }
 
+// Tile-sort plan: #bits of the tile id split into equal passes of <= 8 bits (both fwd and bwd derive the final
+// ping/pong slot from it) -- or, up to 4096 tiles (800 x 800 and below), ONE counting pass over the whole tile id (binning.hip
+// launch_tile_sort12: histogram, column prefix, stable scatter; the scatter also knows every tile's range, so no ranges kernel).
+struct TileSortPlan { int bits, passes, bits_per_pass; bool single; };
+constexpr int TS12_BINS = 4096, TS12_KEYS = 2048;   // bins of the single-pass tile sort; keys per workgroup
+inline bool tile_sort_single_enabled() {
+    static const bool on = [] { const char* e = getenv("SVGIR_TILE_SORT12"); return !(e && e[0] == '0'); }();
+    return on;
+}
+inline TileSortPlan tile_sort_plan(int T) {
+    int bits = 1;
+    while ((1 << bits) < T) bits++;
+    TileSortPlan p;
+    p.bits = bits;
+    p.single = T <= TS12_BINS && tile_sort_single_enabled();
+    p.passes = p.single ? 1 : (bits + 7) / 8;
+    p.bits_per_pass = p.single ? bits : (bits + p.passes - 1) / p.passes;
+    return p;
+}
+// scratch of the single-pass sort for up to n keys: per-block histogram rows + the column totals
+inline size_t tile12_table_words(int n) { return ((size_t)((n > 0 ? n : 1) + TS12_KEYS - 1) / TS12_KEYS + 1) * TS12_BINS; }
+
 struct BinLayout {
     uint32_t* key[2];  // [R] tile ids ping/pong
     uint32_t* val[2];  // [R] Gaussian ids ping/pong
@@ -235,7 +260,7 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate, long long slot
     b.key[1] = (uint32_t*)take(r * 4);
     b.val[0] = (uint32_t*)take(r * 4);
     b.val[1] = (uint32_t*)take(r * 4);
-    b.radix_tbl = (uint32_t*)take(radix_table_words(R) * 4);
+    b.radix_tbl = (uint32_t*)take(std::max(radix_table_words(R), tile_sort_plan(T).single ? tile12_table_words(R) : (size_t)0) * 4);
     b.sub_list = (uint2*)take(r * 4 * 8);
     b.seg_cap = seg_capacity(R, T);
     b.seg_list = (uint32_t*)take(b.seg_cap * 4);
@@ -260,19 +285,6 @@ inline int binning_capacity_from_bytes(size_t bytes, int T, int nstate) {
         if (bin_layout(nullptr, (int)(mid * 4096), T, nstate).bytes < bytes) lo = mid + 1; else hi = mid;
     }
     return (int)(lo * 4096);
-}
-
-// Tile-sort plan: #bits of the tile id split into equal passes of <= 8 bits (both fwd and bwd derive the final
-// ping/pong slot from it).
-struct TileSortPlan { int bits, passes, bits_per_pass; };
-inline TileSortPlan tile_sort_plan(int T) {
-    int bits = 1;
-    while ((1 << bits) < T) bits++;
-    TileSortPlan p;
-    p.bits = bits;
-    p.passes = (bits + 7) / 8;
-    p.bits_per_pass = (bits + p.passes - 1) / p.passes;
-    return p;
 }
 
 // The svgss `config` tensor ([surface, normalize_depth, per_pixel_depth, (lrn_cam)]) stays on the device, exactly as
@@ -396,6 +408,10 @@ void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
                  uint32_t* seg_count, uint32_t* sort_table, hipStream_t s);
 void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
+// single-pass stable counting sort of (tile id, value) pairs for T <= TS12_BINS tiles: slot 0 -> slot 1; writes ranges[2 T] (zero for empty
+// tiles, like identifyTileRanges); table: tile12_table_words(n)
+void launch_tile_sort12(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, uint32_t* table, uint32_t* ranges, int T,
+                        hipStream_t s);
 // order[] = item ids sorted by descending counts[] (longest-processing-time-first dispatch of the composite waves); also
 // prefix[i] = exclusive prefix sum of counts[], slot_prefix[i] = the same of seg_slots(counts[]), totals[1] / totals[2] = the two sums,
 // host_totals[0] / [1] = host_tag << 32 | sum in pinned host memory (any of them may be null)
