@@ -1000,8 +1000,6 @@ def main():
                          "shading": shading_record(w3, st3), "stage_ms": {k: round(v[0], 4) for k, v in st3.items()}}
         res["value_shaded"] = res["shaded"]["value"]   # north_star's "shaded + blended" number (cfg3_train with the SV-BRDF shading)
         del w3
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(wl, args)
     if rank == 0 and world == 1 and not args.no_concurrent:   # (last: it creates streams of its own)
         torch.cuda.empty_cache()
         # (HIP streams share a few hardware queues, dealt in creation order: each record creates its streams right before it runs)
@@ -1010,6 +1008,9 @@ def main():
             res["one_thread_batch"] = ob
         torch.cuda.empty_cache()
         res["two_streams"] = two_streams(name, dev, args)
+    # (last: the OpenMP oracle leaves its worker threads spinning for a while, which would slow the host-side launch loops above)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(wl, args)
     if rank == 0:
         print(json.dumps(res))
     if torch.distributed.is_initialized():
