@@ -44,7 +44,7 @@ struct PbgiLayout {
     uint32_t* parent;       // [2P-1]
     uint32_t* arrive;       // [P-1]
     float4* rec;            // [P][6] leaf records (sorted order), filled per trace call
-    unsigned long long* queue;   // [1] next ray of the launch that no wave has claimed yet (reset per trace call)
+    unsigned long long* queue;   // [8] per XCD: next ray of its part of the launch that no wave has claimed yet (reset per trace call)
     uint32_t* rkey[2];      // [P] Morton codes of the ray origins of a trace call (rows are traced in that order), ping/pong
     uint32_t* rval[2];      // [P] row ids, ping/pong
     size_t bytes;
@@ -231,7 +231,13 @@ __global__ void __launch_bounds__(BLOCK) pbgi_row_code_kernel(int n, const float
     vals[i] = (uint32_t)i;
 }
 
-__global__ void pbgi_queue_init_kernel(unsigned long long* queue, unsigned long long first) { queue[0] = first; }
+// The rays of a launch (rows in Morton order of their origins) are dealt to the XCDs in eight contiguous parts: the waves of XCD c
+// (workgroups go to the XCDs round-robin: blockIdx.x & 7) start in part c and take its chunks from queue[c], so that an XCD's L2
+// serves one eighth of the scene's neighbourhoods instead of all of them; a wave whose part is used up helps the next one.
+__global__ void pbgi_queue_init_kernel(unsigned long long* queue, unsigned long long part, unsigned long long chunk, unsigned nw) {
+    const unsigned c = threadIdx.x;
+    if (c < 8u) queue[c] = (unsigned long long)c * part + (unsigned long long)((nw + 7u - c) / 8u) * chunk;   // the first chunks belong to the waves from the start
+}
 
 // ---- leaf records (per trace call: the reference reads these tensors at every visited leaf) --------------------------------
 // {c.xyz, sx} {sy, opacity, nw.xy} {nw.z, i00 i01 i02} {i10 i11 i12, n.x} {n.yz, ci0 ci1} {ci2 .. ci5}
@@ -444,7 +450,7 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
                                                                const float* __restrict__ ray_d, const float* __restrict__ centers,
                                                                const float* __restrict__ shs, float* __restrict__ radiance,
                                                                float* __restrict__ visibility, int32_t* __restrict__ hit_indices, float* __restrict__ uvs,
-                                                               int chunk, unsigned long long* __restrict__ queue,
+                                                               int chunk, unsigned long long* __restrict__ queue, long long part,
                                                                const uint32_t* __restrict__ row_order, int row_base) {
 #pragma clang fp contract(off)
     __shared__ int s_ids[PBGI_LDS_DEPTH * PBGI_WAVE];
@@ -458,9 +464,11 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
     float* s_en = s_ens + lane;
     const long long total = (long long)N * S;
     // wave-uniform: the wave's current chunk of consecutive rays [next_ray, pool_end); further chunks come from the launch-wide queue
-    long long next_ray = (long long)blockIdx.x * chunk;
-    long long pool_end = min(total, next_ray + (long long)chunk);
-    bool drained = false;   // the launch-wide queue is empty
+    // (the wave's XCD part first: [q_cur * part, (q_cur + 1) * part) of the launch's rays in tracing order, see pbgi_queue_init_kernel)
+    int q_cur = (int)(blockIdx.x & 7u), q_tried = 0;
+    long long next_ray = (long long)q_cur * part + (long long)(blockIdx.x >> 3) * chunk;
+    long long pool_end = min(min(total, (long long)(q_cur + 1) * part), next_ray + (long long)chunk);
+    bool drained = false;   // every part's queue is empty
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const float t_max = 0.2f;
     const int L = P - 1;
@@ -537,12 +545,18 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
             {   // lanes without a ray take the next rays of the wave's chunk, in lane order; an empty chunk is replaced from the queue
                 const bool want = !walking && !have_ray;
                 if (next_ray >= pool_end && !drained && __any(want)) {
-                    unsigned long long got = 0;
-                    if (lane == 0) got = atomicAdd(queue, (unsigned long long)chunk);
-                    got = (unsigned long long)__shfl((long long)got, 0);
-                    next_ray = (long long)got;
-                    pool_end = min(total, next_ray + (long long)chunk);
-                    drained = next_ray >= total;
+                    for (;;) {
+                        unsigned long long got = 0;
+                        if (lane == 0) got = atomicAdd(queue + q_cur, (unsigned long long)chunk);
+                        got = (unsigned long long)__shfl((long long)got, 0);
+                        const long long part_end = min(total, (long long)(q_cur + 1) * part);
+                        next_ray = (long long)got;
+                        pool_end = min(part_end, next_ray + (long long)chunk);
+                        if (next_ray < part_end) break;
+                        // this part is used up: the next XCD's part (its own waves are still on it, its tree neighbourhoods are the nearest)
+                        q_cur = (q_cur + 1) & 7;
+                        if (++q_tried == 8) { drained = true; next_ray = pool_end = total; break; }
+                    }
                 }
                 const unsigned long long m = __ballot(want);
                 const long long mine = next_ray + (long long)__popcll(m & lt_mask);
@@ -849,10 +863,11 @@ int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const 
         launch_radix_sort(B.rkey, B.rval, n, nullptr, PBGI_SORT_BITS, 8, B.radix_tbl, s);
         const long long rays = (long long)n * S;
         const long long nw = std::min<long long>((rays + chunk - 1) / chunk, slots);
-        const unsigned long long first = (unsigned long long)(nw * chunk);   // the chunks [0, nw) belong to the waves from the start
-        hipLaunchKernelGGL(pbgi_queue_init_kernel, dim3(1), dim3(1), 0, s, B.queue, first);
+        const long long nchunks = (rays + chunk - 1) / chunk;
+        const long long part = (nchunks + 7) / 8 * chunk;   // rays per XCD part (whole chunks)
+        hipLaunchKernelGGL(pbgi_queue_init_kernel, dim3(1), dim3(64), 0, s, B.queue, (unsigned long long)part, (unsigned long long)chunk, (unsigned)nw);
         hipLaunchKernelGGL(pbgi_trace_kernel, dim3((unsigned)nw), dim3(PBGI_WAVE), 0, s, P, B.node, B.pair, B.rec, B.val[fin], n, S, ray_o,
-                           ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)chunk, B.queue, B.rval[PBGI_SORT_PASSES & 1], row0);
+                           ray_d, centers, shs, radiance, visibility, hit_indices, uvs, (int)chunk, B.queue, part, B.rval[PBGI_SORT_PASSES & 1], row0);
     }
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }
