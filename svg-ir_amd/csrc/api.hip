@@ -687,6 +687,11 @@ struct ForwardCall {
         pa.rec = G.rec; pa.cov3D = G.cov3D; pa.clamped = G.clamped; pa.tiles = G.tiles; pa.key = G.key[0]; pa.idx = G.idx[0];
         pa.radii = o->radii;
         pa.out_weights = o->out_weights;
+        pa.features = nullptr; pa.embed_S = 0;
+        if (rec_embeds_features(p->S, svgss ? p->VS : 0)) {
+            // (the preprocess reads the rows: an event that says when they are complete is waited for here, not in front of the composite)
+            if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
+            features_ready = nullptr; pa.features = p->features; pa.embed_S = p->S; }   // feature rows ride in the records
         shade_subset = p->shade && !p->shade->all_surfels;   // shade the view's working set only (subset.hip)
         // With many incident samples per surfel (evaluation: 384) shading a surfel costs far more than compositing it, and a geometry-only
         // pass of the composite (the alpha / transmittance chain of the very same arithmetic: no channels, no outputs) first finds the surfels

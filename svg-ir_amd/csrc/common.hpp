@@ -37,6 +37,19 @@ enum RecField {
                                                        // x0 | y0 << 10 | (x1 - x0) << 20 (u32 bits)
 };
 
+// Without vfeatures (every rgss call; svgss with VS = 0) the records carry the Gaussian's feature row: nothing reads the tangent-plane
+// terms (J, 1/umax) then, and with S <= 5
+// the row fits their floats -- the specialised composite kernels then make ONE gather per candidate (the 96-byte record) instead of
+// record + feature row (a second, 20-byte-strided gather: its own cache lines, its own scalar loads in the backward).
+// Channel ch sits at rec_feature_slot(ch); preprocess writes it, render_fwd_kernel<S, 0, .> / render_bwd_plain_kernel<S, .> read it.
+#if defined(__HIPCC__)
+#define SVGIR_HD __host__ __device__
+#else
+#define SVGIR_HD
+#endif
+SVGIR_HD constexpr bool rec_embeds_features(int S, int VS) { return VS == 0 && S >= 1 && S <= 5; }
+SVGIR_HD constexpr int rec_feature_slot(int ch) { return ch < 4 ? 8 + ch : 19; }   // R_J0 .. R_J3, R_IU
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // ---- radix sort geometry -----------------------------------------------------------------------------------
@@ -324,6 +337,7 @@ struct PreArgs {
     uint32_t* zero_words; int n_zero_words;   // small table cleared in passing (the depth sort's group totals)
     int spec_top; uint32_t* key_top;   // speculated common top byte of the visible depth keys (-1: none) -> key of a culled Gaussian; per-wave summary out
     uint32_t* prefilter_violation;   // non-null <=> `prefiltered`: set to 1 when a frustum / back-face cull fires (auxiliary.h:163-167)
+    const float* features; int embed_S;   // rec_embeds_features(): the [P][embed_S] feature rows copied into the records (0: none)
 };
 
 struct RenderArgs {
@@ -466,6 +480,10 @@ int shade_backward_impl(const svgir_shade_params* p, const float* dL_dreduced, c
 // ---- device helpers ----------------------------------------------------------------------------------------
 // Wave64 sum with DPP row shifts + row broadcasts (gfx9 family); the total lands in lane 63.  All 64 lanes must
 // be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {   // v of the lane DPP control CTRL names; 0 where it names none
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_scan_last(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));

@@ -46,12 +46,15 @@ struct PairGeom {
     static constexpr int VSLOT = 16;                       // lanes per candidate in a vfeature load (VC <= 16)
     static constexpr int VCPL = 4;
     static constexpr int KVF = SV ? CH / VCPL : 0;         // vfeature loads per lane per batch
-    static constexpr int KF = (CH * S + 63) / 64;          // feature floats per lane per batch
+    static constexpr bool EMB = rec_embeds_features(S, 4 * VC);   // features inside the record
+    static constexpr int KF = EMB ? 0 : (CH * S + 63) / 64; // feature floats per lane per batch (separate feature rows)
+    static constexpr int KE = EMB ? (CH + 63) / 64 : 0;    // embedded features: record piece 2, lane = candidate, per batch
     // blend-weight panels (the MFMA A operands of the forward accumulation): 4 rows (candidates of a group) + svgss 16 rows
     // (candidate x corner); at least 16 rows, the panel doubles as the 16 x 64 transposition tile of the accumulators
     static constexpr int PS = 80;                          // panel row stride (floats): rows of a 4-row A operand hit disjoint banks
-    static constexpr int PROWS = SV ? 20 : 16;
-    static constexpr size_t off_q = (size_t)(CH / 2) * PF * 4, off_w = off_q + (size_t)QN * 8, off_p = off_w + (size_t)2 * CH * 4;
+    static constexpr int PROWS = SV ? 20 : 0;              // (packed-FMA accumulators live in registers: no panel)
+    static constexpr int WROWS = 4;                        // blend-weight sums are parked per 16-lane row (render_fwd.hip, step 4)
+    static constexpr size_t off_q = (size_t)(CH / 2) * PF * 4, off_w = off_q + (size_t)QN * 8, off_p = off_w + (size_t)2 * WROWS * CH * 4;
     static constexpr size_t lds_bytes() { return off_p + (size_t)PROWS * PS * 4; }
     static_assert(PF % 4 == 0 && (2 * GEOF) % 4 == 0, "float4-aligned blocks");
     static_assert(NCH <= 16 && VC <= 16, "one 16-column MFMA tile per channel group");
@@ -104,6 +107,10 @@ __device__ __forceinline__ void rec_piece_dest(int piece, int j, int& off, int& 
     int k = X, i = 0;
 #pragma unroll
     for (int q = 0; q < 24; q++) if (q == f) { k = kind[q]; i = idx[q]; }
+    if (PG::EMB) {   // floats 8..11 and 19 of the record are feature channels 0..3 and 4 (common.hpp rec_feature_slot)
+        if (f >= 8 && f < 12) { k = (f - 8 < S) ? C : X; i = 6 + (f - 8); }
+        if (f == 19) { k = S > 4 ? C : X; i = 10; }
+    }
     if (k == G && i < PG::GEOF) { off = 2 * i; odd_step = 1; }
     else if (k == C) { off = PG::CH_OFF + i; odd_step = PG::CHP; }
     else { off = -1; odd_step = 0; }
@@ -115,6 +122,7 @@ struct PairRegs {
     f32x4 r[PG::KR];
     f32x4 v[PG::KVF > 0 ? PG::KVF : 1];
     float f[PG::KF > 0 ? PG::KF : 1];
+    f32x4 e[PG::KE > 0 ? PG::KE : 1];   // embedded feature piece (record float4 #2) of candidate u * 64 + lane
 };
 
 // Per-lane constants of the scatter: byte addresses (relative to the staging buffer) of the four destinations of the
@@ -163,7 +171,13 @@ __device__ __forceinline__ void pair_stage_load(PairRegs<S, VC, CHN>& r, const P
             r.v[u] = vf4[id * VC + vch];
         }
     }
-    if (S > 0) {
+    if (PG::EMB) {
+#pragma unroll
+        for (int u = 0; u < PG::KE; u++) {
+            const size_t id = (size_t)gid_of(min(u * 64 + lane, m - 1));
+            r.e[u] = rec4[id * 6 + 2];
+        }
+    } else if (S > 0) {
         const int totf = m * S;
 #pragma unroll
         for (int u = 0; u < PG::KF; u++) {
@@ -199,7 +213,19 @@ __device__ __forceinline__ void pair_stage_store(const PairRegs<S, VC, CHN>& r, 
             }
         }
     }
-    if (S > 0) {
+    if (PG::EMB) {
+#pragma unroll
+        for (int u = 0; u < PG::KE; u++) {
+            const int s = u * 64 + lane;
+            if (s < m) {
+                float* d = sD + (s >> 1) * PG::PF + PG::CH_OFF + (s & 1) * PG::CHP + 6;
+                d[0] = r.e[u].x;
+                if (S > 1) d[1] = r.e[u].y;
+                if (S > 2) d[2] = r.e[u].z;
+                if (S > 3) d[3] = r.e[u].w;
+            }
+        }
+    } else if (S > 0) {
         const int totf = m * S;
 #pragma unroll
         for (int u = 0; u < PG::KF; u++) {

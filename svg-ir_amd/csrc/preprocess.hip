@@ -294,6 +294,11 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     const int area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
     if (area == 0) return;
 
+    float emb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // no vfeatures: the feature row travels in the record (common.hpp rec_embeds_features)
+    if (a.embed_S > 0) {
+#pragma unroll
+        for (int ch = 0; ch < 5; ch++) emb[ch] = ch < a.embed_S ? a.features[(size_t)idx * a.embed_S + ch] : 0.f;
+    }
     uint32_t cmask = 0;
     if (!a.colors_precomp) cmask = sh_to_rgb(a, sh, campos, po, rgb);
     a.clamped[idx] = cmask;
@@ -324,9 +329,10 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     // depth-differencing coefficients (common.hpp R_DA / R_DB)
     const float da = J[0] * J[6] + J[2] * J[9], db = J[1] * J[6] + J[3] * J[9];
     rec[1] = make_float4(conic[2], opacity, pv[2], da);
-    rec[2] = make_float4(J[0], J[1], J[2], J[3]);
+    const bool embed = a.embed_S > 0;
+    rec[2] = embed ? make_float4(emb[0], emb[1], emb[2], emb[3]) : make_float4(J[0], J[1], J[2], J[3]);
     rec[3] = make_float4(db, rgb[0], rgb[1], rgb[2]);
-    rec[4] = make_float4(nv[0], nv[1], nv[2], iu);
+    rec[4] = make_float4(nv[0], nv[1], nv[2], embed ? emb[4] : iu);
     rec[5] = make_float4(iv, 0.f, 0.f, 0.f);
 }
 

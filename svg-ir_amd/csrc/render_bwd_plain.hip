@@ -176,16 +176,21 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         Cand c;
         c.X = r[R_X]; c.Y = r[R_Y]; c.cxx = r[R_CX]; c.cxy = r[R_CY]; c.cyy = r[R_CZ]; c.op = r[R_OP]; c.dep = r[R_DEPTH]; c.DA = r[R_DA];
         c.DB = r[R_DB]; c.cr = r[R_R]; c.cg = r[R_G]; c.cb = r[R_B]; c.nx = r[R_NX]; c.ny = r[R_NY]; c.nz = r[R_NZ];
-        cfloat* f = (cfloat*)(feat_b + (uint32_t)(e.gid * (uint32_t)(S * 4)));
-        if (S >= 4) {   // (scalar loads only need dword alignment: one x4 + singles instead of S singles)
-            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            const f32x4u f4 = *reinterpret_cast<const __attribute__((address_space(4))) f32x4u*>(f);
-            c.f[0] = f4.x; c.f[1 % SS] = f4.y; c.f[2 % SS] = f4.z; c.f[3 % SS] = f4.w;
+        if (rec_embeds_features(S, 0)) {   // the feature row rides in the record (preprocess; common.hpp rec_feature_slot)
 #pragma unroll
-            for (int ch = 4; ch < S; ch++) c.f[ch] = f[ch];
+            for (int ch = 0; ch < SS; ch++) c.f[ch] = ch < S ? r[rec_feature_slot(ch)] : 0.f;
         } else {
-#pragma unroll
-            for (int ch = 0; ch < SS; ch++) c.f[ch] = ch < S ? f[ch] : 0.f;
+            cfloat* f = (cfloat*)(feat_b + (uint32_t)(e.gid * (uint32_t)(S * 4)));
+            if (S >= 4) {   // (scalar loads only need dword alignment: one x4 + singles instead of S singles)
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                const f32x4u f4 = *reinterpret_cast<const __attribute__((address_space(4))) f32x4u*>(f);
+                c.f[0] = f4.x; c.f[1 % SS] = f4.y; c.f[2 % SS] = f4.z; c.f[3 % SS] = f4.w;
+    #pragma unroll
+                for (int ch = 4; ch < S; ch++) c.f[ch] = f[ch];
+            } else {
+    #pragma unroll
+                for (int ch = 0; ch < SS; ch++) c.f[ch] = ch < S ? f[ch] : 0.f;
+            }
         }
         c.slot = e.slot;
         return c;

@@ -168,7 +168,7 @@ render_fwd_kernel(const RenderArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sD = reinterpret_cast<float*>(smem);                  // [CH / 2][PF] staged pairs (pairstage.hpp)
     uint2* sQ = reinterpret_cast<uint2*>(smem + PG::off_q);      // [2][CH] {gid, slot}: this batch / next batch
-    float* sW = reinterpret_cast<float*>(smem + PG::off_w);      // [2][CH] blend-weight sums
+    float* sW = reinterpret_cast<float*>(smem + PG::off_w);      // [2][4][CH] blend-weight sums of the four 16-lane rows
     float* sP = reinterpret_cast<float*>(smem + PG::off_p);      // [PROWS][PS] blend-weight panel (MFMA A operand) / transposition tile
     constexpr int PS = PG::PS;
 
@@ -299,7 +299,8 @@ render_fwd_kernel(const RenderArgs a) {
         // batch's gathers: a wait for those gathers then never waits for an atomic that was issued after them.
         auto flush_weights = [&](int bprev) {
             if (lane < nflush) {
-                const float wsum = sW[(bprev & 1) * CH + lane];
+                const float* wp = sW + (bprev & 1) * (4 * CH) + lane;
+                const float wsum = (wp[0] + wp[CH]) + (wp[2 * CH] + wp[3 * CH]);
                 if (wsum != 0.f && !a.dump_only) atomic_add_f32(&a.out_weights[sQ[(bprev & 1) * CH + lane].x], wsum);
                 // contribution pre-pass (dump_only == 2): the surfel received a blend weight from this sub-tile -> its packed rows will be read
                 if (wsum != 0.f && a.dump_only == 2) a.needed[sQ[(bprev & 1) * CH + lane].x] = 1;
@@ -309,7 +310,7 @@ render_fwd_kernel(const RenderArgs a) {
         for (; b < nb && !wave_done; b++) {
             const int m = min(CH, total - b * CH);
             const uint2* q_cur = sQ + (b & 1) * CH;
-            float* w_cur = sW + (b & 1) * CH;
+            float* w_cur = sW + (b & 1) * (4 * CH);
             wave_lds_sync();   // previous batch fully consumed
             pair_stage_store<S, VC, CH>(sr, pmap, sD, m, lane);
             flush_weights(b - 1);
@@ -430,13 +431,19 @@ render_fwd_kernel(const RenderArgs a) {
                     }
                     wave_lds_sync();   // panel consumed before the next group overwrites it
                 }
-                // ---- (4) out_weights: KB interleaved wave reductions, parked in LDS ----
-                float ws[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) ws[k] = wave_scan_last(w[k]);
-                if (lane == 63) {
-#pragma unroll
-                    for (int k = 0; k < KB; k++) w_cur[c0 + k] = ws[k];
+                // ---- (4) out_weights: the pixel sums of the KB = 4 weights, parked in LDS ----
+                // ONE reduction tree for the four candidates: the first two levels (lane pairs, quads) exchange instead of
+                // add-and-discard -- a lane keeps the candidate its low bits name and hands the other one over -- so that after them
+                // lane l holds the quad's sum for candidate l & 3; two row shifts then leave each 16-lane row's sums in its lanes
+                // 12..15, and the four rows meet when the batch's sums are flushed (13 instead of 28 instructions per group).
+                {
+                    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+                    const float t01 = (o1 ? w[1] : w[0]) + dpp_f32<0xB1>(o1 ? w[0] : w[1]);   // quad_perm [1,0,3,2]
+                    const float t23 = (o1 ? w[3] : w[2]) + dpp_f32<0xB1>(o1 ? w[2] : w[3]);
+                    float u = (o2 ? t23 : t01) + dpp_f32<0x4E>(o2 ? t01 : t23);                // quad_perm [2,3,0,1]
+                    u += dpp_f32<0x114>(u);   // row_shr:4
+                    u += dpp_f32<0x118>(u);   // row_shr:8
+                    if ((lane & 12) == 12) w_cur[(lane >> 4) * CH + c0 + (lane & 3)] = u;
                 }
                 if (__all(done)) { wave_done = true; nproc = min(m, c0 + KB); break; }
             }
