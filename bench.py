@@ -134,6 +134,8 @@ def parse():
                     "instead of a side stream that overlaps the binning (svgir_params.features_ready)")
     ap.add_argument("--unfused", action="store_true", help="svgss workloads: shade ALL surfels with svgir_shade_forward / _backward around "
                     "the rasterizer calls (rounds 1-4) instead of the view's working set inside them (svgir_params.shade)")
+    ap.add_argument("--radiance-grad", action="store_true", help="svgss training workloads: differentiate the [P,Ns,3] radiance cache itself "
+                    "(rounds 1-5a) instead of the reference's get_radiances = nan_to_num(_radiances.detach() * _radiance_ratio)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-oracle steps (0 = as many as fit ~12 s)")
     ap.add_argument("--no-shade", action="store_true", help="svgss workloads: skip the SV-BRDF shading stage")
     ap.add_argument("--streamed-dirs", action="store_true", help="shading reads [P,Ns,3] incident directions from HBM "
@@ -265,7 +267,12 @@ class Workload:
             else:   # incident directions generated in the kernels; training lattices carry random offsets
                 offs = torch.rand(self.P, device=dev) * 6.2831855 if self.training else None
                 self.dirs, self.areas = shading.FibonacciLattice(torch.nn.functional.normalize(geo_n, dim=-1), self.Ns, offs), None
-            self.leaves = {k: sd[k].clone().requires_grad_(self.training) for k in ("base_color", "roughness", "normals", "radiance", "env")}
+            # the radiance cache enters as the reference's get_radiances (scene/gaussian_model.py:323-324): detached, times the learnable
+            # scalar _radiance_ratio -- the product is formed inside the kernels and the backward returns the scalar's gradient
+            self.rad_grad = bool(getattr(args, "radiance_grad", False))
+            self.leaves = {k: sd[k].clone().requires_grad_(self.training and (k != "radiance" or self.rad_grad))
+                           for k in ("base_color", "roughness", "normals", "radiance", "env")}
+            self.ratio = None if self.rad_grad else torch.ones((), device=dev, requires_grad=self.training)
             self.light = shade_inputs.Light(self.leaves["env"])
             # the shading forward does not depend on the binning of the view (and vice versa): it runs on a side stream and only
             # the composite kernel waits for it (include/svgir_raster.h: svgir_params.features_ready)
@@ -277,9 +284,12 @@ class Workload:
                 self.vf_buf = torch.empty((self.P, self.VS), dtype=torch.float32, device=dev)
                 self.sgrads = None
                 if self.training:   # (the per-surfel gradient tensors are carved out of the rasterizer's gradient allocation per step)
-                    self.senv = (torch.empty_like(sd["env"]), torch.empty(sd["env"].numel(), device=dev))
+                    self.senv = (torch.empty_like(sd["env"]), torch.empty(sd["env"].numel() + self.shading.RATIO_WORK, device=dev))
                     self.sshapes = dict(dL_dbase_color=sd["base_color"].shape, dL_droughness=sd["roughness"].shape,
-                                        dL_dshade_normals=sd["normals"].shape, dL_dradiance=sd["radiance"].shape)
+                                        dL_dshade_normals=sd["normals"].shape)
+                    if self.rad_grad:
+                        self.sshapes["dL_dradiance"] = sd["radiance"].shape
+                    self.sratio = torch.empty(1, device=dev)
 
     def shading_light(self):
         from svgir_harness import shade_inputs
@@ -294,7 +304,7 @@ class Workload:
             lv, sd = self.leaves, self.sd
             fs, keep = self.shading.fused_shade(lv["base_color"].detach(), lv["roughness"].detach(), lv["normals"].detach(), sd["viewdirs"],
                                                 lv["radiance"].detach(), self.shading_light(), sd["visibility"], self.dirs, self.areas,
-                                                st.viewmatrix, self.training)
+                                                st.viewmatrix, self.training, radiance_ratio=self.ratio)
             out = _C.rasterize_gaussians(st.bg, sct["means3D"], self.f_buf, self.vf_buf, empty, sct["opacities"], sct["scales"],
                                          sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
                                          st.patch_bbox, st.tanfovx, st.tanfovy, st.image_height, st.image_width, sct["shs"],
@@ -306,6 +316,8 @@ class Workload:
             if self.training:
                 self.sgrads = dict(dL_denv=self.senv[0], env_grad_work=self.senv[1], dL_dreduced=None, out_weights=weights,
                                    _shapes=dict(self.sshapes))
+                if self.ratio is not None:
+                    self.sgrads["dL_dradiance_ratio"] = self.sratio
                 kw = dict(shade=fs, shade_grads=self.sgrads)
             g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], self.f_buf, self.vf_buf, radii, empty, sct["scales"],
                                                 sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
@@ -324,7 +336,7 @@ class Workload:
                 with torch.cuda.stream(self.side if self.side is not None else main), torch.set_grad_enabled(self.training):
                     feats_in, vfeats_in, _ = self.shading.shade_and_pack(
                         lv["base_color"], lv["roughness"], lv["normals"], sd["viewdirs"], lv["radiance"], self.light,
-                        sd["visibility"], self.dirs, self.areas, st.viewmatrix, self.training)
+                        sd["visibility"], self.dirs, self.areas, st.viewmatrix, self.training, radiance_ratio=self.ratio)
                 if self.side is not None:
                     self.feat_ev.record(self.side)
                     feats_in.record_stream(main); vfeats_in.record_stream(main)
@@ -570,6 +582,8 @@ def shading_record(wl, stage, counts=None):
     sf = Pf * wl.Ns * sf_per_sample + Pf * (31 + 70 + (0 if wl.training else wl.S + wl.VS) + (0 if sf_per_sample == 32 else 4)) * 4
     rec = {"surfels": wl.P, "surfels_shaded_fwd": nf, "surfels_shaded_bwd": nb if wl.training else None,
            "mode": "fused into svgir_forward / svgir_backward: the view's working set" if getattr(wl, "fused", False) else "all surfels (svgir_shade_forward / _backward around the rasterizer)",
+           "radiance": ("the [P,Ns,3] cache is differentiated (--radiance-grad)" if getattr(wl, "rad_grad", False) else
+                        "get_radiances = nan_to_num(_radiances.detach() * _radiance_ratio) formed in the kernels; the backward returns dL/d_radiance_ratio"),
            "config": f"rendering_equation4 + packing, Ns={wl.Ns} incident samples/surfel, env 32x64, incident directions "
                      f"{'streamed from HBM' if sf_per_sample == 32 else 'generated in the kernels (Fibonacci lattice)'}, "
                      f"{'forward+backward' if wl.training else 'forward only (eval)'}",
@@ -577,7 +591,8 @@ def shading_record(wl, stage, counts=None):
                    "achieved": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
                    "frac": sf / (stage["shade_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     if wl.training and "shade_bwd" in stage:
-        sb = nb * wl.Ns * (sf_per_sample + 12) + nb * (31 + 70 + 28) * 4 + (wl.P - nb) * (wl.Ns * 12 + 28 * 4)   # + dL_dradiance per sample, per-surfel gradients (zero rows for the rest)
+        rg = 12 if getattr(wl, "rad_grad", False) else 0   # dL_dradiance per sample (only when the cache itself is differentiated)
+        sb = nb * wl.Ns * (sf_per_sample + rg) + nb * (31 + 70 + 28) * 4 + (wl.P - nb) * (wl.Ns * rg + 28 * 4)   # + per-surfel gradients (zero rows for the rest)
         rec["bwd"] = {"avg_launch_ms": stage["shade_bwd"][0], "algorithmic_bytes_per_launch": sb,
                       "achieved": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9, "unit": "GB/s",
                       "frac": sb / (stage["shade_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}

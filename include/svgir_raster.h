@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 12
+#define SVGIR_ABI_VERSION 13
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -151,9 +151,9 @@ typedef struct svgir_grads {
     float* dL_dbase_color;      /* [P,12] */
     float* dL_droughness;       /* [P,4] */
     float* dL_dshade_normals;   /* [P,4,3] */
-    float* dL_dradiance;        /* [P,Ns,3] */
+    float* dL_dradiance;        /* [P,Ns,3]; may be NULL when shade->sp.radiance_ratio is set (ABI 13: the cache is detached) */
     float* dL_denv;             /* [env_h,env_w,3] */
-    float* env_grad_work;       /* scratch, env_h*env_w*3 floats */
+    float* env_grad_work;       /* scratch, env_h*env_w*3 (+ SVGIR_SHADE_RATIO_WORK with dL_dradiance_ratio) floats */
     const float* dL_dreduced;   /* optional [P,70]: upstream gradient of svgir_fused_shade.reduced (needs all_surfels != 0) */
     const float* out_weights;   /* optional (required by the fused shading): the forward's out_weights [P].  A surfel that received no
                                  * blend weight has no gradient rows and all-zero composite gradients; with the weights at hand the
@@ -161,6 +161,7 @@ typedef struct svgir_grads {
                                  * shading's backward) walk the list of blended surfels -- 13-29 % of the model on the BASELINE scenes --
                                  * instead of all P.  Used where building the list costs less than it saves: svgss with vfeatures from 50 000
                                  * surfels on, otherwise from 400 000. */
+    float* dL_dradiance_ratio;  /* optional [1] (ABI 13; needs shade->sp.radiance_ratio): see svgir_shade_backward */
 } svgir_grads;
 
 int svgir_abi_version(void);
@@ -307,9 +308,16 @@ typedef struct svgir_shade_params {
      * output is still written completely.  Rows of shaded surfels are bit-identical to an all-P call. */
     const uint32_t* subset;
     const uint32_t* subset_count;
+    /* The reference's radiance cache enters the shading as  get_radiances = nan_to_num(_radiances.detach() * _radiance_ratio, nan=0)
+     * (scene/gaussian_model.py:323-324): a [P,Ns,3] product and its clean-up per iteration, and in the backward a [P,Ns,3] gradient
+     * whose only use is the sum that gives dL/d_radiance_ratio.  ABI 13: `radiance_ratio` (NULL: `radiance` is used as it is) points
+     * to that scalar in device memory; the kernels then use nan_to_num(radiance * ratio) (torch.nan_to_num: NaN -> 0, +-inf -> the
+     * largest finite floats) -- the same fp32 product, bit for bit -- and the backward can return the scalar's gradient directly. */
+    const float* radiance_ratio;
 } svgir_shade_params;
 
 #define SVGIR_SHADE_REDUCED 70
+#define SVGIR_SHADE_RATIO_WORK 256   /* extra floats of env_grad_work when dL_dradiance_ratio is requested */
 
 int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* features, float* vfeatures, void* stream);
 
@@ -319,11 +327,15 @@ int svgir_shade_forward(const svgir_shade_params* p, float* reduced, float* feat
  * ignored: visibility is not differentiable in the reference either).  The packing's direct terms (vfeatures
  * carries base_color, view-space normals and roughness, svgss.py:152-166) are included.  All outputs are
  * overwritten; dL_denv [env_h,env_w,3] is the gradient w.r.t. the RAW env (softplus' included).
- * `env_grad_work`: scratch of env_h*env_w*3 floats. */
+ * `env_grad_work`: scratch of env_h*env_w*3 floats.
+ * With p->radiance_ratio (ABI 13): dL_dradiance is the gradient w.r.t. the RAW radiance (ratio and the nan_to_num mask included) and
+ * may be NULL (the reference detaches the cache); dL_dradiance_ratio [1] (optional, NULL without p->radiance_ratio) receives
+ * sum(dL/d(incident) * isfinite(radiance * ratio) * radiance), what autograd returns for the scalar -- summed per workgroup and then
+ * in a fixed order (reproducible); env_grad_work then holds SVGIR_SHADE_RATIO_WORK more floats. */
 int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
                          const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
-                         float* env_grad_work, void* stream);
+                         float* env_grad_work, float* dL_dradiance_ratio, void* stream);
 
 /* Shading fused into the rasterizer calls (svgir_params.shade; ABI 12).  The only consumers of the shading's outputs are the packed
  * `features` / `vfeatures` rows the svgss composite blends (gaussian_renderer/svgss.py:143-182), and it reads the rows of the surfels

@@ -1136,7 +1136,8 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     if (p->shade) {
         // dL_dfeatures / dL_dvfeatures are complete: the shading's backward, for the surfels that received a blend weight (the rows of all
         // others are exactly zero: no pixel blended them)
-        if (!g->dL_dbase_color || !g->dL_droughness || !g->dL_dshade_normals || !g->dL_dradiance || !g->dL_denv || !g->env_grad_work)
+        if (!g->dL_dbase_color || !g->dL_droughness || !g->dL_dshade_normals || (!g->dL_dradiance && !p->shade->sp.radiance_ratio) || !g->dL_denv ||
+            !g->env_grad_work)
             return fail(SVGIR_ERR_INVALID, "fused shading: the gradient outputs of the shading inputs must be provided");
         if (generic) return fail(SVGIR_ERR_INVALID, "fused shading without a specialised composite");
         const bool all = p->shade->all_surfels != 0;
@@ -1160,9 +1161,11 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
         };
         const size_t Pz = (size_t)P;
         const bool precleared = in_clear(g->dL_dbase_color, 12 * Pz) && in_clear(g->dL_droughness, 4 * Pz) &&
-                                in_clear(g->dL_dshade_normals, 12 * Pz) && in_clear(g->dL_dradiance, 3 * Pz * (size_t)sp.Ns);
+                                in_clear(g->dL_dshade_normals, 12 * Pz) &&
+                                (!g->dL_dradiance || in_clear(g->dL_dradiance, 3 * Pz * (size_t)sp.Ns));
         if (shade_backward_impl(&sp, g->dL_dreduced, g->dL_dfeatures, g->dL_dvfeatures, g->dL_dbase_color, g->dL_droughness,
-                                g->dL_dshade_normals, g->dL_dradiance, g->dL_denv, g->env_grad_work, precleared, shade_tabs.env != nullptr, s) != 0)
+                                g->dL_dshade_normals, g->dL_dradiance, g->dL_denv, g->env_grad_work, g->dL_dradiance_ratio, precleared,
+                                shade_tabs.env != nullptr, s) != 0)
             return fail(SVGIR_ERR_INVALID, "fused shading: svgir_shade_backward rejected its parameters");
         tm.mark("shade_bwd");
     }

@@ -474,7 +474,7 @@ ShadeTables shade_tables(const svgir_shade_params* p, float* zero, int nzero);
 int shade_forward_impl(const svgir_shade_params* p, float* reduced, float* features, float* vfeatures, bool tables_ready, void* stream);
 int shade_backward_impl(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures, const float* dL_dvfeatures,
                         float* dL_dbase_color, float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
-                        float* env_grad_work, bool rows_precleared, bool tables_ready, void* stream);
+                        float* env_grad_work, float* dL_dradiance_ratio, bool rows_precleared, bool tables_ready, void* stream);
 
 #if defined(__HIPCC__)
 // ---- device helpers ----------------------------------------------------------------------------------------

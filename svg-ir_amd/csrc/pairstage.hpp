@@ -193,6 +193,10 @@ __device__ __forceinline__ void pair_stage_store(const PairRegs<S, VC, CHN>& r, 
                                                  int m, int lane) {
     using PG = PairGeom<S, VC, CHN>;
     const int rc = lane / PG::RSLOT;
+    if (m < CHN) {   // (uniform; the walk's last batch) the rest of the last group of four: opacity 0, i.e. alpha 0 -- the blend loop tests no bounds
+        const int s = m + lane;
+        if (s < ((m + 3) & ~3)) sD[(s >> 1) * PG::PF + 2 * 5 + (s & 1)] = 0.f;
+    }
 #pragma unroll
     for (int u = 0; u < PG::KR; u++) {
         if (u * PG::RCPL + rc < m && mp.rpiece >= 0) {

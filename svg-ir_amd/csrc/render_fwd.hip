@@ -250,7 +250,7 @@ render_fwd_kernel(const RenderArgs a) {
     };
     auto chan = [&](int c) -> float { return chv[c]; };
     auto vchan = [&](int c) -> float { return vfv[c]; };
-    uint32_t last_contributor = 0;
+    uint32_t last_walk = 0;   // 1 + position (in the sub-tile's candidate list) of the pixel's last contributor, 0: none
 
     // segment-boundary state dumps (see common.hpp SEG)
     constexpr int NST = 8 + S + VC;
@@ -330,7 +330,6 @@ render_fwd_kernel(const RenderArgs a) {
                 f32x2 dx[NP], dy[NP];
                 f32x4 Gd[NP], Ge[NP];   // (depth, DA) pairs; (DB, 1/umax) pairs
                 float pw[KB], al[KB];
-                uint32_t slot[KB];
 #pragma unroll
                 for (int p = 0; p < NP; p++) {
                     const f32x4* P = reinterpret_cast<const f32x4*>(sD + ((c0 >> 1) + p) * PF);
@@ -345,23 +344,24 @@ render_fwd_kernel(const RenderArgs a) {
                     }
                     pw[2 * p] = pw2.x; pw[2 * p + 1] = pw2.y;
                     al[2 * p] = fminf(0.99f, a2.x); al[2 * p + 1] = fminf(0.99f, a2.y);
-                    slot[2 * p] = q_cur[c0 + 2 * p].y; slot[2 * p + 1] = q_cur[c0 + 2 * p + 1].y;
                 }
+                // (slots beyond the batch hold opacity 0 -- pair_stage_store -- i.e. alpha 0: no bounds test per candidate)
                 bool pre[KB];
 #pragma unroll
-                for (int k = 0; k < KB; k++) pre[k] = (c0 + k < m) && pw[k] <= 0.0f && al[k] >= (1.0f / 255.0f);
+                for (int k = 0; k < KB; k++) pre[k] = pw[k] <= 0.0f && al[k] >= (1.0f / 255.0f);
                 // ---- (2) the sequential part: transmittance chain and cut-off (forward.cu:541-560) ----
                 float w[KB];
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
                     const bool live = pre[k] && !done;
                     const float test_T = T * (1.f - al[k]);
-                    const bool term = live && test_T < 0.0001f;
-                    const bool pass = live && !term;
-                    done = done || term;
+                    const bool stop = test_T < 0.0001f;   // (one comparison: `pass` and `term` are mask operations on it)
+                    const bool pass = live && !stop;
+                    done = done || (live && stop);
                     w[k] = pass ? al[k] * T : 0.f;
                     T = pass ? test_T : T;
-                    last_contributor = pass ? slot[k] + 1u : last_contributor;
+                    // the last contributor as its position in the walk (wave-uniform operand); its slot in the tile list is looked up once, at the end
+                    last_walk = pass ? head + (uint32_t)(c0 + k) + 1u : last_walk;
                 }
                 // ---- (3) accumulations (weight 0 for everything that did not pass) ----
                 f32x2 wq[NP][4];   // svgss: bilinear corner weights x blend weight, per pair
@@ -476,7 +476,7 @@ render_fwd_kernel(const RenderArgs a) {
         const size_t pid = (size_t)a.W * py + px;
         T = fminf((float)(1 - 0.000001), T);
         a.final_T[pid] = T;
-        a.n_contrib[pid] = (int32_t)last_contributor;
+        a.n_contrib[pid] = last_walk ? (int32_t)(list[last_walk - 1u].y + 1u) : 0;   // (forward.cu:553: index in the TILE's list + 1)
         a.out_color[pid] = chan(0) + T * a.bg[0];
         a.out_color[N_ + pid] = chan(1) + T * a.bg[1];
         a.out_color[2 * N_ + pid] = chan(2) + T * a.bg[2];

@@ -267,6 +267,25 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
     corner_consts(load_corner_in(p, g, k), V, c);
 }
 
+// get_radiances (scene/gaussian_model.py:323-324): the incident radiance is nan_to_num(_radiances.detach() * _radiance_ratio, nan = 0)
+// -- with svgir_shade_params.radiance_ratio the product and its clean-up happen here, on the value just loaded
+struct RadRatio { float ratio; bool on; };
+__device__ __forceinline__ RadRatio rad_ratio(const svgir_shade_params& p) {
+    RadRatio r;
+    r.on = p.radiance_ratio != nullptr;
+    r.ratio = r.on ? *p.radiance_ratio : 1.f;
+    return r;
+}
+__device__ __forceinline__ bool ratio_finite(float raw, const RadRatio& rr) {   // isfinite(raw * ratio): where nan_to_num passes its gradient
+    const float v = raw * rr.ratio;
+    return fabsf(v) <= 3.402823466e+38f;   // (false for NaN)
+}
+__device__ __forceinline__ float incident_of(float raw, const RadRatio& rr) {
+    if (!rr.on) return raw;
+    const float v = raw * rr.ratio;
+    return v != v ? 0.f : fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);   // torch.nan_to_num(v, nan = 0.0)
+}
+
 // the raw inputs of one incident sample (lane = sample), loadable a chunk / a Gaussian ahead of their use
 struct RawSample { float d[3], rad[3], vis, area; };
 
@@ -298,7 +317,8 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         float d[3];
         if (p.incident_dirs) { d[0] = p.incident_dirs[o * 3]; d[1] = p.incident_dirs[o * 3 + 1]; d[2] = p.incident_dirs[o * 3 + 2]; }
         else lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[s], s, p.lattice_offsets != nullptr, d);
-        const float rad[3] = {p.radiance[o * 3], p.radiance[o * 3 + 1], p.radiance[o * 3 + 2]};
+        const RadRatio rr = rad_ratio(p);
+        const float rad[3] = {incident_of(p.radiance[o * 3], rr), incident_of(p.radiance[o * 3 + 1], rr), incident_of(p.radiance[o * 3 + 2], rr)};
         const float vis = p.visibility[o], area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
         const float il = inv_norm(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // = 1 / max(|.|, 1e-12)
         const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
@@ -554,13 +574,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
 
     // raw inputs of the lane's sample of a step, fetched one step ahead
     struct Raw { float d[3], rad[3], vis, area; };
+    const RadRatio rrq = rad_ratio(p);
     auto load_raw_q = [&](int s) -> Raw {
         Raw r;
         const int sc = min(s, Ns - 1);
         const size_t o = gg * (size_t)Ns + (size_t)sc;
         if (!lattice) { r.d[0] = p.incident_dirs[o * 3]; r.d[1] = p.incident_dirs[o * 3 + 1]; r.d[2] = p.incident_dirs[o * 3 + 2]; }
         else { r.d[0] = r.d[1] = r.d[2] = 0.f; }
-        r.rad[0] = p.radiance[o * 3]; r.rad[1] = p.radiance[o * 3 + 1]; r.rad[2] = p.radiance[o * 3 + 2];
+        r.rad[0] = incident_of(p.radiance[o * 3], rrq); r.rad[1] = incident_of(p.radiance[o * 3 + 1], rrq); r.rad[2] = incident_of(p.radiance[o * 3 + 2], rrq);
         r.vis = p.visibility[o];
         r.area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
         return r;
@@ -724,7 +745,8 @@ struct ShadeBwdArgs {
     svgir_shade_params p;
     const float* g_red;          // may be null when g_feat / g_vfeat carry the upstream gradient
     const float *g_feat, *g_vfeat;  // optional: gradients w.r.t. the packed features [P,S] / vfeatures [P,VS]
-    float *d_base, *d_rough, *d_normals, *d_radiance, *d_envtab;  // d_envtab: gradient w.r.t. the f(env) table
+    float *d_base, *d_rough, *d_normals, *d_radiance, *d_envtab;  // d_envtab: gradient w.r.t. the f(env) table; d_radiance may be null (radiance_ratio)
+    float* ratio_part;   // [gridDim.x] or null: per-workgroup partial sums of dL/d(radiance_ratio)
     int zero_rest;   // subset launches: the waves also zero-fill the gradient rows of the surfels OUTSIDE the subset (a few rows per processed
                      // surfel: stores nobody waits for, in a kernel that is bound by instruction issue)
 };
@@ -752,7 +774,7 @@ constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
 constexpr int KB_G = SHADE_KB_G, KREC = 52;   // Gaussians prepared per batch; floats per (Gaussian, corner) record (13 float4)
 
 __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const RawSample& x, int lane, const float* V,
-                                              float* __restrict__ sS) {
+                                              float* __restrict__ sS, const RadRatio& rr) {
     const float* d = x.d;
     const float il = inv_norm(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // = 1 / max(|.|, 1e-12)
     const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
@@ -801,7 +823,7 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     for (int ch = 0; ch < 3; ch++) {
         const float Es = E[ch] * p.env_scale;
         r[ch] = d[ch]; r[4 + ch] = H[ch];
-        r[8 + ch] = fminf(64.f, fmaxf(0.f, Es)) * x.vis; r[12 + ch] = x.rad[ch];
+        r[8 + ch] = fminf(64.f, fmaxf(0.f, Es)) * x.vis; r[12 + ch] = incident_of(x.rad[ch], rr);
         flags |= (Es >= 0.f && Es <= 64.f) ? (1u << ch) : 0u;
     }
     r[3] = il; r[7] = frac0; r[11] = x.area; r[15] = x.vis * p.env_scale;
@@ -867,12 +889,16 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             const size_t gz = (size_t)sub[(uint32_t)p.P - 1u - zj];
             if (lane < 12) { a.d_base[gz * 12 + lane] = 0.f; a.d_normals[gz * 12 + lane] = 0.f; }
             if (lane < 4) a.d_rough[gz * 4 + lane] = 0.f;
-            float* row = a.d_radiance + gz * (size_t)(3 * Ns);
-            for (int e = lane; e < 3 * Ns; e += 64) row[e] = 0.f;
+            if (a.d_radiance) {
+                float* row = a.d_radiance + gz * (size_t)(3 * Ns);
+                for (int e = lane; e < 3 * Ns; e += 64) row[e] = 0.f;
+            }
         }
     };
     DEV_TRACE_DECL();
     [[maybe_unused]] unsigned dev_n = 0;
+    const RadRatio rr = rad_ratio(p);
+    float ratio_acc = 0.f;   // this lane's share of dL/d(radiance_ratio) = sum dL/d(incident) * isfinite(raw * ratio) * raw
     RawSample raw;
     if (g < P) raw = load_raw(p, sid(g), 0, lane, min(64, Ns));
     // The per-(Gaussian, corner) constants -- unit view vector, corner frame, and the upstream gradients folded into the
@@ -986,7 +1012,8 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         for (int s0 = 0; s0 < Ns; s0 += 64) {
             const int cnt = min(64, Ns - s0);
             wave_lds_sync();   // previous chunk consumed
-            if (lane < cnt && (SHADE_ABL != 3 || s0 + g == 0)) stage_raw_bwd(p, raw, lane, V, sS);
+            if (lane < cnt && (SHADE_ABL != 3 || s0 + g == 0)) stage_raw_bwd(p, raw, lane, V, sS, rr);
+            const float raw_rad[3] = {raw.rad[0], raw.rad[1], raw.rad[2]};   // (of sample s0 + lane: the ratio's gradient needs the raw values)
             {   // prefetch the next chunk (of this Gaussian or of the wave's next one)
                 const bool more = s0 + 64 < Ns;
                 const int gn = more ? g : g + gstep;
@@ -1086,7 +1113,19 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             // dL/dradiance of the chunk: the values parked in the records leave as whole rows (3 cnt consecutive floats)
             wave_lds_sync();
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next Gaussian's inputs (LDS-DMA) and the next chunk's samples, both issued an inner loop ago
-            if (SHADE_ABL != 2) {
+            if (rr.on) {   // lane = sample: dL/d(incident) -> the scalar's gradient and (if asked for) dL/d(raw radiance), in place
+                float* q = sS + lane * BREC + 12;
+                if (lane < cnt) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float gm = ratio_finite(raw_rad[ch], rr) ? q[ch] : 0.f;
+                        ratio_acc += gm * raw_rad[ch];
+                        q[ch] = gm * rr.ratio;
+                    }
+                }
+                wave_lds_sync();
+            }
+            if (SHADE_ABL != 2 && a.d_radiance) {
                 float* out = a.d_radiance + (gg * Ns + s0) * 3;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
@@ -1128,6 +1167,17 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     zero_rows(0x7fffffff);   // (what is left of this wave's share: waves with few or no surfels of their own)
     DEV_TRACE_END(0, dev_n, (unsigned)Ns, 0u);
     __syncthreads();
+    if (a.ratio_part) {   // the workgroup's partial sum, waves in order (the epilogue adds the workgroups in order: reproducible)
+        const float ws = wave_sum(ratio_acc);
+        if (lane == 0) smem[wave] = ws;   // (the sample records are free: every wave passed the barrier above)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < BWAVES; w++) t += smem[w];
+            a.ratio_part[blockIdx.x] = t;
+        }
+        __syncthreads();
+    }
     if (env_in_lds) {
         for (int i = threadIdx.x; i < ntex; i += BWAVES * 64) {
             const float v = (float)sEnv[i];
@@ -1138,7 +1188,13 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 
 // dL/d env_raw = dL/d f(env) * f'(env);  softplus' = sigmoid
 __global__ void __launch_bounds__(BLOCK) env_grad_kernel(const float* __restrict__ env, const float* __restrict__ dtab,
-                                                         float* __restrict__ denv, int n, int softplus) {
+                                                         float* __restrict__ denv, int n, int softplus,
+                                                         const float* __restrict__ ratio_part, int nparts, float* __restrict__ d_ratio) {
+    if (d_ratio && blockIdx.x == 0 && threadIdx.x == 0) {   // dL/d(radiance_ratio): the workgroups' partial sums, in order
+        float t = 0.f;
+        for (int w = 0; w < nparts; w++) t += ratio_part[w];
+        *d_ratio = t;
+    }
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float x = env[i];
@@ -1216,9 +1272,9 @@ extern "C" {
 int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
                          const float* dL_dvfeatures, float* dL_dbase_color,
                          float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
-                         float* env_grad_work, void* stream) {
+                         float* env_grad_work, float* dL_dradiance_ratio, void* stream) {
     return svgir::shade_backward_impl(p, dL_dreduced, dL_dfeatures, dL_dvfeatures, dL_dbase_color, dL_droughness, dL_dnormals, dL_dradiance,
-                                      dL_denv, env_grad_work, false, false, stream);
+                                      dL_denv, env_grad_work, dL_dradiance_ratio, false, false, stream);
 }
 
 }  // extern "C"
@@ -1226,12 +1282,14 @@ int svgir_shade_backward(const svgir_shade_params* p, const float* dL_dreduced, 
 int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dreduced, const float* dL_dfeatures,
                                const float* dL_dvfeatures, float* dL_dbase_color,
                                float* dL_droughness, float* dL_dnormals, float* dL_dradiance, float* dL_denv,
-                               float* env_grad_work, bool rows_precleared, bool tables_ready, void* stream) {
+                               float* env_grad_work, float* dL_dradiance_ratio, bool rows_precleared, bool tables_ready, void* stream) {
     if (!p || p->P < 0 || p->Ns <= 0 || p->env_h <= 0 || p->env_w <= 0) return SVGIR_ERR_INVALID;
     if (p->P == 0) return 0;
-    if ((!dL_dreduced && !dL_dfeatures && !dL_dvfeatures) || (dL_dvfeatures && !p->viewmatrix) || !dL_dbase_color || !dL_droughness || !dL_dnormals || !dL_dradiance || !dL_denv ||
+    if ((!dL_dreduced && !dL_dfeatures && !dL_dvfeatures) || (dL_dvfeatures && !p->viewmatrix) || !dL_dbase_color || !dL_droughness || !dL_dnormals || !dL_denv ||
         !env_grad_work || !p->env_work)
         return SVGIR_ERR_INVALID;
+    // (with radiance_ratio the cache itself is detached in the reference: its gradient is optional; the scalar's gradient needs the scalar)
+    if ((!dL_dradiance && !p->radiance_ratio) || (dL_dradiance_ratio && !p->radiance_ratio)) return SVGIR_ERR_INVALID;
     if (!p->incident_dirs && !(p->lattice_normals && p->lattice_work)) return SVGIR_ERR_INVALID;
     if (((uintptr_t)p->env_work & 15) || (p->lattice_work && ((uintptr_t)p->lattice_work & 15))) return SVGIR_ERR_INVALID;   // read as float4
     if ((p->subset != nullptr) != (p->subset_count != nullptr)) return SVGIR_ERR_INVALID;
@@ -1243,6 +1301,7 @@ int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dred
     ShadeBwdArgs a;
     a.p = *p; a.g_red = dL_dreduced; a.g_feat = dL_dfeatures; a.g_vfeat = dL_dvfeatures; a.d_base = dL_dbase_color; a.d_rough = dL_droughness; a.d_normals = dL_dnormals;
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
+    a.ratio_part = dL_dradiance_ratio ? env_grad_work + ntex : nullptr;   // (SVGIR_SHADE_RATIO_WORK floats behind the env-gradient table)
     a.zero_rest = (p->subset && !rows_precleared) ? 1 : 0;   // (every output is written completely: rows outside the subset are zero)
     const size_t per_wave = (size_t)(64 * BREC + 4 * KB_G * KREC) * 4;
     size_t lds = BWAVES * per_wave;
@@ -1261,11 +1320,12 @@ int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dred
         }
     }
     const int blocks = std::min((p->P + BWAVES - 1) / BWAVES, 256 * std::max(1, SHADE_BWPE * 4 / BWAVES));
+    static_assert(256 * (SHADE_BWPE * 4 / BWAVES > 1 ? SHADE_BWPE * 4 / BWAVES : 1) <= SVGIR_SHADE_RATIO_WORK, "one partial sum per workgroup");
     stage_mark(tm, "shade_bwd_prologue");
     hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(BWAVES * 64), lds, s, a, env_in_lds);
     stage_mark(tm, "shade_bwd");
     hipLaunchKernelGGL(env_grad_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, env_grad_work,
-                       dL_denv, ntex, p->env_softplus);
+                       dL_denv, ntex, p->env_softplus, a.ratio_part, blocks, dL_dradiance_ratio);
     stage_mark(tm, "shade_env_grad");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
 }

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
 
 RGSS, SVGSS = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -47,7 +47,7 @@ class Grads(C.Structure):
         "dL_ddepth", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dviewmat",
         "dL_dprojmat", "dL_dcampos", "clear_base")] + [("clear_bytes", C.c_size_t)] + [(n, C.c_void_p) for n in (
         "dL_dbase_color", "dL_droughness", "dL_dshade_normals", "dL_dradiance", "dL_denv", "env_grad_work", "dL_dreduced",
-        "out_weights")]
+        "out_weights", "dL_dradiance_ratio")]
 
 
 class ViewCall(C.Structure):
@@ -66,7 +66,7 @@ class ShadeParams(C.Structure):
                 ("incident_dirs", C.c_void_p), ("incident_areas", C.c_void_p), ("env", C.c_void_p),
                 ("viewmatrix", C.c_void_p), ("env_work", C.c_void_p), ("env_transform", C.c_void_p),
                 ("lattice_normals", C.c_void_p), ("lattice_offsets", C.c_void_p), ("lattice_work", C.c_void_p),
-                ("subset", C.c_void_p), ("subset_count", C.c_void_p)]
+                ("subset", C.c_void_p), ("subset_count", C.c_void_p), ("radiance_ratio", C.c_void_p)]
 
 
 class FusedShade(C.Structure):

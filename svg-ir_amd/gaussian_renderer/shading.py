@@ -26,7 +26,7 @@ ShadeParams = N.ShadeParams
 N.lib.svgir_shade_forward.restype = C.c_int
 N.lib.svgir_shade_forward.argtypes = [C.POINTER(ShadeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 N.lib.svgir_shade_backward.restype = C.c_int
-N.lib.svgir_shade_backward.argtypes = [C.POINTER(ShadeParams)] + [C.c_void_p] * 10
+N.lib.svgir_shade_backward.argtypes = [C.POINTER(ShadeParams)] + [C.c_void_p] * 11
 N.lib.svgir_incident_dirs.restype = C.c_int
 N.lib.svgir_incident_dirs.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 6
 N.lib.svgir_resample_bilinear.restype = C.c_int
@@ -82,8 +82,11 @@ def sample_incident_rays(normals, is_training=False, sample_num=24, materialize=
     return lat._materialise(True, True)
 
 
+RATIO_WORK = 256   # SVGIR_SHADE_RATIO_WORK: floats behind the env-gradient scratch when the ratio's gradient is asked for
+
+
 def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
-            viewmatrix=None, training=True, env_transform=None):
+            viewmatrix=None, training=True, env_transform=None, ratio=None):
     dev = base_color.device
     if dev.type != "cuda":
         raise RuntimeError("shading: tensors must live on the GPU (libsvgir_raster.so has no CPU path)")
@@ -101,6 +104,12 @@ def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs
     p.radiance, p.visibility, p.incident_dirs, p.incident_areas = N.ptr(ra), N.ptr(vi), N.ptr(di), N.ptr(ar)
     p.env, p.viewmatrix, p.env_work, p.env_transform = N.ptr(en), N.ptr(vm), work.data_ptr(), N.ptr(et)
     keep.append(work)
+    if ratio is not None:   # get_radiances = nan_to_num(_radiances.detach() * _radiance_ratio) inside the kernels (gaussian_model.py:323-324)
+        if ratio.numel() != 1:
+            raise RuntimeError("radiance_ratio must hold one value")
+        rt = N.f32c(ratio.detach().reshape(1), dev)
+        p.radiance_ratio = rt.data_ptr()
+        keep.append(rt)
     if lattice is not None:
         if lattice.sample_num != Ns or lattice.normals.shape[0] != P:
             raise RuntimeError("FibonacciLattice does not match the radiance tensor's [P, Ns]")
@@ -110,41 +119,56 @@ def _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs
     return p, keep, dev, P, Ns, env_h, env_w
 
 
+def _radiance_grads(ctx, i_rad, i_ratio, rad, ratio, env_h, env_w, dev):
+    """(dL_dradiance or None, dL_dradiance_ratio or None, env-gradient scratch) of a shading backward.  Without a ratio the library
+    always writes dL_dradiance; with one the cache is usually detached (the reference's get_radiances) and only the scalar's gradient
+    is produced -- no [P, Ns, 3] tensor at all."""
+    want_ratio = ratio is not None and ctx.needs_input_grad[i_ratio]
+    want_rad = ratio is None or ctx.needs_input_grad[i_rad]
+    d_rad = torch.empty_like(rad) if want_rad else None
+    d_ratio = torch.empty(1, dtype=torch.float32, device=dev) if want_ratio else None
+    gwork = torch.empty(env_h * env_w * 3 + (RATIO_WORK if want_ratio else 0), dtype=torch.float32, device=dev)
+    return d_rad, d_ratio, gwork
+
+
 class _Shade(torch.autograd.Function):
     """reduced[P,70] = [pbr12, diffuse_light12, specular12, direct12, indirect12, mean_incident3, mean_local3,
     mean_global3, mean_visibility1]; differentiable w.r.t. base_color, roughness, normals, radiance, env."""
 
     @staticmethod
     def forward(ctx, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
-                env_transform=None):
+                env_transform=None, ratio=None):
         p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
-                                            env, softplus, scale, env_transform=env_transform)
+                                            env, softplus, scale, env_transform=env_transform, ratio=ratio)
         reduced = torch.empty((P, NRED), dtype=torch.float32, device=dev)
         if P:
             N.check(N.lib.svgir_shade_forward(p, reduced.data_ptr(), None, None, N.stream_ptr(dev)), "shade_forward")
         lat = dirs if isinstance(dirs, FibonacciLattice) else None
-        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, None if lat else dirs, areas, env)
+        ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, None if lat else dirs, areas, env, ratio)
         ctx.cfg = (softplus, scale, env_transform, lat)
         return reduced
 
     @staticmethod
     def backward(ctx, g_reduced):
-        base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env = ctx.saved_tensors
+        base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, ratio = ctx.saved_tensors
         softplus, scale, env_transform, lat = ctx.cfg
         p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility,
                                                     lat if lat is not None else dirs, areas, env, softplus, scale,
-                                                    env_transform=env_transform)
+                                                    env_transform=env_transform, ratio=ratio)
         g = N.f32c(g_reduced, dev)
-        d_base, d_rough, d_norm, d_rad, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 4, 8))  # all overwritten
-        gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+        d_base, d_rough, d_norm, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 8))  # all overwritten
+        d_rad, d_ratio, gwork = _radiance_grads(ctx, 4, 12, keep[4], ratio, env_h, env_w, dev)
         if P:
             N.check(N.lib.svgir_shade_backward(p, g.data_ptr(), None, None, d_base.data_ptr(), d_rough.data_ptr(), d_norm.data_ptr(),
-                                               d_rad.data_ptr(), d_env.data_ptr(), gwork.data_ptr(), N.stream_ptr(dev)),
+                                               N.ptr(d_rad), d_env.data_ptr(), gwork.data_ptr(), N.ptr(d_ratio), N.stream_ptr(dev)),
                     "shade_backward")
         else:
             d_env.zero_()
+            if d_ratio is not None:
+                d_ratio.zero_()
         return (d_base.reshape(base_color.shape), d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
-                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None)
+                None if d_rad is None else d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None,
+                None if d_ratio is None else d_ratio.reshape(ratio.shape))
 
 
 class _ShadePack(torch.autograd.Function):
@@ -153,10 +177,10 @@ class _ShadePack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix,
-                softplus, scale, training, env_transform=None):
+                softplus, scale, training, env_transform=None, ratio=None):
         p, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas,
                                             env, softplus, scale, viewmatrix=viewmatrix, training=training,
-                                            env_transform=env_transform)
+                                            env_transform=env_transform, ratio=ratio)
         S, VS = (4, 52) if training else (7, 64)
         red = torch.empty((P, NRED), dtype=torch.float32, device=dev)
         feats = torch.empty((P, S), dtype=torch.float32, device=dev)
@@ -166,31 +190,34 @@ class _ShadePack(torch.autograd.Function):
                     "shade_forward")
         lat = dirs if isinstance(dirs, FibonacciLattice) else None
         ctx.save_for_backward(base_color, roughness, normals, viewdirs, radiance, visibility, None if lat else dirs, areas, env,
-                              viewmatrix)
+                              viewmatrix, ratio)
         ctx.cfg = (softplus, scale, training, env_transform, lat)
         ctx.set_materialize_grads(False)
         return feats, vfeats, red
 
     @staticmethod
     def backward(ctx, g_feat, g_vfeat, g_red):
-        base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix = ctx.saved_tensors
+        base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix, ratio = ctx.saved_tensors
         softplus, scale, training, env_transform, lat = ctx.cfg
         p, keep, dev, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility,
                                                     lat if lat is not None else dirs, areas, env, softplus, scale,
-                                                    viewmatrix=viewmatrix, training=training, env_transform=env_transform)
+                                                    viewmatrix=viewmatrix, training=training, env_transform=env_transform, ratio=ratio)
         if g_feat is None and g_vfeat is None and g_red is None:
-            return (None,) * 14
+            return (None,) * 15
         gf, gv, gr = (N.f32c(t, dev) for t in (g_feat, g_vfeat, g_red))
-        d_base, d_rough, d_norm, d_rad, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 4, 8))
-        gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+        d_base, d_rough, d_norm, d_env = (torch.empty_like(keep[i]) for i in (0, 1, 2, 8))
+        d_rad, d_ratio, gwork = _radiance_grads(ctx, 4, 14, keep[4], ratio, env_h, env_w, dev)
         if P:
             N.check(N.lib.svgir_shade_backward(p, N.ptr(gr), N.ptr(gf), N.ptr(gv), d_base.data_ptr(), d_rough.data_ptr(),
-                                               d_norm.data_ptr(), d_rad.data_ptr(), d_env.data_ptr(), gwork.data_ptr(),
+                                               d_norm.data_ptr(), N.ptr(d_rad), d_env.data_ptr(), gwork.data_ptr(), N.ptr(d_ratio),
                                                N.stream_ptr(dev)), "shade_backward")
         else:
             d_env.zero_()
+            if d_ratio is not None:
+                d_ratio.zero_()
         return (d_base.reshape(base_color.shape), d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
-                d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None, None, None)
+                None if d_rad is None else d_rad.reshape(radiance.shape), None, None, None, d_env.reshape(env.shape), None, None, None,
+                None, None, None if d_ratio is None else d_ratio.reshape(ratio.shape))
 
 
 def _env_of(light):
@@ -208,12 +235,16 @@ def _env_of(light):
 
 
 def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light=None,
-                        visibility_precompute=None, incident_dirs_precompute=None, incident_areas_precompute=None):
-    """Drop-in for gaussian_renderer/svgss.py:537-593.  Returns (pbr [n,12], extra_results)."""
+                        visibility_precompute=None, incident_dirs_precompute=None, incident_areas_precompute=None, *,
+                        radiance_ratio=None):
+    """Drop-in for gaussian_renderer/svgss.py:537-593.  Returns (pbr [n,12], extra_results).
+    `radiance_ratio` (extension, keyword only): the reference hands in `pc.get_radiances` = nan_to_num(_radiances.detach() *
+    _radiance_ratio) (gaussian_model.py:323-324); pass the RAW cache as `radiance` and the scalar here and the kernels form the product
+    themselves -- no [n, Ns, 3] temporaries, and the backward returns the scalar's gradient directly."""
     dirs, areas = incident_dirs_precompute, incident_areas_precompute
     env, softplus, scale, transform = _env_of(direct_light_env_light)
     red = _Shade.apply(base_color, roughness, normals, viewdirs, radiance, visibility_precompute, dirs, areas, env,
-                       softplus, scale, transform)
+                       softplus, scale, transform, radiance_ratio)
     extra_results = {
         # (with a FibonacciLattice the [n, Ns, 3] tensor is never built: an empty stand-in keeps the chunk loop's
         #  torch.cat over every key working, `incident_dirs_precompute.dirs()` materialises the real thing)
@@ -223,7 +254,7 @@ def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, dire
         # kernel never materialises the per-sample values: the tensor carries the mean as its single "sample", so both
         # the concatenation and the mean (exactly) keep working.
         "incident_lights": red[:, 60:63].unsqueeze(-2),
-        "local_incident_lights": radiance,
+        "local_incident_lights": radiance if radiance_ratio is None else torch.nan_to_num(radiance.detach() * radiance_ratio, nan=0.0),
         "global_incident_lights": red[:, 66:69].unsqueeze(-2),
         "incident_visibility": visibility_precompute,
         "diffuse_light": red[:, 12:24],
@@ -235,12 +266,12 @@ def rendering_equation4(base_color, roughness, normals, viewdirs, radiance, dire
 
 
 def shade_and_pack(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light, visibility, dirs, areas,
-                   viewmatrix, is_training):
+                   viewmatrix, is_training, radiance_ratio=None):
     """Shading + the packing of svgss.py:143-166: returns (features [n,S], vfeatures [n,VS], reduced [n,70]).
     The packing and its adjoint are done inside the kernels in both the no-grad and the autograd path."""
     env, softplus, scale, transform = _env_of(direct_light_env_light)
     return _ShadePack.apply(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, viewmatrix,
-                            softplus, scale, bool(is_training), transform)
+                            softplus, scale, bool(is_training), transform, radiance_ratio)
 
 
 # ---- shading fused into the rasterizer calls: "shade only what the view reads" ---------------------------------------------------
@@ -261,12 +292,13 @@ class _ShadedRasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, base_color, roughness, normals, viewdirs, radiance,
-                visibility, dirs, areas, env, raster_settings, softplus, scale, training, env_transform, all_surfels, want_reduced):
+                visibility, dirs, areas, env, raster_settings, softplus, scale, training, env_transform, all_surfels, want_reduced,
+                ratio=None):
         from .svgss_rasterization import _C
         st = raster_settings
         sp, keep, dev, P, Ns, _, _ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env,
                                              softplus, scale, viewmatrix=st.viewmatrix, training=training,
-                                             env_transform=env_transform)
+                                             env_transform=env_transform, ratio=ratio)
         if P != means3D.shape[0]:
             raise RuntimeError("render_shaded: the material tensors and means3D disagree on the number of surfels")
         S, VS = (4, 52) if training else (7, 64)
@@ -281,7 +313,7 @@ class _ShadedRasterize(torch.autograd.Function):
         (R, color, normal, depth, opacity, feature, vfeature, weights, radii, gb, bb, ib) = out
         lat = dirs if isinstance(dirs, FibonacciLattice) else None
         ctx.save_for_backward(means3D, sh, scales, rotations, base_color, roughness, normals, viewdirs, radiance, visibility,
-                              None if lat else dirs, areas, env, feats, vfeats, weights, radii, gb, bb, ib)
+                              None if lat else dirs, areas, env, feats, vfeats, weights, radii, gb, bb, ib, ratio)
         ctx.cfg = (st, R, softplus, scale, training, env_transform, lat, all_surfels)
         ctx.mark_non_differentiable(weights, radii)
         ctx.set_materialize_grads(False)
@@ -293,13 +325,13 @@ class _ShadedRasterize(torch.autograd.Function):
     def backward(ctx, _gR, g_color, g_normal, g_opacity, g_depth, g_feature, g_vfeature, _gw, _gr, g_red):
         from .svgss_rasterization import _C
         (means3D, sh, scales, rotations, base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, feats,
-         vfeats, weights, radii, gb, bb, ib) = ctx.saved_tensors
+         vfeats, weights, radii, gb, bb, ib, ratio) = ctx.saved_tensors
         st, R, softplus, scale, training, env_transform, lat, all_surfels = ctx.cfg
         dev = means3D.device
         H, W = st.image_height, st.image_width
         sp, keep, _, P, Ns, env_h, env_w = _params(base_color, roughness, normals, viewdirs, radiance, visibility,
                                                    lat if lat is not None else dirs, areas, env, softplus, scale,
-                                                   viewmatrix=st.viewmatrix, training=training, env_transform=env_transform)
+                                                   viewmatrix=st.viewmatrix, training=training, env_transform=env_transform, ratio=ratio)
         if g_red is not None and not all_surfels:
             raise RuntimeError("render_shaded: a loss on `reduced` needs all_surfels=True (rows of unshaded surfels are zero)")
         def _g(g, ch):  # autograd hands None for outputs that did not take part in the loss: an empty tensor = all zero for the library
@@ -310,41 +342,52 @@ class _ShadedRasterize(torch.autograd.Function):
                 st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy, _g(g_color, 3), _g(g_normal, 3), _g(g_depth, 1), _g(g_opacity, 1),
                 _g(g_feature, feats.shape[1]), _g(g_vfeature, vfeats.shape[1] // 4), sh, st.sh_degree, st.campos, gb, R, bb, ib,
                 st.debug, st.config)
-        if not any(ctx.needs_input_grad[i] for i in (6, 7, 8, 10, 14)):   # frozen materials (evaluation): the rasterizer's backward alone
+        if not any(ctx.needs_input_grad[i] for i in (6, 7, 8, 10, 14, 22)):   # frozen materials (evaluation): the rasterizer's backward alone
             res = _C.rasterize_gaussians_backward(*args)
-            return (res[3], res[0], res[7], res[2], res[8], res[9]) + (None,) * 16
+            return (res[3], res[0], res[7], res[2], res[8], res[9]) + (None,) * 17
         fs = _fused_struct(sp, None, all_surfels)
         d_env = N.out_tensor(keep[8].shape, torch.float32, dev)
-        gwork = torch.empty(env_h * env_w * 3, dtype=torch.float32, device=dev)
+        want_ratio = ratio is not None and ctx.needs_input_grad[22]
+        want_rad = ratio is None or ctx.needs_input_grad[10]   # (with a ratio the cache is normally detached: no [P, Ns, 3] gradient)
+        d_ratio = N.out_tensor((1,), torch.float32, dev) if want_ratio else None
+        gwork = torch.empty(env_h * env_w * 3 + (RATIO_WORK if want_ratio else 0), dtype=torch.float32, device=dev)
         # (the four per-surfel gradient tensors are carved out of the rasterizer's gradient allocation by the binding: the composite
         # backward clears that region in passing, the shading backward then writes the rows of the surfels that were blended.  Measured
         # at cfg3_train: +28 us in render_bwd / grad_reduce for the 160 MB; a zero-fill launch costs 37 us, zero-fill stores from the
         # shading backward's own waves 40 us -- its per-chunk vmcnt(0) waits for them)
         sg = dict(dL_denv=d_env, env_grad_work=gwork, dL_dreduced=None if g_red is None else N.f32c(g_red, dev), out_weights=weights,
-                  _shapes=dict(dL_dbase_color=keep[0].shape, dL_droughness=keep[1].shape, dL_dshade_normals=keep[2].shape,
-                               dL_dradiance=keep[4].shape))
+                  _shapes=dict(dL_dbase_color=keep[0].shape, dL_droughness=keep[1].shape, dL_dshade_normals=keep[2].shape))
+        if want_rad:
+            sg["_shapes"]["dL_dradiance"] = keep[4].shape
+        if want_ratio:
+            sg["dL_dradiance_ratio"] = d_ratio
         if P == 0:
             d_env.zero_()
+            if want_ratio:
+                d_ratio.zero_()
         res = _C.rasterize_gaussians_backward(*args, shade=fs, shade_grads=sg)
-        d_base, d_rough, d_norm, d_rad = sg["dL_dbase_color"], sg["dL_droughness"], sg["dL_dshade_normals"], sg["dL_dradiance"]
+        d_base, d_rough, d_norm, d_rad = sg["dL_dbase_color"], sg["dL_droughness"], sg["dL_dshade_normals"], sg.get("dL_dradiance")
         (g_means2D, _gc, g_opac, g_means3D, _gf, _gvf, _gcov, g_sh, g_scales, g_rot, _gv, _gp, _gcp) = res
         return (g_means3D, g_means2D, g_sh, g_opac, g_scales, g_rot, d_base.reshape(base_color.shape),
-                d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None, d_rad.reshape(radiance.shape), None, None,
-                None, d_env.reshape(env.shape), None, None, None, None, None, None, None)
+                d_rough.reshape(roughness.shape), d_norm.reshape(normals.shape), None,
+                None if d_rad is None else d_rad.reshape(radiance.shape), None, None,
+                None, d_env.reshape(env.shape), None, None, None, None, None, None, None,
+                None if d_ratio is None else d_ratio.reshape(ratio.shape))
 
 
 def fused_shade(base_color, roughness, normals, viewdirs, radiance, direct_light_env_light, visibility, dirs, areas, viewmatrix,
-                is_training, reduced=None, all_surfels=False):
+                is_training, reduced=None, all_surfels=False, radiance_ratio=None):
     """(`_native.FusedShade`, keep-alive list) for the `shade=` keyword of `_C.rasterize_gaussians{,_backward}`: the binding-level
     form of render_shaded (no autograd)."""
     env, softplus, scale, transform = _env_of(direct_light_env_light)
     sp, keep, *_ = _params(base_color, roughness, normals, viewdirs, radiance, visibility, dirs, areas, env, softplus, scale,
-                           viewmatrix=viewmatrix, training=bool(is_training), env_transform=transform)
+                           viewmatrix=viewmatrix, training=bool(is_training), env_transform=transform, ratio=radiance_ratio)
     return _fused_struct(sp, reduced, all_surfels), keep + [reduced]
 
 
 def render_shaded(raster_settings, means3D, means2D, opacities, shs, scales, rotations, base_color, roughness, normals, viewdirs,
-                  radiance, direct_light_env_light, visibility, dirs, areas, is_training, all_surfels=False, want_reduced=False):
+                  radiance, direct_light_env_light, visibility, dirs, areas, is_training, all_surfels=False, want_reduced=False,
+                  radiance_ratio=None):
     """Shading + packing + svgss rasterization of one view (the reference's svgss.py:116-182) with the shading restricted to the
     surfels the view reads.  Returns the rasterizer's 9-tuple (num_rendered, color, normal, opacity, depth, feature, vfeature,
     weights, radii) and `reduced` [P,70] (rows of unshaded surfels zero; an empty tensor unless want_reduced).
@@ -353,5 +396,5 @@ def render_shaded(raster_settings, means3D, means2D, opacities, shs, scales, rot
     env, softplus, scale, transform = _env_of(direct_light_env_light)
     out = _ShadedRasterize.apply(means3D, means2D, shs, opacities, scales, rotations, base_color, roughness, normals, viewdirs,
                                  radiance, visibility, dirs, areas, env, raster_settings, softplus, scale, bool(is_training),
-                                 transform, bool(all_surfels), bool(want_reduced))
+                                 transform, bool(all_surfels), bool(want_reduced), radiance_ratio)
     return out[:9], out[9]

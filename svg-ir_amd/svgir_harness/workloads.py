@@ -41,13 +41,17 @@ class TrainStep:
 
     LAMBDA_DSSIM = 0.2   # arguments/__init__.py: lambda_dssim
 
-    def __init__(self, dev, seed=5, name="cfg3_train", Ns=64, fused=True, scene=None):
+    def __init__(self, dev, seed=5, name="cfg3_train", Ns=64, fused=True, scene=None, radiance_grad=False):
         from gaussian_renderer import shading
         from gaussian_renderer.svgss_rasterization import GaussianRasterizer
         from . import losses, optim, render_view
         self.shading, self.render_view, self.losses, self.optim = shading, render_view, losses, optim
         self.GaussianRasterizer = GaussianRasterizer
         self.dev, self.name, self.Ns, self.fused = dev, name, Ns, fused
+        # The reference shades with pc.get_radiances = nan_to_num(_radiances.detach() * _radiance_ratio, nan=0) (gaussian_model.py:323-324):
+        # the cache sits in the optimizer (group 'radiances', :527) but never receives a gradient; what learns is the scalar ratio
+        # (lr 0.01, :526-528).  radiance_grad=True is the earlier rounds' form (the [P, Ns, 3] cache itself is a differentiated leaf).
+        self.radiance_grad = radiance_grad
         sc = self.sc = scenes.make(name) if scene is None else scene
         sct = self.sct = runner.to_torch(sc, dev)
         self.P, self.W, self.H = int(sc["means3D"].shape[0]), sc["W"], sc["H"]
@@ -62,13 +66,16 @@ class TrainStep:
         par = {"xyz": sct["means3D"], "scaling": sct["scales"], "rotation": sct["rotations"], "opacity": sct["opacities"],
                "shs": sct["shs"], "base_color": sd["base_color"], "roughness": sd["roughness"], "normal": sd["normals"],
                "radiance": sd["radiance"], "env": sd["env"]}
+        if not radiance_grad:
+            par["radiance_ratio"] = torch.ones((), device=dev)
         self.params = {k: torch.nn.Parameter(v.detach().clone().contiguous()) for k, v in par.items()}
         lrs = {"xyz": 1.6e-6, "scaling": 5e-5, "rotation": 1e-5, "opacity": 5e-4, "shs": 2.5e-5, "base_color": 1e-4,
-               "roughness": 1e-4, "normal": 1e-5, "radiance": 1e-4, "env": 1e-4}
+               "roughness": 1e-4, "normal": 1e-5, "radiance": 1e-4, "env": 1e-4, "radiance_ratio": 0.01}
         self.optimizer = optim.FusedAdam([{"params": [self.params[k]], "lr": lrs[k], "name": k} for k in par], lr=0.0, eps=1e-15)
         self.nan_values = {"base_color": 0.0, "roughness": 0.0, "normal": 0.0, "xyz": 0.0, "scaling": 0.0, "rotation": 0.0,
                            "opacity": 0.0, "shs": 0.0}
-        self.n_param_elems = sum(p.numel() for p in self.params.values())
+        # elements the optimizer actually updates per step (a group without a gradient is skipped, as torch.optim.Adam does)
+        self.n_param_elems = sum(p.numel() for k, p in self.params.items() if radiance_grad or k != "radiance")
         self.xyz_gradient_accum = torch.zeros(P, 1, device=dev)
         self.weights_accum = torch.zeros(P, 1, device=dev)
         self.denom = torch.zeros(P, 1, device=dev)
@@ -93,13 +100,16 @@ class TrainStep:
         lattice = self.shading.FibonacciLattice(self.geo_n, self.Ns, offs)
         self.last_offsets = offs
         means2D = torch.zeros_like(p["xyz"], requires_grad=True)
+        ratio = None if self.radiance_grad else p["radiance_ratio"]
+        radiance = p["radiance"] if self.radiance_grad else p["radiance"].detach()
         if self.fused:   # the shading runs inside the rasterizer calls, for the surfels this view reads (include/svgir_raster.h: svgir_fused_shade)
             rendered, _ = self.shading.render_shaded(st, p["xyz"], means2D, p["opacity"], p["shs"], p["scaling"], p["rotation"],
-                                                     p["base_color"], p["roughness"], p["normal"], viewdirs, p["radiance"], self.light,
-                                                     self.visibility, lattice, None, True)
+                                                     p["base_color"], p["roughness"], p["normal"], viewdirs, radiance, self.light,
+                                                     self.visibility, lattice, None, True, radiance_ratio=ratio)
         else:
-            feats, vfeats, _ = self.shading.shade_and_pack(p["base_color"], p["roughness"], p["normal"], viewdirs, p["radiance"],
-                                                          self.light, self.visibility, lattice, None, st.viewmatrix, True)
+            feats, vfeats, _ = self.shading.shade_and_pack(p["base_color"], p["roughness"], p["normal"], viewdirs, radiance,
+                                                          self.light, self.visibility, lattice, None, st.viewmatrix, True,
+                                                          radiance_ratio=ratio)
             self._mark("shade_fwd")
             rast = self.GaussianRasterizer(st)
             rendered = rast(means3D=p["xyz"], means2D=means2D, opacities=p["opacity"], shs=p["shs"], scales=p["scaling"],

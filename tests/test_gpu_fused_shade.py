@@ -124,7 +124,7 @@ def test_shade_subset_rows_equal_the_all_surfel_call(built, Ns, training):
         outs = [N.out_tensor(t.shape, torch.float32, dev) for t in (d["base_color"], d["roughness"], d["normals"], d["radiance"], d["env"])]
         gwork = torch.empty(d["env"].numel(), device=dev)
         N.check(N.lib.svgir_shade_backward(sp, None, gf.data_ptr(), gvf.data_ptr(), *[t.data_ptr() for t in outs], gwork.data_ptr(),
-                                           N.stream_ptr(dev)), "shade_backward")
+                                           None, N.stream_ptr(dev)), "shade_backward")
         torch.cuda.synchronize()
         return [red, f, vf] + outs
 

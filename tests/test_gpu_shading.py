@@ -415,3 +415,93 @@ def test_shading_cfg5_scale_in_chunks(built):
         _close(f"chunk{c} vfeatures", vf[pick], vr)
         del radiance, vis, pbr, ex, f, vf
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("api", ["rendering_equation4", "shade_and_pack"])
+def test_radiance_ratio_equals_the_reference_product(built, api):
+    """`radiance_ratio=` (ABI 13) = the reference's get_radiances, nan_to_num(_radiances.detach() * _radiance_ratio, nan=0)
+    (scene/gaussian_model.py:323-324), formed inside the kernels: the outputs and every material gradient must be BIT-identical to
+    the calls fed with the product torch computes, the scalar's gradient must be what autograd returns for the product form (and what
+    autograd of the fp64 oracle returns), and no [n, Ns, 3] gradient is produced for the detached cache."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _random_case(257, 96, 41, rough_lo=0.3)
+    raw = d["radiance"].float().to(dev)
+    names = ("base", "rough", "normals", "env")
+    c = {k: d[k].float().to(dev) for k in ("viewdirs", "vis", "dirs", "areas")}
+    vm = torch.eye(4, device=dev)
+    g = torch.Generator().manual_seed(9)
+
+    def run(fused):
+        lg = {k: d[k].float().to(dev).requires_grad_(True) for k in names}
+        ratio = torch.tensor(0.83, device=dev, requires_grad=True)
+        if fused:
+            rad, kw = raw, dict(radiance_ratio=ratio)
+        else:
+            rad, kw = torch.nan_to_num(raw.detach() * ratio, nan=0.0), {}
+        if api == "rendering_equation4":
+            pbr, ex = shading.rendering_equation4(lg["base"], lg["rough"], lg["normals"], c["viewdirs"], rad, _Light(lg["env"]),
+                                                  visibility_precompute=c["vis"], incident_dirs_precompute=c["dirs"],
+                                                  incident_areas_precompute=c["areas"], **kw)
+            outs = [pbr, ex["diffuse_light"], ex["specular"], ex["indirect"], ex["local_incident_lights"].mean(-2)]
+        else:
+            outs = list(shading.shade_and_pack(lg["base"], lg["rough"], lg["normals"], c["viewdirs"], rad, _Light(lg["env"]), c["vis"],
+                                               c["dirs"], c["areas"], vm, True, **kw))
+        return lg, ratio, outs
+
+    # forward with non-finite cache entries: nan_to_num -> 0, +max, -max (their gradient w.r.t. the scalar is NaN in torch as well:
+    # 0 * NaN -- hence the gradient checks below run on a finite cache)
+    finite_raw = raw
+    raw = finite_raw.clone()
+    raw[3, 5, 1] = float("nan"); raw[7, 0, 0] = float("inf"); raw[9, 70, 2] = -float("inf")
+    with torch.no_grad():
+        for i, (oa, ob) in enumerate(zip(run(True)[2], run(False)[2])):
+            assert torch.equal(oa, ob), f"output {i} (non-finite cache entries) differs from the product form"
+    raw = finite_raw
+    lg_a, ratio_a, out_a = run(True)
+    lg_b, ratio_b, out_b = run(False)
+    ws = [torch.randn(o.shape, generator=g).to(dev) for o in out_a]
+    for i, (oa, ob) in enumerate(zip(out_a, out_b)):
+        assert torch.equal(oa, ob), f"output {i} differs from the product form"
+    sum((o * w).sum() for o, w in zip(out_a, ws)).backward()
+    sum((o * w).sum() for o, w in zip(out_b, ws)).backward()
+    for k in names:
+        if k == "env":   # (float atomics: order of the adds)
+            _close("grad_env", lg_a[k].grad, lg_b[k].grad, tol=1e-5)
+        else:
+            assert torch.equal(lg_a[k].grad, lg_b[k].grad), f"grad_{k} differs from the product form"
+    ga, gb = float(ratio_a.grad), float(ratio_b.grad)
+    assert np.isfinite(ga) and abs(ga - gb) <= 2e-5 * max(abs(gb), 1e-6) + 1e-6, (ga, gb)
+    # ... and against autograd of the fp64 oracle on the cleaned product
+    r64 = torch.tensor(0.83, dtype=torch.float64, requires_grad=True)
+    inc = raw.double().cpu() * r64
+    if api == "rendering_equation4":
+        ref = so.shade(d["base"], d["rough"], d["normals"], d["viewdirs"], inc, d["vis"], d["dirs"], d["areas"], d["env"])
+        ro = [ref["pbr"], ref["diffuse_light"], ref["specular"], ref["indirect"], ref["mean_local"]]
+        sum((o * w.double().cpu().reshape(o.shape)).sum() for o, w in zip(ro, ws)).backward()
+        assert abs(ga - float(r64.grad)) <= 5e-4 * max(abs(float(r64.grad)), 1e-6) + 1e-5, (ga, float(r64.grad))
+
+
+def test_radiance_ratio_can_also_return_the_cache_gradient(built):
+    """A caller that does differentiate the cache gets dL/d(raw radiance) = dL/d(incident) * ratio where the product is finite."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _random_case(130, 64, 43, rough_lo=0.3)
+    c = {k: d[k].float().to(dev) for k in ("base", "rough", "normals", "viewdirs", "vis", "dirs", "areas", "env")}
+    raw = d["radiance"].float().to(dev)
+    raw[2, 3, 0] = float("nan")
+
+    def run(fused):
+        r = raw.clone().requires_grad_(True)
+        ratio = torch.tensor(1.7, device=dev, requires_grad=True)
+        rad, kw = (r, dict(radiance_ratio=ratio)) if fused else (torch.nan_to_num(r * ratio, nan=0.0), {})
+        pbr, ex = shading.rendering_equation4(c["base"], c["rough"], c["normals"], c["viewdirs"], rad, _Light(c["env"]),
+                                              visibility_precompute=c["vis"], incident_dirs_precompute=c["dirs"],
+                                              incident_areas_precompute=c["areas"], **kw)
+        (pbr.sum() + 0.3 * ex["specular"].sum()).backward()
+        return r.grad, ratio.grad
+
+    (ga, gra), (gb, grb) = run(True), run(False)
+    m = torch.isfinite(gb)   # (torch: 0 * NaN = NaN at the NaN entry; the kernel writes the masked 0 there)
+    assert torch.equal(ga[m], gb[m]) and float(ga[~m].abs().sum()) == 0.0
+    assert not torch.isfinite(gra) or abs(float(gra) - float(grb)) <= 2e-5 * abs(float(grb)) + 1e-6

@@ -47,17 +47,29 @@ def _shade_chunks(par, ids, vis, dirs, campos, view3, training, g_feat=None, g_v
     S, VS = (4, 52) if training else (7, 64)
     F_, VF = np.zeros((len(ids), S)), np.zeros((len(ids), VS))
     grads = None
+    # the reference's get_radiances (scene/gaussian_model.py:323-324): the cache is detached, the scalar ratio learns
+    ratio_form = "radiance_ratio" in par
+    mats = ("base_color", "roughness", "normal") + (() if ratio_form else ("radiance",))
     if g_feat is not None:
-        grads = {k: np.zeros(par[k][ids].shape) for k in ("base_color", "roughness", "normal", "radiance")}
+        grads = {k: np.zeros(par[k][ids].shape) for k in mats}
         grads["env"] = np.zeros(par["env"].shape)
+        if ratio_form:
+            grads["radiance_ratio"] = np.zeros(())
     for c0 in range(0, len(ids), chunk):
         ii = ids[c0:c0 + chunk]
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()  # noqa: E731
-        lv = {k: t(par[k][ii]).requires_grad_(g_feat is not None) for k in ("base_color", "roughness", "normal", "radiance")}
+        lv = {k: t(par[k][ii]).requires_grad_(g_feat is not None) for k in mats}
         env = t(par["env"]).requires_grad_(g_feat is not None)
+        if ratio_form:   # (the product is an fp32 product in the reference and in the kernels: rounded to fp32 here too)
+            ratio = torch.tensor(float(par["radiance_ratio"]), dtype=torch.float64, requires_grad=g_feat is not None)
+            raw = t(par["radiance"][ii])
+            prod32 = torch.from_numpy((par["radiance"][ii].astype(np.float32) * np.float32(par["radiance_ratio"])).astype(np.float64))
+            incident = torch.nan_to_num(prod32 + (raw * ratio - (raw * ratio).detach()), nan=0.0)   # fp32 value, fp64 gradient path
+        else:
+            incident = lv["radiance"]
         xyz = t(par["xyz"][ii])
         viewdirs = torch.nn.functional.normalize(t(campos)[None] - xyz, dim=-1)
-        ref = so.shade(lv["base_color"], lv["roughness"], lv["normal"], viewdirs, lv["radiance"], t(vis[ii]), t(dirs[c0:c0 + chunk]),
+        ref = so.shade(lv["base_color"], lv["roughness"], lv["normal"], viewdirs, incident, t(vis[ii]), t(dirs[c0:c0 + chunk]),
                        torch.full((len(ii), dirs.shape[1], 1), 2 * math.pi, dtype=torch.float64), env)
         f, vf = so.pack(ref, lv["base_color"], lv["roughness"], lv["normal"], t(view3), training)
         F_[c0:c0 + chunk], VF[c0:c0 + chunk] = f.detach().numpy(), vf.detach().numpy()
@@ -66,6 +78,8 @@ def _shade_chunks(par, ids, vis, dirs, campos, view3, training, g_feat=None, g_v
             for k in lv:
                 grads[k][c0:c0 + chunk] = lv[k].grad.numpy()
             grads["env"] += env.grad.numpy()
+            if ratio_form:
+                grads["radiance_ratio"] += ratio.grad.numpy()
     return F_, VF, grads
 
 
@@ -103,8 +117,11 @@ def oracle_iteration(sc, par, vis, geo_n, offsets, gt, Ns, want_grads=True):
     g = {"xyz": gr["means3D"], "scaling": gr["scales"], "rotation": gr["rotations"], "opacity": gr["opacity"], "shs": gr["sh"],
          "env": sg["env"]}
     for k in ("base_color", "roughness", "normal", "radiance"):
-        g[k] = np.zeros(par[k].shape)
-        g[k][ids] = sg[k]
+        if k in sg:
+            g[k] = np.zeros(par[k].shape)
+            g[k][ids] = sg[k]
+    if "radiance_ratio" in sg:
+        g["radiance_ratio"] = sg["radiance_ratio"]
     out["grads"] = {k: np.asarray(v, dtype=np.float32).reshape(par[k].shape) for k, v in g.items()}
     vf_ = im["radii"] > 0   # add_densification_stats (scene/gaussian_model.py:1270-1276)
     out["stat_grad"] = np.where(vf_, np.linalg.norm(gr["means2D"][:, :2].astype(np.float64), axis=-1), 0.0)[:, None]
@@ -134,9 +151,15 @@ def _run_and_compare(ts, sc, steps, tol=2e-4, flip=5e-4):
         assert abs(float(loss) - ref["loss"]) <= 2e-5 * abs(ref["loss"]), (it, float(loss), ref["loss"])
         _cmp(f"pbr[{it}]", pbr, ref["pbr"], tol, flip)
         for k, p in ts.params.items():
+            if k not in ref["grads"]:   # the detached radiance cache: in the optimizer (gaussian_model.py:527), never a gradient
+                assert k == "radiance" and p.grad is None
+                continue
+            if p.dim() == 0:
+                assert abs(float(p.grad) - float(ref["grads"][k])) <= 1e-3 * abs(float(ref["grads"][k])) + 1e-7, (k, float(p.grad), float(ref["grads"][k]))
+                continue
             _cmp(f"grad {k}[{it}]", p.grad, ref["grads"][k], tol=5e-4, flip_frac=2e-3)
         for k, p in ref_p.items():
-            p.grad = torch.from_numpy(ref["grads"][k].copy())
+            p.grad = torch.from_numpy(ref["grads"][k].copy()) if k in ref["grads"] else None
         adam.step()
         acc_g += ref["stat_grad"]; acc_d += ref["stat_denom"]; acc_w += ref["weights"]
         _cmp(f"xyz_gradient_accum[{it}]", ts.xyz_gradient_accum, acc_g, tol=5e-4, flip_frac=2e-3)
@@ -147,6 +170,12 @@ def _run_and_compare(ts, sc, steps, tol=2e-4, flip=5e-4):
         for k, p in ts.params.items():
             upd = (p.detach().cpu().double() - torch.from_numpy(par0[k]).double()) / lrs[k]
             upd_ref = (ref_p[k].detach().double() - torch.from_numpy(par0[k]).double()) / lrs[k]
+            if k not in ref["grads"]:
+                assert float(upd.abs().max()) == 0.0, k   # untouched
+                continue
+            if p.dim() == 0:
+                assert abs(float(upd) - float(upd_ref)) <= 2e-3, (k, float(upd), float(upd_ref))
+                continue
             big = torch.from_numpy(np.abs(ref["grads"][k]) > 1e-3 * np.abs(ref["grads"][k]).max())   # gradients above the noise
             if int(big.sum()):
                 _cmp(f"update {k}[{it}]", upd[big], upd_ref[big], tol=2e-3, flip_frac=5e-3)
@@ -157,8 +186,8 @@ def _run_and_compare(ts, sc, steps, tol=2e-4, flip=5e-4):
 def test_train_step_matches_the_oracle_chain_small(built):
     dev = torch.device(DEV)
     sc = scenes.surface_scene(P=4000, W=160, H=128, seed=71, sh_degree=3, variant="svgss", S=4, VS=52, scale_lo=0.02, scale_hi=0.07)
-    for fused in (True, False):
-        ts = workloads.TrainStep(dev, seed=9, Ns=32, fused=fused, scene=sc)
+    for fused, rad_grad in ((True, False), (False, False), (True, True)):
+        ts = workloads.TrainStep(dev, seed=9, Ns=32, fused=fused, scene=sc, radiance_grad=rad_grad)
         _run_and_compare(ts, sc, steps=2)
 
 
