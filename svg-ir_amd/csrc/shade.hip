@@ -309,7 +309,7 @@ __device__ __forceinline__ RawSample load_raw(const svgir_shade_params& p, size_
 // phase 1 for one chunk of <= 64 samples [s0, s0+cnt) of one Gaussian: fills the wave's sample records (slot =
 // sample - s0) and adds this lane's sample to the per-lane light sums m[10].
 __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_t g, int lane, const float* V,
-                                              float* __restrict__ sS, float* m, int s0, int cnt, const LatticeFrame& lf) {
+                                              float* __restrict__ sS, float* m, int s0, int cnt, const LatticeFrame& lf, const RadRatio& rr) {
     const int Ns = p.Ns;
     if (lane < cnt) {
         const int s = s0 + lane;
@@ -317,7 +317,6 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         float d[3];
         if (p.incident_dirs) { d[0] = p.incident_dirs[o * 3]; d[1] = p.incident_dirs[o * 3 + 1]; d[2] = p.incident_dirs[o * 3 + 2]; }
         else lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[s], s, p.lattice_offsets != nullptr, d);
-        const RadRatio rr = rad_ratio(p);
         const float rad[3] = {incident_of(p.radiance[o * 3], rr), incident_of(p.radiance[o * 3 + 1], rr), incident_of(p.radiance[o * 3 + 2], rr)};
         const float vis = p.visibility[o], area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
         const float il = inv_norm(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // = 1 / max(|.|, 1e-12)
@@ -382,11 +381,14 @@ __device__ __forceinline__ void zero_rest_rows(const ShadeArgs& a, size_t wave_i
 #endif
 // One wave per Gaussian.  (A persistent variant that loads the next Gaussian's samples and corner data while the current one
 // is processed was built and measured: 282 us at 4 waves/SIMD, 332 us at 5 (spills) against 250 us for this one.)
+// (RATIO: svgir_shade_params.radiance_ratio is set -- a template parameter so that the plain kernels are exactly the code they were)
+template <bool RATIO>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_FWPE, SHADE_FWPE))) shade_fwd_kernel(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Ns = p.Ns;
+    const RadRatio rr = RATIO ? rad_ratio(p) : RadRatio{1.f, false};
     float* sS = smem + (size_t)wave * (64 * SREC + 80 + 32);
     float* sOut = sS + 64 * SREC;
     float* sIn = sOut + 80;   // base_color[12] | normals[12] | roughness[4] of this Gaussian, for the packing in the epilogue
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
       const int cnt = min(64, Ns - s0);
       wave_lds_sync();   // previous chunk consumed
       DEV_TRACE_MARK(0);
-      stage_samples(p, gg, lane, V, sS, m, s0, cnt, lf);
+      stage_samples(p, gg, lane, V, sS, m, s0, cnt, lf, rr);
       wave_lds_sync();
       DEV_TRACE_MARK(1);
       for (int s = sg; s < cnt; s += 16) {
@@ -526,6 +528,7 @@ __device__ __forceinline__ float quad_bcast(float v) {   // value of lane (quad 
 
 struct FqSample { float d[3], il, ih, frac0, LgA[3], LlA[3]; };   // the staged, corner-independent part of one incident sample
 
+template <bool RATIO>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_FQ_WPE, SHADE_FQ_WPE))) shade_fwd_quad_kernel(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
@@ -574,14 +577,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
 
     // raw inputs of the lane's sample of a step, fetched one step ahead
     struct Raw { float d[3], rad[3], vis, area; };
-    const RadRatio rrq = rad_ratio(p);
+    const RadRatio rrq = RATIO ? rad_ratio(p) : RadRatio{1.f, false};
     auto load_raw_q = [&](int s) -> Raw {
         Raw r;
         const int sc = min(s, Ns - 1);
         const size_t o = gg * (size_t)Ns + (size_t)sc;
         if (!lattice) { r.d[0] = p.incident_dirs[o * 3]; r.d[1] = p.incident_dirs[o * 3 + 1]; r.d[2] = p.incident_dirs[o * 3 + 2]; }
         else { r.d[0] = r.d[1] = r.d[2] = 0.f; }
-        r.rad[0] = incident_of(p.radiance[o * 3], rrq); r.rad[1] = incident_of(p.radiance[o * 3 + 1], rrq); r.rad[2] = incident_of(p.radiance[o * 3 + 2], rrq);
+        r.rad[0] = p.radiance[o * 3]; r.rad[1] = p.radiance[o * 3 + 1]; r.rad[2] = p.radiance[o * 3 + 2];
         r.vis = p.visibility[o];
         r.area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
         return r;
@@ -590,8 +593,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
     for (int s0 = 0; s0 < Ns; s0 += 4) {
         const int s = s0 + k;
         const bool act = s < Ns;
-        const Raw x = raw;
+        Raw x = raw;
         raw = load_raw_q(s + 4);
+        if (RATIO) {   // (at the values' USE, not at their load: the loads above are a step ahead)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) x.rad[ch] = incident_of(x.rad[ch], rrq);
+        }
         // ---- stage the lane's sample (stage_samples above, without the record) ----
         FqSample f;
         {
@@ -830,7 +837,15 @@ __device__ __forceinline__ void stage_raw_bwd(const svgir_shade_params& p, const
     // footprint origin, biased by +1 (x0, y0 >= -1 by construction), 14 bits each (the launcher checks the map's size)
     const int xb = min(max(x0 + 1, 0), 16383), yb = min(max(y0 + 1, 0), 16383);
     r[16] = __builtin_bit_cast(float, (uint32_t)xb | ((uint32_t)yb << 14) | (flags << 28));
-    r[17] = fx; r[18] = fy; r[19] = 0.f;
+    r[17] = fx; r[18] = fy;
+    {   // radiance_ratio: which channels' products were not finite (nan_to_num passes no gradient there), bits 0..2
+        uint32_t nf = 0;
+        if (rr.on) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) nf |= ratio_finite(x.rad[ch], rr) ? 0u : (1u << ch);
+        }
+        r[19] = __builtin_bit_cast(float, nf);
+    }
     float4* o = reinterpret_cast<float4*>(sS + lane * BREC);
 #pragma unroll
     for (int i = 0; i < BREC / 4; i++) o[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
@@ -855,6 +870,7 @@ __device__ __forceinline__ float stride4_sum(float v) {
 // the 12 atomic instructions per 64 samples were ~500 of the kernel's 552 us of LDS time, hidden behind nothing.  (And
 // the per-workgroup partial sums are exact to fp32 precision whatever the order of the adds.)  The next chunk of samples
 // is prefetched into registers while the current one is processed.
+template <bool RATIO>
 __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_eu(SHADE_BWPE, SHADE_BWPE))) shade_bwd_kernel(const ShadeBwdArgs a, int env_in_lds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
@@ -897,8 +913,16 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     };
     DEV_TRACE_DECL();
     [[maybe_unused]] unsigned dev_n = 0;
-    const RadRatio rr = rad_ratio(p);
+    // (the scalar is re-read where it is used -- twice per chunk, scalar-cache hits -- instead of living in an SGPR across the kernel:
+    // the kernel sits at its SGPR limit)
+    auto ratio_now = [&]() -> RadRatio {
+        if (!RATIO) return RadRatio{1.f, false};
+        const float* rp = p.radiance_ratio;
+        asm volatile("" : "+s"(rp));
+        return RadRatio{*rp, true};
+    };
     float ratio_acc = 0.f;   // this lane's share of dL/d(radiance_ratio) = sum dL/d(incident) * isfinite(raw * ratio) * raw
+    const bool ratio_zero = RATIO && ratio_now().ratio == 0.f;
     RawSample raw;
     if (g < P) raw = load_raw(p, sid(g), 0, lane, min(64, Ns));
     // The per-(Gaussian, corner) constants -- unit view vector, corner frame, and the upstream gradients folded into the
@@ -1012,8 +1036,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         for (int s0 = 0; s0 < Ns; s0 += 64) {
             const int cnt = min(64, Ns - s0);
             wave_lds_sync();   // previous chunk consumed
-            if (lane < cnt && (SHADE_ABL != 3 || s0 + g == 0)) stage_raw_bwd(p, raw, lane, V, sS, rr);
-            const float raw_rad[3] = {raw.rad[0], raw.rad[1], raw.rad[2]};   // (of sample s0 + lane: the ratio's gradient needs the raw values)
+            if (lane < cnt && (SHADE_ABL != 3 || s0 + g == 0)) stage_raw_bwd(p, raw, lane, V, sS, ratio_now());
             {   // prefetch the next chunk (of this Gaussian or of the wave's next one)
                 const bool more = s0 + 64 < Ns;
                 const int gn = more ? g : g + gstep;
@@ -1088,7 +1111,19 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                     if (SHADE_ABL != 2) {   // parked in the sample's (consumed) local-light slots, written out below (lane k = 3: the pad
                         // slot; lanes beyond the chunk: records nobody reads)
                         const float v = k == 0 ? xl[0] : (k == 1 ? xl[1] : xl[2]);
-                        sS[s * BREC + (k < 3 ? 12 + k : BREC - 1)] = v + grad_const;
+                        float gk = v + grad_const;   // dL/d(incident radiance), channel k of this sample
+                        if (RATIO) {
+                            // dL/d(ratio) = sum gk * isfinite(raw * ratio) * raw.  The record holds incident = nan_to_num(raw * ratio): with
+                            // ratio != 0 the sum is taken over gk * incident and divided by the ratio once, at the end (where the product
+                            // was not finite -- flagged in the record -- there is no gradient, as for nan_to_num; torch then adds
+                            // 0 * inf = NaN to the scalar's gradient, here the entry adds nothing); with ratio == 0 (uniform, rare) the
+                            // raw values are read again where the chunk's rows leave (below).
+                            const float inc = k == 0 ? r[12] : (k == 1 ? r[13] : r[14]);
+                            const bool fin = ((__builtin_bit_cast(uint32_t, r[19]) >> k) & 1u) == 0u;   // (stage_raw_bwd)
+                            gk = fin ? gk : 0.f;
+                            ratio_acc += (act && k < 3) ? gk * inc : 0.f;
+                        }
+                        sS[s * BREC + (k < 3 ? 12 + k : BREC - 1)] = gk;
                     }
                     const uint32_t xy = __builtin_bit_cast(uint32_t, r[16]);
                     const int tx = (int)(xy & 0x3fffu) - 1 + (k & 1), ty = (int)((xy >> 14) & 0x3fffu) - 1 + (k >> 1);
@@ -1113,24 +1148,21 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             // dL/dradiance of the chunk: the values parked in the records leave as whole rows (3 cnt consecutive floats)
             wave_lds_sync();
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next Gaussian's inputs (LDS-DMA) and the next chunk's samples, both issued an inner loop ago
-            if (rr.on) {   // lane = sample: dL/d(incident) -> the scalar's gradient and (if asked for) dL/d(raw radiance), in place
-                float* q = sS + lane * BREC + 12;
-                if (lane < cnt) {
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        const float gm = ratio_finite(raw_rad[ch], rr) ? q[ch] : 0.f;
-                        ratio_acc += gm * raw_rad[ch];
-                        q[ch] = gm * rr.ratio;
-                    }
-                }
-                wave_lds_sync();
-            }
-            if (SHADE_ABL != 2 && a.d_radiance) {
-                float* out = a.d_radiance + (gg * Ns + s0) * 3;
+            if (RATIO && ratio_zero) {   // (uniform, rare: incident = 0 everywhere, the sum above is 0 -- the scalar's gradient from the raw cache)
+                const float* rawp = p.radiance + (gg * Ns + s0) * 3;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int i = lane + 64 * j;
-                    if (i < 3 * cnt) out[i] = sS[(i / 3) * BREC + 12 + (i % 3)];
+                    if (i < 3 * cnt) ratio_acc += sS[(i / 3) * BREC + 12 + (i % 3)] * rawp[i];
+                }
+            }
+            if (SHADE_ABL != 2 && a.d_radiance) {
+                float* out = a.d_radiance + (gg * Ns + s0) * 3;
+                const float rsc = RATIO ? ratio_now().ratio : 1.f;   // (RATIO: the parked values are masked dL/d(incident); d(incident)/d(raw) = ratio)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int i = lane + 64 * j;
+                    if (i < 3 * cnt) out[i] = RATIO ? sS[(i / 3) * BREC + 12 + (i % 3)] * rsc : sS[(i / 3) * BREC + 12 + (i % 3)];
                 }
             }
         }
@@ -1167,8 +1199,9 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
     zero_rows(0x7fffffff);   // (what is left of this wave's share: waves with few or no surfels of their own)
     DEV_TRACE_END(0, dev_n, (unsigned)Ns, 0u);
     __syncthreads();
-    if (a.ratio_part) {   // the workgroup's partial sum, waves in order (the epilogue adds the workgroups in order: reproducible)
-        const float ws = wave_sum(ratio_acc);
+    if (RATIO && a.ratio_part) {   // the workgroup's partial sum, waves in order (the epilogue adds the workgroups in a fixed order: reproducible)
+        const float rz = ratio_now().ratio;
+        const float ws = wave_sum(ratio_acc) * (rz != 0.f ? 1.f / rz : 1.f);   // (sum over gk * incident -> sum over gk * raw)
         if (lane == 0) smem[wave] = ws;   // (the sample records are free: every wave passed the barrier above)
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1190,10 +1223,15 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 __global__ void __launch_bounds__(BLOCK) env_grad_kernel(const float* __restrict__ env, const float* __restrict__ dtab,
                                                          float* __restrict__ denv, int n, int softplus,
                                                          const float* __restrict__ ratio_part, int nparts, float* __restrict__ d_ratio) {
-    if (d_ratio && blockIdx.x == 0 && threadIdx.x == 0) {   // dL/d(radiance_ratio): the workgroups' partial sums, in order
-        float t = 0.f;
-        for (int w = 0; w < nparts; w++) t += ratio_part[w];
-        *d_ratio = t;
+    if (d_ratio && blockIdx.x == 0) {   // dL/d(radiance_ratio): the workgroups' partial sums (<= 256), a fixed tree
+        __shared__ float part[BLOCK];
+        part[threadIdx.x] = (int)threadIdx.x < nparts ? ratio_part[threadIdx.x] : 0.f;
+        __syncthreads();
+        for (int h = BLOCK / 2; h >= 1; h >>= 1) {
+            if ((int)threadIdx.x < h) part[threadIdx.x] += part[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *d_ratio = part[0];
     }
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -1258,10 +1296,12 @@ int svgir::shade_forward_impl(const svgir_shade_params* p, float* reduced, float
     // per load; 771 us against 1 001 us at Ns = 384)
     if (SHADE_FWD_QUAD && p->Ns <= SHADE_FWD_QUAD_MAX_NS) {
         const size_t lds = (size_t)4 * (FQ_SURF * (FQ_ROW + FQ_IN) + FQ_SURF) * 4;
-        hipLaunchKernelGGL(shade_fwd_quad_kernel, dim3((p->P + 4 * FQ_SURF - 1) / (4 * FQ_SURF)), dim3(BLOCK), lds, s, a);
+        if (p->radiance_ratio) hipLaunchKernelGGL(shade_fwd_quad_kernel<true>, dim3((p->P + 4 * FQ_SURF - 1) / (4 * FQ_SURF)), dim3(BLOCK), lds, s, a);
+        else hipLaunchKernelGGL(shade_fwd_quad_kernel<false>, dim3((p->P + 4 * FQ_SURF - 1) / (4 * FQ_SURF)), dim3(BLOCK), lds, s, a);
     } else {
         const size_t lds = (size_t)4 * (64 * SREC + 80 + 32) * 4;
-        hipLaunchKernelGGL(shade_fwd_kernel, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
+        if (p->radiance_ratio) hipLaunchKernelGGL(shade_fwd_kernel<true>, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
+        else hipLaunchKernelGGL(shade_fwd_kernel<false>, dim3((p->P + 3) / 4), dim3(BLOCK), lds, s, a);
     }
     stage_mark(tm, "shade_fwd");
     return hipGetLastError() == hipSuccess ? 0 : SVGIR_ERR_HIP;
@@ -1303,6 +1343,7 @@ int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dred
     a.d_radiance = dL_dradiance; a.d_envtab = env_grad_work;
     a.ratio_part = dL_dradiance_ratio ? env_grad_work + ntex : nullptr;   // (SVGIR_SHADE_RATIO_WORK floats behind the env-gradient table)
     a.zero_rest = (p->subset && !rows_precleared) ? 1 : 0;   // (every output is written completely: rows outside the subset are zero)
+    const bool ratio = p->radiance_ratio != nullptr;
     const size_t per_wave = (size_t)(64 * BREC + 4 * KB_G * KREC) * 4;
     size_t lds = BWAVES * per_wave;
     int env_in_lds = 0;
@@ -1314,7 +1355,8 @@ int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dred
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return SVGIR_ERR_HIP;
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(shade_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(shade_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(shade_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return SVGIR_ERR_HIP;
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
@@ -1322,7 +1364,8 @@ int svgir::shade_backward_impl(const svgir_shade_params* p, const float* dL_dred
     const int blocks = std::min((p->P + BWAVES - 1) / BWAVES, 256 * std::max(1, SHADE_BWPE * 4 / BWAVES));
     static_assert(256 * (SHADE_BWPE * 4 / BWAVES > 1 ? SHADE_BWPE * 4 / BWAVES : 1) <= SVGIR_SHADE_RATIO_WORK, "one partial sum per workgroup");
     stage_mark(tm, "shade_bwd_prologue");
-    hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(BWAVES * 64), lds, s, a, env_in_lds);
+    if (ratio) hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3(blocks), dim3(BWAVES * 64), lds, s, a, env_in_lds);
+    else hipLaunchKernelGGL(shade_bwd_kernel<false>, dim3(blocks), dim3(BWAVES * 64), lds, s, a, env_in_lds);
     stage_mark(tm, "shade_bwd");
     hipLaunchKernelGGL(env_grad_kernel, dim3((ntex + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p->env, env_grad_work,
                        dL_denv, ntex, p->env_softplus, a.ratio_part, blocks, dL_dradiance_ratio);

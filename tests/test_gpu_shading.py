@@ -502,6 +502,33 @@ def test_radiance_ratio_can_also_return_the_cache_gradient(built):
         return r.grad, ratio.grad
 
     (ga, gra), (gb, grb) = run(True), run(False)
-    m = torch.isfinite(gb)   # (torch: 0 * NaN = NaN at the NaN entry; the kernel writes the masked 0 there)
-    assert torch.equal(ga[m], gb[m]) and float(ga[~m].abs().sum()) == 0.0
-    assert not torch.isfinite(gra) or abs(float(gra) - float(grb)) <= 2e-5 * abs(float(grb)) + 1e-6
+    assert torch.equal(ga, gb) and float(ga[2, 3, 0]) == 0.0   # (no gradient through the scrubbed entry)
+    # the scalar: torch adds 0 * NaN = NaN for the scrubbed entry; the kernel's sum skips it and stays finite
+    assert not bool(torch.isfinite(grb)) and bool(torch.isfinite(gra))
+    r2 = raw.clone(); r2[2, 3, 0] = 0.0
+    ratio = torch.tensor(1.7, device=dev, requires_grad=True)
+    pbr, ex = shading.rendering_equation4(c["base"], c["rough"], c["normals"], c["viewdirs"], torch.nan_to_num(r2 * ratio, nan=0.0),
+                                          _Light(c["env"]), visibility_precompute=c["vis"], incident_dirs_precompute=c["dirs"],
+                                          incident_areas_precompute=c["areas"])
+    (pbr.sum() + 0.3 * ex["specular"].sum()).backward()
+    assert abs(float(gra) - float(ratio.grad)) <= 2e-5 * abs(float(ratio.grad)) + 1e-6
+
+
+def test_radiance_ratio_zero_still_has_a_gradient(built):
+    """ratio == 0: the incident radiance vanishes, the scalar's gradient does not (sum dL/d(incident) * raw)."""
+    from gaussian_renderer import shading
+    dev = torch.device("cuda:0")
+    d = _random_case(90, 70, 47, rough_lo=0.3)
+    c = {k: d[k].float().to(dev) for k in ("base", "rough", "normals", "viewdirs", "vis", "dirs", "areas", "env")}
+    raw = d["radiance"].float().to(dev)
+    out = []
+    for fused in (True, False):
+        ratio = torch.zeros((), device=dev, requires_grad=True)
+        rad, kw = (raw, dict(radiance_ratio=ratio)) if fused else (torch.nan_to_num(raw * ratio, nan=0.0), {})
+        pbr, ex = shading.rendering_equation4(c["base"], c["rough"], c["normals"], c["viewdirs"], rad, _Light(c["env"]),
+                                              visibility_precompute=c["vis"], incident_dirs_precompute=c["dirs"],
+                                              incident_areas_precompute=c["areas"], **kw)
+        (pbr.sum() + 0.3 * ex["indirect"].sum()).backward()
+        out.append((pbr.detach(), float(ratio.grad)))
+    assert torch.equal(out[0][0], out[1][0])
+    assert abs(out[1][1]) > 1e-3 and abs(out[0][1] - out[1][1]) <= 2e-5 * abs(out[1][1]) + 1e-6, (out[0][1], out[1][1])
