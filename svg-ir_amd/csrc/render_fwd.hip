@@ -186,7 +186,11 @@ render_fwd_kernel(const RenderArgs a) {
     const int len = (int)(r1 - r0);
     if (len == 0) return;   // empty tile: the cull kernel has written its background pixels
     DEV_TRACE_DECL();
+#if defined(FWD_ABL_CAP)   // (ablation builds only: lists cut off at FWD_ABL_CAP candidates -- wrong results; what would a shorter critical path buy?)
+    const int total = min((int)a.sub_total[sid], FWD_ABL_CAP);
+#else
     const int total = (int)a.sub_total[sid];
+#endif
     // The kernel ends when its longest candidate list has been walked (the walk is sequential per pixel), and waves are
     // dispatched longest-first: blockIdx.x is the wave's rank.  The SIMD's instruction arbiter serves the longer list first.
 #ifndef FWD_PRIO
