@@ -270,11 +270,8 @@ __device__ __forceinline__ void load_corner(const svgir_shade_params& p, size_t 
 // get_radiances (scene/gaussian_model.py:323-324): the incident radiance is nan_to_num(_radiances.detach() * _radiance_ratio, nan = 0)
 // -- with svgir_shade_params.radiance_ratio the product and its clean-up happen here, on the value just loaded
 struct RadRatio { float ratio; bool on; };
-__device__ __forceinline__ RadRatio rad_ratio(const svgir_shade_params& p) {
-    RadRatio r;
-    r.on = p.radiance_ratio != nullptr;
-    r.ratio = r.on ? *p.radiance_ratio : 1.f;
-    return r;
+__device__ __forceinline__ RadRatio rad_ratio(const svgir_shade_params& p) {   // (the RATIO kernels: launched only with the pointer set)
+    return RadRatio{*p.radiance_ratio, true};
 }
 __device__ __forceinline__ bool ratio_finite(float raw, const RadRatio& rr) {   // isfinite(raw * ratio): where nan_to_num passes its gradient
     const float v = raw * rr.ratio;
@@ -283,7 +280,9 @@ __device__ __forceinline__ bool ratio_finite(float raw, const RadRatio& rr) {   
 __device__ __forceinline__ float incident_of(float raw, const RadRatio& rr) {
     if (!rr.on) return raw;
     const float v = raw * rr.ratio;
-    return v != v ? 0.f : fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);   // torch.nan_to_num(v, nan = 0.0)
+    // torch.nan_to_num(v, nan = 0.0): +-inf -> the largest finite floats (the median of three), NaN -> 0
+    const float c = __builtin_amdgcn_fmed3f(v, -3.402823466e+38f, 3.402823466e+38f);
+    return v != v ? 0.f : c;
 }
 
 // the raw inputs of one incident sample (lane = sample), loadable a chunk / a Gaussian ahead of their use
@@ -317,7 +316,8 @@ __device__ __forceinline__ void stage_samples(const svgir_shade_params& p, size_
         float d[3];
         if (p.incident_dirs) { d[0] = p.incident_dirs[o * 3]; d[1] = p.incident_dirs[o * 3 + 1]; d[2] = p.incident_dirs[o * 3 + 2]; }
         else lattice_dir(lf, reinterpret_cast<const float4*>(p.lattice_work)[s], s, p.lattice_offsets != nullptr, d);
-        const float rad[3] = {incident_of(p.radiance[o * 3], rr), incident_of(p.radiance[o * 3 + 1], rr), incident_of(p.radiance[o * 3 + 2], rr)};
+        const float raw3[3] = {p.radiance[o * 3], p.radiance[o * 3 + 1], p.radiance[o * 3 + 2]};   // (one 96-bit load)
+        const float rad[3] = {incident_of(raw3[0], rr), incident_of(raw3[1], rr), incident_of(raw3[2], rr)};
         const float vis = p.visibility[o], area = p.incident_areas ? p.incident_areas[o] : kTwoPi;
         const float il = inv_norm(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   // = 1 / max(|.|, 1e-12)
         const float L[3] = {d[0] * il, d[1] * il, d[2] * il};
