@@ -52,23 +52,59 @@ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 #else
 #define GEOM_SHS a.shs
 #endif
-__global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
-    const int w = blockIdx.x * BLOCK + threadIdx.x;
+// The 48-float coefficient row of a Gaussian (and its gradient row) is 192 contiguous bytes, the lanes of a wave are 192 bytes -- with a
+// list, anything -- apart: read or written per lane, each of the 12 float4 accesses of a wave touches one cache line per visible lane
+// (~28 of 64 on the BASELINE scenes) and the kernel is bound by exactly that, the number of line accesses of its ~80 per-lane memory
+// instructions.  The two rows therefore move ROW-wise through LDS: 12 lanes per row, five rows per instruction (visible Gaussians only),
+// i.e. ~6 instructions of ~10 lines each instead of 12 of ~28.
+// One wave per workgroup: 12.3 KB of LDS each, i.e. 13 waves per CU -- P = 200 000 is then still ONE round of waves (the kernel costs
+// its chain of memory latencies once).
+constexpr int GB_BLOCK = 64;
+__global__ void __launch_bounds__(GB_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) geom_bwd_kernel(const GeomBwdArgs a) {
+    __shared__ float4 sRow[1][64][12];
+    __shared__ int sIdx[1][64];
+    const int w = blockIdx.x * GB_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = 0;
     // (with a list: only the Gaussians that received a blend weight have non-zero composite gradients; the outputs of the others stay
     // at the zeros svgir_backward cleared them to)
-    if (w >= (a.list ? (int)min(*a.list_count, (uint32_t)a.P) : a.P)) return;
-    const int idx = a.list ? (int)a.list[w] : w;
-    if (!(a.radii[idx] > 0)) return;
+    const bool in_range = w < (a.list ? (int)min(*a.list_count, (uint32_t)a.P) : a.P);
+    const int idx = in_range ? (a.list ? (int)a.list[w] : w) : 0;
+    const bool visible = in_range && a.radii[idx] > 0;
+    // The 48-float coefficient row of a Gaussian (M = 16) is contiguous and 16-byte aligned
+    const bool vec = GEOM_SHS && a.M == 16 && ((((size_t)GEOM_SHS) | ((size_t)a.dL_dsh)) & 15) == 0;
+    const bool coop = vec && a.D == 3;   // (wave-uniform) rows through LDS
+    const unsigned long long vmask = __ballot(visible);
+    const int nvis = __popcll(vmask);
+    const int rank = __popcll(vmask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    const int rsub = lane / 12, rpart = lane - rsub * 12;   // cooperative row access: row slot (0..4; lanes 60..63 idle), float4 of the row
+    if (nvis == 0) return;   // (wave-uniform)
+    constexpr int CR = 6;   // row loads held in registers (5 rows each: 30 rows, the usual wave) while the per-lane inputs are requested
+    float4 cr[CR];
+    if (coop) {
+        if (visible) sIdx[wave][rank] = idx;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < CR; j++) {
+            const int r = 5 * j + rsub;
+            cr[j] = (rsub < 5 && r < nvis) ? reinterpret_cast<const float4*>(GEOM_SHS)[(size_t)sIdx[wave][r] * 12 + rpart]
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     const bool surface = cfg_flag(a.cfg, 0);
     const bool lrn_cam = a.svgss && a.cfg.len >= 0 && cfg_flag(a.cfg, 3);
-    // (the uniform inputs as well: a load the compiler cannot prove untouched by an earlier store is not a scalar load any more)
     float V[16], PR[16], campos[3] = {0.f, 0.f, 0.f};
+    float in_color[3] = {0.f, 0.f, 0.f}, in_normal[3] = {0.f, 0.f, 0.f}, in_depth = 0.f, in_m2d[2] = {0.f, 0.f}, in_conic[3] = {0.f, 0.f, 0.f}, in_opacity = 0.f;
+    float mean[3] = {0.f, 0.f, 0.f}, c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc_in[3] = {0.f, 0.f, 0.f};
+    uint32_t cm = 0;
+    if (visible) {
+    // (the uniform inputs as well: a load the compiler cannot prove untouched by an earlier store is not a scalar load any more)
 #pragma unroll
     for (int i = 0; i < 16; i++) { V[i] = a.view[i]; PR[i] = a.proj[i]; }
     if (GEOM_SHS) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
 
     // ---------------- every input of this Gaussian ----------------
-    float in_color[3], in_normal[3], in_depth, in_m2d[2], in_conic[3], in_opacity = 0.f;
     if (a.packed) {
         // rgss: the backward composite accumulated this Gaussian's gradients in one packed row (common.hpp GradRowGeom:
         // colour3, normal3, depth, feature S | pad | mean2D.xy, conic.xyz, opacity); it is unpacked into the caller's tensors below
@@ -89,21 +125,41 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         in_m2d[0] = a.dL_dmean2D[3 * idx]; in_m2d[1] = a.dL_dmean2D[3 * idx + 1];
         in_conic[0] = a.dL_dconic[4 * idx]; in_conic[1] = a.dL_dconic[4 * idx + 1]; in_conic[2] = a.dL_dconic[4 * idx + 3];
     }
-    const float mean[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    float c3[6];
+    mean[0] = a.means3D[3 * idx]; mean[1] = a.means3D[3 * idx + 1]; mean[2] = a.means3D[3 * idx + 2];
 #pragma unroll
     for (int i = 0; i < 6; i++) c3[i] = a.cov3D[6 * idx + i];
-    // The 48-float coefficient row of a Gaussian (M = 16) is contiguous and 16-byte aligned: it is read and its
-    // gradient row written with 12 float4 accesses per lane instead of 48 dword accesses (the lanes of a wave are
-    // 192 bytes apart, so the number of memory transactions is what this stage costs).
-    const bool vec = GEOM_SHS && a.M == 16 && ((((size_t)GEOM_SHS) | ((size_t)a.dL_dsh)) & 15) == 0;
+    if (GEOM_SHS) cm = a.clamped[idx];
+    if (a.scales) {
+        qq = reinterpret_cast<const float4*>(a.rotations)[idx];
+#pragma unroll
+        for (int i = 0; i < 3; i++) sc_in[i] = a.scales[3 * idx + i];
+    }
+    }   // visible: inputs requested
+    if (coop) {   // the coefficient rows -> LDS (the loads were issued first: one memory latency for rows and per-lane inputs together)
+#pragma unroll
+        for (int j = 0; j < CR; j++) {
+            const int r = 5 * j + rsub;
+            if (rsub < 5 && r < nvis) sRow[wave][r][rpart] = cr[j];
+        }
+        for (int r0 = 5 * CR; r0 < nvis; r0 += 5) {   // (more than 30 visible Gaussians in the wave)
+            const int r = r0 + rsub;
+            if (rsub < 5 && r < nvis)
+                sRow[wave][r][rpart] = reinterpret_cast<const float4*>(GEOM_SHS)[(size_t)sIdx[wave][r] * 12 + rpart];
+        }
+    }
+    if (visible) {
     const int nk = (a.D + 1) * (a.D + 1);
     float sh[48];
-    uint32_t cm = 0;
     if (GEOM_SHS) {
         const float* shp = GEOM_SHS + (size_t)idx * a.M * 3;
-        cm = a.clamped[idx];
-        if (vec) {
+        if (coop) {
+            wave_lds_sync();   // (the rows are in LDS: the DS operations of a wave execute in order)
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const float4 v = sRow[wave][rank][i];
+                sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+            }
+        } else if (vec) {
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 const float4 v = reinterpret_cast<const float4*>(shp)[i];
@@ -113,13 +169,6 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 48; i++) sh[i] = i < 3 * nk ? shp[i] : 0.f;
         }
-    }
-    float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
-    float sc_in[3] = {0.f, 0.f, 0.f};
-    if (a.scales) {
-        qq = reinterpret_cast<const float4*>(a.rotations)[idx];
-#pragma unroll
-        for (int i = 0; i < 3; i++) sc_in[i] = a.scales[3 * idx + i];
     }
     if (a.packed) {   // (run-time feature width: row -> tensor, behind the loads above)
         const int P4 = (7 + a.S + 3) / 4 * 4, RS = (P4 + 6 + 3) / 4 * 4;
@@ -288,13 +337,12 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
 #undef SH
         // dL_dsh[k][c] = cf[k] * g[c]; coefficients above the active degree are left untouched (the caller zero-fills)
         float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
-        if (vec && a.D == 3) {
+        if (coop) {   // (the gradient row leaves row-wise, behind the per-Gaussian part: below)
             float o[48];
 #pragma unroll
             for (int k = 0; k < 16; k++) { o[3 * k] = cf[k] * g[0]; o[3 * k + 1] = cf[k] * g[1]; o[3 * k + 2] = cf[k] * g[2]; }
 #pragma unroll
-            for (int i = 0; i < 12; i++)
-                reinterpret_cast<float4*>(dsh)[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+            for (int i = 0; i < 12; i++) sRow[wave][rank][i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -381,12 +429,21 @@ __global__ void __launch_bounds__(BLOCK) geom_bwd_kernel(const GeomBwdArgs a) {
         for (int i = 0; i < 3; i++) a.dL_dscale[3 * idx + i] = dsc[i];
         reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
     }
+    }   // visible
+    if (coop) {   // dL_dsh rows of the wave's visible Gaussians, 12 lanes per row
+        wave_lds_sync();
+        for (int r0 = 0; r0 < nvis; r0 += 5) {
+            const int r = r0 + rsub;
+            if (rsub < 5 && r < nvis)
+                reinterpret_cast<float4*>(a.dL_dsh)[(size_t)sIdx[wave][r] * 12 + rpart] = sRow[wave][r][rpart];
+        }
+    }
 }
 
 }  // namespace
 
 void launch_geom_bwd(const GeomBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(geom_bwd_kernel, dim3((a.P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(geom_bwd_kernel, dim3((a.P + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, a);
 }
 
 }  // namespace svgir
