@@ -753,7 +753,7 @@ def bench_train_step(args, dev):
     import torch
     from gaussian_renderer import _native
     from svgir_harness import workloads
-    ts = workloads.TrainStep(dev)
+    ts = workloads.TrainStep(dev, radiance_grad=bool(getattr(args, "radiance_grad", False)))
     regions = _time_regions(ts.step, args, dev)
     med = float(np.median(regions))
     # kernel-level stage marks of the library (rasterizer + shading stages) over one more region, and the phase table
@@ -786,7 +786,10 @@ def bench_train_step(args, dev):
         "config": {"workload": f"train_step: cfg3_train scene (svgss, P={ts.P}, {ts.W}x{ts.H}, S=4, VS=52, Ns={ts.Ns}), one optimisation step per "
                                f"step: FibonacciLattice (random azimuths) -> shade_and_pack -> GaussianRasterizer -> unpack -> l1_ssim -> "
                                f"loss.backward() -> add_densification_stats -> FusedAdam.step(nan scrub, zero_grad) over {n_adam} parameter "
-                               f"elements (geometry, SH, SV-BRDF, radiance cache, env map)",
+                               f"elements (geometry, SH, SV-BRDF, env map and " +
+                               ("the radiance cache as a differentiated leaf: --radiance-grad)" if ts.radiance_grad else
+                                "the scalar _radiance_ratio: the radiance cache enters detached as get_radiances = nan_to_num(_radiances.detach() * "
+                                "_radiance_ratio), scene/gaussian_model.py:323-324, 526-528 -- it sits in the optimizer but never has a gradient)"),
                    "num_rendered": int(R), "reference": "train.py:133-134, gaussian_renderer/svgss.py:15-262, scene/gaussian_model.py:775-813, 1270-1276"},
         "phase_ms": {k: round(v, 4) for k, v in phases.items()},
         "stage_ms": {k: round(v[0], 4) for k, v in stage.items()},
