@@ -13,7 +13,7 @@ _cmp0 = T._cmp
 def _cmp(name, a, b, tol=T.TOL, flip_frac=T.FLIP_FRAC, flip_bound=T.FLIP_BOUND, rel=True, **kw):
     n = max(1, int(np.asarray(b).size))
     if "rel_frac" in kw:   # (the same for the relative criterion: with 50 entries ONE nearly cancelling sum is 2 % of them)
-        kw["rel_frac"] = max(kw["rel_frac"], 3.0 / n)
+        kw["rel_frac"] = max(kw["rel_frac"], 5.0 / n)
     return _cmp0(name, a, b, tol=tol, flip_frac=max(flip_frac, 8.0 / n), flip_bound=flip_bound, rel=rel, **kw)
 T._cmp = _cmp
 
