@@ -96,7 +96,7 @@ class TrainStep:
         self._mark("begin")
         campos = st.campos
         viewdirs = torch.nn.functional.normalize(campos[None, :] - p["xyz"].detach(), dim=-1)
-        offs = torch.rand(self.P, device=self.dev) * (2 * math.pi) if offsets is None else offsets   # sample_incident_rays(training): random azimuths
+        offs = torch.empty(self.P, device=self.dev).uniform_(0.0, 2 * math.pi) if offsets is None else offsets   # sample_incident_rays(training): random azimuths
         lattice = self.shading.FibonacciLattice(self.geo_n, self.Ns, offs)
         self.last_offsets = offs
         means2D = torch.zeros_like(p["xyz"], requires_grad=True)
@@ -116,8 +116,7 @@ class TrainStep:
                             rotations=p["rotation"], features=feats, vfeatures=vfeats)
         self._mark("raster_fwd")
         res = self.render_view.unpack(rendered, st.bg, True)
-        l1, ssim = self.losses.l1_ssim(res["pbr"], self.gt)
-        loss = (1.0 - self.LAMBDA_DSSIM) * l1 + self.LAMBDA_DSSIM * (1.0 - ssim)
+        loss = self.losses.l1_ssim_loss(res["pbr"], self.gt, self.LAMBDA_DSSIM)   # (1 - lambda) L1 + lambda (1 - SSIM), one node
         self._mark("unpack_loss_fwd")
         loss.backward()
         self._mark("backward")

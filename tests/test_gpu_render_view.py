@@ -161,6 +161,12 @@ def test_l1_ssim_kernels_match_reference_losses(built, tag):
     ref = ((1 - lam) * ol_ - lam * os_).numpy()
     assert np.abs(g.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
     assert float(losses.ssim(img.detach(), gt)) == float(s)
+    # the one-node form of the same combination (svgir_harness.losses.l1_ssim_loss): same value, a scaled upstream gradient included
+    img2 = img.detach().clone().requires_grad_(True)
+    fused = losses.l1_ssim_loss(img2, gt, lam)
+    assert abs(float(fused) - float(loss)) <= 1e-6
+    (3.0 * fused).backward()
+    assert np.abs(img2.grad.cpu().numpy() - 3.0 * ref).max() <= 1e-4 * np.abs(3.0 * ref).max()
 
 
 def test_l1_ssim_full_size_properties(built):
