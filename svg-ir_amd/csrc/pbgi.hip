@@ -386,11 +386,10 @@ __device__ __forceinline__ void eval_sh3(const float* __restrict__ sh, F3 dir, f
 // t >= t_min, power <= 0, alpha >= 1/255), so the plane intersection and the acceptance come first and the ellipse -- four IEEE
 // divisions -- last.  `d` is the direction in effect at this visit (re-normalised by the caller, Q-c).
 struct LeafRes { bool acc, hit; float t, alpha, u, v; };
-__device__ __forceinline__ LeafRes leaf_eval(const float4* __restrict__ rec, int j, F3 o, F3 d, float t_min) {
+__device__ __forceinline__ LeafRes leaf_eval_regs(const float4 A, const float4 B, const float4 C, const float4 D, const float4 E, const float4 G, F3 o,
+                                                  F3 d, float t_min) {
 #pragma clang fp contract(off)
     LeafRes r = {false, false, 0.f, 0.f, 0.5f, 0.5f};
-    const float4* lr = rec + 6 * (size_t)j;
-    const float4 A = lr[0], B = lr[1], C = lr[2], D = lr[3], E = lr[4], G = lr[5];
     const F3 c = {A.x, A.y, A.z};
     const float sx = A.w, sy = B.x;
     const F3 nw = {B.z, B.w, C.x};
@@ -423,6 +422,11 @@ __device__ __forceinline__ LeafRes leaf_eval(const float4* __restrict__ rec, int
         }
     }
     return r;
+}
+
+__device__ __forceinline__ LeafRes leaf_eval(const float4* __restrict__ rec, int j, F3 o, F3 d, float t_min) {
+    const float4* lr = rec + 6 * (size_t)j;
+    return leaf_eval_regs(lr[0], lr[1], lr[2], lr[3], lr[4], lr[5], o, d, t_min);
 }
 
 // gs_bvh_hit (intersect_test.slang:251-437) inside render_radiance_with_sampling_SH (:1879-1990).
@@ -709,6 +713,15 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
 #endif
         if (walking) {
             // ---- one traversal step ----
+            // The node's record -- the pair record of an internal node (64 bytes) or the leaf record (96 bytes) -- is requested BEFORE the
+            // lanes split by node type: one memory round trip per step for all lanes (requested inside the two branches they were two,
+            // one after the other).  A node that still has to pass its own box (rare: the root, nodes pushed while the direction could
+            // change) has it requested speculatively.
+            const bool is_int = cur < L;
+            const float4* nrec = is_int ? pair + 4 * (size_t)cur : rec + 6 * (size_t)(cur - L);
+            const float4 n0 = nrec[0], n1 = nrec[1], n2 = nrec[2], n3 = nrec[3];
+            float4 n4 = n0, n5 = n0;
+            if (!is_int) { n4 = nrec[4]; n5 = nrec[5]; }
             bool alive = true;
             if (own_test) {
                 const float4* q = reinterpret_cast<const float4*>(node + cur);
@@ -721,8 +734,7 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
                 PBGI_STAT(2);
                 if (cur < L) {
                     // ---- internal node: both children's boxes ----
-                    const float4* q = pair + 4 * (size_t)cur;
-                    const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
+                    const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
                     const int left = __builtin_bit_cast(int, r3.x), right = __builtin_bit_cast(int, r3.y);
                     const float lo0[3] = {r0.x, r0.y, r0.z}, hi0[3] = {r0.w, r1.x, r1.y}, lo1[3] = {r1.z, r1.w, r2.x}, hi1[3] = {r2.y, r2.z, r2.w};
                     if (fixed) {
@@ -745,7 +757,7 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
                         if (l != 1.0f) { d = {d.x / l, d.y / l, d.z / l}; sd = slab_dir(d); fixed = sqrtf(dot3(d, d)) == 1.0f; }
                         else fixed = true;
                     }
-                    const LeafRes lf = leaf_eval(rec, j, o, d, t_min);
+                    const LeafRes lf = leaf_eval_regs(n0, n1, n2, n3, n4, n5, o, d, t_min);
                     if (lf.acc) {
                         PBGI_STAT(4);
                         const bool update = lf.hit && lf.t < closest;
