@@ -270,10 +270,14 @@ __global__ void __launch_bounds__(BVH_WAVE) bvh_trace_kernel(int P, long long nu
     while (sp > 0 && !blocked) {
         --sp;
         const uint32_t nid = sp < BVH_LDS_DEPTH ? st[sp * BVH_WAVE] : deep[sp - BVH_LDS_DEPTH];
-        if (nid & 0x80000000u) {
+        // leaf record and node record are both 64 bytes: requested BEFORE the lanes split by node type -- one memory round trip per
+        // step for all lanes (inside the two branches they were two, one after the other)
+        const bool is_leaf = (nid & 0x80000000u) != 0u;
+        const float4* q = is_leaf ? rec + 4 * (size_t)(~nid) : nodes + 4 * (size_t)nid;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        if (is_leaf) {
             // ---- leaf: one surfel (trace.cu:218-247) ----
-            const float4* q = rec + 4 * (size_t)(~nid);
-            const float4 A = q[0], C0 = q[1], C1 = q[2], N = q[3];
+            const float4 A = q0, C0 = q1, C1 = q2, N = q3;
             if (A.w < 1.f / 255.f) continue;
             if (C1.z * d[0] + C1.w * d[1] + N.x * d[2] > 0) continue;   // back-facing
             const float c0 = C0.x, c1 = C0.y, c2 = C0.z, c3 = C0.w, c4 = C1.x, c5 = C1.y;
@@ -294,8 +298,7 @@ __global__ void __launch_bounds__(BVH_WAVE) bvh_trace_kernel(int P, long long nu
             if (ray_opacity <= 0.9f) blocked = true;   // trace.cu:240 (double)ray_opacity < 0.9  <=>  <= 0.9f (0.9f < 0.9 < its successor)
         } else {
             // ---- internal node: both child boxes come with it; the child with the larger exit distance is pushed first ----
-            const float4* q = nodes + 4 * (size_t)nid;
-            const float4 a = q[0], b = q[1], c = q[2], w = q[3];
+            const float4 a = q0, b = q1, c = q2, w = q3;
             const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y}, lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
             const float tl = slab_tmax(lo0, hi0, o, d), tr = slab_tmax(lo1, hi1, o, d);
             const uint32_t lid = __builtin_bit_cast(uint32_t, w.x), rid = __builtin_bit_cast(uint32_t, w.y);
