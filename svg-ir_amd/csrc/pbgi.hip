@@ -311,9 +311,9 @@ __device__ __forceinline__ bool box_hit(const float4 q0, const float4 q1, F3 o, 
 constexpr int PBGI_STACK = 64;        // the reference's MAX_STACK_SIZE; the tree is at most 30 + 32 - clz(P) + 1 < 63 levels deep (30-bit
                                       // codes, equal codes split by position), and the stack holds at most one pending sibling per level
 #ifndef PBGI_LDS_DEPTH_V
-#define PBGI_LDS_DEPTH_V 24
+#define PBGI_LDS_DEPTH_V 20
 #endif
-constexpr int PBGI_LDS_DEPTH = PBGI_LDS_DEPTH_V;   // (32 / 24 / 16 levels in LDS = 10 / 13 / 16 waves per CU: 1 017 / 963 / 1 023 ms on the cfg3 geometry, 1 735 / 1 392 / 1 238 ms on the shell scene)    // stack levels kept in LDS ([level][lane]: conflict-free whatever the lanes' depths); deeper ones in scratch
+constexpr int PBGI_LDS_DEPTH = PBGI_LDS_DEPTH_V;   // (round 4, 129 VGPRs = 12 waves per CU whatever the LDS: 32 / 24 / 16 levels: 1 017 / 963 / 1 023 ms on the cfg3 geometry, 1 735 / 1 392 / 1 238 ms on the shell scene.  Round 5, 124 VGPRs: 24 levels = 13 waves per CU 873 / 1 255 ms; 20 levels = 16 waves per CU 866 / 1 060 ms; 16 levels at 5 waves per SIMD spills: 1 508 / 2 120 ms)    // stack levels kept in LDS ([level][lane]: conflict-free whatever the lanes' depths); deeper ones in scratch
 constexpr int PBGI_WAVE = 64;         // one wave per workgroup
 #ifndef PBGI_COOP_CAP_V
 #define PBGI_COOP_CAP_V 512
@@ -447,7 +447,7 @@ __device__ __forceinline__ LeafRes leaf_eval(const float4* __restrict__ rec, int
 //     ends finishes its query (shading update, next query or outputs) and pulls the next ray of the pool at once, while the other
 //     lanes keep walking: one loop, one traversal step per iteration, per-lane state.
 #ifndef PBGI_WPE
-#define PBGI_WPE 3
+#define PBGI_WPE 4
 #endif
 __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(PBGI_WPE, 8))) pbgi_trace_kernel(int P, const PbgiNode* __restrict__ node, const float4* __restrict__ pair, const float4* __restrict__ rec,
                                                                const uint32_t* __restrict__ prim, int N, int S, const float* __restrict__ ray_o,
@@ -860,7 +860,7 @@ int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const 
     const int fin = PBGI_SORT_PASSES & 1;
     hipLaunchKernelGGL(pbgi_leaf_rec_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, B.val[fin], centers, scales, rotations, normals,
                        opacity, cov3D_inverse, B.rec);
-    // Persistent waves (one per resident slot: 16 KB of LDS each, 10 per CU) take chunks of consecutive rays (whole rows: the rays of a row
+    // Persistent waves (one per resident slot: 10 KB of LDS each, 16 per CU) take chunks of consecutive rays (whole rows: the rays of a row
     // share their origin) from a launch-wide queue, so no wave slot idles while rays are left and the end of the launch is one ray deep.
     // (Static pools, measured on the cfg3 geometry, 4.27 M rays per launch: 256 / 1 024 / 4 096 / 16 384 rays per wave = 2 129 / 1 329 /
     // 1 534 / 4 249 ms -- small pools end with 63 lanes waiting for one long ray, large ones leave wave slots empty.)
