@@ -586,6 +586,7 @@ struct ForwardCall {
         ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_total = I.sub_total; ra.sub_order = I.sub_order;
         ra.sub_pair_base = I.sub_pair_base; ra.sub_slot_base = I.sub_slot_base; ra.slot_cap = (uint32_t)std::min<size_t>(B.slot_cap, 0xffffffffu);
         ra.dump_only = 0;
+        ra.bg_in_render = render_specialised(p->S, svgss ? p->VS : 0, svgss) ? 1 : 0;
         ra.sub_count = I.sub_count;
         ra.sub_ndump = I.sub_ndump; ra.seg_list = B.seg_list; ra.seg_desc = B.seg_desc; ra.seg_count = I.counters; ra.seg_block = I.seg_block; ra.seg_state = B.seg_state;
         ra.final_T = I.final_T; ra.final_D = I.final_D; ra.n_contrib = I.n_contrib;

@@ -349,6 +349,8 @@ struct RenderArgs {
     uint2* sub_list; uint32_t* sub_total; uint32_t* sub_order; uint32_t* sub_count;
     uint32_t* sub_ndump; uint32_t* seg_list; SegDesc* seg_desc; uint32_t* seg_count; uint32_t* seg_block; float* seg_state;
     uint32_t* sub_pair_base; uint32_t* sub_slot_base; uint32_t slot_cap;
+    int bg_in_render;   // 1: the pixels of EMPTY tiles and the all-zero planes (zero_a / zero_b) are written by the composite kernel's waves -- the
+                        // empty sub-tiles' waves run last, in the kernel's idle tail -- instead of by the cull kernel (specialised kernels)
     int dump_only;   // composite forward: 1 = replay for the state dumps alone (svgir_backward, a view that exceeded its slot capacity): no output
                      // is written; 2 = contribution pre-pass of the fused shading (S = VS = 0): nothing is written but needed[id] = 1 for
                      // every surfel that receives a blend weight

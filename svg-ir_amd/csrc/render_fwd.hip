@@ -46,6 +46,23 @@ namespace {
 #define CULL_THREADS 256
 #endif
 constexpr int CT = CULL_THREADS, CNW = CT / 64;   // threads / waves of a cull workgroup (a tile's list is walked CT entries per round)
+
+// the result of a pixel nothing is blended into (forward.cu:665-700 with an empty list)
+__device__ __forceinline__ void write_background(const RenderArgs& a, size_t pid, size_t N_) {
+    const float T = (float)(1 - 0.000001);   // forward.cu:671
+    a.final_T[pid] = T; a.final_D[pid] = 0.f; a.n_contrib[pid] = 0;
+    a.out_color[pid] = T * a.bg[0]; a.out_color[N_ + pid] = T * a.bg[1]; a.out_color[2 * N_ + pid] = T * a.bg[2];
+    for (int ch = 0; ch < a.S; ch++) a.out_feature[ch * N_ + pid] = 0.f;
+    for (int ch = 0; ch < a.VS / 4; ch++) a.out_vfeature[ch * N_ + pid] = 0.f;
+    a.out_normal[pid] = 0.f; a.out_normal[N_ + pid] = 0.f; a.out_normal[2 * N_ + pid] = 0.f;
+    a.out_depth[pid] = cfg_flag(a.cfg, 1) ? 0.f / (1.f - T) : 0.f + T * 10.f;
+    a.out_opacity[pid] = 1.f - T;
+}
+__device__ __forceinline__ void write_zero_planes(const RenderArgs& a, size_t pid, size_t N_) {   // planes this call leaves at zero
+    if (a.zero_a) { a.zero_a[pid] = 0.f; a.zero_a[N_ + pid] = 0.f; a.zero_a[2 * N_ + pid] = 0.f; }
+    if (a.zero_b) { a.zero_b[pid] = 0.f; a.zero_b[N_ + pid] = 0.f; a.zero_b[2 * N_ + pid] = 0.f; }
+}
+
 __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
     __shared__ uint32_t wcnt[CNW][4];   // [wave][sub-tile] survivors of the current round
     const int tile = blockIdx.x;
@@ -53,31 +70,18 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
     const int len = (int)(r1 - r0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    if (t < 256 && (a.zero_a || a.zero_b)) {   // planes this call leaves at zero: one thread per pixel of the tile
+    // (bg_in_render: the specialised composite kernel writes the empty tiles' pixels and the all-zero planes itself -- its empty
+    // sub-tiles' waves are dispatched last and run in its idle tail: 6.5 us less here at cfg2, nothing more there)
+    if (!a.bg_in_render && t < 256 && (a.zero_a || a.zero_b)) {   // planes this call leaves at zero: one thread per pixel of the tile
         const int px = tx * TILE + (t & 15), py = ty * TILE + (t >> 4);
-        if (px < a.W && py < a.H) {
-            const size_t N_ = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
-            if (a.zero_a) { a.zero_a[pid] = 0.f; a.zero_a[N_ + pid] = 0.f; a.zero_a[2 * N_ + pid] = 0.f; }
-            if (a.zero_b) { a.zero_b[pid] = 0.f; a.zero_b[N_ + pid] = 0.f; a.zero_b[2 * N_ + pid] = 0.f; }
-        }
+        if (px < a.W && py < a.H) write_zero_planes(a, (size_t)a.W * py + px, (size_t)a.W * a.H);
     }
     if (len == 0) {
-        // Empty tile: nothing will ever be blended here.  The 256 threads write the background result of the whole
-        // 16x16 tile (64-byte rows) and the four composite waves of the tile exit at once (render_fwd_kernel).
+        // Empty tile: nothing will ever be blended here.  Run-time-width composite: the 256 threads write the background result of the
+        // whole 16x16 tile (64-byte rows) and the four composite waves of the tile exit at once.
         if (t < 4) { a.sub_total[4 * tile + t] = 0u; a.sub_count[4 * tile + t] = 0u; a.sub_ndump[4 * tile + t] = 0u; }
         const int px = tx * TILE + (t & 15), py = ty * TILE + (t >> 4);
-        if (t < 256 && px < a.W && py < a.H) {
-            const size_t N_ = (size_t)a.W * a.H;
-            const size_t pid = (size_t)a.W * py + px;
-            const float T = (float)(1 - 0.000001);   // forward.cu:671
-            a.final_T[pid] = T; a.final_D[pid] = 0.f; a.n_contrib[pid] = 0;
-            a.out_color[pid] = T * a.bg[0]; a.out_color[N_ + pid] = T * a.bg[1]; a.out_color[2 * N_ + pid] = T * a.bg[2];
-            for (int ch = 0; ch < a.S; ch++) a.out_feature[ch * N_ + pid] = 0.f;
-            for (int ch = 0; ch < a.VS / 4; ch++) a.out_vfeature[ch * N_ + pid] = 0.f;
-            a.out_normal[pid] = 0.f; a.out_normal[N_ + pid] = 0.f; a.out_normal[2 * N_ + pid] = 0.f;
-            a.out_depth[pid] = cfg_flag(a.cfg, 1) ? 0.f / (1.f - T) : 0.f + T * 10.f;
-            a.out_opacity[pid] = 1.f - T;
-        }
+        if (!a.bg_in_render && t < 256 && px < a.W && py < a.H) write_background(a, (size_t)a.W * py + px, (size_t)a.W * a.H);
         return;
     }
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
@@ -184,7 +188,13 @@ render_fwd_kernel(const RenderArgs a) {
     const f32x2 pxx = {pxf, pxf}, pyy = {pyf, pyf};
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int len = (int)(r1 - r0);
-    if (len == 0) return;   // empty tile: the cull kernel has written its background pixels
+    if (len == 0) {   // empty tile: its pixels are the background (written here, or -- run-time widths -- by the cull kernel)
+        if (a.bg_in_render && !a.dump_only && inside) {
+            write_background(a, (size_t)a.W * py + px, (size_t)a.W * a.H);
+            write_zero_planes(a, (size_t)a.W * py + px, (size_t)a.W * a.H);
+        }
+        return;
+    }
     DEV_TRACE_DECL();
 #if defined(FWD_ABL_CAP)   // (ablation builds only: lists cut off at FWD_ABL_CAP candidates -- wrong results; what would a shorter critical path buy?)
     const int total = min((int)a.sub_total[sid], FWD_ABL_CAP);
@@ -478,6 +488,7 @@ render_fwd_kernel(const RenderArgs a) {
     if (inside && !a.dump_only) {
         const size_t N_ = (size_t)a.W * a.H;
         const size_t pid = (size_t)a.W * py + px;
+        if (a.bg_in_render) write_zero_planes(a, pid, N_);
         T = fminf((float)(1 - 0.000001), T);
         a.final_T[pid] = T;
         a.n_contrib[pid] = last_walk ? (int32_t)(list[last_walk - 1u].y + 1u) : 0;   // (forward.cu:553: index in the TILE's list + 1)
