@@ -318,7 +318,7 @@ class Workload:
                                    _shapes=dict(self.sshapes))
                 if self.ratio is not None:
                     self.sgrads["dL_dradiance_ratio"] = self.sratio
-                kw = dict(shade=fs, shade_grads=self.sgrads)
+                kw = dict(shade=fs, shade_grads=self.sgrads, scratch_feature_grads=True)
             g = _C.rasterize_gaussians_backward(st.bg, sct["means3D"], self.f_buf, self.vf_buf, radii, empty, sct["scales"],
                                                 sct["rotations"], st.scale_modifier, empty, st.viewmatrix, st.projmatrix, st.prcppoint,
                                                 st.patch_bbox, st.tanfovx, st.tanfovy, gt["color"], gt["normal"], gt["depth"],

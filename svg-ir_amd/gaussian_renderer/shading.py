@@ -365,7 +365,7 @@ class _ShadedRasterize(torch.autograd.Function):
             d_env.zero_()
             if want_ratio:
                 d_ratio.zero_()
-        res = _C.rasterize_gaussians_backward(*args, shade=fs, shade_grads=sg)
+        res = _C.rasterize_gaussians_backward(*args, shade=fs, shade_grads=sg, scratch_feature_grads=not all_surfels)
         d_base, d_rough, d_norm, d_rad = sg["dL_dbase_color"], sg["dL_droughness"], sg["dL_dshade_normals"], sg.get("dL_dradiance")
         (g_means2D, _gc, g_opac, g_means3D, _gf, _gvf, _gcov, g_sh, g_scales, g_rot, _gv, _gp, _gcp) = res
         return (g_means3D, g_means2D, g_sh, g_opac, g_scales, g_rot, d_base.reshape(base_color.shape),

@@ -114,11 +114,15 @@ class _CBinding:
                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox,
                                      tan_fovx, tan_fovy, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac,
                                      dL_dout_feature, dL_dout_vfeature, sh, degree, campos, geomBuffer, R,
-                                     binningBuffer, imageBuffer, debug, config, *, shade=None, shade_grads=None, out_weights=None):
+                                     binningBuffer, imageBuffer, debug, config, *, shade=None, shade_grads=None, out_weights=None,
+                                     scratch_feature_grads=False):
         """`shade` / `shade_grads` (extension, keyword only): the `_native.FusedShade` of the forward and a dict of the shading's
         gradient outputs + `out_weights` (+ optional `dL_dreduced`), written by svgir_backward (gaussian_renderer/shading.py).
         `out_weights` (extension, keyword only): the forward's weights [P,1] -- the per-Gaussian kernels behind the composite then walk
-        the blended Gaussians only (all others have zero gradients); worth it from a few hundred thousand surfels on."""
+        the blended Gaussians only (all others have zero gradients); worth it from a few hundred thousand surfels on.
+        `scratch_feature_grads` (with `shade`): dL_dfeatures / dL_dvfeatures are intermediates of the fused call -- written for the blended
+        surfels, read back by the shading's backward for exactly those -- so they need no zero rows: they are taken out of the cleared
+        allocation (45 MB less to clear at P = 200 k); the rows of unblended surfels in the two returned tensors are then UNDEFINED."""
         dev = means3D.device
         P = means3D.size(0)
         S = features.size(1) if features.dim() == 2 else 0
@@ -132,10 +136,15 @@ class _CBinding:
         # (fused shading: per-surfel gradient tensors the caller asks for by shape -- shade_grads["_shapes"] -- live in the same
         # allocation, so the composite backward's clearing sweep zeroes them too; svgir_backward then writes the differentiated rows)
         extra = list((shade_grads or {}).pop("_shapes", {}).items()) if shade is not None else []
-        views, gblob = N.grad_blob(dev, [(P, 3), (P, 3), (P, S), (P, VS), (P, 3), (P, 3), (P, 1), (P, 2, 2), (P, 1), (P, 6),
-                                         (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)] + [tuple(sh) for _, sh in extra], zero=(P == 0))
+        scratch_fg = bool(scratch_feature_grads) and shade is not None and P != 0
+        views, gblob = N.grad_blob(dev, [(P, 3), (P, 3), (0 if scratch_fg else P, S), (0 if scratch_fg else P, VS), (P, 3), (P, 3), (P, 1),
+                                         (P, 2, 2), (P, 1), (P, 6), (P, M, 3), (P, 3), (P, 4), (4, 4), (4, 4), (3,)] +
+                                   [tuple(sh) for _, sh in extra], zero=(P == 0))
         (dL_dmeans3D, dL_dmeans2D, dL_dfeatures, dL_dvfeatures, dL_dcolors, dL_dnormal, dL_ddepth, dL_dconic,
          dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos) = views[:16]
+        if scratch_fg:   # (outside the cleared region: only the blended surfels' rows are ever written and read)
+            dL_dfeatures = torch.empty((P, S), dtype=torch.float32, device=dev)
+            dL_dvfeatures = torch.empty((P, VS), dtype=torch.float32, device=dev)
         for (name, _), v in zip(extra, views[16:]):
             shade_grads[name] = v
         if P != 0:
