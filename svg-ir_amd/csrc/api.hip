@@ -596,7 +596,6 @@ struct ForwardCall {
         const bool clear_stencil = !svgss && !p->computer_pseudo_normal;
         ra.zero_a = clear_stencil ? o->out_pseudo_normal : nullptr;
         ra.zero_b = clear_stencil ? o->out_surface_xyz : nullptr;
-        ra.pair_stream = B.pair_stream;
         ra.needed = nullptr;
         launch_cull(ra, s);
         // dispatch order of the sub-tiles, first gradient row / first state slot of each, and the two totals (device + tagged host copy)
@@ -610,10 +609,8 @@ struct ForwardCall {
         if (cull_only) return 0;   // (the sizing phase of a workload's first view: see finish())
         if (prepass) {
             RenderArgs rp = ra;
-            rp.S = 0; rp.VS = 0; rp.features = nullptr; rp.vfeatures = nullptr; rp.dump_only = 2; rp.needed = G.needed;
-            static const bool full = getenv("SVGIR_PREPASS_FULL") != nullptr;   // (A/B: the composite kernel itself in its no-output mode)
-            if (!full) launch_contrib_prepass(rp, s);
-            else if (launch_render_fwd(rp, svgss, s) < 0) return fail(SVGIR_ERR_HIP, "contribution pre-pass: no composite kernel");
+            rp.S = 0; rp.VS = 0; rp.features = nullptr; rp.vfeatures = nullptr; rp.needed = G.needed;
+            launch_contrib_prepass(rp, s);
             if (int rc = check("prepass")) return rc;
             if (timed) tm.mark("prepass");
         }
@@ -634,11 +631,6 @@ struct ForwardCall {
             if (int rc = check("shade")) return rc;
             if (timed) tm.mark("shade");
         }
-#if defined(BWDP_STREAM)
-        if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
-        launch_pair_stream(ra, s);
-        if (timed) tm.mark("pair_stream");
-#endif
         if (features_ready && hipStreamWaitEvent(s, features_ready, 0) != hipSuccess) return fail(SVGIR_ERR_HIP, "waiting for the features event");
         if (launch_render_fwd(ra, svgss, s) < 0) launch_render_fwd_generic(ra, svgss, s);   // run-time-width kernels
         if (int rc = check("render")) return rc;
@@ -1011,7 +1003,6 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     ba.cfg = cfg; ba.sub_list = B.sub_list; ba.sub_count = I.sub_count;
     ba.sub_ndump = I.sub_ndump; ba.seg_list = B.seg_list; ba.seg_desc = B.seg_desc; ba.seg_count = I.counters; ba.seg_state = seg_state;
     ba.seg_cap = (int)B.seg_cap;
-    ba.pair_stream = B.pair_stream;
     ba.backward_geometry = p->backward_geometry;
     ba.final_T = I.final_T; ba.final_D = I.final_D; ba.n_contrib = I.n_contrib;
     ba.g_color = g->dL_dout_color; ba.g_normal = g->dL_dout_normal; ba.g_depth = g->dL_dout_depth;

@@ -204,7 +204,10 @@ inline int seg_class(uint32_t nent) { return nent >= (uint32_t)SEG ? 0 : 4 - (in
 // Work id w (workgroups are dealt to the XCDs round-robin: w & 7 = XCD) -> list position: XCD c takes the blocks c, c + 8,
 // c + 16, ... of SEG_XCD_BLOCK consecutive items.  Independent of the item count (a wave can fetch its descriptor and the
 // count with two independent loads); ids >= 8 * ceil(n / 8 / B) * B ... are simply past the end (position >= n).
-constexpr uint32_t SEG_XCD_BLOCK = 32;
+#ifndef SEG_XCD_BLOCK_V
+#define SEG_XCD_BLOCK_V 32
+#endif
+constexpr uint32_t SEG_XCD_BLOCK = SEG_XCD_BLOCK_V;   // (experiment builds: -DSEG_XCD_BLOCK_V=...)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -256,7 +259,6 @@ struct BinLayout {
     uint32_t* seg_list; // [seg_capacity] live backward segments, longest first (seg_build_kernel)
     SegDesc* seg_desc;  // [seg_capacity + 256] their descriptors (same order)
     float* seg_state;  // [slot_cap][nstate][64] dumped forward states: T, colour3, normal3, depth, feature S, vfeature VC
-    float* pair_stream; // (experiment builds, -DBWDP_STREAM) [4*R][24] per-(sub-tile, candidate) records in list order, else null
     size_t seg_cap;    // entries of seg_list / seg_desc
     size_t slot_cap;   // state slots of seg_state
     size_t bytes;
@@ -280,11 +282,6 @@ inline BinLayout bin_layout(char* base, int R, int T, int nstate, long long slot
     b.seg_desc = (SegDesc*)take((b.seg_cap + 8 * SEG_XCD_BLOCK) * sizeof(SegDesc));
     b.slot_cap = slots < 0 ? b.seg_cap : (size_t)slots;
     b.seg_state = (float*)take((b.slot_cap > 0 ? b.slot_cap : 1) * (size_t)nstate * 64 * 4);
-#if defined(BWDP_STREAM)
-    b.pair_stream = (float*)take(r * 4 * 24 * 4);
-#else
-    b.pair_stream = nullptr;
-#endif
     b.bytes = off + (slots < 0 ? 0 : 128);
     return b;
 }
@@ -352,13 +349,11 @@ struct RenderArgs {
     int bg_in_render;   // 1: the pixels of EMPTY tiles and the all-zero planes (zero_a / zero_b) are written by the composite kernel's waves -- the
                         // empty sub-tiles' waves run last, in the kernel's idle tail -- instead of by the cull kernel (specialised kernels)
     int dump_only;   // composite forward: 1 = replay for the state dumps alone (svgir_backward, a view that exceeded its slot capacity): no output
-                     // is written; 2 = contribution pre-pass of the fused shading (S = VS = 0): nothing is written but needed[id] = 1 for
-                     // every surfel that receives a blend weight
+                     // is written
     float *final_T, *final_D; int32_t* n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opacity, *out_feature, *out_vfeature, *out_weights;
     float *zero_a, *zero_b;   // [3,H,W] planes the cull pass clears (rgss pseudo normal / surface xyz when not computed), or null
-    uint8_t* needed;          // [P] or null: contribution pre-pass (dump_only == 2) marks every Gaussian that receives a blend weight
-    float* pair_stream;       // (experiment builds) see BinLayout
+    uint8_t* needed;          // [P] or null: contrib_prepass_kernel marks every Gaussian that receives a blend weight
 };
 
 struct RenderBwdArgs {
@@ -373,7 +368,6 @@ struct RenderBwdArgs {
     const float *g_color, *g_normal, *g_depth, *g_opacity, *g_feature, *g_vfeature;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dfeature, *dL_dvfeature, *dL_dnormal, *dL_ddepth;
     float* grad_rows; uint32_t* row_of; uint32_t rows_cap;   // svgss (VS > 0): compact gradient rows + reverse map; else: packed rows [P][RS]
-    const float* pair_stream;               // (experiment builds) see BinLayout
     uint4* clear; size_t clear_n16;         // the caller's gradient allocation, zeroed in passing by the composite backward's waves (or null)
 };
 
@@ -442,8 +436,6 @@ void launch_contrib_prepass(const RenderArgs& a, hipStream_t s);
 // `clear_bytes` bytes at `clear` (a multiple of 16; the backward's scratch clear rides on this launch)
 void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, const ShadeTables& tabs, const float* weights, int P, uint32_t* part_sums,
                       hipStream_t s);   // (+ the shading tables of the fused path; + per-chunk counts of weights > 0 for launch_partition_scatter)
-// (experiment builds, -DBWDP_STREAM) gather-free candidate stream: one 24-float record per (sub-tile, candidate) pair, in list order
-void launch_pair_stream(const RenderArgs& a, hipStream_t s);
 int launch_render_fwd(const RenderArgs& a, bool svgss, hipStream_t s);      // <0 (nothing launched) if (S,VS) has no specialised kernel
 int launch_render_bwd(const RenderBwdArgs& a, bool svgss, hipStream_t s);  // <0 (nothing launched) if (S,VS) has no specialised kernel
 int launch_render_bwd_plain(const RenderBwdArgs& a, bool svgss, hipStream_t s);   // VS = 0 widths (render_bwd_plain.hip); <0 if not specialised

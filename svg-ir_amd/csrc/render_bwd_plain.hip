@@ -48,12 +48,7 @@ struct PlainGeom {
     static constexpr size_t off_m = (size_t)PROWS * PS * 4;            // moments + Q5 sums [SB][8]
     static constexpr size_t off_c = off_m + (size_t)SB * 8 * 4;        // per-candidate constants of the block [3][SB] float4 (LDS-DMA target)
     static constexpr size_t off_q = off_c + (size_t)3 * SB * 16;       // the segment's {gid, slot} entries, deepest first
-#if defined(BWDP_PF_L2)
-    static constexpr size_t off_pf = off_q + (size_t)SEG * 8;          // landing zone of the L2 prefetch (LDS-DMA, never read)
-    static constexpr size_t lds_bytes = off_pf + 256;
-#else
     static constexpr size_t lds_bytes = off_q + (size_t)SEG * 8;
-#endif
     static_assert(NC0 <= 16, "one 16-wide MFMA column tile");
     static_assert((size_t)64 * GROW * 4 <= off_m, "the G transposition tile aliases the panel");
 };
@@ -153,23 +148,6 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         e.slot = i < nent ? sl : 0xffffffffu;   // (slot 2^32-1: never blends)
         return e;
     };
-#if defined(BWDP_STREAM)
-    // experiment: the candidate's attributes come from the sequential per-pair stream (launch_pair_stream): the address depends on
-    // the walk position only, not on a list entry
-    cchar* strm_b = (cchar*)(uintptr_t)(a.pair_stream + ((size_t)4 * r0 + (size_t)sub * tlen) * 24);
-    auto fetch_stream = [&](int i) -> Cand {
-        const int ci = seg_hi - 1 - min(i, nent - 1);
-        cfloat* r = (cfloat*)(strm_b + (uint32_t)ci * 96u);
-        Cand c;
-        c.X = r[0]; c.Y = r[1]; c.cxx = r[2]; c.cxy = r[3]; c.cyy = r[4]; c.op = r[5]; c.dep = r[6]; c.DA = r[7];
-        c.DB = r[8]; c.cr = r[9]; c.cg = r[10]; c.cb = r[11]; c.nx = r[12]; c.ny = r[13]; c.nz = r[14];
-#pragma unroll
-        for (int ch = 0; ch < SS; ch++) c.f[ch] = ch < S ? r[15 + ch] : 0.f;
-        const uint32_t sl = __builtin_bit_cast(uint32_t, r[20]);
-        c.slot = i < nent ? sl : 0xffffffffu;
-        return c;
-    };
-#endif
     auto fetch_rec = [&](const Entry& e) -> Cand {
         // 32-bit byte offsets: P * 96 B < 4 GiB (api.hip validate)
         cfloat* r = (cfloat*)(rec_b + (uint32_t)(e.gid * (uint32_t)(REC * 4)));
@@ -196,15 +174,9 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         return c;
     };
     // speculative: the replay usually starts at entry 0 -- its record is fetched while the per-pixel loads are in flight
-#if defined(BWDP_STREAM)
-    const Cand spec_cur = fetch_stream(0);
-    const Entry spec_en1 = {0u, 0u};
-    asm volatile("" :: "s"(spec_cur.X));
-#else
     const Cand spec_cur = fetch_rec(fetch_entry(0));
     const Entry spec_en1 = fetch_entry(1);
     asm volatile("" :: "s"(spec_cur.X), "s"(spec_en1.gid));
-#endif   // (keeps the scalar loads here instead of at their first use)
 
     const float T_final = inside ? a.final_T[pid] : 0.f;
     const float D_final = (inside && normalize_depth) ? a.final_D[pid] : 0.f;
@@ -283,22 +255,6 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         if (lane < nent) e = sub_in[seg_hi - 1 - lane];
         sQ[lane] = e;
         nskip = __popcll(__ballot(lane < nent && e.y >= wmax));
-#if defined(BWDP_PF_L2)
-        // The scalar loads of the replay miss the scalar cache on every record (a record is touched once per wave); whether
-        // they then hit L2 or go to HBM decides their latency.  Every lane pulls the lines of ITS entry's record / features into
-        // this XCD's L2 now (LDS-DMA into a landing zone nobody reads: no VGPRs, nothing waits for it).
-        if (lane < nent) {
-            const char* rsrc = reinterpret_cast<const char*>(a.rec) + (uint32_t)(e.x * (uint32_t)(REC * 4));
-            __attribute__((address_space(3))) void* lz = (__attribute__((address_space(3))) void*)(smem + PG::off_pf);
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(rsrc), lz, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(rsrc + 64), lz, 4, 0, 0);
-            if (S > 0) {
-                const char* fsrc = reinterpret_cast<const char*>(a.features) + (uint32_t)(e.x * (uint32_t)(S * 4));
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(fsrc), lz, 4, 0, 0);
-                if (S > 1) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(fsrc + (S - 1) * 4), lz, 4, 0, 0);
-            }
-        }
-#endif
     }
     // flags folded into the per-pixel factors: the replay itself is branch-free
     const float gNe0 = surface ? gN[0] : 0.f, gNe1 = surface ? gN[1] : 0.f, gNe2 = surface ? gN[2] : 0.f;
@@ -312,12 +268,8 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
     Cand cur = spec_cur;
     Entry en1 = spec_en1;
     if (cstart != 0) {   // (uniform) the deepest entries lie behind every pixel of the wave: start further in
-#if defined(BWDP_STREAM)
-        cur = fetch_stream(cstart);
-#else
         cur = fetch_rec(fetch_entry(cstart));
         en1 = fetch_entry(cstart + 1);
-#endif
     }
     // Per-candidate constants of a block for its geometric epilogue (lane = (chunk, candidate)): copied global -> LDS by the
     // DMA path (no VGPRs, nothing waits) one block ahead -- issued here for the first block, then at the end of every block
@@ -341,34 +293,10 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
         // (scalar loads and LDS stores share one completion counter: the panel stores of candidate k are issued right AFTER the
         // wait for candidate k+1's attributes, so that wait never includes a fresh LDS store)
         float hw = 0.f, hv = 0.f, hu = 0.f;
-#if defined(BWDP_PF_K)
-        // Burst prefetch into the scalar cache: the records the NEXT block's scalar loads will ask for are touched now, all at
-        // once (dummy s_loads of their cache lines), and waited for ONCE at the end of this block's first candidate -- one exposed
-        // miss latency per block of SB candidates instead of one per candidate.
-        uint32_t pf_tmp = 0;
-        if (c0 + SB < nent) {
-            int lK = lane;
-            asm volatile("" : "+v"(lK));
-            const uint32_t gq = sQ[min(c0 + SB + 1 + (lK & 7), SEG - 1)].x;
-#pragma unroll
-            for (int j = 0; j < SB; j++) {
-                const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)gq, j);
-                const uint32_t ro = gj * (uint32_t)(REC * 4), fo = gj * (uint32_t)(S * 4);
-                asm volatile("s_load_dword %0, %1, %2 offset:0x0\n\ts_load_dword %0, %1, %2 offset:0x40"
-                             : "+s"(pf_tmp) : "s"(a.rec), "s"(ro));
-                if (S > 0) asm volatile("s_load_dword %0, %1, %2 offset:0x0\n\ts_load_dword %0, %1, %2 offset:%3"
-                                        : "+s"(pf_tmp) : "s"(a.features), "s"(fo), "n"((S - 1) * 4));
-            }
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < SB; k++) {
-#if defined(BWDP_STREAM)
-            const Cand nxt = fetch_stream(c0 + k + 1);
-#else
             const Cand nxt = fetch_rec(en1);
             en1 = fetch_entry(c0 + k + 2);
-#endif
             const float dx = cur.X - pxf, dy = cur.Y - pyf;
             if (k > 0) {
                 sP[(k - 1) * PS + lane] = hw; sP[(SB + k - 1) * PS + lane] = hv; sP[(2 * SB + k - 1) * PS + lane] = hu;
@@ -400,12 +328,6 @@ render_bwd_plain_kernel(const RenderBwdArgs a) {
             hu = pre ? q5g : 0.f;                  // u: its pixel sum is the Q5 term (0 unless per-pixel depth is on)
             live |= (__builtin_amdgcn_ballot_w64(pre) != 0ull ? 1u : 0u) << k;
             cur = nxt;
-#if defined(BWDP_PF_K)
-            if (k == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf_tmp));   // (the prefetch's scratch register is free again only now)
-#endif
-#ifdef BWDP_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         sP[(SB - 1) * PS + lane] = hw; sP[(2 * SB - 1) * PS + lane] = hv; sP[(3 * SB - 1) * PS + lane] = hu;
         DEV_TRACE_MARK(2);   // phase A

@@ -131,36 +131,6 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
     if (t < 4) a.sub_total[4 * tile + t] = t == 0 ? run[0] : t == 1 ? run[1] : t == 2 ? run[2] : run[3];
 }
 
-// ---- (experiment builds, -DBWDP_STREAM) gather-free candidate stream ---------------------------------------------------------
-// One 24-float record per (sub-tile, candidate) pair at the position of its list entry: what the plain backward replays per
-// candidate {x y cxx cxy | cyy op depth DA | DB r g b | nx ny nz f0 | f1..f4 | slot gid . .}, so that the replay reads a
-// sequential stream (scalar loads with known addresses) instead of list entry -> record -> features gathers.
-template <int S>
-__global__ void __launch_bounds__(256) pair_stream_kernel(const RenderArgs a) {
-    const int tile = blockIdx.x;
-    const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
-    const int len = (int)(r1 - r0);
-    if (len == 0) return;
-    const float4* __restrict__ rec4 = reinterpret_cast<const float4*>(a.rec);
-    for (int w = 0; w < 4; w++) {
-        const int n = (int)a.sub_total[4 * tile + w];
-        const size_t base = (size_t)4 * r0 + (size_t)w * len;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const uint2 e = a.sub_list[base + i];
-            const float4 q0 = rec4[(size_t)e.x * 6], q1 = rec4[(size_t)e.x * 6 + 1], q3 = rec4[(size_t)e.x * 6 + 3], q4 = rec4[(size_t)e.x * 6 + 4];
-            float f[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ch = 0; ch < S && ch < 5; ch++) f[ch] = a.features[(size_t)e.x * S + ch];
-            float4* o = reinterpret_cast<float4*>(a.pair_stream + (base + i) * 24);
-            o[0] = q0; o[1] = q1;
-            o[2] = q3;                                        // DB, r, g, b
-            o[3] = make_float4(q4.x, q4.y, q4.z, f[0]);       // view normal, f0
-            o[4] = make_float4(f[1], f[2], f[3], f[4]);
-            o[5] = make_float4(__builtin_bit_cast(float, e.y), __builtin_bit_cast(float, e.x), 0.f, 0.f);
-        }
-    }
-}
-
 // ---- blend --------------------------------------------------------------------------------------------------
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(StageGeom<S, VC>::WPE, StageGeom<S, VC>::WPE)))
@@ -196,11 +166,7 @@ render_fwd_kernel(const RenderArgs a) {
         return;
     }
     DEV_TRACE_DECL();
-#if defined(FWD_ABL_CAP)   // (ablation builds only: lists cut off at FWD_ABL_CAP candidates -- wrong results; what would a shorter critical path buy?)
-    const int total = min((int)a.sub_total[sid], FWD_ABL_CAP);
-#else
     const int total = (int)a.sub_total[sid];
-#endif
     // The kernel ends when its longest candidate list has been walked (the walk is sequential per pixel), and waves are
     // dispatched longest-first: blockIdx.x is the wave's rank.  The SIMD's instruction arbiter serves the longer list first.
 #ifndef FWD_PRIO
@@ -271,7 +237,6 @@ render_fwd_kernel(const RenderArgs a) {
     const uint32_t dump_base = a.sub_slot_base[sid];   // first state slot of this sub-tile (compact: common.hpp SEG)
     uint32_t ndump = 0;
     auto dump_state = [&](uint32_t j, bool last) {
-        if (a.dump_only == 2) return;   // (contribution pre-pass: no state is kept, nothing is written)
         // no slot: a speculative launch whose capacity guess was too small (the view's backward dumps the states again), or a
         // forward_only view (slot capacity 0) -- then the accumulators are only gathered for the epilogue (`last`)
         const bool slot = dump_base + j < a.slot_cap;
@@ -316,8 +281,6 @@ render_fwd_kernel(const RenderArgs a) {
                 const float* wp = sW + (bprev & 1) * (4 * CH) + lane;
                 const float wsum = (wp[0] + wp[CH]) + (wp[2 * CH] + wp[3 * CH]);
                 if (wsum != 0.f && !a.dump_only) atomic_add_f32(&a.out_weights[sQ[(bprev & 1) * CH + lane].x], wsum);
-                // contribution pre-pass (dump_only == 2): the surfel received a blend weight from this sub-tile -> its packed rows will be read
-                if (wsum != 0.f && a.dump_only == 2) a.needed[sQ[(bprev & 1) * CH + lane].x] = 1;
             }
         };
         int b = 0;
@@ -735,14 +698,6 @@ void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, cons
     int grid = (int)std::max<size_t>((size_t)nblk, std::min<size_t>((n16 + 255) / 256, 2048));
     if (weights) grid = std::max(grid, std::min((P + PART_ELEMS - 1) / PART_ELEMS, 2048));
     hipLaunchKernelGGL(seg_build_kernel, dim3(grid), dim3(256), 0, s, a, T, nblk, (uint4*)clear, n16, tabs, weights, P, part_sums);
-}
-
-void launch_pair_stream(const RenderArgs& a, hipStream_t s) {
-    if (!a.pair_stream || a.VS != 0) return;   // (the experiment covers the plain backward's widths)
-    if (a.S == 5) hipLaunchKernelGGL((pair_stream_kernel<5>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
-    else if (a.S == 3) hipLaunchKernelGGL((pair_stream_kernel<3>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
-    else if (a.S == 1) hipLaunchKernelGGL((pair_stream_kernel<1>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
-    else if (a.S == 0) hipLaunchKernelGGL((pair_stream_kernel<0>), dim3(a.gx * a.gy), dim3(256), 0, s, a);
 }
 
 void launch_contrib_prepass(const RenderArgs& a, hipStream_t s) {
