@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SVGIR_ABI_VERSION 13
+#define SVGIR_ABI_VERSION 14
 
 enum svgir_variant { SVGIR_RGSS = 0, SVGIR_SVGSS = 1 };
 
@@ -92,6 +92,12 @@ typedef struct svgir_params {
     const svgir_fused_shade* shade; /* optional (svgss, ABI 12): the per-splat shading of this view, run INSIDE svgir_forward /
                                        svgir_backward for the surfels the view's composite actually reads (see svgir_fused_shade);
                                        `features` / `vfeatures` are then OUTPUT buffers of svgir_forward.  NULL: the caller shaded. */
+    int32_t workload_scope;         /* (ABI 14) scope of the speculation history, 0 = the process-wide default.  svgir_forward sizes its
+                                       speculative launches (instance capacity, state slots, three-pass depth sort) from the recent views of
+                                       the same WORKLOAD = (device, W, H, S, VS, variant, workload_scope, Gaussian count within a factor of
+                                       two).  Two models that share all of that and alternate in one process would feed one history: give
+                                       each its own scope id.  Results never depend on it -- only how often a view's dependent stages are
+                                       re-run.  See svgir_reset_workload_history. */
 } svgir_params;
 
 /* Outputs of forward.  Every buffer is written completely: the caller need not clear any of them (the reference's glue
@@ -215,6 +221,10 @@ int svgir_forward_batch(svgir_view_call* views, int32_t count);
  * passes}.  The reference has no counterpart: its forward waits for the
  * instance count (rasterizer_impl.cu:307-312) and always sorts 64-bit keys. */
 void svgir_speculation_stats(int64_t* out5);
+/* Forgets the speculation history (ABI 14) of one scope (svgir_params.workload_scope), or of every scope (scope < 0): the next view of
+ * such a workload is launched like a first view (exact instance capacity after a host wait, state slots sized from its own cull, four
+ * depth passes).  For callers that recycle scope ids, or that switch scenes under one id.  Blobs of earlier forwards stay valid. */
+void svgir_reset_workload_history(int32_t scope);
 
 /* Backward pass.  Replaces CudaRasterizer::Rasterizer::backward (svgss rasterizer_impl.cu:386-523,
  * rgss :411-535).  `R` and the three blobs are what the matching svgir_forward produced; `radii` is its

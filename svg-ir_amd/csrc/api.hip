@@ -33,18 +33,22 @@ std::atomic<bool> g_prof{false};
 // Gaussian count, channel widths, variant), so that scenes / resolutions that alternate in one process (a 256x256
 // preview next to a 1600x1600 render, several scenes, several devices) neither re-run each other's dependent stages nor
 // over-allocate each other's blobs.  A small fixed table, least-recently-used replacement.
-struct CapKey { int dev, W, H, P, S, VS, variant; };
-// (P is NOT part of a workload's identity: densification / pruning changes it every few hundred iterations,
+struct CapKey { int dev, W, H, P, S, VS, variant, scope; };
+// (P is NOT part of a workload's identity as long as it moves slowly: densification / pruning changes it every few hundred iterations,
 // scene/gaussian_model.py:1229-1253, and the history must survive that -- every sample remembers the Gaussian count it was taken at and
-// is scaled to the caller's: instances and state slots grow with the surfel count on a fixed view)
+// is scaled to the caller's: instances and state slots grow with the surfel count on a fixed view.  A caller whose P is more than a
+// factor of two away from the entry's latest sample is another model: it gets its own entry, and a scaled sample never exceeds four
+// times the largest unscaled one.  `scope` = svgir_params.workload_scope: models that share (device, image size, widths, variant) keep
+// separate histories by giving each its own id.)
 struct CapEntry { CapKey key; int hist[8]; int hist_P[8]; long long hist_slots[8]; int hist_slots_P[8]; unsigned next, next_slots; unsigned long long stamp; bool used;
                   int top_byte, top_streak;   // common top byte of the visible depth keys of the last `top_streak` views (0: none / not common)
                   const void* last_view; int last_view_P; };   // image blob of the workload's latest forward: its slot total is read when the next one starts
 std::mutex g_cap_mu;
 CapEntry g_cap[16];
 unsigned long long g_cap_clock = 0;
-bool same_key(const CapKey& a, const CapKey& b) {
-    return a.dev == b.dev && a.W == b.W && a.H == b.H && a.S == b.S && a.VS == b.VS && a.variant == b.variant;
+bool same_key(const CapKey& a, const CapKey& b) {   // a: the entry's key (P = the Gaussian count of its latest sample), b: the caller's
+    if (!(a.dev == b.dev && a.W == b.W && a.H == b.H && a.S == b.S && a.VS == b.VS && a.variant == b.variant && a.scope == b.scope)) return false;
+    return a.P <= 0 || b.P <= 0 || ((long long)a.P <= 2ll * b.P && (long long)b.P <= 2ll * a.P);
 }
 CapEntry* cap_entry(const CapKey& k, bool create) {
     CapEntry* lru = &g_cap[0];
@@ -65,23 +69,24 @@ inline long long scale_to(long long v, int from_P, int to_P) {   // a count meas
 int guess_R(const CapKey& k) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     const CapEntry* e = cap_entry(k, false);
-    long long m = 0;
-    if (e) for (unsigned i = 0; i < std::min(e->next, 8u); i++) m = std::max(m, scale_to(e->hist[i], e->hist_P[i], k.P));
-    return (int)std::min<long long>(m, 0x7ffff000LL);
+    long long m = 0, raw = 0;
+    if (e) for (unsigned i = 0; i < std::min(e->next, 8u); i++) { m = std::max(m, scale_to(e->hist[i], e->hist_P[i], k.P)); raw = std::max<long long>(raw, e->hist[i]); }
+    return (int)std::min<long long>(std::min(m, 4 * raw), 0x7ffff000LL);
 }
 void record_R(const CapKey& k, int R) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     CapEntry* e = cap_entry(k, true);
     e->hist[e->next % 8] = R; e->hist_P[e->next % 8] = k.P;
     e->next++;
+    e->key.P = k.P;   // (the entry follows its model's Gaussian count)
 }
 // state slots (common.hpp seg_slots summed over the sub-tiles) of recent views of the workload: -1 = none seen yet
 long long guess_slots(const CapKey& k) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     const CapEntry* e = cap_entry(k, false);
-    long long m = -1;
-    if (e && e->next_slots) for (unsigned i = 0; i < std::min(e->next_slots, 8u); i++) m = std::max(m, scale_to(e->hist_slots[i], e->hist_slots_P[i], k.P));
-    return m;
+    long long m = -1, raw = 0;
+    if (e && e->next_slots) for (unsigned i = 0; i < std::min(e->next_slots, 8u); i++) { m = std::max(m, scale_to(e->hist_slots[i], e->hist_slots_P[i], k.P)); raw = std::max(raw, e->hist_slots[i]); }
+    return m < 0 ? m : std::min(m, 4 * raw + 64);
 }
 void record_slots(const CapKey& k, long long slots) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
@@ -196,7 +201,8 @@ bool pinned_spin(volatile unsigned long long* at, uint32_t tag, uint32_t* w0, ui
 // binning blob out for: the backward and svgir_backward_scratch_bytes_for() find them there.  A host wait right behind the cull costs
 // nothing: the composite is still queued (measured with a full event synchronisation there: 0.4353 vs 0.4361 ms per cfg2 step).
 struct ViewEntry { const void* key = nullptr; uint32_t tag = 0; int cap_R = 0; long long cap_slots = -1; unsigned long long stamp = 0;
-                   bool recorded = false; };   // its slot total has entered the workload's history
+                   bool recorded = false;   // its slot total has entered the workload's history
+                   hipStream_t stream = nullptr; bool has_stream = false; };   // the stream the forward ran on: what a waiter without a stream of its own blocks on   // its slot total has entered the workload's history
 constexpr int kViewEntries = 1024;   // forwards whose backward may still come (least recently used entry replaced)
 std::mutex g_view_mu;
 ViewEntry g_view[kViewEntries];
@@ -204,7 +210,7 @@ unsigned long long* g_view_pinned = nullptr;   // [kViewEntries][2] {tag << 32 |
 unsigned long long g_view_clock = 0;
 uint32_t g_view_tag = 0;
 // registers the launch sequence of the forward that owns `image_blob`: returns where order_desc_kernel writes its totals and the tag
-unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_slots, uint32_t* tag) {
+unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_slots, uint32_t* tag, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_view_mu);
     if (!g_view_pinned) {
         void* ptr = nullptr;
@@ -219,6 +225,7 @@ unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_s
     }
     ViewEntry& e = g_view[slot];
     e.key = image_blob; e.stamp = ++g_view_clock; e.cap_R = cap_R; e.cap_slots = cap_slots; e.recorded = false;
+    e.stream = stream; e.has_stream = true;
     e.tag = ++g_view_tag ? g_view_tag : ++g_view_tag;   // (never 0: the slots start as 0)
     *tag = e.tag;
     return g_view_pinned + 2 * slot;
@@ -239,18 +246,21 @@ bool view_from_blob(const uint32_t* counters_dev, ViewCounts* out) {
 }
 // the entry of the forward that owns `image_blob` (capacities; counts when `wait`): false = unknown blob.  The counts are in host memory
 // as soon as the forward's order kernel has run.  wait = 1: poll for spin_budget_s(), then BLOCK -- on `*sync_stream` when the caller has
-// the stream the forward ran on (or one ordered behind it), else on the device -- and look again: a backlog in front of the forward is
-// not an error.  pairs / slots stay -1 only if the forward never wrote them (it failed on the device) or the entry was recycled.
+// the stream the forward ran on (or one ordered behind it), else on the stream the forward itself was launched on (remembered in the
+// entry; the whole device only if that stream no longer exists) -- and look again: a backlog in front of the forward is not an error,
+// and backlogs on OTHER streams (tracer updates of another view, a second model) are not waited for.  pairs / slots stay -1 only if the forward never wrote them (it failed on the device) or the entry was recycled.
 // wait = 2: one look.
 bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_slots, long long* pairs, long long* slots,
                  const hipStream_t* sync_stream = nullptr) {
     volatile unsigned long long* at = nullptr;
     uint32_t tag = 0;
+    hipStream_t fwd_stream = nullptr; bool have_fwd_stream = false;
     {
         std::lock_guard<std::mutex> lk(g_view_mu);
         for (int i = 0; i < kViewEntries; i++)
             if (g_view[i].key == image_blob && g_view_pinned) {
                 at = g_view_pinned + 2 * i; tag = g_view[i].tag;
+                fwd_stream = g_view[i].stream; have_fwd_stream = g_view[i].has_stream;
                 if (cap_R) *cap_R = g_view[i].cap_R;
                 if (cap_slots) *cap_slots = g_view[i].cap_slots;
                 break;
@@ -263,7 +273,14 @@ bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_sl
     uint32_t w0 = 0, w1 = 0;
     bool got = wait == 2 ? tagged_pair(at, tag, &w0, &w1) : pinned_spin(at, tag, &w0, &w1);
     if (!got && wait == 1) {
-        const hipError_t e = sync_stream ? hipStreamSynchronize(*sync_stream) : hipDeviceSynchronize();
+        hipError_t e = hipErrorInvalidHandle;
+        if (sync_stream) e = hipStreamSynchronize(*sync_stream);
+        else if (have_fwd_stream) {   // (the handle may be stale: a query tells; the null stream is always valid)
+            const hipError_t q = fwd_stream ? hipStreamQuery(fwd_stream) : hipSuccess;
+            if (q == hipSuccess || q == hipErrorNotReady) e = hipStreamSynchronize(fwd_stream);
+            else (void)hipGetLastError();
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipDeviceSynchronize(); }
         if (e != hipSuccess) (void)hipGetLastError();
         got = tagged_pair(at, tag, &w0, &w1);
     }
@@ -600,7 +617,7 @@ struct ForwardCall {
         launch_cull(ra, s);
         // dispatch order of the sub-tiles, first gradient row / first state slot of each, and the two totals (device + tagged host copy)
         uint32_t vtag = 0;
-        unsigned long long* vslot = view_note(iblob, cap, cap_slots, &vtag);
+        unsigned long long* vslot = view_note(iblob, cap, cap_slots, &vtag, s);
         const bool row_path = svgss && p->VS > 0 && render_specialised(p->S, p->VS, true);   // (only the svgss backward writes gradient rows)
         launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, I.sub_slot_base, I.counters, vslot, vtag,
                           (uint32_t)cap, cap_slots, kBlobMagic, s);
@@ -698,7 +715,7 @@ struct ForwardCall {
         pa.zero_words = radix_gtot(G.radix_tbl, P); pa.n_zero_words = (int)radix_gtot_words(P);
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
-        ckey = CapKey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
+        ckey = CapKey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant, p->workload_scope};
         static const bool key_spec_env = getenv("SVGIR_NO_KEY_SPEC") == nullptr;
         spec_top = (key_spec && key_spec_env) ? guess_top(ckey) : -1;
         pa.spec_top = spec_top; pa.key_top = G.key_top;
@@ -881,6 +898,11 @@ int svgir_forward_batch(svgir_view_call* views, int32_t count) {
     if (!begin_err.empty()) g_err = begin_err;
     return first_err;
 }
+void svgir_reset_workload_history(int32_t scope) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    for (auto& e : g_cap)
+        if (e.used && (scope < 0 || e.key.scope == scope)) e = CapEntry{};
+}
 void svgir_speculation_stats(int64_t* out5) {
     if (out5) for (int i = 0; i < 5; i++) out5[i] = (int64_t)g_spec_stats[i].load();
 }
@@ -924,6 +946,14 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     if (p->P == 0) return 0;
     if (!g || !radii || !geom_blob || !binning_blob || !image_blob)
         return fail(SVGIR_ERR_INVALID, "grads / radii / blobs must be provided");
+    if (p->shade) {   // fused shading: everything its backward needs, checked BEFORE anything is launched (no half-written gradients on a bad call)
+        if (!g->dL_dbase_color || !g->dL_droughness || !g->dL_dshade_normals || (!g->dL_dradiance && !p->shade->sp.radiance_ratio) || !g->dL_denv ||
+            !g->env_grad_work)
+            return fail(SVGIR_ERR_INVALID, "fused shading: the gradient outputs of the shading inputs must be provided");
+        if (!render_specialised(p->S, p->VS, true)) return fail(SVGIR_ERR_INVALID, "fused shading without a specialised composite");
+        if (g->dL_dreduced && !p->shade->all_surfels) return fail(SVGIR_ERR_INVALID, "fused shading: dL_dreduced needs all_surfels");
+        if (!p->shade->all_surfels && !g->out_weights) return fail(SVGIR_ERR_INVALID, "fused shading: out_weights (the forward's) must be provided");
+    }
     hipStream_t s = (hipStream_t)stream;
     const int P = p->P, W = p->W, H = p->H;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
@@ -963,7 +993,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     {
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
-        const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant};
+        const CapKey ckey{dev_id, W, H, P, p->S, svgss ? p->VS : 0, p->variant, p->workload_scope};
         note_view_slots(ckey, image_blob, 1, &s);
         long long slots = -1;
         bool seen = cap_slots >= 0 && R > 0 && view_lookup(image_blob, 1, nullptr, nullptr, nullptr, &slots, &s) && slots >= 0;
@@ -1128,13 +1158,7 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
     if (p->shade) {
         // dL_dfeatures / dL_dvfeatures are complete: the shading's backward, for the surfels that received a blend weight (the rows of all
         // others are exactly zero: no pixel blended them)
-        if (!g->dL_dbase_color || !g->dL_droughness || !g->dL_dshade_normals || (!g->dL_dradiance && !p->shade->sp.radiance_ratio) || !g->dL_denv ||
-            !g->env_grad_work)
-            return fail(SVGIR_ERR_INVALID, "fused shading: the gradient outputs of the shading inputs must be provided");
-        if (generic) return fail(SVGIR_ERR_INVALID, "fused shading without a specialised composite");
-        const bool all = p->shade->all_surfels != 0;
-        if (g->dL_dreduced && !all) return fail(SVGIR_ERR_INVALID, "fused shading: dL_dreduced needs all_surfels");
-        if (!all && !g->out_weights) return fail(SVGIR_ERR_INVALID, "fused shading: out_weights (the forward's) must be provided");
+        const bool all = p->shade->all_surfels != 0;   // (the arguments were validated before the first launch)
         svgir_shade_params sp = p->shade->sp;
         sp.subset = nullptr; sp.subset_count = nullptr;
         if (!all) {

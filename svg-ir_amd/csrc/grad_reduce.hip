@@ -31,8 +31,14 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
     const int32_t radius = a.radii[g];
     const uint32_t ntiles = a.tiles[g];
     const size_t base = (size_t)4 * __builtin_bit_cast(uint32_t, a.rec[(size_t)g * REC + R_IBASE]);
-    if (!(radius > 0) || ntiles == 0) return;
-    const uint32_t nslots = 4u * ntiles;
+    // A LISTED Gaussian always gets its row written -- zeros if it owns none: with a list the binder may keep dL_dfeatures / dL_dvfeatures
+    // outside the cleared allocation (svgir_grads: scratch feature gradients of the fused shading), and the consumer behind this kernel
+    // reads the row of every listed Gaussian.  The list (forward: out_weights > 0) and the rows (backward: the replayed alpha / T tests)
+    // come from two evaluations that agree bit for bit today; this keeps a disagreement from ever reading uninitialised memory.
+    const bool listed = a.list != nullptr;
+    const bool visible = radius > 0 && ntiles != 0;
+    if (!visible && !listed) return;
+    const uint32_t nslots = visible ? 4u * ntiles : 0u;
     float acc0 = 0.f, acc1 = 0.f;
     bool any = false;
     for (uint32_t s0 = 0; s0 < nslots; s0 += 64) {
@@ -63,7 +69,7 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
                 if (b[k] >= 0) { acc0 += v0[k]; acc1 += v1[k]; }
         }
     }
-    if (!any) return;   // outputs stay at the caller's zeros
+    if (!any && !listed) return;   // outputs stay at the caller's zeros
     // scatter the summed row to the output tensors (the caller zero-fills them; this is the only writer)
     auto put = [&](int e, float v) {
         if (e < 3) a.dL_dcolor[(size_t)g * 3 + e] = v;

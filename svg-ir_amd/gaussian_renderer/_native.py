@@ -5,6 +5,7 @@ There is NO fallback: if the shared library is missing or fails to load, importi
 """
 import ctypes as C
 import os
+import threading
 import time
 
 import torch
@@ -13,7 +14,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVGIR_RASTER_LIB", os.path.join(_PKG, "libsvgir_raster.so"))
 
 RGSS, SVGSS = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -31,6 +32,7 @@ class Params(C.Structure):
         ("cy", C.c_float),
         ("prefiltered", C.c_int32), ("computer_pseudo_normal", C.c_int32), ("backward_geometry", C.c_int32),
         ("debug", C.c_int32), ("features_ready", C.c_void_p), ("forward_only", C.c_int32), ("shade", C.c_void_p),
+        ("workload_scope", C.c_int32),
     ]
 
 
@@ -107,6 +109,8 @@ def _load():
     lib.svgir_backward_scratch_bytes_for.argtypes = [C.c_int32, C.c_int32, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.svgir_speculation_stats.restype = None
     lib.svgir_speculation_stats.argtypes = [C.POINTER(C.c_int64)]
+    lib.svgir_reset_workload_history.restype = None
+    lib.svgir_reset_workload_history.argtypes = [C.c_int32]
     lib.svgir_mark_visible.restype = C.c_int
     lib.svgir_mark_visible.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.svgir_set_profiling.argtypes = [C.c_int]
@@ -122,7 +126,7 @@ lib = _load()
 
 EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_binning_bytes",
            "svgir_image_ncontrib_offset", "svgir_image_ranges_offset", "svgir_binning_point_list_offset", "svgir_forward", "svgir_forward_batch", "svgir_backward", "svgir_mark_visible",
-           "svgir_backward_scratch_bytes", "svgir_backward_scratch_bytes_for", "svgir_speculation_stats", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
+           "svgir_backward_scratch_bytes", "svgir_backward_scratch_bytes_for", "svgir_speculation_stats", "svgir_reset_workload_history", "svgir_set_profiling", "svgir_last_timings", "svgir_last_error", "svgir_shade_forward",
            "svgir_shade_backward", "svgir_incident_dirs", "svgir_resample_bilinear", "svgir_unpack_planes",
            "svgir_unpack_forward", "svgir_unpack_backward", "svgir_depth2normal", "svgir_depth2normal_backward", "svgir_pack_rgss_forward",
            "svgir_pack_rgss_backward", "svgir_unpack_rgss_forward", "svgir_unpack_rgss_backward", "svgir_l1_ssim_partials",
@@ -131,6 +135,40 @@ EXPORTS = ("svgir_abi_version", "svgir_geom_bytes", "svgir_image_bytes", "svgir_
            "svgir_split_transform", "svgir_bvh_bytes", "svgir_bvh_build",
            "svgir_bvh_trace_visibility", "svgir_pbgi_bvh_bytes", "svgir_pbgi_bvh_build", "svgir_pbgi_bvh_export",
            "svgir_pbgi_trace_radiance")
+
+
+_scope = threading.local()
+
+
+class workload_scope:
+    """`with workload_scope(7): ...` -- every rasterizer call of this thread inside the block carries svgir_params.workload_scope = 7.
+    The reference's settings tuples are fixed (GaussianRasterizationSettings), so the scope travels next to them: a caller that keeps
+    several models with equal image sizes / widths in one process gives each its own id, and their speculation histories (instance
+    capacity, state slots, depth-key byte: include/svgir_raster.h) stay apart."""
+
+    def __init__(self, scope):
+        self.scope, self.prev = int(scope), 0
+
+    def __enter__(self):
+        self.prev = getattr(_scope, "id", 0)
+        _scope.id = self.scope
+        return self
+
+    def __exit__(self, *exc):
+        _scope.id = self.prev
+        return False
+
+
+def new_params():
+    """A zeroed svgir_params carrying the calling thread's workload scope."""
+    p = Params()
+    p.workload_scope = getattr(_scope, "id", 0)
+    return p
+
+
+def reset_workload_history(scope=-1):
+    """svgir_reset_workload_history: forget the speculation history of one scope (or all, scope < 0)."""
+    lib.svgir_reset_workload_history(int(scope))
 
 
 def speculation_stats():

@@ -72,7 +72,7 @@ class _CBinding:
             keep = [N.f32c(t, dev) for t in (background, means3D, sh, colors, features, opacity, scales, rotations,
                                               cov3D_precomp, viewmatrix, projmatrix, campos)]
             (bg, m3, shc, col, fe, op, sc, ro, cv, vm, pm, cp) = keep
-            p = N.Params()
+            p = N.new_params()
             p.variant, p.P, p.S, p.VS, p.D, p.W, p.H = N.RGSS, P, S, 0, int(degree), W, H
             p.M = shc.size(1) if (shc is not None and shc.numel() != 0) else 0
             p.background, p.means3D, p.shs, p.colors_precomp = N.ptr(bg), N.ptr(m3), N.ptr(shc), N.ptr(col)
@@ -122,7 +122,7 @@ class _CBinding:
                                               viewmatrix, projmatrix, campos, dL_dout_color, dL_dout_normal,
                                               dL_dout_depth, dL_dout_opacity, dL_dout_feature)]
             (bg, m3, shc, col, fe, sc, ro, cv, vm, pm, cp, gc, gn, gd, go, gf) = keep
-            p = N.Params()
+            p = N.new_params()
             p.variant, p.P, p.S, p.VS, p.D, p.M, p.W, p.H = N.RGSS, P, S, 0, int(degree), M, W, H
             p.background, p.means3D, p.shs, p.colors_precomp = N.ptr(bg), N.ptr(m3), N.ptr(shc), N.ptr(col)
             p.features = N.ptr(fe)

@@ -82,7 +82,7 @@ class _CBinding:
                                               rotations, cov3D_precomp, viewmatrix, projmatrix, campos, prcppoint,
                                               patchbbox, config)]
             (bg, m3, shc, col, fe, vf, op, sc, ro, cv, vm, pm, cp, pr, pb, cfg) = keep
-            p = N.Params()
+            p = N.new_params()
             p.variant, p.P, p.S, p.VS, p.D, p.W, p.H = N.SVGSS, P, S, VS, int(degree), W, H
             p.M = shc.size(1) if (shc is not None and shc.numel() != 0) else 0
             p.background, p.means3D, p.shs, p.colors_precomp = N.ptr(bg), N.ptr(m3), N.ptr(shc), N.ptr(col)
@@ -143,8 +143,8 @@ class _CBinding:
         (dL_dmeans3D, dL_dmeans2D, dL_dfeatures, dL_dvfeatures, dL_dcolors, dL_dnormal, dL_ddepth, dL_dconic,
          dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos) = views[:16]
         if scratch_fg:   # (outside the cleared region: only the blended surfels' rows are ever written and read)
-            dL_dfeatures = torch.empty((P, S), dtype=torch.float32, device=dev)
-            dL_dvfeatures = torch.empty((P, VS), dtype=torch.float32, device=dev)
+            dL_dfeatures = N.out_tensor((P, S), torch.float32, dev)      # (NaN-filled under SVGIR_POISON: the tests see a row that is
+            dL_dvfeatures = N.out_tensor((P, VS), torch.float32, dev)    # read without having been written)
         for (name, _), v in zip(extra, views[16:]):
             shade_grads[name] = v
         if P != 0:
@@ -153,7 +153,7 @@ class _CBinding:
                                               dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac,
                                               dL_dout_feature, dL_dout_vfeature, config)]
             (bg, m3, shc, col, fe, vf, sc, ro, cv, vm, pm, cp, pr, pb, gc, gn, gd, go, gf, gvf, cfg) = keep
-            p = N.Params()
+            p = N.new_params()
             p.variant, p.P, p.S, p.VS, p.D, p.M, p.W, p.H = N.SVGSS, P, S, VS, int(degree), M, W, H
             p.background, p.means3D, p.shs, p.colors_precomp = N.ptr(bg), N.ptr(m3), N.ptr(shc), N.ptr(col)
             p.features, p.vfeatures = N.ptr(fe), N.ptr(vf)

@@ -20,7 +20,7 @@ def test_library_exports_every_symbol_of_the_header(built):
     lib = C.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.svgir_abi_version() == _native.ABI_VERSION == 13
+    assert lib.svgir_abi_version() == _native.ABI_VERSION == 14
 
 
 def test_struct_layouts_match_header_field_order(built):

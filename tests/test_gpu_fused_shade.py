@@ -196,6 +196,47 @@ def test_fused_all_surfels_and_reduced_gradient(built):
         (_loss(oc, gt) + (red_c * wr).sum()).backward()
 
 
+def test_listed_surfel_without_gradient_rows_reads_zeros(built):
+    """The shading backward reads the dL_dfeatures / dL_dvfeatures row of every surfel with out_weights > 0; those two tensors live
+    OUTSIDE the cleared gradient allocation (scratch_feature_grads) and are NaN-poisoned here.  The rows come from the composite
+    backward's own alpha / transmittance replay: a surfel that is listed but owns no row (a 1-ulp disagreement between the two
+    evaluations, an undersized row scratch) must read zeros, not uninitialised memory.  Forced here by marking surfels the forward did
+    NOT blend -- a culled one (radius 0) and visible ones with weight 0 -- as blended before the backward runs."""
+    assert N.POISON
+    dev = torch.device(DEV)
+    sc = scenes.surface_scene(P=5000, W=160, H=128, seed=47, sh_degree=1, variant="svgss", S=4, VS=52, scale_lo=0.01, scale_hi=0.06)
+    sct = runner.to_torch(sc, dev)
+    st = runner.settings(sct, "svgss")
+    d = _materials(sct, st, 32, True, seed=9)
+    gt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in scenes.upstream_grads(sc, "svgss", seed=10).items()}
+
+    def run(tamper):
+        lv = _leaves(sct, d)
+        out, m2, _ = _fused(sct, st, d, lv, True)
+        weights, radii = out[7], out[8]
+        extra = torch.zeros(5000, dtype=torch.bool, device=dev)
+        if tamper:
+            culled = torch.nonzero(radii == 0)[:3, 0]
+            unblended = torch.nonzero((radii > 0) & (weights[:, 0] == 0))[:40, 0]
+            assert culled.numel() == 3 and unblended.numel() > 0
+            extra[culled] = True; extra[unblended] = True
+            weights.data[extra] = 1.0   # (.data: the saved tensor's version counter must not change)
+        _loss(out, gt).backward()
+        torch.cuda.synchronize()
+        return lv, m2, extra
+
+    (la, m2a, _), (lb, m2b, extra) = run(False), run(True)
+    for k in list(la) + ["means2D"]:
+        ga, gb = (m2a.grad, m2b.grad) if k == "means2D" else (la[k].grad, lb[k].grad)
+        assert torch.isfinite(gb).all(), k
+        if k == "env":
+            assert torch.allclose(ga, gb, rtol=2e-5, atol=2e-6 * float(ga.abs().max()))
+        else:
+            assert torch.equal(ga, gb), k   # the extra surfels contribute exactly nothing
+    for k in ("base_color", "roughness", "normals"):
+        assert float(lb[k].grad[extra].abs().max()) == 0.0, k
+
+
 @pytest.mark.parametrize("name", ["cfg3_train", "cfg3_eval"])
 def test_fused_view_is_bit_identical_at_baseline_size(built, name):
     """BASELINE configs[2] at full size (P = 200 000, 800 x 800; Ns = 64 at the training widths with the in-kernel lattice, 384 at the
