@@ -128,7 +128,8 @@ def parse():
     ap.add_argument("--workload", default=None, help="default: cfg2 (N = 1), cfg4 (N > 1); also cfg3_train, cfg3_eval, cfg5, cfg5_dense, "
                     "train_step (whole stage-2 iteration), tracers (visibility / radiance cache producers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-shaded", action="store_true", help="skip the extra cfg3_train (shaded + blended) record")
+    ap.add_argument("--no-shaded", action="store_true", help="skip the extra records of the default line: cfg3_train (shaded + blended), the "
+                                                              "compact cfg3_eval / cfg4 / cfg5 records and the rotating-camera records")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the supplementary two-views-on-two-streams record")
     ap.add_argument("--no-overlap", action="store_true", help="svgss workloads: run the shading forward on the rasterizer's stream "
                     "instead of a side stream that overlaps the binning (svgir_params.features_ready)")
@@ -295,6 +296,32 @@ class Workload:
         from svgir_harness import shade_inputs
         return shade_inputs.Light(self.leaves["env"].detach())
 
+    def add_orbit_views(self, n, seed):
+        """n seeded cameras on the radius-4 sphere around the scene (azimuth: n equal sectors of 0-360 degrees with a random offset inside
+        each, elevation uniform in [-60, 80] degrees), looking at the origin; use_view(k) makes camera k the one step() renders.  The
+        reference pops a random training camera every iteration (train.py:127): no two consecutive steps share a view."""
+        import numpy as np
+        import torch
+        from svgir_harness import cameras, runner
+        rng = np.random.default_rng(seed)
+        self.views = []
+        for k in range(n):
+            az = (k + rng.random()) * 360.0 / n
+            el = -60.0 + 140.0 * rng.random()
+            cam = cameras.make_camera(self.W, self.H, cameras.orbit_eye(4.0, az, el))
+            sct = dict(self.sct)
+            sct.update(runner.to_torch(cam, self.dev))
+            st = runner.settings(sct, self.variant)
+            vd = torch.nn.functional.normalize(st.campos[None, :] - self.sct["means3D"], dim=-1) if self.shade else None
+            self.views.append((st, vd, (az, el)))
+        return self.views
+
+    def use_view(self, k):
+        st, vd, _ = self.views[k]
+        self.st = st
+        if vd is not None:
+            self.sd["viewdirs"] = vd
+
     def step(self):
         """One forward (+ backward) through the binding layer; returns (R, colour image, a gradient tensor)."""
         import torch
@@ -371,12 +398,14 @@ class Workload:
         return R, color, g[3]
 
 
-def timed(wl, args, world, dev, dry=None):
+def timed(wl, args, world, dev, dry=None, solo=False, step_fn=None, stages=True):
     """warm-up, then `repeats` x (barrier, sync, K steps, barrier, sync); returns (per-region seconds [max over ranks], R,
-    stage timings)."""
+    stage timings).  solo: this rank alone (no barrier, no collective: the other ranks of a multi-GPU job wait outside);
+    step_fn: what a step is (default wl.step); stages: run the extra region with the library's stage marks."""
     import torch
     from svgir_harness import view_parallel as vp
     mvec = torch.zeros(3, dtype=torch.float32, device=dev)
+    barrier = (lambda: None) if solo else vp.barrier
 
     def metrics(R, color, gmean):
         # "loss"-like scalars gathered across ranks with ONE collective per step.  They are bench scaffolding, not the hot
@@ -389,8 +418,8 @@ def timed(wl, args, world, dev, dry=None):
         return torch.stack([color.sum(), gmean.sum(), torch.tensor(float(R), device=dev)])
 
     sync = (lambda: None) if dry else torch.cuda.synchronize
-    coll = world > 1 or vp.FORCE   # (FORCE: a one-rank job that issues its collectives anyway, tests/test_gpu_view_parallel.py)
-    step = dry or wl.step
+    coll = (world > 1 or vp.FORCE) and not solo   # (FORCE: a one-rank job that issues its collectives anyway, tests/test_gpu_view_parallel.py)
+    step = dry or step_fn or wl.step
     gatherer = vp.MetricsGatherer(3, dev)   # async: the collective of step i overlaps with step i+1
     R = 0
     # (untimed, like the warm-up: the library sizes its speculative launches -- instance capacity, state slots, depth-sort passes --
@@ -399,8 +428,10 @@ def timed(wl, args, world, dev, dry=None):
         step()
     for _ in range(args.warmup):
         R, color, gm = step()
-        gatherer.submit(metrics(R, color, gm))
-    gatherer.drain()
+        if not solo:
+            gatherer.submit(metrics(R, color, gm))
+    if not solo:
+        gatherer.drain()
     if not dry:
         from gaussian_renderer import _native
     regions = []
@@ -408,7 +439,7 @@ def timed(wl, args, world, dev, dry=None):
 
     def region():
         nonlocal R, color, gm
-        vp.barrier()
+        barrier()
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -417,7 +448,7 @@ def timed(wl, args, world, dev, dry=None):
                 gatherer.submit(metrics(R, color, gm))
         if coll:
             gatherer.results()   # inside the timed region: the last collective has completed
-        vp.barrier()
+        barrier()
         sync()
         return time.perf_counter() - t0
 
@@ -435,7 +466,7 @@ def timed(wl, args, world, dev, dry=None):
     # (an event record per stage boundary costs ~4 us on the stream -- ~50 us per cfg2 step -- so the regions that
     # produce `value` run without them; this region is not part of `value`).
     stage = {}
-    if not dry:
+    if not dry and stages:
         # (the stage marks sit on ONE stream: the shading goes back to the rasterizer's stream for this region, otherwise the
         # composite's mark would include its wait for the side stream)
         side = getattr(wl, "side", None)
@@ -448,6 +479,8 @@ def timed(wl, args, world, dev, dry=None):
         if side is not None:
             wl.side = side
     el = torch.tensor(regions, dtype=torch.float64, device=dev)
+    if solo:
+        return el.cpu().numpy(), int(R), stage, None
     if coll:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     if gatherer.results() is None:   # (no warm-up steps on one rank)
@@ -603,6 +636,80 @@ def shading_record(wl, stage, counts=None):
             if ir and ir.get("issue_frac") is not None:
                 rec[part]["issue_frac"] = ir["issue_frac"]
                 rec[part]["bound"] = "issue" if ir["issue_frac"] > rec[part]["frac"] else "hbm"
+    return rec
+
+
+def compact_record(name, dev, args, repeats=9):
+    """One more BASELINE configuration in the default line: the same region protocol as the headline (K steps between barrier +
+    synchronize), a fixed number of regions, and the two composite roofline fractions with the measured instance count."""
+    import numpy as np
+    import torch
+    sa = argparse.Namespace(**vars(args))
+    sa.repeats = repeats
+    wl = Workload(name, dev, 0, 1, sa)
+    reg, R, st, _ = timed(wl, sa, 1, dev)
+    med = float(np.median(reg))
+    rf = roofline_of(wl, R, st, name)
+    rec = {"workload": f"{name}: {wl.variant} path, P={wl.P}, {wl.W}x{wl.H}, S={wl.S}, VS={wl.VS}" + (f", shading Ns={wl.Ns}" if wl.shade else "") + ", fwd+bwd",
+           "value": wl.P * sa.steps / med, "unit": "surfels/s", "ms_per_step": med / sa.steps * 1e3, "repeats": len(reg), "num_rendered": int(R),
+           "bwd_composite": {k: rf.get(k) for k in ("frac", "achieved", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "issue_frac", "bound")},
+           "fwd_composite": {k: rf.get("fwd_composite", {}).get(k) for k in ("frac", "achieved", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "issue_frac")},
+           "walked_share_of_num_rendered": (rf.get("walked") or {}).get("share_of_num_rendered"),
+           "dominant_stage_by_time": rf.get("dominant_stage_by_time"),
+           "stage_ms": {k: round(v[0], 4) for k, v in st.items()}}
+    if wl.shade and "shade_fwd" in st:
+        sr = shading_record(wl, st)
+        rec["shade_fwd"] = {k: sr["fwd"].get(k) for k in ("avg_launch_ms", "frac", "issue_frac")}
+        rec["surfels_shaded_fwd"] = sr["surfels_shaded_fwd"]
+    del wl
+    torch.cuda.empty_cache()
+    return rec
+
+
+def rotating_views(name, dev, args, fixed_ms, n_views=24, seed=606, repeats=9):
+    """The same workload with a DIFFERENT camera every step: n_views seeded orbit cameras (Workload.add_orbit_views) visited in a seeded
+    random order, fwd+bwd, same region protocol -- the reference never renders one view twice in a row (train.py:127), and a repeated view
+    is the best case of every speculation in the library (instance capacity, state slots, three-pass depth sort) and of the 256 MB
+    Infinity Cache.  Reports the step time next to the fixed-view one and what the speculative launches did during the regions."""
+    import numpy as np
+    import torch
+    from gaussian_renderer import _native
+    sa = argparse.Namespace(**vars(args))
+    sa.repeats = repeats
+    wl = Workload(name, dev, 0, 1, sa)
+    views = wl.add_orbit_views(n_views, seed)
+    order = np.random.default_rng(seed + 1).permutation(n_views * 64) % n_views
+    for i in range(1, len(order)):   # (never the same camera twice in a row)
+        if order[i] == order[i - 1]:
+            order[i] = (order[i] + 1) % n_views
+    pos = [0]
+
+    def step():
+        wl.use_view(int(order[pos[0] % len(order)]))
+        pos[0] += 1
+        return wl.step()
+
+    for k in range(n_views):   # every camera once, untimed: per-view instance counts for the record (and the allocator's pools)
+        wl.use_view(k)
+        wl.step()
+    torch.cuda.synchronize()
+    Rs = []
+    for k in range(n_views):
+        wl.use_view(k)
+        Rs.append(int(wl.step()[0]))
+    torch.cuda.synchronize()
+    before = _native.speculation_stats()
+    reg, R, _, _ = timed(wl, sa, 1, dev, step_fn=step, stages=False)
+    after = _native.speculation_stats()
+    med = float(np.median(reg))
+    ms = med / sa.steps * 1e3
+    rec = {"workload": name, "views": n_views, "order": "seeded random, no camera twice in a row", "azimuth_deg": "0-360", "elevation_deg": "-60..80",
+           "value": wl.P * sa.steps / med, "unit": "surfels/s", "ms_per_step": ms, "repeats": len(reg), "steps_timed": len(reg) * sa.steps,
+           "fixed_view_ms_per_step": fixed_ms, "ratio_to_fixed_view": ms / fixed_ms if fixed_ms else None,
+           "num_rendered_min": min(Rs), "num_rendered_max": max(Rs), "num_rendered_mean": float(np.mean(Rs)),
+           "speculation": {k: after[k] - before[k] for k in after}}
+    del wl
+    torch.cuda.empty_cache()
     return rec
 
 
@@ -946,6 +1053,13 @@ def main():
         def dry_step():
             return 100 + rank, tok * 2.0, tok + 1.0
 
+        n1 = None
+        if world > 1:   # the same-workload single-rank reference of the N > 1 line (see below): rank 0 alone, the others wait
+            vp.barrier()
+            if rank == 0:
+                sreg, _, _, _ = timed(None, args, world, dev, dry=dry_step, solo=True)
+                n1 = float(np.median(sreg))
+            vp.barrier()
         regions, R, stage, table = timed(None, args, world, dev, dry=dry_step)
         core_tab = vp.gather_rows(torch.tensor([float(len(cores)), float(cores[0]) if cores else -1.0, float(cores[-1]) if cores else -1.0]))
         if rank == 0:
@@ -955,7 +1069,9 @@ def main():
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": name + " (dry run)", "views_per_step": world},
                               "per_rank_R": [int(r[2]) for r in table],
-                              "per_rank_cpus": [list(range(int(c[1]), int(c[2]) + 1)) if c[0] > 0 else [] for c in core_tab]}))
+                              "per_rank_cpus": [list(range(int(c[1]), int(c[2]) + 1)) if c[0] > 0 else [] for c in core_tab],
+                              **({"n1_same_workload": {"value": args.steps / n1, "unit": "steps/s", "ms_per_step": n1 / args.steps * 1e3},
+                                  "scaling_efficiency": (world * args.steps / med) / (world * args.steps / n1)} if n1 else {})}))
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -972,6 +1088,18 @@ def main():
         print(json.dumps(bench_train_step(args, dev) if name == "train_step" else bench_tracers(args, dev)))
         return
     wl = Workload(name, dev, rank, world, args)
+    # N > 1: the line must carry its own single-GPU reference -- the SAME workload (rank 0's view of it) on ONE GPU of the same node,
+    # measured by the same process right before the concurrent regions while the other ranks wait at a barrier.  value / (N x that) is the
+    # view-parallel scaling efficiency; the N = 1 default line times another workload (cfg2, BASELINE's headline) and is not comparable.
+    n1 = None
+    if world > 1:
+        vp.barrier()
+        if rank == 0:
+            sa = argparse.Namespace(**vars(args))
+            sa.repeats = args.repeats if args.repeats > 0 else 15
+            sreg, sR, _, _ = timed(wl, sa, world, dev, solo=True, stages=False)
+            n1 = (float(np.median(sreg)), int(sR))
+        vp.barrier()
     regions, R, stage, table = timed(wl, args, world, dev)
     # which physical GPU every rank ran on (a rank that silently fell back to another device would show up here)
     pr = torch.cuda.get_device_properties(dev)
@@ -1003,6 +1131,15 @@ def main():
             srec = shading_record(wl, stage)
             res["config"]["shading"] = srec["config"]
             res["shading"] = {k: v for k, v in srec.items() if k != "config"}
+        if n1:
+            v1 = wl.P * args.steps / n1[0]
+            res["n1_same_workload"] = {"value": v1, "unit": "surfels/s", "ms_per_step": n1[0] / args.steps * 1e3, "num_rendered": n1[1],
+                                       "what": f"{name}, rank 0's view alone on one GPU of this node (the other {world - 1} ranks idle at a barrier), "
+                                               "same process, same region protocol, right before the concurrent regions"}
+            res["scaling_efficiency"] = res["value"] / (world * v1)
+            res["scaling_note"] = ("the scaling curve of this job = value (N views in flight on N GPUs) over N x n1_same_workload.value; the "
+                                   "N = 1 default line (cfg2) is BASELINE's headline and a different workload -- its cfg4 record "
+                                   "(`configs.cfg4`) is the N = 1 point on another box")
     # the "shaded + blended" number of north_star: cfg3_train with the shading stage, same measurement, extra keys
     if world == 1 and args.workload is None and not args.no_shaded:
         wl.sct = wl.gt = None
@@ -1018,6 +1155,22 @@ def main():
                          "shading": shading_record(w3, st3), "stage_ms": {k: round(v[0], 4) for k, v in st3.items()}}
         res["value_shaded"] = res["shaded"]["value"]   # north_star's "shaded + blended" number (cfg3_train with the SV-BRDF shading)
         del w3
+        torch.cuda.empty_cache()
+        # the other BASELINE configurations, compactly: cfg3_eval (configs[2], evaluation widths), cfg4 (configs[3]: the workload of the
+        # N > 1 line -- this record is its N = 1 point), cfg5 (configs[4]: the one where bandwidth can bind)
+        res["configs"] = {}
+        for cname in ("cfg3_eval", "cfg4", "cfg5"):
+            try:
+                res["configs"][cname] = compact_record(cname, dev, args)
+            except Exception as e:   # noqa: BLE001 -- supplementary records never cost the headline
+                res["configs"][cname] = {"error": repr(e)[:300]}
+        # a different camera every step (the reference's training loop), cfg2 and cfg3_train
+        res["rotating_views"] = {}
+        for cname, fixed in (("cfg2", res["ms_per_step"]), ("cfg3_train", res["shaded"]["ms_per_step"])):
+            try:
+                res["rotating_views"][cname] = rotating_views(cname, dev, args, fixed)
+            except Exception as e:   # noqa: BLE001
+                res["rotating_views"][cname] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_concurrent:   # (last: it creates streams of its own)
         torch.cuda.empty_cache()
         # (HIP streams share a few hardware queues, dealt in creation order: each record creates its streams right before it runs)

@@ -41,6 +41,7 @@ struct CapKey { int dev, W, H, P, S, VS, variant, scope; };
 // times the largest unscaled one.  `scope` = svgir_params.workload_scope: models that share (device, image size, widths, variant) keep
 // separate histories by giving each its own id.)
 struct CapEntry { CapKey key; int hist[8]; int hist_P[8]; long long hist_slots[8]; int hist_slots_P[8]; unsigned next, next_slots; unsigned long long stamp; bool used;
+                  long long fill; int fill_P;   // non-empty 8x8 sub-tiles of the workload's latest view (-1 / 0: none seen), and its Gaussian count
                   int top_byte, top_streak;   // common top byte of the visible depth keys of the last `top_streak` views (0: none / not common)
                   const void* last_view; int last_view_P; };   // image blob of the workload's latest forward: its slot total is read when the next one starts
 std::mutex g_cap_mu;
@@ -88,11 +89,20 @@ long long guess_slots(const CapKey& k) {
     if (e && e->next_slots) for (unsigned i = 0; i < std::min(e->next_slots, 8u); i++) { m = std::max(m, scale_to(e->hist_slots[i], e->hist_slots_P[i], k.P)); raw = std::max(raw, e->hist_slots[i]); }
     return m < 0 ? m : std::min(m, 4 * raw + 64);
 }
-void record_slots(const CapKey& k, long long slots) {
+void record_slots(const CapKey& k, long long slots, long long nonempty) {
     std::lock_guard<std::mutex> lk(g_cap_mu);
     CapEntry* e = cap_entry(k, true);
     e->hist_slots[e->next_slots % 8] = slots; e->hist_slots_P[e->next_slots % 8] = k.P;
     e->next_slots++;
+    if (nonempty >= 0) { e->fill = nonempty + 1; e->fill_P = k.P; }   // (stored + 1: a zero-initialised entry has seen none)
+}
+// The FILL of the composite launch: non-empty sub-tiles (= waves with work) of the workload's latest view.  The forward composite exists in
+// two occupancy variants (render_fwd.hip): below ~4 rounds of waves the machine is under-filled and the variant with more registers per
+// wave wins; above, the one with more resident waves.  -1: no view seen yet.
+long long guess_fill(const CapKey& k) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    const CapEntry* e = cap_entry(k, false);
+    return (e && e->fill > 0) ? e->fill - 1 : -1;
 }
 // Depth-key speculation.  The depth keys are positive floats; in a bounded scene they share their top byte (sign + 7 exponent bits: all
 // depths in [2, 8), or [8, 32) ...), and then the fourth 8-bit pass of the depth sort orders nothing.  The preprocess reports AND / OR of
@@ -206,7 +216,8 @@ struct ViewEntry { const void* key = nullptr; uint32_t tag = 0; int cap_R = 0; l
 constexpr int kViewEntries = 1024;   // forwards whose backward may still come (least recently used entry replaced)
 std::mutex g_view_mu;
 ViewEntry g_view[kViewEntries];
-unsigned long long* g_view_pinned = nullptr;   // [kViewEntries][2] {tag << 32 | pairs, tag << 32 | slots}
+constexpr int kViewWords = 4;
+unsigned long long* g_view_pinned = nullptr;   // [kViewEntries][kViewWords] {tag << 32 | pairs, tag << 32 | slots, tag << 32 | non-empty sub-tiles, -}
 unsigned long long g_view_clock = 0;
 uint32_t g_view_tag = 0;
 // registers the launch sequence of the forward that owns `image_blob`: returns where order_desc_kernel writes its totals and the tag
@@ -214,9 +225,9 @@ unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_s
     std::lock_guard<std::mutex> lk(g_view_mu);
     if (!g_view_pinned) {
         void* ptr = nullptr;
-        if (hipHostMalloc(&ptr, kViewEntries * 2 * sizeof(unsigned long long), hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostMalloc(&ptr, kViewEntries * kViewWords * sizeof(unsigned long long), hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         g_view_pinned = (unsigned long long*)ptr;
-        for (int i = 0; i < 2 * kViewEntries; i++) g_view_pinned[i] = 0ull;
+        for (int i = 0; i < kViewWords * kViewEntries; i++) g_view_pinned[i] = 0ull;
     }
     int slot = 0;
     for (int i = 0; i < kViewEntries; i++) {
@@ -228,7 +239,7 @@ unsigned long long* view_note(const void* image_blob, int cap_R, long long cap_s
     e.stream = stream; e.has_stream = true;
     e.tag = ++g_view_tag ? g_view_tag : ++g_view_tag;   // (never 0: the slots start as 0)
     *tag = e.tag;
-    return g_view_pinned + 2 * slot;
+    return g_view_pinned + kViewWords * slot;
 }
 // The same four numbers live in the image blob itself (ImageLayout::counters, written by order_desc_kernel): a blob the host table no
 // longer knows -- more than kViewEntries forwards ago, or a binder that moved / cloned the saved buffer -- is still self-describing, like
@@ -251,7 +262,7 @@ bool view_from_blob(const uint32_t* counters_dev, ViewCounts* out) {
 // and backlogs on OTHER streams (tracer updates of another view, a second model) are not waited for.  pairs / slots stay -1 only if the forward never wrote them (it failed on the device) or the entry was recycled.
 // wait = 2: one look.
 bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_slots, long long* pairs, long long* slots,
-                 const hipStream_t* sync_stream = nullptr) {
+                 const hipStream_t* sync_stream = nullptr, long long* nonempty = nullptr) {
     volatile unsigned long long* at = nullptr;
     uint32_t tag = 0;
     hipStream_t fwd_stream = nullptr; bool have_fwd_stream = false;
@@ -259,7 +270,7 @@ bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_sl
         std::lock_guard<std::mutex> lk(g_view_mu);
         for (int i = 0; i < kViewEntries; i++)
             if (g_view[i].key == image_blob && g_view_pinned) {
-                at = g_view_pinned + 2 * i; tag = g_view[i].tag;
+                at = g_view_pinned + kViewWords * i; tag = g_view[i].tag;
                 fwd_stream = g_view[i].stream; have_fwd_stream = g_view[i].has_stream;
                 if (cap_R) *cap_R = g_view[i].cap_R;
                 if (cap_slots) *cap_slots = g_view[i].cap_slots;
@@ -268,6 +279,7 @@ bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_sl
     }
     if (pairs) *pairs = -1;
     if (slots) *slots = -1;
+    if (nonempty) *nonempty = -1;
     if (!at) return false;
     if (!wait) return true;
     uint32_t w0 = 0, w1 = 0;
@@ -287,14 +299,16 @@ bool view_lookup(const void* image_blob, int wait, int* cap_R, long long* cap_sl
     if (got) {
         if (pairs) *pairs = (long long)w0;
         if (slots) *slots = (long long)w1;
+        const unsigned long long v2 = at[2];
+        if (nonempty && (uint32_t)(v2 >> 32) == tag) *nonempty = (long long)(uint32_t)v2;
     }
     return true;
 }
 // A view's state-slot total enters its workload's history once, through whoever sees it first: the workload's next forward (mode 2:
 // a look, no wait -- the forward itself never waits for the cull) or the view's own backward (mode 1: the value is there by then).
 void note_view_slots(const CapKey& k, const void* image_blob, int mode, const hipStream_t* sync_stream = nullptr) {
-    long long slots = -1;
-    if (!image_blob || !view_lookup(image_blob, mode, nullptr, nullptr, nullptr, &slots, sync_stream) || slots < 0) return;
+    long long slots = -1, nonempty = -1;
+    if (!image_blob || !view_lookup(image_blob, mode, nullptr, nullptr, nullptr, &slots, sync_stream, &nonempty) || slots < 0) return;
     {
         std::lock_guard<std::mutex> lk(g_view_mu);
         bool found = false;
@@ -306,7 +320,7 @@ void note_view_slots(const CapKey& k, const void* image_blob, int mode, const hi
             }
         if (!found) return;
     }
-    record_slots(k, slots);
+    record_slots(k, slots, nonempty);
 }
 // Side stream of the backward: the gradient tensors are cleared there while the composite backward (which only writes the
 // scratch) runs on the caller's stream.  One per device, created on first use; fork / join through events.
@@ -428,6 +442,13 @@ CfgRef cfg_ref(const svgir_params* p) {
 // (measured: cfg3_train, P = 200 k, svgss rows: grad_reduce 85 -> 64 us, geom_bwd 28 -> 24 us against ~10 us for the partition; cfg2,
 // P = 200 k, rgss packed rows: only geom_bwd gains, 31 -> ~25 us: not worth it; cfg5, P = 2 M: 498 -> 345 us and 171 -> 88 us)
 constexpr int kListMinP = 400000, kListMinPRows = 50000;   // (round 5, rgss at P = 200 k with the count folded into seg_build: geom_bwd -7 us, scatter launch +5, seg_build +2: no gain)
+
+// Does a composite launch with `nonempty` waves of work fill the machine several times over?  (256 CUs x 8-11 resident waves: from ~4
+// rounds on; SVGIR_FWD_FILL = 0 / 1 forces the low- / high-occupancy variant)
+bool high_fill(long long nonempty) {
+    static const int forced = [] { const char* e = getenv("SVGIR_FWD_FILL"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    return forced >= 0 ? forced != 0 : nonempty >= 8192;
+}
 
 // fused shading: run the contribution pre-pass?  (SVGIR_PREPASS = 0 / 1 forces it off / on)
 bool shade_prepass(int Ns) {
@@ -603,6 +624,8 @@ struct ForwardCall {
         ra.cfg = cfg; ra.sub_list = B.sub_list; ra.sub_total = I.sub_total; ra.sub_order = I.sub_order;
         ra.sub_pair_base = I.sub_pair_base; ra.sub_slot_base = I.sub_slot_base; ra.slot_cap = (uint32_t)std::min<size_t>(B.slot_cap, 0xffffffffu);
         ra.dump_only = 0;
+        ra.hi_fill = high_fill(guess_fill(ckey)) ? 1 : 0;
+        ra.order_n = (int)order_entries(gx, gy);
         ra.bg_in_render = render_specialised(p->S, svgss ? p->VS : 0, svgss) ? 1 : 0;
         ra.sub_count = I.sub_count;
         ra.sub_ndump = I.sub_ndump; ra.seg_list = B.seg_list; ra.seg_desc = B.seg_desc; ra.seg_count = I.counters; ra.seg_block = I.seg_block; ra.seg_state = B.seg_state;
@@ -619,8 +642,11 @@ struct ForwardCall {
         uint32_t vtag = 0;
         unsigned long long* vslot = view_note(iblob, cap, cap_slots, &vtag, s);
         const bool row_path = svgss && p->VS > 0 && render_specialised(p->S, p->VS, true);   // (only the svgss backward writes gradient rows)
+        // (a launch of many rounds of waves gets one longest-first list per XCD instead of one global list: common.hpp ORDER_NONE)
+        static const int xcd_forced = [] { const char* e = getenv("SVGIR_FWD_XCD"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        const bool per_xcd = ra.bg_in_render && (xcd_forced >= 0 ? xcd_forced != 0 : ra.hi_fill != 0);   // (specialised composite kernels only)
         launch_order_desc(I.sub_total, 4 * T, I.sub_order, row_path ? I.sub_pair_base : nullptr, I.sub_slot_base, I.counters, vslot, vtag,
-                          (uint32_t)cap, cap_slots, kBlobMagic, s);
+                          (uint32_t)cap, cap_slots, kBlobMagic, gx, ra.order_n, per_xcd, s);
         if (int rc = check("cull")) return rc;
         if (timed) tm.mark("cull");
         if (cull_only) return 0;   // (the sizing phase of a workload's first view: see finish())
@@ -1020,6 +1046,8 @@ int svgir_backward(const svgir_params* p, const svgir_grads* g, int32_t R, const
             ra.sub_pair_base = I.sub_pair_base; ra.sub_slot_base = I.sub_slot_base; ra.slot_cap = (uint32_t)std::min<long long>(slots, 0xffffffffll);
             ra.sub_count = I.sub_count; ra.sub_ndump = I.sub_ndump; ra.seg_block = I.seg_block; ra.seg_state = seg_state;
             ra.dump_only = 1;
+            ra.hi_fill = 0;
+            ra.order_n = (int)order_entries(gx, gy);
             if (launch_render_fwd(ra, svgss, s) < 0) { (void)hipFreeAsync(redump, s); return fail(SVGIR_ERR_INVALID, "state re-dump: no specialised composite"); }
             tm.mark("state_redump");
         }

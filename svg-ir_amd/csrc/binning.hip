@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
                                                           uint32_t* __restrict__ order, uint32_t* __restrict__ prefix,
                                                           uint32_t* __restrict__ slot_prefix, uint32_t* __restrict__ total,
                                                           unsigned long long* __restrict__ host_total, uint32_t host_tag,
-                                                          uint32_t cap_R, long long cap_slots, uint32_t magic) {
+                                                          uint32_t cap_R, long long cap_slots, uint32_t magic, int order_n) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     __shared__ unsigned long long wsum2[16];
@@ -600,6 +600,8 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
         // the host's copy: {sum, tag of this forward} as 8-byte stores into pinned host memory -- no copy operation and no event on the
         // stream; the host recognises the values by their tag (api.hip view_lookup)
         if (host_total) {
+            // (third word: the number of non-empty items -- composite waves with work; the forward picks its occupancy variant from it)
+            __hip_atomic_store(host_total + 2, ((unsigned long long)host_tag << 32) | (unsigned long long)((uint32_t)n - hist[1023]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_total, ((unsigned long long)host_tag << 32) | (all & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_total + 1, ((unsigned long long)host_tag << 32) | (all >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -627,14 +629,128 @@ __global__ void __launch_bounds__(1024) order_desc_kernel(const uint32_t* __rest
     } else {
         for (int i0 = c0; i0 < c1; i0 += 64) place(i0, i0 + lane < c1 ? counts[i0 + lane] : 0u);
     }
+    for (int i = n + t; i < order_n; i += 1024) order[i] = ORDER_NONE;   // padding (common.hpp ORDER_NONE)
+}
+
+// The same products for launches that fill the machine several times over (api.hip high_fill): ONE LONGEST-FIRST LIST PER XCD, and one
+// workgroup per XCD to build it.  Workgroups are dealt to the eight XCDs round-robin (workgroup b of the composite runs on XCD b & 7), and
+// each XCD has its own 4 MiB L2: with one global order the ~3 sub-tiles that gather a splat's record and vfeature rows run on three
+// different XCDs, and each L2 fetches them again.  Here the image is cut into blocks of 4 x 4 tiles, block (bx, by) belongs to XCD
+// (bx + 3 by) & 7 (common.hpp xcd_of_tile); workgroup c counting-sorts the sub-tiles of XCD c by descending count and writes its j-th item
+// to order[8 j + c] (the lists differ in length by a few blocks: the tail is padded with ORDER_NONE up to order_n = order_entries()).
+// With tens of thousands of waves the XCDs' sums are balanced to a few per cent; with one round of waves they are not (the exact order
+// wins there: cfg4 render 220 vs 231 us).  The index-order prefixes are split eight ways too: workgroup c scans the c-th eighth of the
+// items behind a reduction of everything in front of it (every workgroup reads all n counts twice: 40 loads per thread at 1600 x 1600),
+// and the last one -- which has seen every item -- publishes the totals.  cfg5 (40 000 sub-tiles): 49 us for the single workgroup.
+__global__ void __launch_bounds__(1024) order_xcd_kernel(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ prefix, uint32_t* __restrict__ slot_prefix,
+                                                         uint32_t* __restrict__ total, unsigned long long* __restrict__ host_total,
+                                                         uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, int gx,
+                                                         int order_n) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long wsum2[16];
+    __shared__ uint32_t wzero[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t c = blockIdx.x;   // XCD whose list this workgroup builds; also its eighth of the prefixes
+    hist[t] = 0;
+    auto both = [](uint32_t v) { return (unsigned long long)v | ((unsigned long long)seg_slots(v) << 32); };
+    const int per = ((n + 7) / 8 + 1023) / 1024 * 1024;       // items per workgroup (prefix part), a multiple of the workgroup size
+    const int p0 = min(n, (int)c * per), p1 = min(n, p0 + per);
+    __syncthreads();
+    // ---- pass 1 over ALL items: histogram of this XCD's items; sum (counts | slots) and number of empty items in front of p0
+    unsigned long long before = 0;
+    uint32_t zeros = 0;
+    for (int i = t; i < n; i += 1024) {
+        const uint32_t len = counts[i];
+        const int tile = i >> 2;
+        if (xcd_of_tile(tile % gx, tile / gx) == c) atomicAdd(&hist[1023u - min(1023u, len)], 1u);
+        if (i < p0) before += both(len);
+        zeros += len == 0u ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += (unsigned long long)__shfl_xor((long long)before, d);
+        zeros += (uint32_t)__shfl_xor((int)zeros, d);
+    }
+    if (lane == 0) { wsum2[wave] = before; wzero[wave] = zeros; }
+    __syncthreads();
+    unsigned long long run = 0;
+    uint32_t n_empty = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { run += wsum2[w]; n_empty += wzero[w]; }
+    // ---- bucket cursors of this XCD
+    const uint32_t hv = hist[t];
+    uint32_t incl = hv;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, n_mine = 0;
+    for (int w = 0; w < 16; w++) { woff += w < wave ? wsum[w] : 0u; n_mine += wsum[w]; }
+    hist[t] = woff + incl - hv;
+    __syncthreads();
+    // ---- prefixes of this workgroup's eighth, in index order: 1024 items per round (wave scans + a scan over the 16 wave totals)
+    auto scan32 = [](uint32_t v) {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+        return v;
+    };
+    for (int i0 = p0; i0 < p1; i0 += 1024) {
+        const int i = i0 + t;
+        const unsigned long long v = both(i < p1 ? counts[i] : 0u);
+        const unsigned long long inc = (unsigned long long)scan32((uint32_t)v) | ((unsigned long long)scan32((uint32_t)(v >> 32)) << 32);
+        __syncthreads();   // (wsum2 of the previous round has been read)
+        if (lane == 63) wsum2[wave] = inc;
+        __syncthreads();
+        unsigned long long wo = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const unsigned long long x = wsum2[w]; wo += w < wave ? x : 0ull; all += x; }
+        if (i < p1) {
+            const unsigned long long ex = run + wo + inc - v;
+            if (prefix) prefix[i] = (uint32_t)ex;
+            if (slot_prefix) slot_prefix[i] = (uint32_t)(ex >> 32);
+        }
+        run += all;
+    }
+    // (the workgroup that owns the last eighth has now summed every item: it publishes the totals; an eighth may be empty: p0 == p1 == n)
+    if (c == 7 && t == 0) {
+        if (total) {
+            total[1] = (uint32_t)run; total[2] = (uint32_t)(run >> 32);
+            total[3] = magic; total[4] = cap_R; total[5] = (uint32_t)(unsigned long long)cap_slots; total[6] = (uint32_t)((unsigned long long)cap_slots >> 32);
+        }
+        if (host_total) {
+            __hip_atomic_store(host_total + 2, ((unsigned long long)host_tag << 32) | (unsigned long long)((uint32_t)n - n_empty), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_total, ((unsigned long long)host_tag << 32) | (run & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_total + 1, ((unsigned long long)host_tag << 32) | (run >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // ---- pass 2: this XCD's items to order[8 j + c] (equal sizes in arrival order), then the padding behind the list
+    for (int i = t; i < n; i += 1024) {
+        const int tile = i >> 2;
+        if (xcd_of_tile(tile % gx, tile / gx) != c) continue;
+        const uint32_t len = counts[i];
+        order[8u * atomicAdd(&hist[1023u - min(1023u, len)], 1u) + c] = (uint32_t)i;
+    }
+    for (uint32_t j = n_mine + (uint32_t)t; 8u * j + c < (uint32_t)order_n; j += 1024u) order[8u * j + c] = ORDER_NONE;
 }
 
 }  // namespace
 
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* slot_prefix, uint32_t* totals,
-                       unsigned long long* host_totals, uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, hipStream_t s) {
-    hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order, prefix, slot_prefix, totals, host_totals, host_tag,
-                       cap_R, cap_slots, magic);
+                       unsigned long long* host_totals, uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, int gx, int order_n,
+                       bool per_xcd, hipStream_t s) {
+    if (per_xcd) hipLaunchKernelGGL(order_xcd_kernel, dim3(8), dim3(1024), 0, s, counts, n, order, prefix, slot_prefix, totals, host_totals,
+                                    host_tag, cap_R, cap_slots, magic, gx, order_n);
+    else hipLaunchKernelGGL(order_desc_kernel, dim3(1), dim3(1024), 0, s, counts, n, order, prefix, slot_prefix, totals, host_totals,
+                            host_tag, cap_R, cap_slots, magic, order_n);
 }
 
 template <int ITEMS>

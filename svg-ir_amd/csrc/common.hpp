@@ -110,6 +110,24 @@ inline GeomLayout geom_layout(char* base, int P) {
     return g;
 }
 
+// Dispatch order of the composite forward's waves (ImageLayout::sub_order, written by order_desc_kernel): workgroup b takes sub-tile
+// sub_order[b]; ORDER_NONE = padding (the workgroup exits).  Two orders exist (binning.hip): one global longest-first list, or one
+// longest-first list per XCD, interleaved (entry 8 j + c = the j-th item of XCD c), where an XCD owns the image blocks of 4 x 4 tiles
+// with (bx + 3 by) & 7 == c.  order_entries() = entries of the padded per-XCD form (>= 4 T): 8 x the longest XCD list.
+constexpr uint32_t ORDER_NONE = 0xffffffffu;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t xcd_of_tile(int tx, int ty) { return (uint32_t)((tx >> 2) + 3 * (ty >> 2)) & 7u; }
+inline size_t order_entries(int gx, int gy) {
+    size_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int by = 0; 4 * by < gy; by++)
+        for (int bx = 0; 4 * bx < gx; bx++) cnt[xcd_of_tile(4 * bx, 4 * by)] += (size_t)std::min(4, gx - 4 * bx) * (size_t)std::min(4, gy - 4 * by);
+    size_t m = 0;
+    for (size_t c : cnt) m = std::max(m, c);
+    return std::max((size_t)8 * 4 * m, (size_t)4 * gx * gy);
+}
+
 constexpr int SEG_CLASSES = 5, SEG_BLOCK_STRIDE = 8;   // backward-segment length classes (see SEG); per-256-tile-block counters padded to 8
 
 struct ImageLayout {
@@ -120,7 +138,7 @@ struct ImageLayout {
     uint32_t* seg_block; // [ceil(T / 256)][SEG_BLOCK_STRIDE] live backward segments per block of 256 tiles and length class (summed by the
                          // forward; directly behind ranges)
     uint32_t* sub_total; // [4*T] #entries of each 8x8 sub-tile's compact candidate list (written by the cull kernel)
-    uint32_t* sub_order; // [4*T] sub-tiles sorted by descending candidate count (heaviest work is dispatched first)
+    uint32_t* sub_order; // [order_entries] sub-tiles sorted by descending candidate count (heaviest work is dispatched first), see ORDER_NONE
     uint32_t* sub_count; // [4*T] #candidates the forward composite consumed before every pixel was done (<= sub_total)
     uint32_t* sub_ndump; // [4*T] #segment-boundary states the forward dumped for the sub-tile (see SEG)
     uint32_t* sub_pair_base; // [4*T] exclusive prefix of sub_total over the sub-tiles: first gradient row of a sub-tile's candidates
@@ -144,7 +162,7 @@ inline ImageLayout image_layout(char* base, int W, int H) {
     im.ranges = (uint32_t*)take((T * 2 + (T + 255) / 256 * SEG_BLOCK_STRIDE) * 4);
     im.seg_block = im.ranges ? im.ranges + T * 2 : nullptr;
     im.sub_total = (uint32_t*)take(T * 4 * 4);
-    im.sub_order = (uint32_t*)take(T * 4 * 4);
+    im.sub_order = (uint32_t*)take(order_entries((W + TILE - 1) / TILE, (H + TILE - 1) / TILE) * 4);
     im.sub_count = (uint32_t*)take(T * 4 * 4);
     im.sub_ndump = (uint32_t*)take(T * 4 * 4);
     im.sub_pair_base = (uint32_t*)take(T * 4 * 4);
@@ -348,6 +366,8 @@ struct RenderArgs {
     uint32_t* sub_pair_base; uint32_t* sub_slot_base; uint32_t slot_cap;
     int bg_in_render;   // 1: the pixels of EMPTY tiles and the all-zero planes (zero_a / zero_b) are written by the composite kernel's waves -- the
                         // empty sub-tiles' waves run last, in the kernel's idle tail -- instead of by the cull kernel (specialised kernels)
+    int order_n;     // entries of sub_order = workgroups of the composite forward (4 T, or order_entries() with one list per XCD)
+    int hi_fill;     // != 0: the launch has many rounds of waves (api.hip guess_fill): the composite's high-occupancy variant (render_fwd.hip)
     int dump_only;   // composite forward: 1 = replay for the state dumps alone (svgir_backward, a view that exceeded its slot capacity): no output
                      // is written
     float *final_T, *final_D; int32_t* n_contrib;
@@ -426,8 +446,10 @@ void launch_tile_sort12(uint32_t* const key[2], uint32_t* const val[2], int n, c
 // prefix[i] = exclusive prefix sum of counts[], slot_prefix[i] = the same of seg_slots(counts[]), totals[1] / totals[2] = the two sums,
 // host_totals[0] / [1] = host_tag << 32 | sum in pinned host memory (any of them may be null)
 // totals[3..6] = {magic, cap_R, cap_slots lo, hi}: the capacities of the launch sequence, kept in the image blob
+// gx: tiles per image row; order_n: entries of order[] (>= n; the rest is padded with ORDER_NONE); per_xcd: one longest-first list per XCD
 void launch_order_desc(const uint32_t* counts, int n, uint32_t* order, uint32_t* prefix, uint32_t* slot_prefix, uint32_t* totals,
-                       unsigned long long* host_totals, uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, hipStream_t s);
+                       unsigned long long* host_totals, uint32_t host_tag, uint32_t cap_R, long long cap_slots, uint32_t magic, int gx, int order_n,
+                       bool per_xcd, hipStream_t s);
 // per-tile cull of the depth-ordered splat lists against the four 8x8 sub-tiles -> sub_list, sub_total
 void launch_cull(const RenderArgs& a, hipStream_t s);
 // fused shading: needed[id] = 1 for every surfel that receives a blend weight in this view (the composite's transmittance walk alone)

@@ -58,9 +58,9 @@ struct BwdGeom {
     // other (scripts/probes/valu_rate_probe.hip), so lock-step groups buy no speed and cost registers and LDS.
     static constexpr int KB = BWD_KB_V;                  // candidates replayed per branch-free group
 #ifndef BWD_CHB_V
-#define BWD_CHB_V 8
+#define BWD_CHB_V 4
 #endif
-    static constexpr int CHB = BWD_CHB_V;                // candidates staged per batch
+    static constexpr int CHB = BWD_CHB_V;                // candidates staged per batch (4: 12.2 KB of LDS per wave = 12 waves per CU; 8: 11 -- 1 495 -> 1 406 us at cfg5, 344 -> 329 us at cfg4; 16: 1 655 us)
     static constexpr int SB = 4;                         // candidates per phase-B contraction (16 panel rows = 4 x 4 corners)
     static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S  (<= 16)
     static constexpr int GPROW = NC0 + 1;                // row stride of the transposition tile of the NC0 "plain" columns

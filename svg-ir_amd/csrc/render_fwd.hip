@@ -132,8 +132,12 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
 }
 
 // ---- blend --------------------------------------------------------------------------------------------------
-template <int S, int VC, bool SVGSS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(StageGeom<S, VC>::WPE, StageGeom<S, VC>::WPE)))
+// WPE = waves per SIMD the register allocation is held to.  The svgss widths exist in two variants: 2 (up to 256 VGPRs: nothing spills;
+// 8 waves per CU) for launches that do not fill the machine anyway, and FWD_WPE_HI = 3 (168 VGPRs, 9-15 spilled dwords; 11 waves per CU, the
+// LDS limit) for launches of many rounds of waves, where resident waves are what hides the gathers' latency (cfg5: 666 -> 593 us,
+// cfg5_dense 910 -> 834 us; cfg4, one round of waves: 213 -> 222 us) -- chosen per launch from the workload's fill (RenderArgs::hi_fill).
+template <int S, int VC, bool SVGSS, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 render_fwd_kernel(const RenderArgs a) {
     using PG = PairGeom<S, VC>;
     constexpr int CH = PG::CH, PF = PG::PF;
@@ -146,8 +150,8 @@ render_fwd_kernel(const RenderArgs a) {
     float* sP = reinterpret_cast<float*>(smem + PG::off_p);      // [PROWS][PS] blend-weight panel (MFMA A operand) / transposition tile
     constexpr int PS = PG::PS;
 
-    if ((int)blockIdx.x >= 4 * a.gx * a.gy) return;
-    const uint32_t sid = a.sub_order[blockIdx.x];
+    const uint32_t sid = a.sub_order[blockIdx.x];   // (grid = RenderArgs::order_n)
+    if (sid == ORDER_NONE) return;                  // padding of the per-XCD order (common.hpp)
     const int tile = (int)(sid >> 2), sub = (int)(sid & 3u);
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int lane = threadIdx.x;
@@ -484,8 +488,8 @@ __global__ void __launch_bounds__(64) contrib_prepass_kernel(const RenderArgs a)
     // one ds_read_b128 yields the aligned register pairs of TWO candidates and their alphas are packed fp32 instructions
     __shared__ __attribute__((aligned(16))) float sQ[2][32][12];
     __shared__ uint32_t sG[2][64];
-    if ((int)blockIdx.x >= 4 * a.gx * a.gy) return;
     const uint32_t sid = a.sub_order[blockIdx.x];
+    if (sid == ORDER_NONE) return;
     const int tile = (int)(sid >> 2), sub = (int)(sid & 3u);
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int len = (int)(r1 - r0);
@@ -682,11 +686,17 @@ __global__ void __launch_bounds__(256) seg_build_kernel(const RenderArgs a, int 
 #ifndef FWD_LDS_MIN
 #define FWD_LDS_MIN 0
 #endif
+#ifndef FWD_WPE_HI
+#define FWD_WPE_HI 3
+#endif
 template <int S, int VC, bool SVGSS>
 void launch(const RenderArgs& a, hipStream_t s) {
     using PG = PairGeom<S, VC>;
-    hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS>), dim3(4 * a.gx * a.gy), dim3(64),
-                       std::max(PG::lds_bytes(), (size_t)FWD_LDS_MIN), s, a);
+    constexpr int W0 = StageGeom<S, VC>::WPE;
+    constexpr int W1 = (VC >= 13 && FWD_WPE_HI > W0) ? FWD_WPE_HI : W0;   // (the callers' two svgss widths; everything else has one variant)
+    const size_t lds = std::max(PG::lds_bytes(), (size_t)FWD_LDS_MIN);
+    if (W1 != W0 && a.hi_fill) hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS, W1>), dim3(a.order_n), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((render_fwd_kernel<S, VC, SVGSS, W0>), dim3(a.order_n), dim3(64), lds, s, a);
 }
 
 }  // namespace
@@ -701,7 +711,7 @@ void launch_seg_build(const RenderArgs& a, void* clear, size_t clear_bytes, cons
 }
 
 void launch_contrib_prepass(const RenderArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(contrib_prepass_kernel, dim3(4 * a.gx * a.gy), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(contrib_prepass_kernel, dim3(a.order_n), dim3(64), 0, s, a);
 }
 
 void launch_cull(const RenderArgs& a, hipStream_t s) {

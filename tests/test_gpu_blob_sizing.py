@@ -93,7 +93,7 @@ def test_two_models_with_equal_widths_keep_separate_histories(built):
     own = rounds(True)
     assert shared["big"][-1][1] > 3 * shared["small"][-1][1], "the two models must differ in their instance counts"
     # one history: the small model's steady-state blob is laid out for the big model's instance count
-    assert shared["small"][-1][0] > 0.8 * shared["big"][-1][0], shared
+    assert shared["small"][-1][0] > 0.6 * shared["big"][-1][0], shared
     # own scopes: sized from its own views
     assert own["small"][-1][0] < 0.5 * own["big"][-1][0], own
     assert own["big"][-1][0] <= shared["big"][-1][0]

@@ -104,6 +104,10 @@ def test_bench_self_launches_ranks_dry_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["repeats"] == 3 and d["scaling"] == "weak"
     assert d["per_rank_R"] == [100, 101] and d["config"]["workload"].startswith("cfg4")
+    # the N > 1 line carries its own single-rank reference of the same workload (rank 0 alone, the others wait at a barrier): the two
+    # numbers that form the scaling curve are `value` and N x n1_same_workload.value
+    assert d["n1_same_workload"]["value"] > 0 and d["n1_same_workload"]["ms_per_step"] > 0
+    assert abs(d["scaling_efficiency"] - d["value"] / (2 * d["n1_same_workload"]["value"])) < 1e-9
     # a request for more GPUs than the machine has fails loudly instead of silently running one rank
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
                          capture_output=True, text=True, timeout=300)
