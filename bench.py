@@ -46,7 +46,7 @@ for p in (os.path.join(ROOT, "svg-ir_amd"), ROOT):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# Instruction-issue roof of the chip, measured (profiles/r03_valu_rate_probe.txt): a SIMD issues one wave64 VALU
+# Instruction-issue roof of the chip, measured (profiles/r03_valu_rate_probe.txt, HISTORY.md 4): a SIMD issues one wave64 VALU
 # instruction per 1.67 cycles at best (8 resident waves), a scalar instruction costs 1.3 more; 256 CUs x 4 SIMDs at 2.4 GHz
 SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES, SALU_ISSUE_CYCLES = 1024, 2.4e9, 1.67, 1.3
 
@@ -724,7 +724,7 @@ def rotating_views(name, dev, args, fixed_ms, n_views=24, seed=606, repeats=9):
 
 def two_streams(name, dev, args):
     """Supplementary record (never the headline `value`): TWO views of the workload in flight on one GPU, one HIP stream and one
-    host thread each.  One view leaves the SIMDs under-occupied (cfg2: 2 930 forward waves for 1 024 SIMDs); a
+    host thread each.  One view leaves the SIMDs under-occupied (cfg2: 2 930 forward waves for 1 024 SIMDs, HISTORY.md 4); a
     per-GPU driver that keeps two views in flight fills those issue slots."""
     import threading
     import time

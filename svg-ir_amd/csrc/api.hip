@@ -842,7 +842,7 @@ struct ForwardCall {
         record_R(ckey, R);
         // (whether the state-slot guess held is the backward's business -- svgir_backward re-dumps the states of a view that exceeded it; the
         // forward does not wait for the cull.  Measured on the host-bound training step, bench.py --workload train_step: 2.11 ms with
-        // the wait and a re-run here)
+        // the wait and a re-run here, see HISTORY.md 4)
         if (!bblob || R > cap) {
             // first view, or the scene grew past a guess: (re)do the dependent stages -- exact instance capacity, worst-case state slots
             const bool redo = bblob != nullptr;

@@ -19,14 +19,13 @@ namespace {
 #ifndef GRAD_REDUCE_RB
 #define GRAD_REDUCE_RB 8
 #endif
-#ifndef GRAD_REDUCE_K
-#define GRAD_REDUCE_K 4
-#endif
 constexpr int RB = GRAD_REDUCE_RB;   // gradient rows in flight per Gaussian
-constexpr int GK = GRAD_REDUCE_K;    // Gaussians per wave: their dependent chains (id -> radius / tiles / first instance -> reverse map -> rows)
-                                     // advance TOGETHER, one memory round trip per link for all of them (a wave per Gaussian paid the four
-                                     // links one after the other for a handful of rows: the kernel lasted its waves' latency chains, not its bytes)
-
+// GK = Gaussians per wave: their dependent chains (id -> radius / tiles / first instance -> reverse map -> rows) advance TOGETHER, one
+// memory round trip per link for all of them -- a wave per Gaussian pays the four links one after the other for a handful of rows, and with
+// hundreds of thousands of blended Gaussians the kernel lasts its waves' latency chains, not its bytes (cfg5, 267 k blended of 2 M: 337 ->
+// 269 us with GK = 4; cfg5_dense 367 -> 296 us).  With few Gaussians the waves are what is scarce (cfg3_train, 57 k blended: 59 -> 67 us
+// with GK = 4), so the launcher picks GK from the model size.
+template <int GK>
 __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs a, const GradRowGeom rg) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -152,8 +151,11 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
 
 void launch_grad_reduce(const GradReduceArgs& a, hipStream_t s) {
     const GradRowGeom rg = grad_row_geom(a.S, a.VS);
-    const int per = (BLOCK / 64) * GK;   // Gaussians per workgroup (sized for all P: with a list the surplus workgroups exit at once)
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((a.P + per - 1) / per), dim3(BLOCK), 0, s, a, rg);
+    // (grids are sized for all P: with a list the surplus workgroups exit at once)
+    auto grid = [&](int gk) { const int per = (BLOCK / 64) * gk; return dim3((a.P + per - 1) / per); };
+    if (a.P >= 1000000) hipLaunchKernelGGL(grad_reduce_kernel<4>, grid(4), dim3(BLOCK), 0, s, a, rg);
+    else if (a.P >= 500000) hipLaunchKernelGGL(grad_reduce_kernel<2>, grid(2), dim3(BLOCK), 0, s, a, rg);
+    else hipLaunchKernelGGL(grad_reduce_kernel<1>, grid(1), dim3(BLOCK), 0, s, a, rg);
 }
 
 }  // namespace svgir

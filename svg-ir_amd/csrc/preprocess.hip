@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     }
 
     float iu = 0.f, iv = 0.f;
-    if (SVGSS && a.scales) {
+    if (SVGSS) {   // (no scales -- cov3D_precomp -- means lambda = 0, i.e. the footprint's 0.1 floor: svgss forward.cu:383, oracle idem)
         const float umx = (float)(0.5 * (double)sc_in[0] + 0.1);
         const float umy = (float)(0.5 * (double)sc_in[1] + 0.1);
         iu = 1.0f / umx; iv = 1.0f / umy;

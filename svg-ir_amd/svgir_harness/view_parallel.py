@@ -191,7 +191,7 @@ def render_in_flight(render_view, views, device, in_flight=2):
     """Renders `views` on ONE GPU keeping `in_flight` of them in flight: one HIP stream and one host thread each.
 
     A single view leaves the SIMDs under-occupied (the composite kernels run fewer than three waves per SIMD on the BASELINE
-    scenes); with two views in flight the same GPU renders 1.3-1.4x as many views per second (bench.py
+    scenes, HISTORY.md 4); with two views in flight the same GPU renders 1.3-1.4x as many views per second (bench.py
     `two_streams`; 4+ gain nothing: the host threads serialise on the per-view read-back).  The library's shared state
     (capacity cache, side stream, allocator callbacks) is thread-safe: tests/test_gpu_concurrency.py.
 

@@ -1,5 +1,5 @@
 """Two views rendered concurrently on two HIP streams from two host threads (the way a per-GPU driver fills the issue slots one
-view leaves idle: DESIGN.md 4) must give what each gives alone.  Exercises the library's shared state under concurrency: the
+view leaves idle: HISTORY.md 4) must give what each gives alone.  Exercises the library's shared state under concurrency: the
 speculative-capacity cache, the per-device side stream of the backward, the allocator callbacks."""
 import threading
 

@@ -88,8 +88,9 @@ ANCHOR_FLOOR = 1e-4   # north_star's tolerance: what the product may be from the
 
 def _check_backward(leaves, o, variant, exact=None):
     """`exact`: gradients of the fp64 oracle.  Where given, NO flat element-wise tolerance is used: per tensor, the distribution of
-    the product's relative error against the exact gradient (p99.99 over the signal-carrying entries, and the share beyond REL_TOL)
-    must be within 1.5 x that of the reference's own fp32 arithmetic (the fp32 oracle) + north_star's 1e-4.  Sums of tens of
+    the product's relative error against the exact gradient (its tail quantile over the signal-carrying entries -- p99.99 from 100 000
+    entries on, p99.9 from 10 000, else p99: parity_util.tail_quantile -- and the share beyond REL_TOL) must be within 1.5 x that of the
+    reference's own fp32 arithmetic (the fp32 oracle) + north_star's 1e-4.  Sums of tens of
     thousands of nearly cancelling (pixel, splat) terms per Gaussian differ between ANY two fp32 summation orders; the product must
     be as close to the exact gradient as the reference arithmetic is, not equal to one particular order."""
     gr = o.grads()
@@ -105,10 +106,10 @@ def _check_backward(leaves, o, variant, exact=None):
         if exact is not None:
             ref = pu.stats(gr[ok], exact[ok], tol=TOL, rel_tol=REL_TOL)
             own = pu.stats(g.detach().cpu().numpy(), exact[ok], tol=TOL, rel_tol=REL_TOL)
-            assert own["p9999_rel"] <= 1.5 * ref["p9999_rel"] + ANCHOR_FLOOR, \
-                f"grad_{lk}: p99.99 relative error vs the exact gradient {own['p9999_rel']:.2e}, the fp32 oracle's {ref['p9999_rel']:.2e}"
-            assert own["p9999_norm"] <= 1.5 * ref["p9999_norm"] + ANCHOR_FLOOR, \
-                f"grad_{lk}: p99.99 normalised error vs the exact gradient {own['p9999_norm']:.2e}, the fp32 oracle's {ref['p9999_norm']:.2e}"
+            assert own["tail_rel"] <= 1.5 * ref["tail_rel"] + ANCHOR_FLOOR, \
+                f"grad_{lk}: p{100 * own['tail_q']:g} relative error vs the exact gradient {own['tail_rel']:.2e}, the fp32 oracle's {ref['tail_rel']:.2e}"
+            assert own["tail_norm"] <= 1.5 * ref["tail_norm"] + ANCHOR_FLOOR, \
+                f"grad_{lk}: tail normalised error vs the exact gradient {own['tail_norm']:.2e}, the fp32 oracle's {ref['tail_norm']:.2e}"
             assert own["rel_frac"] <= 1.5 * ref["rel_frac"] + REL_FRAC, f"grad_{lk}: {own['rel_frac']:.2e} of the entries beyond {REL_TOL:g} of the exact gradient, the fp32 oracle {ref['rel_frac']:.2e}"
             budget = max(REL_FRAC, 2.5 * ref["rel_frac"] + REL_FRAC)   # (two fp32 evaluations, each that far from the exact one)
         _cmp("grad_" + lk, g, gr[ok], flip_frac=GRAD_FLIP_FRAC, rel_frac=budget)
