@@ -18,9 +18,8 @@
 //     flight while the current one is replayed;
 //   * per-pixel replay state (running accumulators, last values, upstream gradients) lives in VGPRs thanks to
 //     compile-time channel counts (the reference keeps ~330 floats per thread in scratch, backward.cu:617-635);
-//   * the replay is written in lock-step over groups of KB candidates and without branches: alphas, corner weights
-//     and the dot products with the upstream gradients are KB independent instruction streams, only the (T, A)
-//     recurrence is sequential;
+//   * the replay handles one candidate at a time (a wave issues one instruction per ~8 cycles whether or not instructions depend on each
+//     other, so lock-step groups buy nothing and cost registers); only the (T, A) recurrence is inherently sequential;
 //   * gradient accumulation.  The reference issues 13 + S + VS global float atomics per (pixel, splat) pair
 //     (18 / 69 / 84).  Here every per-Gaussian gradient is first reduced over the 64 pixels of the wave:
 //       - all gradients except the 6 geometric ones have the form  dL/dq[g][ch] = sum_pixels a_v[pixel] G[pixel][ch]
@@ -28,15 +27,10 @@
 //         per-pair scalars a_v: phase A (lane = pixel) writes the scalars to an LDS panel [row][64 pixels], phase B
 //         runs the contraction panel[rows][64] x G[64][channels] on the matrix pipe (v_mfma_f32_16x16x4_f32, exact
 //         fp32; the one genuinely dense contraction of the path -- the blending itself stays scalar);
-//       - the 6 geometric gradients (mean2D.xy, conic.xyz, opacity) are written to a second LDS panel
-//         [candidate][6][64 pixels] and summed lane-parallel: 2-4 lanes per (candidate, value) row read 16-32 pixels
-//         with ds_read_b128 and finish with 1-2 DPP adds (instead of 18 DPP steps + masked stores per candidate);
-//     the per-(wave, splat) results then go to memory as
-//       - rgss: float atomics into ONE packed row per Gaussian (common.hpp GradRowGeom, 20 floats at S=5): a single
-//         scalar base + 32-bit offset per atomic, one atomic instruction per 16 candidates x 4 register rows;
-//         geom_bwd.hip unpacks the rows into the caller's tensors;
-//       - svgss: plain stores of the complete gradient row of the (instance, sub-tile) pair, summed per Gaussian by
-//         grad_reduce.hip (no atomics, bit-reproducible).
+//       - the 6 geometric gradients (mean2D.xy, conic.xyz, opacity) are summed over the pixels in registers: a transposed DPP
+//         reduction tree + two v_permlane*_swap steps (no LDS panel: the wave's LDS footprint decides its occupancy, BwdGeom);
+//     the per-(wave, splat) results go to memory as plain stores of the complete gradient row of the (instance, sub-tile) pair,
+//     summed per Gaussian by grad_reduce.hip (no atomics, bit-reproducible).  (Widths without vfeatures: render_bwd_plain.hip.)
 #include <algorithm>
 
 #include "common.hpp"
@@ -65,29 +59,46 @@ struct BwdGeom {
     static constexpr int NC0 = 7 + S;                    // colour3, normal3, depth, feature S  (<= 16)
     static constexpr int GPROW = NC0 + 1;                // row stride of the transposition tile of the NC0 "plain" columns
     static constexpr int GV = VC + 1;                    // row stride of the vfeature columns of G kept in LDS
-    static constexpr int PS = 68;                        // panel row stride (floats): 16-byte aligned, bank-staggered rows
-    static constexpr int GEO_ROWS = KB * 6;              // geometric panel rows of one group
-    static constexpr int LPR = KB >= 4 ? 2 : (KB == 2 ? 4 : 8);   // lanes that share one geometric row
+    static constexpr int PS = 64;                        // panel row stride (floats); rows are XOR-swizzled instead of padded (panel_at)
 #ifndef BWD_WPE_V
-#define BWD_WPE_V 3
+#define BWD_WPE_V 4
 #endif
-    // waves per SIMD the register budget is held to (LDS: 12.8 KB per wave at the training widths -> 12 waves per CU)
+    // Waves per SIMD the register budget is held to.  The kernel is bound by latency at its occupancy (measured by padding the LDS
+    // request, cfg5 / cfg3_train: 12 waves per CU 1 395 / 322 us, 11: 1 507 / 333, 10: 1 539 / 349, 9: 1 665 / 371, 8: 1 765 / 397, 5: 2 412 /
+    // 547 -- T = a + b / waves with a = 655 / 170 us), so the footprint of a wave is what counts: 4 waves per SIMD need <= 128 VGPRs and
+    // <= 10 240 B of LDS (160 KB / 16, allocated in 1 280-byte granules).  Hence: the segment's {gid, slot} entries live in registers
+    // (lane = list position; read with v_readlane / ds_bpermute) instead of a 512-byte LDS copy; the weight panel's rows are XOR-swizzled
+    // instead of padded; and the six geometric gradients of a candidate are summed over the pixels by one transposed DPP tree + two
+    // v_permlane*_swap steps instead of a 6 x 64 LDS panel: 12.2 KB -> 9.8 KB per wave.
     static constexpr int WPE = BWD_WPE_V;
-    static constexpr size_t off_q = (size_t)CHB * SG::NF * 4;
-    static constexpr size_t off_p = off_q + (size_t)SEG * 8;          // the whole segment's {gid, slot} entries
+    static constexpr size_t off_p = (size_t)CHB * SG::NF * 4;
     static constexpr int PROWS = 16;                                  // weight panel rows: (candidate, corner)
-    static constexpr size_t off_pg = off_p + (size_t)PROWS * PS * 4;
-    static constexpr size_t geo_bytes = (size_t)GEO_ROWS * PS * 4;
     static constexpr size_t g_bytes = (size_t)64 * GV * 4;
     // G (the MFMA B operand): its NC0 plain columns are transposed once per segment through LDS (a tile that aliases the
     // weight panel) into 16 VGPRs; the VC vfeature columns stay in LDS for the whole segment (they are also the A operand of
-    // the h contraction).  A wave's LDS footprint decides how many waves a CU holds: see WPE.
-    static constexpr size_t off_g = off_pg + geo_bytes;
+    // the h contraction; row pitch GV = VC + 1: with a pitch of 16 the phase-B reads of the four 16-pixel groups would hit the same banks).
+    static constexpr size_t off_g = off_p + (size_t)PROWS * PS * 4;
     static constexpr size_t lds_bytes = off_g + g_bytes;
     static_assert(NC0 <= 16 && VC <= 16, "one 16-wide MFMA column tile per channel group");
-    static_assert(SB % KB == 0 && CHB % SB == 0 && GEO_ROWS * LPR <= 64, "batch nesting");
+    static_assert(KB == 1 && SB % KB == 0 && CHB % SB == 0, "batch nesting");
+    static_assert(lds_bytes <= 10240, "4 waves per SIMD = 16 per CU need <= 10 KB of LDS per wave");
     static_assert((size_t)64 * GPROW * 4 <= (size_t)PROWS * PS * 4, "the transposition tile aliases the weight panel");
 };
+
+// element (row r, pixel / column c) of the 16 x 64 weight panel: the row's 16-byte granules are permuted by the row number, so that the
+// column-wise accesses of the MFMA operand loads (16 rows, same columns) hit 16 different bank groups without padding the rows
+__device__ __forceinline__ int panel_at(int r, int c) { return r * 64 + (c ^ ((r & 15) << 2)); }
+
+// lane l of every 16-lane row <- sum over the four rows of lane (l & 15): two v_permlane*_swap of the register with a copy of itself
+// (gfx950; scripts/probes/permlane_probe.hip) -- inline asm: with the builtins' two-element result this compiler adds element 0 to itself
+__device__ __forceinline__ float rows_total(float u) {
+    float x = u, y = u;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    const float s = x + y;
+    float p = s, q = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p), "+v"(q));
+    return p + q;
+}
 
 template <int S, int VC, bool SVGSS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BwdGeom<S, VC>::WPE, BwdGeom<S, VC>::WPE)))
@@ -95,14 +106,12 @@ render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int VS = VC * 4;
     using SG = StageGeom<S, VC>;
     using BG = BwdGeom<S, VC>;
-    constexpr int SB = BG::SB, KB = BG::KB, NC0 = BG::NC0, GV = BG::GV, GPROW = BG::GPROW, CHB = BG::CHB, PS = BG::PS, LPR = BG::LPR;
+    constexpr int SB = BG::SB, NC0 = BG::NC0, GV = BG::GV, GPROW = BG::GPROW, CHB = BG::CHB, PS = BG::PS;
     constexpr int SS = S > 0 ? S : 1, VV = VC > 0 ? VC : 1;
     constexpr int P4 = (NC0 + 3) / 4 * 4, GEO = P4 + VS, RS = (GEO + 6 + 3) / 4 * 4;   // common.hpp GradRowGeom
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sD = reinterpret_cast<float*>(smem);                    // [CHB][NF] staged candidates
-    uint2* sQ = reinterpret_cast<uint2*>(smem + BG::off_q);        // [SEG] {gid, slot} of the segment, deepest first
-    float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [16][PS] blend-weight panel (MFMA A operand)
-    float* sPg = reinterpret_cast<float*>(smem + BG::off_pg);      // [KB*6][PS] geometric gradients per pixel
+    float* sP = reinterpret_cast<float*>(smem + BG::off_p);        // [16][64] blend-weight panel (MFMA A operand), swizzled: panel_at
     float* sG = reinterpret_cast<float*>(smem + BG::off_g);        // [64][GV] upstream vfeature gradients of the sub-tile (MFMA operands)
 
     const int lane = threadIdx.x;
@@ -115,7 +124,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
 
     // The staging buffer and the weight panel start as zeros: slots beyond a batch's size then always hold finite values
     // (zeros or an older candidate), so the replay needs no per-candidate bounds branches -- such slots get weight 0.
-    for (int i = lane; i < (int)(BG::off_q / 16); i += 64) reinterpret_cast<float4*>(sD)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < (int)(BG::off_p / 16); i += 64) reinterpret_cast<float4*>(sD)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = lane; i < BG::PROWS * PS / 4; i += 64) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // The waves stride over the list of live depth segments (common.hpp SEG; seg_build_kernel): one 32-byte descriptor per
@@ -163,35 +172,21 @@ render_bwd_kernel(const RenderBwdArgs a) {
     // gradient row of the candidate at segment position i (0 = deepest): compact, in list order (common.hpp)
     const uint32_t row_top = d_pb + (uint32_t)(seg_hi - 1);
 
-    // ---- every load of the set-up that depends only on the descriptor is issued here, together: the segment's list entries
-    // (deepest first: the replay walks back to front), the pixel's forward results and upstream gradients, and the two dumped
-    // forward states -- one memory round trip instead of four dependent ones
+    // ---- set-up loads that depend only on the descriptor, issued together: the segment's list entries (deepest first: the replay
+    // walks back to front; lane = list position, they STAY in these two registers), the pixel's forward results and upstream gradients
     static_assert(SEG == 64, "one list entry per lane");
     uint2 ent = make_uint2(0u, 0u);
     if (lane < nent) ent = sub_in[seg_hi - 1 - lane];
     const float T_final = inside ? a.final_T[pid] : 0.f;
     const float D_final = (inside && normalize_depth) ? a.final_D[pid] : 0.f;
     const uint32_t last_contributor = inside ? (uint32_t)a.n_contrib[pid] : 0u;
-    float gC[3], gN[3], gF[SS], gVF[VV], gD = 0.f, gO = 0.f;
+    float gC[3], gN[3], gF[SS], gD = 0.f, gO = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; i++) { gC[i] = (inside && a.g_color) ? a.g_color[i * N_ + pid] : 0.f; gN[i] = (inside && a.g_normal) ? a.g_normal[i * N_ + pid] : 0.f; }
 #pragma unroll
     for (int i = 0; i < SS; i++) gF[i] = (inside && i < S && a.g_feature) ? a.g_feature[i * N_ + pid] : 0.f;
-#pragma unroll
-    for (int i = 0; i < VV; i++) gVF[i] = (inside && i < VC && a.g_vfeature) ? a.g_vfeature[i * N_ + pid] : 0.f;
     if (inside) { gD = a.g_depth ? a.g_depth[pid] : 0.f; gO = a.g_opacity ? a.g_opacity[pid] : 0.f; }
     constexpr int NST = 8 + S + VC;
-    float st_T = 0.f, st_d[NST - 1];   // (final - prefix) of the dumped states, channel by channel (only when kseg < ndump)
-#pragma unroll
-    for (int i = 0; i < NST - 1; i++) st_d[i] = 0.f;
-    if (kseg < ndump) {
-        const uint32_t sbase = d_sb;   // state slot of (sub-tile, 0)
-        const float* e = a.seg_state + ((size_t)(sbase + kseg) * NST) * 64 + lane;
-        const float* f = a.seg_state + ((size_t)(sbase + ndump) * NST) * 64 + lane;   // final state
-        st_T = e[0];
-#pragma unroll
-        for (int i = 0; i < NST - 1; i++) st_d[i] = f[(1 + i) * 64] - e[(1 + i) * 64];
-    }
 
     const float bgdot = a.bg[0] * gC[0] + a.bg[1] * gC[1] + a.bg[2] * gC[2];
     const float omt = 1.f - T_final;
@@ -207,39 +202,14 @@ render_bwd_kernel(const RenderBwdArgs a) {
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
     if (wmax == 0) continue;
 
-    // The list entries go to LDS; the first batch's gathers start now and overlap the rest of the set-up.
-    sQ[lane] = ent;
+    // entry of list position i (0 = deepest) from the lanes' registers: per-lane positions through the LDS crossbar (no LDS memory),
+    // wave-uniform ones with v_readlane
+    auto gid_at = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(i << 2, (int)ent.x); };
     const int nskip = __popcll(__ballot(lane < nent && ent.y >= wmax));   // entries behind every pixel of this wave (a prefix: slots descend)
-    wave_lds_sync();
     StageRegs<S, VC, CHB> sr;
     int base = (nskip / CHB) * CHB;
-    if (base < nent)
-        stage_load<S, VC, CHB>(sr, min((int)CHB, nent - base), [&](int s) { return sQ[base + s].x; }, lane, a.rec,
-                               a.features, a.vfeatures);
-
-    // G matrix of this sub-tile: row = pixel (lane), columns = [colour3 | normal3 x10 (Q4) | depth | feature S | vfeature VC].
-    // Phase B needs it as the MFMA B operand (lane l: G[pixel = 16*(l>>4) + kk][channel = l&15], kk = 0..15): the NC0 plain
-    // columns are transposed once through LDS (a tile that aliases the weight panel) into 16 registers, the vfeature columns
-    // stay in LDS (sG, row stride GV).
-    float Bp[16];
-    {
-        float* g = sP + lane * GPROW;
-        g[0] = gC[0]; g[1] = gC[1]; g[2] = gC[2];
-        g[3] = surface ? gN[0] * 10.f : 0.f; g[4] = surface ? gN[1] * 10.f : 0.f; g[5] = surface ? gN[2] * 10.f : 0.f;
-        g[6] = gDn;
-#pragma unroll
-        for (int i = 0; i < S; i++) g[7 + i] = gF[i];
-        float* gv = sG + lane * GV;
-#pragma unroll
-        for (int i = 0; i < VC; i++) gv[i] = gVF[i];
-        wave_lds_sync();
-        const float* gB = sP + (16 * grpB) * GPROW + (colB < NC0 ? colB : 0);
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) Bp[kk] = colB < NC0 ? gB[kk * GPROW] : 0.f;
-        wave_lds_sync();
-        // the weight panel starts as zeros again (slots beyond a batch's size must hold finite values)
-        for (int i = lane; i < BG::PROWS * PS / 4; i += 64) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (base < nent)   // the first batch's gathers start now and overlap the rest of the set-up
+        stage_load<S, VC, CHB>(sr, min((int)CHB, nent - base), [&](int s) { return gid_at(base + s); }, lane, a.rec, a.features, a.vfeatures);
 
     // Replay state.  The reference keeps, per channel, the blend of everything behind the current splat (accum_rec)
     // and the last value, and adds (value - accum) * dL_dchannel to dL_dalpha for every channel.  The upstream
@@ -250,29 +220,73 @@ render_bwd_kernel(const RenderBwdArgs a) {
     float T = T_final;
     float last_alpha = 0.f;
     float A_acc = 0.f, s_last = 0.f;
-    if (kseg < ndump) {
-        // Not the deepest live segment: start from the forward state dumped at this segment's far end.  With
-        // last_alpha = 0 the recurrence takes accum = blend of everything behind = (final - prefix) / T_end.
-        // (state layout: T | colour 3 | normal 3 | depth | feature S | vfeature VC; st_d[i] = channel 1 + i)
-        T = st_T;
-        float dot = st_d[6] * gDn;
+
+    // G matrix of this sub-tile: row = pixel (lane), columns = [colour3 | normal3 x10 (Q4) | depth | feature S | vfeature VC].
+    // Phase B needs it as the MFMA B operand (lane l: G[pixel = 16*(l>>4) + kk][channel = l&15], kk = 0..15): the NC0 plain
+    // columns are transposed once through LDS (a tile that aliases the weight panel) into 16 registers, the vfeature columns
+    // stay in LDS (sG, row stride GV).  The vfeature gradients also enter the start value of A (below) and are dead afterwards:
+    // they are loaded, used and dropped in two halves so that the set-up never holds more than the loop does.
+    float Bp[16];
+    {
+        const bool from_state = kseg < ndump;
+        // Not the deepest live segment: start from the forward state dumped at this segment's far end.  With last_alpha = 0 the
+        // recurrence takes accum = blend of everything behind = (final - prefix) / T_end.
+        // (state layout: T | colour 3 | normal 3 | depth | feature S | vfeature VC)
+        const float* e = a.seg_state + ((size_t)(d_sb + (uint32_t)kseg) * NST) * 64 + lane;
+        const float* f = a.seg_state + ((size_t)(d_sb + (uint32_t)ndump) * NST) * 64 + lane;   // final state
+        float dot = 0.f;
+        if (from_state) {
+            T = e[0];
+            float dd[7 + SS];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            dot += st_d[i] * gC[i];
-            dot += st_d[3 + i] * gN[i];   // zero unless `surface` (the forward leaves N at 0)
+            for (int i = 0; i < 7 + S; i++) dd[i] = f[(1 + i) * 64] - e[(1 + i) * 64];
+            dot = dd[6] * gDn;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                dot += dd[i] * gC[i];
+                dot += dd[3 + i] * gN[i];   // zero unless `surface` (the forward leaves N at 0)
+            }
+            if (bgeom) {
+#pragma unroll
+                for (int i = 0; i < S; i++) dot += dd[7 + i] * gF[i];
+            }
         }
-        if (bgeom) {
+        float* g = sP + lane * GPROW;
+        g[0] = gC[0]; g[1] = gC[1]; g[2] = gC[2];
+        g[3] = surface ? gN[0] * 10.f : 0.f; g[4] = surface ? gN[1] * 10.f : 0.f; g[5] = surface ? gN[2] * 10.f : 0.f;
+        g[6] = gDn;
 #pragma unroll
-            for (int i = 0; i < S; i++) dot += st_d[7 + i] * gF[i];
+        for (int i = 0; i < S; i++) g[7 + i] = gF[i];
+        float* gv = sG + lane * GV;
+        constexpr int VH = (VC + 1) / 2;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float gq[VH], dq[VH];
+#pragma unroll
+            for (int i = 0; i < VH; i++) {
+                const int ch = h * VH + i;
+                gq[i] = (ch < VC && inside && a.g_vfeature) ? a.g_vfeature[(size_t)ch * N_ + pid] : 0.f;
+                dq[i] = (ch < VC && from_state) ? f[(8 + S + ch) * 64] - e[(8 + S + ch) * 64] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VH; i++) {
+                const int ch = h * VH + i;
+                if (ch < VC) { gv[ch] = gq[i]; dot += dq[i] * gq[i]; }
+            }
         }
+        if (from_state) A_acc = dot * __builtin_amdgcn_rcpf(T);
+        wave_lds_sync();
+        const float* gB = sP + (16 * grpB) * GPROW + (colB < NC0 ? colB : 0);
 #pragma unroll
-        for (int i = 0; i < VC; i++) dot += st_d[7 + S + i] * gVF[i];
-        A_acc = dot * __builtin_amdgcn_rcpf(T);
+        for (int kk = 0; kk < 16; kk++) Bp[kk] = colB < NC0 ? gB[kk * GPROW] : 0.f;
+        wave_lds_sync();
+        // the weight panel starts as zeros again (slots beyond a batch's size must hold finite values)
+        for (int i = lane; i < BG::PROWS * PS / 4; i += 64) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     DEV_TRACE_MARK(0);   // segment setup
     dev_items++; dev_cands += (unsigned)nent;
     // Batches of CHB candidates; the gathers of batch b+1 are in flight (registers) while batch b is replayed, so
-    // neither their latency nor the completion of this batch's gradient atomics is waited for.
+    // neither their latency nor the completion of this batch's gradient stores is waited for.
     for (; base < nent; base += CHB) {
         const int m = min((int)CHB, nent - base);
         wave_lds_sync();  // previous batch fully consumed
@@ -280,15 +294,14 @@ render_bwd_kernel(const RenderBwdArgs a) {
         {
             const int nb = base + CHB;
             if (nb < nent)
-                stage_load<S, VC, CHB>(sr, min((int)CHB, nent - nb), [&](int s) { return sQ[nb + s].x; }, lane, a.rec,
-                                       a.features, a.vfeatures);
+                stage_load<S, VC, CHB>(sr, min((int)CHB, nent - nb), [&](int s) { return gid_at(nb + s); }, lane, a.rec, a.features, a.vfeatures);
         }
         wave_lds_sync();
         DEV_TRACE_MARK(1);   // staging
 
         for (int c0 = 0; c0 < m; c0 += SB) {
             uint32_t live = 0;  // bit cs set: candidate c0+cs has at least one blending pixel (wave-uniform)
-            if (VC > 0 && sp) {
+            if (sp) {
                 // h[pixel][(candidate, corner)] = sum_ch vfeature[candidate][ch][corner] * gVF[pixel][ch] for the SB = 4
                 // candidates of this block on the matrix pipe: M = pixels (4 tiles of 16), K = channels (4 steps of 4),
                 // N = (candidate, corner).  A = the gVF columns of sG, B = the staged vfeature floats (lane: channel
@@ -311,216 +324,148 @@ render_bwd_kernel(const RenderBwdArgs a) {
                 }
                 wave_lds_sync();   // (the previous block's phase B has read its panel)
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) *reinterpret_cast<f32x4*>(sP + colB * PS + 16 * mt + 4 * grpB) = hacc[mt];
+                for (int mt = 0; mt < 4; mt++) *reinterpret_cast<f32x4*>(sP + panel_at(colB, 16 * mt + 4 * grpB)) = hacc[mt];
                 wave_lds_sync();
             }
-            // ---------------- phase A: lane = pixel, KB candidates per branch-free group, lock-step ----------------
+            // ---------------- phase A: lane = pixel, one candidate at a time ----------------
 #pragma unroll 1
-            for (int cs0 = 0; cs0 < SB && c0 + cs0 < m; cs0 += KB) {
-                const int cb = c0 + cs0;   // first candidate of the group (slot in the staging buffer)
-                // (1) loads + independent per-candidate work: alpha, corner weights, s = sum_ch value_ch * g_ch
-                float4 A[KB], B[KB], E[KB], Nn[KB];
-                uint32_t slot[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    const float4* q = reinterpret_cast<const float4*>(sD + (cb + k) * SG::NF);
-                    A[k] = q[0];    // x, y, conic.x, conic.y
-                    B[k] = q[1];    // conic.z, opacity, depth, DA
-                    E[k] = q[3];    // DB, r, g, b
-                    Nn[k] = q[4];   // nx, ny, nz, 1/umax
-                    slot[k] = sQ[base + cb + k].y;
+            for (int cs = 0; cs < SB && c0 + cs < m; cs++) {
+                const int cb = c0 + cs;   // the candidate's slot in the staging buffer
+                // (1) alpha, corner weights, s = sum_ch value_ch * g_ch
+                const float4* q = reinterpret_cast<const float4*>(sD + cb * SG::NF);
+                const float4 A = q[0];    // x, y, conic.x, conic.y
+                const float4 B = q[1];    // conic.z, opacity, depth, DA
+                const float4 E = q[3];    // DB, r, g, b
+                const float4 Nn = q[4];   // nx, ny, nz, 1/umax
+                const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)ent.y, base + cb);
+                const float dx = A.x - pxf, dy = A.y - pyf;
+                const float pw = pair_power(A.z, A.w, B.x, dx, dy);
+                const float Gs = exp_nonpos(pw);
+                const float al = fminf(0.99f, B.y * Gs);
+                const bool pre = slot < last_contributor && pw <= 0.0f && al >= (1.0f / 255.0f);
+                const float ioma = __builtin_amdgcn_rcpf(1.f - al);
+                float cw0 = 0.f, cw1 = 0.f, cw2 = 0.f, cw3 = 0.f;
+                if (SVGSS && sp) {
+                    const float4 Jv = q[2];  // J0..J3
+                    const float ivm = q[5].x;
+                    const float du = dx * Jv.x + dy * Jv.y, dv = dx * Jv.z + dy * Jv.w;
+                    float u = du * Nn.w * 0.5f + 0.5f, v = dv * ivm * 0.5f + 0.5f;
+                    u = fminf(0.999f, fmaxf(0.001f, u));
+                    v = fminf(0.999f, fmaxf(0.001f, v));
+                    cw0 = (1.f - u) * (1.f - v); cw1 = u * (1.f - v); cw2 = (1.f - u) * v; cw3 = u * v;
                 }
-                float dx[KB], dy[KB], pw[KB], Gs[KB], al[KB], ioma[KB], sd[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) { dx[k] = A[k].x - pxf; dy[k] = A[k].y - pyf; }
-#pragma unroll
-                for (int k = 0; k < KB; k++) pw[k] = pair_power(A[k].z, A[k].w, B[k].x, dx[k], dy[k]);
-#pragma unroll
-                for (int k = 0; k < KB; k++) { Gs[k] = exp_nonpos(pw[k]); al[k] = fminf(0.99f, B[k].y * Gs[k]); }
-                bool pre[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    pre[k] = (cb + k < m) && slot[k] < last_contributor && pw[k] <= 0.0f && al[k] >= (1.0f / 255.0f);
-                    ioma[k] = __builtin_amdgcn_rcpf(1.f - al[k]);
-                }
-                float cw0[KB], cw1[KB], cw2[KB], cw3[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    cw0[k] = cw1[k] = cw2[k] = cw3[k] = 0.f;
-                    if (SVGSS && VC > 0) {
-                        if (sp) {
-                            const float4* q = reinterpret_cast<const float4*>(sD + (cb + k) * SG::NF);
-                            const float4 Jv = q[2];  // J0..J3
-                            const float ivm = q[5].x;
-                            const float du = dx[k] * Jv.x + dy[k] * Jv.y, dv = dx[k] * Jv.z + dy[k] * Jv.w;
-                            float u = du * Nn[k].w * 0.5f + 0.5f, v = dv * ivm * 0.5f + 0.5f;
-                            u = fminf(0.999f, fmaxf(0.001f, u));
-                            v = fminf(0.999f, fmaxf(0.001f, v));
-                            cw0[k] = (1.f - u) * (1.f - v); cw1[k] = u * (1.f - v); cw2[k] = (1.f - u) * v; cw3[k] = u * v;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    float sdot = E[k].y * gC[0] + E[k].z * gC[1] + E[k].w * gC[2];
-                    if (surface) sdot += Nn[k].x * gN[0] + Nn[k].y * gN[1] + Nn[k].z * gN[2];
-                    float d_cur = B[k].z;
-                    if (sp) d_cur -= dx[k] * B[k].w + dy[k] * E[k].x;   // depth differencing (common.hpp R_DA / R_DB)
-                    sdot += d_cur * gDn;
-                    sd[k] = sdot;
-                }
+                float sd = E.y * gC[0] + E.z * gC[1] + E.w * gC[2];
+                if (surface) sd += Nn.x * gN[0] + Nn.y * gN[1] + Nn.z * gN[2];
+                float d_cur = B.z;
+                if (sp) d_cur -= dx * B.w + dy * E.x;   // depth differencing (common.hpp R_DA / R_DB)
+                sd += d_cur * gDn;
                 if (S > 0 && bgeom) {
+                    const float* fp = sD + cb * SG::NF + SG::F_OFF;
 #pragma unroll
-                    for (int k = 0; k < KB; k++) {
-                        const float* f = sD + (cb + k) * SG::NF + SG::F_OFF;
-#pragma unroll
-                        for (int ch = 0; ch < S; ch++) sd[k] += f[ch] * gF[ch];
-                    }
+                    for (int ch = 0; ch < S; ch++) sd += fp[ch] * gF[ch];
                 }
-                if (VC > 0) {
-#pragma unroll
-                    for (int k = 0; k < KB; k++) {
-                        // sum_ch (c4[ch] . cw) gVF[ch] = cw . (sum_ch c4[ch] gVF[ch]) = cw . h (h: the block's MFMA above)
-                        if (sp) {
-                            const float* hp = sP + ((cs0 + k) * 4) * PS + lane;
-                            const float h0 = hp[0], h1 = hp[PS], h2 = hp[2 * PS], h3 = hp[3 * PS];
-                            sd[k] += (h0 * cw0[k] + h1 * cw1[k]) + (h2 * cw2[k] + h3 * cw3[k]);
-                        }
-                    }
+                // sum_ch (c4[ch] . cw) gVF[ch] = cw . (sum_ch c4[ch] gVF[ch]) = cw . h (h: the block's MFMA above)
+                if (sp) {
+                    const float h0 = sP[panel_at(cs * 4, lane)], h1 = sP[panel_at(cs * 4 + 1, lane)];
+                    const float h2 = sP[panel_at(cs * 4 + 2, lane)], h3 = sP[panel_at(cs * 4 + 3, lane)];
+                    sd += (h0 * cw0 + h1 * cw1) + (h2 * cw2 + h3 * cw3);
                 }
                 // (2) the sequential part: T <- T / (1 - alpha) and the scalar replay recurrence (backward.cu:700-850)
-                float dLa[KB], vw[KB];
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    const bool pass = pre[k];
-                    const float inv_Told = __builtin_amdgcn_rcpf(T);
-                    const float Tn = T * ioma[k];
-                    const float An = last_alpha * s_last + (1.f - last_alpha) * A_acc;
-                    float dL_dalpha = kdn * inv_Told + (sd[k] - An);
-                    dL_dalpha *= Tn;
-                    dL_dalpha += gO_kbg * (T_final * ioma[k]);
-                    T = pass ? Tn : T;
-                    A_acc = pass ? An : A_acc;
-                    s_last = pass ? sd[k] : s_last;
-                    last_alpha = pass ? al[k] : last_alpha;
-                    dLa[k] = pass ? dL_dalpha : 0.f;
-                    vw[k] = pass ? al[k] * Tn : 0.f;
-                }
-                // (3) independent again: weight panel rows and the six geometric gradients per pixel
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    if (VC > 0) {   // rows (candidate, corner); the four corner weights sum to the blend weight
-                        float* pr = sP + ((cs0 + k) * 4) * PS + lane;
-                        pr[0] = sp ? cw0[k] * vw[k] : vw[k]; pr[PS] = cw1[k] * vw[k];
-                        pr[2 * PS] = cw2[k] * vw[k]; pr[3 * PS] = cw3[k] * vw[k];
-                    } else {
-                        sP[(cs0 + k) * PS + lane] = vw[k];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < KB; k++) {
-                    const float dL_ddist = dLa[k] * (B[k].y * -0.5f) * Gs[k];
-                    float ge0 = dL_ddist * 2.f * (A[k].z * dx[k] + A[k].w * dy[k]) * ddelx_dx;
-                    float ge1 = dL_ddist * 2.f * (B[k].x * dy[k] + A[k].w * dx[k]) * ddely_dy;
-                    if (sp) { ge0 += q5g * B[k].w; ge1 += q5g * E[k].x; }   // + Q5, d(depth offset)/d(mean2D) = (DA, DB)
-                    const float ge2 = dL_ddist * (dx[k] * dx[k]);
-                    const float ge3 = dL_ddist * (dx[k] * dy[k]);
-                    const float ge4 = dL_ddist * (dy[k] * dy[k]);
-                    const float ge5 = Gs[k] * dLa[k];
-                    float* pg = sPg + (k * 6) * PS + lane;
-                    pg[0] = pre[k] ? ge0 : 0.f; pg[PS] = pre[k] ? ge1 : 0.f; pg[2 * PS] = pre[k] ? ge2 : 0.f;
-                    pg[3 * PS] = pre[k] ? ge3 : 0.f; pg[4 * PS] = pre[k] ? ge4 : 0.f; pg[5 * PS] = pre[k] ? ge5 : 0.f;
-                }
-                uint32_t glive = 0;
-#pragma unroll
-                for (int k = 0; k < KB; k++) glive |= (__ballot(pre[k]) != 0ull ? 1u : 0u) << k;
-                live |= glive << cs0;
-                wave_lds_sync();   // geometric panel visible
-                // (4) geometric sums: LPR lanes per (candidate, value) row, 64 / LPR pixels each
+                const float inv_Told = __builtin_amdgcn_rcpf(T);
+                const float Tn = T * ioma;
+                const float An = last_alpha * s_last + (1.f - last_alpha) * A_acc;
+                float dL_dalpha = kdn * inv_Told + (sd - An);
+                dL_dalpha *= Tn;
+                dL_dalpha += gO_kbg * (T_final * ioma);
+                T = pre ? Tn : T;
+                A_acc = pre ? An : A_acc;
+                s_last = pre ? sd : s_last;
+                last_alpha = pre ? al : last_alpha;
+                const float dLa = pre ? dL_dalpha : 0.f;
+                const float vw = pre ? al * Tn : 0.f;
+                // (3) weight panel rows (candidate, corner); the four corner weights sum to the blend weight
+                sP[panel_at(cs * 4, lane)] = sp ? cw0 * vw : vw;
+                sP[panel_at(cs * 4 + 1, lane)] = cw1 * vw;
+                sP[panel_at(cs * 4 + 2, lane)] = cw2 * vw;
+                sP[panel_at(cs * 4 + 3, lane)] = cw3 * vw;
+                const bool clive = __ballot(pre) != 0ull;   // (uniform) some pixel blends this candidate
+                live |= (clive ? 1u : 0u) << cs;
+                if (!clive) continue;
+                // (4) the six geometric gradients, summed over the 64 pixels without LDS: a transposed reduction tree (a lane keeps the value
+                // its low bits name and hands the other one over) leaves the quad sums of g0..g3 in u (lane l: value l & 3) and of g4, g5 in
+                // w (value 4 + (l & 1)); two row shifts put every 16-lane row's sums into its lanes 12..15; w moves to lanes 8..11; the four
+                // rows meet in rows_total.  Lanes 12..15 then hold the totals of g0..g3, lanes 8, 9 those of g4, g5.
                 {
-                    constexpr int EPL = 64 / LPR;
-                    const int row = lane / LPR, part = lane % LPR;
-                    const int kq = row / 6, jq = row - kq * 6;
-                    float v = 0.f;
-                    if (row < KB * 6) {
-                        const float4* src = reinterpret_cast<const float4*>(sPg + row * PS + part * EPL);
-                        float4 t[EPL / 4];
-#pragma unroll
-                        for (int i = 0; i < EPL / 4; i++) t[i] = src[i];
-#pragma unroll
-                        for (int i = 0; i < EPL / 4; i++) v += (t[i].x + t[i].y) + (t[i].z + t[i].w);
-                    }
-                    // partner lanes are adjacent: quad_perm [1,0,3,2] (+ [2,3,0,1], + row_half_mirror)
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
-                    if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
-                    if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
-                    const bool mine = row < KB * 6 && part == 0 && ((glive >> kq) & 1u);
-                    if (mine) {
-                        if (VC > 0) {
-                            // gradient row of the (instance, sub-tile) pair (see phase B)
-                            const float* rr = sD + (cb + kq) * SG::NF;
-                            const uint32_t ib = __builtin_bit_cast(uint32_t, rr[R_IBASE]);
-                            const uint32_t rc = __builtin_bit_cast(uint32_t, rr[R_RECT]);
-                            const uint32_t x0 = rc & 1023u, y0 = (rc >> 10) & 1023u, wr = rc >> 20;
-                            const size_t sl = (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
-                            const uint32_t row = row_top - (uint32_t)(base + cb + kq);
-                            if (row < a.rows_cap) {
-                                a.grad_rows[(size_t)row * RS + GEO + jq] = v;
-                                if (jq == 0) a.row_of[sl] = row + 1u;   // where grad_reduce finds this pair's row
-                            }
-                        } else if (v != 0.f) {
-                            atomic_add_f32(a.grad_rows + ((size_t)sQ[base + cb + kq].x * RS + (uint32_t)(GEO + jq)), v);
+                    const float dL_ddist = dLa * (B.y * -0.5f) * Gs;
+                    float g0 = dL_ddist * 2.f * (A.z * dx + A.w * dy) * ddelx_dx;
+                    float g1 = dL_ddist * 2.f * (B.x * dy + A.w * dx) * ddely_dy;
+                    if (sp) { g0 += q5g * B.w; g1 += q5g * E.x; }   // + Q5, d(depth offset)/d(mean2D) = (DA, DB)
+                    g0 = pre ? g0 : 0.f; g1 = pre ? g1 : 0.f;
+                    const float g2 = dL_ddist * (dx * dx), g3 = dL_ddist * (dx * dy), g4 = dL_ddist * (dy * dy);   // (dL_ddist = 0 where !pre)
+                    const float g5 = Gs * dLa;
+                    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+                    const float t01 = (o1 ? g1 : g0) + dpp_f32<0xB1>(o1 ? g0 : g1);   // quad_perm [1,0,3,2]
+                    const float t23 = (o1 ? g3 : g2) + dpp_f32<0xB1>(o1 ? g2 : g3);
+                    float u = (o2 ? t23 : t01) + dpp_f32<0x4E>(o2 ? t01 : t23);         // quad_perm [2,3,0,1]
+                    float w = (o1 ? g5 : g4) + dpp_f32<0xB1>(o1 ? g4 : g5);
+                    w += dpp_f32<0x4E>(w);
+                    u += dpp_f32<0x114>(u); w += dpp_f32<0x114>(w);   // row_shr:4
+                    u += dpp_f32<0x118>(u); w += dpp_f32<0x118>(w);   // row_shr:8
+                    const float w8 = dpp_f32<0x104>(w);               // row_shl:4: lanes 8..11 <- lanes 12..15
+                    const float tot = rows_total((lane & 12) == 8 ? w8 : u);
+                    const int jq = (lane & 4) ? (lane & 3) : 4 + (lane & 1);
+                    if (lane >= 8 && lane < 16 && (lane & 14) != 10) {   // lanes 8, 9, 12, 13, 14, 15
+                        // gradient row of the (instance, sub-tile) pair (see phase B)
+                        const float* rr = sD + cb * SG::NF;
+                        const uint32_t ib = __builtin_bit_cast(uint32_t, rr[R_IBASE]);
+                        const uint32_t rc = __builtin_bit_cast(uint32_t, rr[R_RECT]);
+                        const uint32_t x0 = rc & 1023u, y0 = (rc >> 10) & 1023u, wr = rc >> 20;
+                        const size_t sl = (size_t)4 * (ib + ((uint32_t)ty - y0) * wr + ((uint32_t)tx - x0)) + (uint32_t)sub;
+                        const uint32_t row = row_top - (uint32_t)(base + cb);
+                        if (row < a.rows_cap) {
+                            a.grad_rows[(size_t)row * RS + GEO + jq] = tot;
+                            if (jq == 0) a.row_of[sl] = row + 1u;   // where grad_reduce finds this pair's row
                         }
                     }
                 }
-                wave_lds_sync();   // geometric panel consumed before the next group overwrites it
             }
             DEV_TRACE_MARK(2);   // phase A
             if (live == 0) continue;  // uniform
-            // (the weight panel was made visible by the fences of the last group)
+            wave_lds_sync();          // the weight panel is complete
 
             // ---------------- phase B: panel x G on the matrix pipe ----------------
             {
-                const float4* ap = reinterpret_cast<const float4*>(sP + colB * PS + 16 * grpB);
-                const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
-                const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w,
-                                      a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                float av[16];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(sP + panel_at(colB, 16 * grpB + 4 * j));
+                    av[4 * j] = t4.x; av[4 * j + 1] = t4.y; av[4 * j + 2] = t4.z; av[4 * j + 3] = t4.w;
+                }
                 f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
                 const float* gB = sG + (16 * grpB) * GV;
                 const int colV = colB < VC ? colB : 0;
 #pragma unroll
                 for (int kk = 0; kk < 16; kk++) {
                     accP = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], Bp[kk], accP, 0, 0, 0);
-                    if (VC > 0) {
-                        const float bv = gB[kk * GV + colV];
-                        accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], colB < VC ? bv : 0.f, accV, 0, 0, 0);
-                    }
+                    const float bv = gB[kk * GV + colV];
+                    accV = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], colB < VC ? bv : 0.f, accV, 0, 0, 0);
                 }
                 // D layout: lane l, register r -> row 4*(l>>4) + r, column l&15
-                if (VC > 0) {
-                    // ---- svgss: gradient rows (common.hpp GradRowGeom): plain stores, summed per Gaussian afterwards ----
-                    // rows of the panel = (candidate grpB, corner r); the candidate's gradient row: compact, in list order
-                    const bool mine = c0 + grpB < m && ((live >> grpB) & 1u);
-                    if (mine) {
-                        const uint32_t rowi = row_top - (uint32_t)(base + c0 + grpB);
-                        float* row = a.grad_rows + (size_t)rowi * RS;
-                        if (rowi < a.rows_cap) {
-                            if (colB < NC0) row[colB] = (accP[0] + accP[1]) + (accP[2] + accP[3]);
-                            if (colB < VC)
-                                reinterpret_cast<float4*>(row + P4)[colB] =
-                                    sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    }
-                } else {
-                    // ---- rgss: one packed gradient row per Gaussian, float atomics; rows of the panel = candidates ----
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int cB = 4 * grpB + r;
-                        const bool mine = c0 + cB < m && ((live >> cB) & 1u) && colB < NC0 && accP[r] != 0.f;
-                        if (mine) atomic_add_f32(a.grad_rows + ((size_t)sQ[base + c0 + cB].x * RS + (uint32_t)colB), accP[r]);
+                // ---- gradient rows (common.hpp GradRowGeom): plain stores, summed per Gaussian afterwards ----
+                // rows of the panel = (candidate grpB, corner r); the candidate's gradient row: compact, in list order
+                const bool mine = c0 + grpB < m && ((live >> grpB) & 1u);
+                if (mine) {
+                    const uint32_t rowi = row_top - (uint32_t)(base + c0 + grpB);
+                    float* row = a.grad_rows + (size_t)rowi * RS;
+                    if (rowi < a.rows_cap) {
+                        if (colB < NC0) row[colB] = (accP[0] + accP[1]) + (accP[2] + accP[3]);
+                        if (colB < VC)
+                            reinterpret_cast<float4*>(row + P4)[colB] =
+                                sp ? make_float4(accV[0], accV[1], accV[2], accV[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
             }
+            wave_lds_sync();   // panel consumed before the next block overwrites it
             DEV_TRACE_MARK(3);   // phase B
         }
     }
@@ -528,6 +473,9 @@ render_bwd_kernel(const RenderBwdArgs a) {
     DEV_TRACE_END(1, dev_items, dev_cands, blockIdx.x);
 }
 
+#ifndef BWD_LDS_MIN
+#define BWD_LDS_MIN 0
+#endif
 template <int S, int VC, bool SVGSS>
 void launch(const RenderBwdArgs& a, hipStream_t s) {
     using BG = BwdGeom<S, VC>;
@@ -535,7 +483,8 @@ void launch(const RenderBwdArgs& a, hipStream_t s) {
     // capped by the list's upper bound, and let them stride over the list.  Small workloads get one segment per wave
     // (the dispatcher balances), large ones several; waves beyond the count exit after one scalar load.
     const int grid = std::max(8, std::min(a.seg_cap, 4 * 256 * 4 * BG::WPE) & ~7);   // a multiple of 8: work id & 7 = XCD in every round
-    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(grid), dim3(64), BG::lds_bytes, s, a);
+    // (the LDS request doubles as a residency control for occupancy sweeps: scripts/build_variant.sh -DBWD_LDS_MIN=...)
+    hipLaunchKernelGGL((render_bwd_kernel<S, VC, SVGSS>), dim3(grid), dim3(64), std::max(BG::lds_bytes, (size_t)BWD_LDS_MIN), s, a);
 }
 
 }  // namespace
