@@ -64,9 +64,12 @@ def issue_record(workload, prefixes, launch_ms):
     if tj.get("kernel_source_hash") != kernel_source_hash() or not (tj.get("library_hash") == library_hash() or library_is_current()):
         return {"issue_frac": None, "note": f"profiles/issue_{workload}.json was measured with different kernel sources / another library build"}
     valu = salu = 0.0
-    for kname, kv in tj.get("kernels", {}).items():
-        if kname.startswith(prefixes):
-            valu += kv["valu"]; salu += kv["salu"]
+    for pre in (prefixes if isinstance(prefixes, tuple) else (prefixes,)):
+        # (of a kernel's template variants -- the forward composite's two occupancy variants -- the one with the most launches: the steady state)
+        ks = [(kv.get("launches", 0), kv["valu"], kv["salu"]) for kname, kv in tj.get("kernels", {}).items() if kname.startswith(pre)]
+        if ks:
+            _, v, sa = max(ks)
+            valu += v; salu += sa
     if valu == 0.0:
         return None
     cyc = valu * VALU_ISSUE_CYCLES + salu * SALU_ISSUE_CYCLES
@@ -545,11 +548,13 @@ def roofline_of(wl, R, stage, workload):
             if not same_lib:   # another build of the SAME sources (e.g. rebuilt on the measuring machine)
                 out["traffic_note"] = "library rebuilt from the kernel sources profiles/traffic_%s.json was measured with" % workload
             tr = trf = 0
-            for kname, kv in tj.get("kernels", {}).items():
-                if kname.startswith("render_bwd") or kname.startswith("grad_reduce_kernel"):
-                    tr += kv["read_bytes"] + kv["write_bytes"]
-                if kname.startswith("cull_kernel") or kname.startswith("render_fwd"):
-                    trf += kv["read_bytes"] + kv["write_bytes"]
+            # (a kernel that exists in several template variants -- the forward composite's two occupancy variants, grad_reduce's batch
+            # sizes -- is represented by the variant with the most launches: the steady state, not the workload's first views)
+            def steady(prefix):
+                ks = [(kv.get("launches", 0), kv["read_bytes"] + kv["write_bytes"]) for kn, kv in tj.get("kernels", {}).items() if kn.startswith(prefix)]
+                return max(ks)[1] if ks else 0
+            tr = steady("render_bwd") + steady("grad_reduce_kernel")
+            trf = steady("cull_kernel") + steady("render_fwd")
             if "render_bwd" in stage:
                 out["traffic"] = tr or None
                 out["fwd_composite"]["traffic"] = trf or None

@@ -38,4 +38,4 @@ bash scripts/pmc_tracer.sh ${TAG}_pmct > gpurun_out/${TAG}_tracer_pmc.txt 2>&1; 
 rm -rf gpurun_out/${TAG}_pmct_a gpurun_out/${TAG}_pmct_b gpurun_out/${TAG}_*_rd gpurun_out/${TAG}_*_wr gpurun_out/${TAG}_*_iss
 python scripts/sort_probe.py cfg2 cfg5 cfg5_dense 2>&1 | grep '^cfg' > gpurun_out/${TAG}_sort_probe.txt; cat gpurun_out/${TAG}_sort_probe.txt
 timeout 600 python scripts/blob_sizes.py cfg2 cfg3_train cfg3_eval cfg5 cfg5_dense 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_blob_sizes.txt; cat gpurun_out/${TAG}_blob_sizes.txt
-python scripts/parity_report.py ${PARITY_TAG:-r05} cfg1 cfg2 cfg3_train cfg3_eval cfg4 cfg5 cfg5_dense > gpurun_out/${TAG}_parity.log 2>&1; tail -30 gpurun_out/${TAG}_parity.log
+python scripts/parity_report.py ${PARITY_TAG:-r06} cfg1 cfg2 cfg3_train cfg3_eval cfg4 cfg5 cfg5_dense > gpurun_out/${TAG}_parity.log 2>&1; tail -30 gpurun_out/${TAG}_parity.log

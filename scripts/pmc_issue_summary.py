@@ -27,5 +27,6 @@ for k, cs in acc.items():
     c = {n: sum(v) / len(v) for n, v in cs.items()}
     out["kernels"][short] = {"waves": c.get("SQ_WAVES", 0.0), "valu": c.get("SQ_INSTS_VALU", 0.0), "salu": c.get("SQ_INSTS_SALU", 0.0),
                              "lds": c.get("SQ_INSTS_LDS", 0.0), "vmem": c.get("SQ_INSTS_VMEM", 0.0), "smem": c.get("SQ_INSTS_SMEM", 0.0),
-                             "mfma_mops_f32": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), "profiled_us": sum(dur[k]) / len(dur[k])}
+                             "mfma_mops_f32": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), "profiled_us": sum(dur[k]) / len(dur[k]),
+                             "launches": len(dur[k])}
 print(json.dumps(out))

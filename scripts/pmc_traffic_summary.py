@@ -20,7 +20,7 @@ def load(d):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+    return {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, launches=max(len(v) for v in cs.values())) for k, cs in acc.items()}
 
 
 rd, wr = load(sys.argv[1]), load(sys.argv[2])
@@ -33,5 +33,6 @@ for k in rd:
     wq, w64 = w.get("TCC_EA0_WRREQ_sum", 0.0), w.get("TCC_EA0_WRREQ_64B_sum", 0.0)
     short = k.replace("svgir::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     out["kernels"][short] = {"read_bytes": 2 * 64 * (rq - r32) + 32 * r32, "write_bytes": 64 * w64 + 32 * (wq - w64),
+                             "launches": int(r.get("launches", 0)),   # (the composite forward exists in two variants: the steady state is the one with most launches)
                              "raw": {"RDREQ": rq, "RDREQ_32B": r32, "WRREQ": wq, "WRREQ_64B": w64}}
 print(json.dumps(out))

@@ -601,7 +601,7 @@ struct ForwardCall {
     int run_binning_and_render(char* bblob, int cap, long long cap_slots, bool timed, bool cull_only = false) {
         const BinLayout B = bin_layout(bblob, cap, T, nstate, cap_slots);
         launch_emit(P, depth_order, G.tiles, G.offsets, G.rec, o->radii, gx, gy, B.key[0], B.val[0], cap, I.ranges,
-                    I.counters, B.radix_tbl, s);
+                    I.counters, B.radix_tbl, G.counters + 3, s);
         if (int rc = check("emit")) return rc;
         if (timed) tm.mark("emit");
         if (plan.single) {   // up to 4096 tiles: one counting pass over the whole tile id, which also yields the tile ranges

@@ -355,8 +355,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_2048(uint32_t (&v)[8], 
     return woff + incl - s;
 }
 
+// (the counts gathered here are parked, in depth order, in `offsets`: the write kernel reads them back with coalesced loads instead of
+// repeating the P random gathers, then overwrites them with the prefix)
 __global__ void __launch_bounds__(BLOCK) offsets_reduce_kernel(const uint32_t* __restrict__ tiles,
                                                                const uint32_t* __restrict__ order, int n,
+                                                               uint32_t* __restrict__ counts_out,
                                                                uint32_t* __restrict__ block_sums,
                                                                const uint32_t* __restrict__ key_top, int n_key_top,
                                                                uint32_t* __restrict__ block_key) {
@@ -374,16 +377,22 @@ __global__ void __launch_bounds__(BLOCK) offsets_reduce_kernel(const uint32_t* _
 #pragma unroll
     for (int i = 0; i < 8; i++) oi[i] = order[min(base + i, n - 1)];
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = tiles[oi[i]];
+    for (int i = 0; i < 8; i++) v[i] = tiles[2 * oi[i]];   // (common.hpp GeomLayout::tiles: {count, rectangle})
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? v[i] : 0u;
+    if (base + 8 <= n) {   // (P-sized arrays start 256-byte aligned: two 16-byte stores)
+        reinterpret_cast<uint4*>(counts_out + base)[0] = make_uint4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<uint4*>(counts_out + base)[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (base + i < n) counts_out[base + i] = v[i];
+    }
     uint32_t total;
     block_exclusive_scan_2048(v, wsum, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __restrict__ tiles,
-                                                              const uint32_t* __restrict__ order, int n,
+__global__ void __launch_bounds__(BLOCK) offsets_write_kernel(int n,
                                                               const uint32_t* __restrict__ block_sums,
                                                               uint32_t* __restrict__ offsets, int nblocks,
                                                               uint32_t* __restrict__ total_out,
@@ -395,13 +404,13 @@ __global__ void __launch_bounds__(BLOCK) offsets_write_kernel(const uint32_t* __
     __shared__ uint32_t ksum[4];
     uint32_t v[8];
     const int base = blockIdx.x * SCAN_BLOCK_ELEMS + threadIdx.x * 8;
-    uint32_t oi[8];   // two rounds of independent loads instead of 8 dependent pairs
+    if (base + 8 <= n) {   // the counts the reduce kernel parked in `offsets` (depth order)
+        const uint4 a4 = reinterpret_cast<const uint4*>(offsets + base)[0], b4 = reinterpret_cast<const uint4*>(offsets + base)[1];
+        v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) oi[i] = order[min(base + i, n - 1)];
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = tiles[oi[i]];
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? v[i] : 0u;
+        for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? offsets[base + i] : 0u;
+    }
     // sum of the preceding blocks' totals (the block sums are few: every block adds them up itself, no scan kernel)
     const bool last = blockIdx.x == (unsigned)(nblocks - 1);
     uint32_t pre = 0, kv = 0xff00u;
@@ -454,34 +463,63 @@ __global__ void __launch_bounds__(BLOCK) emit_kernel(int P, const uint32_t* __re
                                                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
                                                      uint32_t cap, uint32_t* __restrict__ ranges, int n_ranges,
                                                      uint32_t* __restrict__ seg_count, uint32_t* __restrict__ gtot,
-                                                     int n_gtot) {
+                                                     int n_gtot, const uint32_t* __restrict__ span) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     // piggy-backed initialisation of three small tables used by later stages (saves three memset launches)
     for (int j = i; j < n_ranges; j += gridDim.x * BLOCK) ranges[j] = 0u;
     for (int j = i; j < n_gtot; j += gridDim.x * BLOCK) gtot[j] = 0u;
     if (i == 0) seg_count[0] = 0u;
-    if (i >= P) return;
-    const uint32_t g = order[i];
-    uint32_t off = offsets[i];
-    // (requested together, one latency behind `order`: the culled Gaussians sit at the end of the depth order)
-    const uint32_t ntiles = tiles[g];
-    const float px = rec[(size_t)g * REC + R_X], py = rec[(size_t)g * REC + R_Y];
-    const float r = (float)radii[g];
-    if (ntiles == 0) return;
-    // same rectangle as the preprocess stage (auxiliary.h:53-63); plain divisions, nothing to contract
-    const int x0 = min(gx, max(0, (int)((px - r) / TILE))), y0 = min(gy, max(0, (int)((py - r) / TILE)));
-    const int x1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE))), y1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
-    // for the backward's gradient rows: first instance index (emit order) and tile rectangle of this Gaussian
-    rec[(size_t)g * REC + R_IBASE] = __builtin_bit_cast(float, off);
-    rec[(size_t)g * REC + R_RECT] = __builtin_bit_cast(float, (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20));
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            if (off < cap) {   // only ever false for a speculative launch whose capacity guess was too small
-                tile_keys[off] = (uint32_t)(y * gx + x);
-                vals[off] = g;
-            }
-            off++;
+    // One wave = 64 consecutive Gaussians of the depth order; their instances are one contiguous run of the output (offsets is the
+    // exclusive scan in this order).  The run is written COOPERATIVELY: instance j of the wave goes to lane j & 63 of round j >> 6, which
+    // finds its Gaussian by a binary search over the lanes' local offsets (6 steps through the LDS crossbar) -- every store instruction
+    // writes 256 contiguous bytes and no lane idles while another one walks a large rectangle.  (A thread per Gaussian looping over its
+    // rectangle wrote 64 dwords 24 bytes apart per instruction and ran as long as the wave's largest splat: 80 us for 5.5 M instances.)
+    const int lane = threadIdx.x & 63;
+    // (order[0 .. *span) holds every Gaussian that touches a tile -- the culled ones, more than half of a closed surface's surfels, sort
+    // behind them)
+    const uint32_t nvis = min((uint32_t)P, span[0]);
+    if ((uint32_t)(i - lane) >= nvis) return;   // (uniform: the whole wave lies behind the visible span)
+    const bool valid = (uint32_t)i < nvis;
+    const uint32_t g = valid ? order[i] : 0u;
+    const uint32_t off = valid ? offsets[i] : 0u;
+    // (requested together, one latency behind `order`: the Gaussian's tile count and rectangle, as the preprocess stage computed them --
+    // auxiliary.h:53-63 -- in one 8-byte gather)
+    const uint2 tr = valid ? reinterpret_cast<const uint2*>(tiles)[g] : make_uint2(0u, 0u);
+    const uint32_t n = tr.x, rect = tr.y;
+    if (n != 0u) {   // for the backward's gradient rows: first instance index (emit order) and tile rectangle of this Gaussian
+        rec[(size_t)g * REC + R_IBASE] = __builtin_bit_cast(float, off);
+        rec[(size_t)g * REC + R_RECT] = __builtin_bit_cast(float, rect);
+    }
+    // local exclusive offsets of the wave's Gaussians and the run's length
+    uint32_t incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t loc = incl - n;
+    const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(off - loc));   // (lane 0 is valid; off = base + loc on every valid lane)
+    for (uint32_t j0 = 0; j0 < M; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        // owner = the last lane whose local offset is <= j (lanes without instances share their successor's offset and lose to it)
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int mid = lo + step;   // (<= 63)
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(mid << 2, (int)loc);
+            lo = v <= j ? mid : lo;
         }
+        const uint32_t t = j - (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)loc);
+        const uint32_t go = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)g);
+        const uint32_t ro = (uint32_t)__builtin_amdgcn_ds_bpermute(lo << 2, (int)rect);
+        const uint32_t w = max(ro >> 20, 1u), ty = t / w, tx = t - ty * w;
+        const uint32_t pos = base + j;
+        if (j < M && pos < cap) {   // (pos >= cap only ever for a speculative launch whose capacity guess was too small)
+            tile_keys[pos] = (((ro >> 10) & 1023u) + ty) * (uint32_t)gx + ((ro & 1023u) + tx);
+            vals[pos] = go;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) ranges_kernel(int R_cap, const uint32_t* __restrict__ R_dev,
@@ -787,17 +825,17 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
                          unsigned long long* host_out, uint32_t host_tag, hipStream_t s) {
     const int nb = scan_blocks(n);
     uint32_t* block_key = scan_tmp + nb + 1;
-    hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp, key_top, n_key_top, block_key);
-    hipLaunchKernelGGL(offsets_write_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, scan_tmp, offsets, nb,
+    hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nb), dim3(BLOCK), 0, s, tiles, order, n, offsets, scan_tmp, key_top, n_key_top, block_key);
+    hipLaunchKernelGGL(offsets_write_kernel, dim3(nb), dim3(BLOCK), 0, s, n, scan_tmp, offsets, nb,
                        total_out, block_key, violation, host_out, host_tag);
 }
 
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
-                 uint32_t* seg_count, uint32_t* sort_table, hipStream_t s) {
+                 uint32_t* seg_count, uint32_t* sort_table, const uint32_t* span, hipStream_t s) {
     hipLaunchKernelGGL(emit_kernel, dim3((P + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P, order, tiles, offsets, rec,
                        radii, gx, gy, tile_keys, vals, (uint32_t)cap, ranges, 2 * gx * gy + (gx * gy + 255) / 256 * SEG_BLOCK_STRIDE, seg_count,
-                       radix_gtot(sort_table, cap), (int)radix_gtot_words(cap));
+                       radix_gtot(sort_table, cap), (int)radix_gtot_words(cap), span);
 }
 
 void launch_tile_sort12(uint32_t* const key[2], uint32_t* const val[2], int n, const uint32_t* n_dev, uint32_t* table, uint32_t* ranges, int T,

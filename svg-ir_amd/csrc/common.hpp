@@ -70,7 +70,8 @@ struct GeomLayout {
     float* rec;            // [P*24]
     float* cov3D;          // [P*6]
     uint32_t* clamped;     // [P] bit c set => SH colour channel c was clamped
-    uint32_t* tiles;       // [P] tiles touched (0 => culled)
+    uint32_t* tiles;       // [2P] per Gaussian {tiles touched (0 => culled), tile rectangle x0 | y0 << 10 | width << 20}: ONE 8-byte gather tells
+                           // the emit kernel everything it needs (it used to gather the count, the radius and the record's mean2D)
     uint32_t* key[2];      // [P] depth keys ping/pong
     uint32_t* idx[2];      // [P] Gaussian ids ping/pong (idx[final] = depth-sorted order)
     uint32_t* offsets;     // [P] exclusive scan of tiles in depth-sorted order
@@ -93,7 +94,7 @@ inline GeomLayout geom_layout(char* base, int P) {
     g.rec = (float*)take(p * REC * 4);
     g.cov3D = (float*)take(p * 6 * 4);
     g.clamped = (uint32_t*)take(p * 4);
-    g.tiles = (uint32_t*)take(p * 4);
+    g.tiles = (uint32_t*)take(p * 8);
     g.key[0] = (uint32_t*)take(p * 4);
     g.key[1] = (uint32_t*)take(p * 4);
     g.idx[0] = (uint32_t*)take(p * 4);
@@ -436,7 +437,7 @@ void launch_offsets_scan(const uint32_t* tiles, const uint32_t* order, uint32_t*
 // sized for `cap` elements)
 void launch_emit(int P, const uint32_t* order, const uint32_t* tiles, const uint32_t* offsets, float* rec,
                  const int32_t* radii, int gx, int gy, uint32_t* tile_keys, uint32_t* vals, int cap, uint32_t* ranges,
-                 uint32_t* seg_count, uint32_t* sort_table, hipStream_t s);
+                 uint32_t* seg_count, uint32_t* sort_table, const uint32_t* span, hipStream_t s);   // span: GeomLayout::counters + 3
 void launch_ranges(int R, const uint32_t* R_dev, const uint32_t* tile_keys, uint32_t* ranges, int T, hipStream_t s);
 // single-pass stable counting sort of (tile id, value) pairs for T <= TS12_BINS tiles: slot 0 -> slot 1; writes ranges[2 T] (zero for empty
 // tiles, like identifyTileRanges); table: tile12_table_words(n)

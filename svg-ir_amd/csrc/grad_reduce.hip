@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(BLOCK) grad_reduce_kernel(const GradReduceArgs
 #pragma unroll
     for (int k = 0; k < GK; k++) {
         radius[k] = a.radii[g[k]];
-        ntiles[k] = a.tiles[g[k]];
+        ntiles[k] = a.tiles[2 * g[k]];   // (common.hpp GeomLayout::tiles: {count, rectangle})
         ibase[k] = __builtin_bit_cast(uint32_t, a.rec[(size_t)g[k] * REC + R_IBASE]);
     }
     // A LISTED Gaussian always gets its row written -- zeros if it owns none: with a list the binder may keep dL_dfeatures / dL_dvfeatures

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     if (idx == 0 && a.span) *a.span = 0u;   // (accumulated with atomicMax by the offsets scan)
     // defaults for a culled Gaussian
     a.radii[idx] = 0;
-    a.tiles[idx] = 0;
+    a.tiles[2 * idx] = 0;
     // (behind every visible key; under a speculated common top byte the depth sort skips that byte, so the culled keys carry it too.
     // Where a culled Gaussian lands in the depth order is immaterial: it emits nothing)
     a.key[idx] = a.spec_top >= 0 ? (((uint32_t)a.spec_top << 24) | 0x00FFFFFFu) : 0xFFFFFFFFu;
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_kernel(const PreArgs a) {
     if (!a.colors_precomp) cmask = sh_to_rgb(a, sh, campos, po, rgb);
     a.clamped[idx] = cmask;
     a.radii[idx] = (int)my_radius;
-    a.tiles[idx] = (uint32_t)area;
+    reinterpret_cast<uint2*>(a.tiles)[idx] = make_uint2((uint32_t)area, (uint32_t)rmin[0] | ((uint32_t)rmin[1] << 10) | ((uint32_t)(rmax[0] - rmin[0]) << 20));
     const uint32_t depth_key = __float_as_uint(pv[2]);
     a.key[idx] = depth_key;
     {   // AND / OR of the top bytes of this wave's visible keys (the lanes still here), for the host's guess of the next view's common byte

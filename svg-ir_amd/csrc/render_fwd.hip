@@ -132,12 +132,14 @@ __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
 }
 
 // ---- blend --------------------------------------------------------------------------------------------------
-// WPE = waves per SIMD the register allocation is held to.  The svgss widths exist in two variants: 2 (up to 256 VGPRs: nothing spills;
-// 8 waves per CU) for launches that do not fill the machine anyway, and FWD_WPE_HI = 3 (168 VGPRs, 9-15 spilled dwords; 11 waves per CU, the
-// LDS limit) for launches of many rounds of waves, where resident waves are what hides the gathers' latency (cfg5: 666 -> 593 us,
-// cfg5_dense 910 -> 834 us; cfg4, one round of waves: 213 -> 222 us) -- chosen per launch from the workload's fill (RenderArgs::hi_fill).
+// WPE = the most waves per SIMD the kernel may run at (the register allocator is told "2 to WPE": it never squeezes the kernel below the
+// 155-157 VGPRs it wants -- a "3 to 3" build spills 9-15 dwords -- and with WPE = 2 the allocation is padded so that no third wave fits).
+// The svgss widths exist in two variants: WPE = 2 (8 waves per CU) for launches that do not fill the machine anyway, where a CU with
+// three long lists on one SIMD is what the kernel ends on, and FWD_WPE_HI = 3 (11 waves per CU, the LDS limit) for launches of many
+// rounds of waves, where resident waves are what hides the gathers' latency (cfg5: 666 -> 593 us, cfg5_dense 910 -> 834 us; cfg4, one
+// round of waves: 213 -> 222 us) -- chosen per launch from the workload's fill (RenderArgs::hi_fill).
 template <int S, int VC, bool SVGSS, int WPE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE < 2 ? WPE : 2, WPE)))
 render_fwd_kernel(const RenderArgs a) {
     using PG = PairGeom<S, VC>;
     constexpr int CH = PG::CH, PF = PG::PF;
