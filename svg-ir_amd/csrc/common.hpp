@@ -129,6 +129,32 @@ inline size_t order_entries(int gx, int gy) {
     return std::max((size_t)8 * 4 * m, (size_t)4 * gx * gy);
 }
 
+// The same ownership for the per-tile cull (one workgroup per tile): work id q runs on XCD q & 7 and takes the (q >> 3)-th tile of that
+// XCD in (block row, block, row-major inside the block) order -- the ~6 tiles a splat touches are then culled on ONE XCD and its
+// 32-byte record header is fetched into one L2 instead of six (ORDER_NONE: past the end of the XCD's list; order_entries() / 4 ids).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t xcd_tile_of_work(uint32_t q, int gx, int gy) {
+    const int c = (int)(q & 7u), nbx = (gx + 3) >> 2, nby = (gy + 3) >> 2;
+    const int wl = gx - 4 * (nbx - 1);   // width of the last block of a row (1..4)
+    uint32_t rem = q >> 3;
+    for (int by = 0; by < nby; by++) {
+        const int bh = gy - 4 * by < 4 ? gy - 4 * by : 4;
+        const int r = (c - 3 * by) & 7;                               // this XCD's blocks of the row: r, r + 8, ...
+        const int nblk = nbx > r ? (nbx - r + 7) / 8 : 0;
+        const bool has_last = nblk > 0 && ((nbx - 1 - r) & 7) == 0;   // ... the row's last (possibly narrower) block among them
+        const uint32_t cnt = (uint32_t)(bh * (4 * nblk - (has_last ? 4 - wl : 0)));
+        if (rem >= cnt) { rem -= cnt; continue; }
+        const int k = (int)(rem / (uint32_t)(bh * 4));                // (only the last block can be narrower, and it is the last of the list)
+        const int bx = r + 8 * k;
+        const uint32_t within = rem - (uint32_t)(k * bh * 4);
+        const int bw = bx == nbx - 1 ? wl : 4;
+        return (uint32_t)((4 * by + (int)(within / (uint32_t)bw)) * gx + 4 * bx + (int)(within % (uint32_t)bw));
+    }
+    return ORDER_NONE;
+}
+
 constexpr int SEG_CLASSES = 5, SEG_BLOCK_STRIDE = 8;   // backward-segment length classes (see SEG); per-256-tile-block counters padded to 8
 
 struct ImageLayout {

@@ -65,7 +65,10 @@ __device__ __forceinline__ void write_zero_planes(const RenderArgs& a, size_t pi
 
 __global__ void __launch_bounds__(CT) cull_kernel(const RenderArgs a) {
     __shared__ uint32_t wcnt[CNW][4];   // [wave][sub-tile] survivors of the current round
-    const int tile = blockIdx.x;
+    // (the tiles are dealt to the XCDs in blocks of 4 x 4: a splat's tiles are culled on one XCD -- common.hpp xcd_tile_of_work)
+    const uint32_t tile_u = xcd_tile_of_work(blockIdx.x, a.gx, a.gy);
+    if (tile_u == ORDER_NONE) return;
+    const int tile = (int)tile_u;
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int len = (int)(r1 - r0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -717,7 +720,7 @@ void launch_contrib_prepass(const RenderArgs& a, hipStream_t s) {
 }
 
 void launch_cull(const RenderArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(cull_kernel, dim3(a.gx * a.gy), dim3(CT), 0, s, a);
+    hipLaunchKernelGGL(cull_kernel, dim3((unsigned)(order_entries(a.gx, a.gy) / 4)), dim3(CT), 0, s, a);
 }
 
 // Channel-count specialisations: the widths the reference's callers use (render.py:91 S=5; svgss.py:148-166
