@@ -518,6 +518,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHAD
 #ifndef SHADE_FQ_WPE
 #define SHADE_FQ_WPE 4
 #endif
+#ifndef SHADE_FQ_WPE_LO
+#define SHADE_FQ_WPE_LO 3   // "3 to 4 waves per SIMD": the allocator takes the 145-148 VGPRs the kernel wants (three waves, nothing spilled); held to 128
+                            // it spills 8-11 dwords inside the sample loop: 141 -> 129 us on the 88.7 k-surfel working set of cfg3_train.  (The
+                            // one-wave-per-surfel kernel above is the opposite case: 5 waves with 2 spilled dwords beat 4 without, 277 vs 315 us.)
+#endif
 constexpr int FQ_SURF = 16;                      // surfels per wave
 constexpr int FQ_ROW = NRED + 2;                 // LDS floats per surfel: the 70 reduced outputs (+ pad: rows of a quad group on distinct banks)
 constexpr int FQ_IN = 28;                        // base_color[12] | normals[12] | roughness[4] of a surfel (for the packing)
@@ -529,7 +534,7 @@ __device__ __forceinline__ float quad_bcast(float v) {   // value of lane (quad 
 struct FqSample { float d[3], il, ih, frac0, LgA[3], LlA[3]; };   // the staged, corner-independent part of one incident sample
 
 template <bool RATIO>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_FQ_WPE, SHADE_FQ_WPE))) shade_fwd_quad_kernel(const ShadeArgs a) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_FQ_WPE_LO, SHADE_FQ_WPE))) shade_fwd_quad_kernel(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const svgir_shade_params& p = a.p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
