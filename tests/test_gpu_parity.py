@@ -143,7 +143,7 @@ def test_forward_backward_parity_small(built, name, kw):
     assert R > 0
     im = _check_forward(out, o, R, variant)
     _check_binning(sc, variant, o, R)
-    _check_backward(leaves, o, variant)
+    _check_backward(leaves, o, variant, exact=_exact_grads(sc, variant, grads, R))
 
 
 @pytest.mark.parametrize("cfg,variant", [("cfg1", "svgss"), ("cfg2", "rgss"), ("cfg3_train", "svgss"), ("cfg3_eval", "svgss"),
@@ -217,7 +217,7 @@ def test_deep_translucent_stack_many_backward_segments(built, variant, S, VS):
     T = ((72 + 15) // 16) * ((56 + 15) // 16)
     assert R / T > 500, "scene not deep enough to exercise the segmented backward"
     _check_forward(out, o, R, variant)
-    _check_backward(leaves, o, variant)
+    _check_backward(leaves, o, variant, exact=_exact_grads(sc, variant, grads, R))
 
 
 def test_config_flags_and_quirks(built):
@@ -230,7 +230,7 @@ def test_config_flags_and_quirks(built):
         grads = scenes.upstream_grads(sc, "svgss", seed=5)
         out, leaves, o, R = _run_both(sc, "svgss", grads)
         _check_forward(out, o, R, "svgss")
-        _check_backward(leaves, o, "svgss")
+        _check_backward(leaves, o, "svgss", exact=_exact_grads(sc, "svgss", grads, R))
     # Q7: 4-entry config with config[3] > 0 switches the camera gradients on
     sc = dict(base)
     sc["config"] = np.array([1, 1, 1, 1], dtype=np.float32)
