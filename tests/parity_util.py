@@ -13,7 +13,7 @@ def stats(a, b, tol=1e-4, rel_tol=1e-3):
     b = np.asarray(b, dtype=np.float64).reshape(-1)
     assert a.shape == b.shape, (a.shape, b.shape)
     if b.size == 0:
-        return dict(n=0, scale=0.0, max_abs=0.0, max_norm=0.0, p9999_norm=0.0, flip_frac=0.0, rel_frac=0.0, p9999_rel=0.0, tail_q=0.99,
+        return dict(n=0, n_signal=0, scale=0.0, max_abs=0.0, max_norm=0.0, p9999_norm=0.0, flip_frac=0.0, rel_frac=0.0, p9999_rel=0.0, tail_q=0.99,
                     tail_rel=0.0, tail_norm=0.0, finite=True)
     scale = max(float(np.abs(b).max()), 1e-30)
     err = np.abs(a - b)
@@ -22,7 +22,7 @@ def stats(a, b, tol=1e-4, rel_tol=1e-3):
     rel = err[big] / np.abs(b[big]) if big.any() else np.zeros(0)
     # `tail`: the extreme quantile a sample of this size supports (the p99.99 of a few thousand entries is its maximum: one element)
     q = tail_quantile(int(big.sum()))
-    return dict(n=int(b.size), scale=scale, max_abs=float(err.max()), max_norm=float(norm.max()),
+    return dict(n=int(b.size), n_signal=int(big.sum()), scale=scale, max_abs=float(err.max()), max_norm=float(norm.max()),
                 p9999_norm=float(np.quantile(norm, 0.9999)), flip_frac=float((norm > tol).mean()),
                 rel_frac=float((rel > rel_tol).mean()) if rel.size else 0.0,
                 p9999_rel=float(np.quantile(rel, 0.9999)) if rel.size else 0.0,

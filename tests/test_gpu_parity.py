@@ -110,8 +110,9 @@ def _check_backward(leaves, o, variant, exact=None):
                 f"grad_{lk}: p{100 * own['tail_q']:g} relative error vs the exact gradient {own['tail_rel']:.2e}, the fp32 oracle's {ref['tail_rel']:.2e}"
             assert own["tail_norm"] <= 1.5 * ref["tail_norm"] + ANCHOR_FLOOR, \
                 f"grad_{lk}: tail normalised error vs the exact gradient {own['tail_norm']:.2e}, the fp32 oracle's {ref['tail_norm']:.2e}"
-            assert own["rel_frac"] <= 1.5 * ref["rel_frac"] + REL_FRAC, f"grad_{lk}: {own['rel_frac']:.2e} of the entries beyond {REL_TOL:g} of the exact gradient, the fp32 oracle {ref['rel_frac']:.2e}"
-            budget = max(REL_FRAC, 2.5 * ref["rel_frac"] + REL_FRAC)   # (two fp32 evaluations, each that far from the exact one)
+            few = 3.0 / max(own["n_signal"], 1)   # (small tensors: three entries -- a few thousand signal-carrying entries make ONE nearly cancelling sum 4e-4 of them)
+            assert own["rel_frac"] <= 1.5 * ref["rel_frac"] + REL_FRAC + few, f"grad_{lk}: {own['rel_frac']:.2e} of the entries beyond {REL_TOL:g} of the exact gradient, the fp32 oracle {ref['rel_frac']:.2e}"
+            budget = max(REL_FRAC, 2.5 * ref["rel_frac"] + REL_FRAC) + few   # (two fp32 evaluations, each that far from the exact one)
         _cmp("grad_" + lk, g, gr[ok], flip_frac=GRAD_FLIP_FRAC, rel_frac=budget)
 
 
