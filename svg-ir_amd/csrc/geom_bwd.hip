@@ -47,11 +47,6 @@ __constant__ float gC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315391
 __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
-#ifdef GEOM_ABL_NOSH   // (ablation builds only: without the SH rows -- wrong results)
-#define GEOM_SHS ((const float*)nullptr)
-#else
-#define GEOM_SHS a.shs
-#endif
 // The 48-float coefficient row of a Gaussian (and its gradient row) is 192 contiguous bytes, the lanes of a wave are 192 bytes -- with a
 // list, anything -- apart: read or written per lane, each of the 12 float4 accesses of a wave touches one cache line per visible lane
 // (~28 of 64 on the BASELINE scenes) and the kernel is bound by exactly that, the number of line accesses of its ~80 per-lane memory
@@ -71,7 +66,7 @@ __global__ void __launch_bounds__(GB_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     const int idx = in_range ? (a.list ? (int)a.list[w] : w) : 0;
     const bool visible = in_range && a.radii[idx] > 0;
     // The 48-float coefficient row of a Gaussian (M = 16) is contiguous and 16-byte aligned
-    const bool vec = GEOM_SHS && a.M == 16 && ((((size_t)GEOM_SHS) | ((size_t)a.dL_dsh)) & 15) == 0;
+    const bool vec = a.shs && a.M == 16 && ((((size_t)a.shs) | ((size_t)a.dL_dsh)) & 15) == 0;
     const bool coop = vec && a.D == 3;   // (wave-uniform) rows through LDS
     const unsigned long long vmask = __ballot(visible);
     const int nvis = __popcll(vmask);
@@ -86,7 +81,7 @@ __global__ void __launch_bounds__(GB_BLOCK) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int j = 0; j < CR; j++) {
             const int r = 5 * j + rsub;
-            cr[j] = (rsub < 5 && r < nvis) ? reinterpret_cast<const float4*>(GEOM_SHS)[(size_t)sIdx[wave][r] * 12 + rpart]
+            cr[j] = (rsub < 5 && r < nvis) ? reinterpret_cast<const float4*>(a.shs)[(size_t)sIdx[wave][r] * 12 + rpart]
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -102,7 +97,7 @@ __global__ void __launch_bounds__(GB_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     // (the uniform inputs as well: a load the compiler cannot prove untouched by an earlier store is not a scalar load any more)
 #pragma unroll
     for (int i = 0; i < 16; i++) { V[i] = a.view[i]; PR[i] = a.proj[i]; }
-    if (GEOM_SHS) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
+    if (a.shs) { campos[0] = a.campos[0]; campos[1] = a.campos[1]; campos[2] = a.campos[2]; }
 
     // ---------------- every input of this Gaussian ----------------
     if (a.packed) {
@@ -128,7 +123,7 @@ __global__ void __launch_bounds__(GB_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     mean[0] = a.means3D[3 * idx]; mean[1] = a.means3D[3 * idx + 1]; mean[2] = a.means3D[3 * idx + 2];
 #pragma unroll
     for (int i = 0; i < 6; i++) c3[i] = a.cov3D[6 * idx + i];
-    if (GEOM_SHS) cm = a.clamped[idx];
+    if (a.shs) cm = a.clamped[idx];
     if (a.scales) {
         qq = reinterpret_cast<const float4*>(a.rotations)[idx];
 #pragma unroll
@@ -144,14 +139,14 @@ __global__ void __launch_bounds__(GB_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         for (int r0 = 5 * CR; r0 < nvis; r0 += 5) {   // (more than 30 visible Gaussians in the wave)
             const int r = r0 + rsub;
             if (rsub < 5 && r < nvis)
-                sRow[wave][r][rpart] = reinterpret_cast<const float4*>(GEOM_SHS)[(size_t)sIdx[wave][r] * 12 + rpart];
+                sRow[wave][r][rpart] = reinterpret_cast<const float4*>(a.shs)[(size_t)sIdx[wave][r] * 12 + rpart];
         }
     }
     if (visible) {
     const int nk = (a.D + 1) * (a.D + 1);
     float sh[48];
-    if (GEOM_SHS) {
-        const float* shp = GEOM_SHS + (size_t)idx * a.M * 3;
+    if (a.shs) {
+        const float* shp = a.shs + (size_t)idx * a.M * 3;
         if (coop) {
             wave_lds_sync();   // (the rows are in LDS: the DS operations of a wave execute in order)
 #pragma unroll
@@ -285,7 +280,7 @@ __global__ void __launch_bounds__(GB_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     }
 
     // ---------------- colour -> SH, view direction -> mean ----------------
-    if (GEOM_SHS) {
+    if (a.shs) {
         const float kC0 = 0.28209479177387814f, kC1 = 0.4886025119029199f;
         const float dor[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
         const float len = sqrtf(dor[0] * dor[0] + dor[1] * dor[1] + dor[2] * dor[2]);

@@ -315,17 +315,6 @@ constexpr int PBGI_STACK = 64;        // the reference's MAX_STACK_SIZE; the tre
 #endif
 constexpr int PBGI_LDS_DEPTH = PBGI_LDS_DEPTH_V;   // (round 4, 129 VGPRs = 12 waves per CU whatever the LDS: 32 / 24 / 16 levels: 1 017 / 963 / 1 023 ms on the cfg3 geometry, 1 735 / 1 392 / 1 238 ms on the shell scene.  Round 5, 124 VGPRs: 24 levels = 13 waves per CU 873 / 1 255 ms; 20 levels = 16 waves per CU 866 / 1 060 ms; 16 levels at 5 waves per SIMD spills: 1 508 / 2 120 ms)    // stack levels kept in LDS ([level][lane]: conflict-free whatever the lanes' depths); deeper ones in scratch
 constexpr int PBGI_WAVE = 64;         // one wave per workgroup
-#ifndef PBGI_COOP_CAP_V
-#define PBGI_COOP_CAP_V 512
-#endif
-constexpr int PBGI_COOP_CAP = PBGI_COOP_CAP_V;    // entries of the wave's ordered worklist (cooperative queries at the end of a launch)
-#ifndef PBGI_COOP_LANES
-#define PBGI_COOP_LANES 0             // > 0: the wave switches to cooperative queries when at most this many of its lanes still hold a ray.
-                                      // Exact (tests/test_gpu_pbgi.py passes with 8 and 32) but OFF: measured 868 -> 828 ms on the cfg3 geometry
-                                      // with 32 and 1 614 -> 1 857 ms on the shell scene (4 KB more LDS and 12 more VGPRs per wave cost more
-                                      // throughput than the shorter tail gives back; a round of the cooperative walk is still one dependent
-                                      // fetch deep).  -DPBGI_COOP_LANES=32 builds it.
-#endif
 constexpr int PBGI_MAX_HITS = 4096;   // guard of the ray loop (every accepted hit removes >= 1/255 of the transmittance: < 1800 hits)
 
 
@@ -459,10 +448,6 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
 #pragma clang fp contract(off)
     __shared__ int s_ids[PBGI_LDS_DEPTH * PBGI_WAVE];
     __shared__ float s_ens[PBGI_LDS_DEPTH * PBGI_WAVE];
-#if PBGI_COOP_LANES > 0
-    __shared__ int wl_id[PBGI_COOP_CAP];      // cooperative queries: the pending nodes of ONE ray in visit order (top = next)
-    __shared__ float wl_en[PBGI_COOP_CAP];
-#endif
     const int lane = threadIdx.x;
     int* s_id = s_ids + lane;
     float* s_en = s_ens + lane;
@@ -589,128 +574,6 @@ __global__ void __launch_bounds__(PBGI_WAVE) __attribute__((amdgpu_waves_per_eu(
             }
             if (!__any(walking)) break;   // the pool is empty and every lane is done
         }
-#if PBGI_COOP_LANES > 0
-        {
-            // ---- the end of the launch: few rays left, each of them a long chain of queries ----
-            // A ray's queries are sequential, a query's visits are sequential per lane (~1 200 visits of ~2 us each): one ray with
-            // 90 queries keeps a lane -- and the launch -- busy for 0.25 s after everything else is done.  When the queue is empty
-            // and at most PBGI_COOP_LANES lanes of the wave still hold a ray, the WAVE finishes their queries one at a time with all 64
-            // lanes.  What makes that exact: with the direction final, a leaf is visited if and only if its own box still beats the
-            // closest hit when its turn comes (its ancestors' boxes contain it, their tests used the same direction and a closest hit
-            // that was no smaller), and the turns are the tree's right-first leaf order.  So the wave keeps the ray's pending nodes
-            // in visit order, expands the next 64 of them a level per round in parallel (children that fail now can never pass
-            // later), evaluates the leaves at the front in parallel and applies the accepted ones strictly in order -- the same
-            // visits, the same decisions, the same last-accepted-leaf side effects (Q-a, Q-b) as the lane's own walk.
-            if (drained && next_ray >= pool_end) {
-                const unsigned long long wm = __ballot(walking);
-                if (wm != 0ull && __popcll(wm) <= PBGI_COOP_LANES) {
-                    unsigned long long todo = __ballot(walking && fixed && count <= PBGI_LDS_DEPTH - 1);
-                    while (todo != 0ull) {
-                        const int Ls = __builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        auto rlf = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), Ls)); };
-                        auto rli = [&](int v) { return __builtin_amdgcn_readlane(v, Ls); };
-                        // the ray's query state, wave-uniform
-                        const F3 qo = {rlf(o.x), rlf(o.y), rlf(o.z)}, qd = {rlf(d.x), rlf(d.y), rlf(d.z)};
-                        const SlabDir qsd = slab_dir(qd);
-                        const float qtmin = rlf(t_min);
-                        float q_closest = rlf(closest), q_cu = rlf(cu), q_cv = rlf(cv), q_hit_t = rlf(hit_t), q_keep = rlf(keep_l), q_hu = rlf(hu), q_hv = rlf(hv);
-                        int q_index = rli((int)closest_index);
-                        bool q_any = rli(any_hit ? 1 : 0) != 0;
-                        int len = rli(count);
-                        // the lane's stack, bottom first, then the node it was about to visit (a passed node: entry below every t)
-                        if (lane < len) { wl_id[lane] = s_ids[lane * PBGI_WAVE + Ls]; wl_en[lane] = s_ens[lane * PBGI_WAVE + Ls]; }
-                        if (lane == 0) { wl_id[len] = rli(cur); wl_en[len] = rli(own_test ? 1 : 0) != 0 ? -INFINITY : -3.0e38f; }
-                        len += 1;
-                        wave_lds_sync();
-                        while (len > 0) {
-                            const int m = len > PBGI_COOP_CAP - 128 ? 1 : min(64, len);   // (full rounds add at most 64 entries; PBGI_COOP_CAP >= 192)   // (one node at a time when the list is nearly full:
-                            // a depth-first walk then adds at most the tree's height)
-                            const bool have = lane < m;
-                            int id = 0;
-                            float en = 0.f;
-                            if (have) { id = wl_id[len - 1 - lane]; en = wl_en[len - 1 - lane]; }
-                            bool alive = have && (en == -INFINITY || q_closest > en);
-                            if (alive && en == -INFINITY) {   // pushed before the direction was final: its own box, now
-                                const float4* qn = reinterpret_cast<const float4*>(node + id);
-                                const float4 q0 = qn[0], q1 = qn[1];
-                                const float lo[3] = {q0.x, q0.y, q0.z}, hi[3] = {q0.w, q1.x, q1.y};
-                                PBGI_STAT(1);
-                                alive = box_entry(lo, hi, qo, qsd, qtmin, en) && q_closest > en;
-                            }
-                            const bool is_leaf = id >= L;
-                            // leaves in front of the first pending internal node are due now
-                            const unsigned long long inner = __ballot(alive && !is_leaf);
-                            const int pfx = inner ? __builtin_ctzll(inner) : 64;
-                            const bool due = alive && is_leaf && lane < pfx;
-                            int c0 = 0, c1 = 0, n_out = 0;
-                            float e0 = 0.f, e1 = 0.f;
-                            LeafRes lf = {false, false, 0.f, 0.f, 0.5f, 0.5f};
-                            int lprim = 0;
-                            if (alive && !is_leaf) {
-                                PBGI_STAT(2);
-                                const float4* qp = pair + 4 * (size_t)id;
-                                const float4 r0 = qp[0], r1 = qp[1], r2 = qp[2], r3 = qp[3];
-                                const int left = __builtin_bit_cast(int, r3.x), right = __builtin_bit_cast(int, r3.y);
-                                const float lo0[3] = {r0.x, r0.y, r0.z}, hi0[3] = {r0.w, r1.x, r1.y}, lo1[3] = {r1.z, r1.w, r2.x}, hi1[3] = {r2.y, r2.z, r2.w};
-                                float eL, eR;
-                                PBGI_STAT(1); PBGI_STAT(1);
-                                const bool pr = box_entry(lo1, hi1, qo, qsd, qtmin, eR) && q_closest > eR;
-                                const bool pl = box_entry(lo0, hi0, qo, qsd, qtmin, eL) && q_closest > eL;
-                                if (pr) { c0 = right; e0 = eR; n_out = 1; }
-                                if (pl) { if (n_out == 0) { c0 = left; e0 = eL; } else { c1 = left; e1 = eL; } n_out++; }
-                            } else if (alive && is_leaf && !due) {
-                                c0 = id; e0 = en; n_out = 1;   // a leaf behind a pending internal node: waits
-                            } else if (due) {
-                                PBGI_STAT(2); PBGI_STAT(3);
-                                lf = leaf_eval(rec, id - L, qo, qd, qtmin);
-                                if (lf.acc) lprim = (int)prim[id - L];
-                            }
-                            // accepted leaves, strictly in visit order
-                            unsigned long long accm = __ballot(due && lf.acc);
-                            while (accm != 0ull) {
-                                const int a = __builtin_ctzll(accm);
-                                accm &= accm - 1ull;
-                                const float ea = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, en), a));
-                                if (q_closest > ea) {   // (visited: its box still beats the closest hit)
-                                    PBGI_STAT(4);
-                                    const float ta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.t), a));
-                                    const bool ha = __builtin_amdgcn_readlane(lf.hit ? 1 : 0, a) != 0;
-                                    const bool update = ha && ta < q_closest;
-                                    q_closest = ha ? fminf(ta, q_closest) : q_closest;
-                                    if (update) {
-                                        q_index = __builtin_amdgcn_readlane(lprim, a);
-                                        q_cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.u), a));
-                                        q_cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.v), a));
-                                    }
-                                    if (ha) {
-                                        q_any = true; q_hit_t = q_closest; q_hu = q_cu; q_hv = q_cv;
-                                        q_keep = 1 - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf.alpha), a));
-                                    }
-                                }
-                            }
-                            // the batch's successors go back on the list, in visit order (first = top)
-                            const unsigned long long b1 = __ballot(n_out >= 1), b2 = __ballot(n_out == 2);
-                            const int before = __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
-                            const int total_out = __popcll(b1) + __popcll(b2);
-                            const int nlen = len - m + total_out;
-                            wave_lds_sync();   // every lane has read its item
-                            if (n_out >= 1) { wl_id[nlen - 1 - before] = c0; wl_en[nlen - 1 - before] = e0; }
-                            if (n_out == 2) { wl_id[nlen - 2 - before] = c1; wl_en[nlen - 2 - before] = e1; }
-                            wave_lds_sync();
-                            len = nlen;
-                        }
-                        if (lane == Ls) {   // the query is over: its results, as the lane's own walk would have left them
-                            closest = q_closest; cu = q_cu; cv = q_cv; hit_t = q_hit_t; keep_l = q_keep; hu = q_hu; hv = q_hv;
-                            closest_index = (uint32_t)q_index; any_hit = q_any;
-                            count = 0; walking = false;
-                        }
-                    }
-                    if (!__any(walking)) continue;   // (every remaining query was finished here: back to the ray bookkeeping)
-                }
-            }
-        }
-#endif
         if (walking) {
             // ---- one traversal step ----
             // The node's record -- the pair record of an internal node (64 bytes) or the leaf record (96 bytes) -- is requested BEFORE the
@@ -866,7 +729,7 @@ int svgir_pbgi_trace_radiance(int32_t P, char* bvh, int32_t N, int32_t S, const 
     // 1 534 / 4 249 ms -- small pools end with 63 lanes waiting for one long ray, large ones leave wave slots empty.)
     long long chunk = std::max<long long>(S, (64 + S - 1) / S * S);   // (64 / 256 / 1 024 rays per chunk: 1 005 / 1 046 / 1 178 ms on the cfg3 geometry)
     if (const char* e = getenv("SVGIR_PBGI_POOL")) { const long long v = atoll(e); if (v > 0) chunk = (v + S - 1) / S * S; }   // (tuning experiments)
-    const int slots = 256 * std::min(8 * 4, (160 * 1024) / (PBGI_LDS_DEPTH * PBGI_WAVE * 8 + (PBGI_COOP_LANES > 0 ? PBGI_COOP_CAP * 8 : 0)));   // resident waves
+    const int slots = 256 * std::min(8 * 4, (160 * 1024) / (PBGI_LDS_DEPTH * PBGI_WAVE * 8));   // resident waves
     for (int row0 = 0; row0 < N; row0 += P) {   // (the row-order buffers hold P rows: more rows than surfels go in blocks)
         const int n = std::min(P, N - row0);
         // rows in the Morton order of their origins

@@ -779,9 +779,6 @@ constexpr int BREC = 20;
 #ifndef SHADE_KB_G
 #define SHADE_KB_G 4
 #endif
-#ifndef SHADE_ABL
-#define SHADE_ABL 0   // (ablation experiments only, scripts/build_variant.sh: 1-4 switch parts of the kernel off -- wrong results)
-#endif
 constexpr int BWAVES = SHADE_BWAVES;   // waves per backward workgroup
 constexpr int KB_G = SHADE_KB_G, KREC = 52;   // Gaussians prepared per batch; floats per (Gaussian, corner) record (13 float4)
 
@@ -1041,7 +1038,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
         for (int s0 = 0; s0 < Ns; s0 += 64) {
             const int cnt = min(64, Ns - s0);
             wave_lds_sync();   // previous chunk consumed
-            if (lane < cnt && (SHADE_ABL != 3 || s0 + g == 0)) stage_raw_bwd(p, raw, lane, V, sS, ratio_now());
+            if (lane < cnt) stage_raw_bwd(p, raw, lane, V, sS, ratio_now());
             {   // prefetch the next chunk (of this Gaussian or of the wave's next one)
                 const bool more = s0 + 64 < Ns;
                 const int gn = more ? g : g + gstep;
@@ -1051,7 +1048,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
             wave_lds_sync();
             DEV_TRACE_MARK(1);   // staging of a chunk (+ issue of the prefetches)
 #pragma unroll 1
-            for (int it = 0; it < (SHADE_ABL == 4 ? 1 : 4); it++) {
+            for (int it = 0; it < 4; it++) {
                 const int s = sg + 16 * it;
                 if (16 * it >= cnt) break;   // wave-uniform
                 const bool act = s < cnt;
@@ -1113,7 +1110,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) { xg[ch] = quad_sum(xg[ch]); xl[ch] = quad_sum(xl[ch]); }
                 {
-                    if (SHADE_ABL != 2) {   // parked in the sample's (consumed) local-light slots, written out below (lane k = 3: the pad
+                    {   // parked in the sample's (consumed) local-light slots, written out below (lane k = 3: the pad
                         // slot; lanes beyond the chunk: records nobody reads)
                         const float v = k == 0 ? xl[0] : (k == 1 ? xl[1] : xl[2]);
                         float gk = v + grad_const;   // dL/d(incident radiance), channel k of this sample
@@ -1140,7 +1137,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                     for (int ch = 0; ch < 3; ch++) dt[ch] = ((xy >> (28 + ch)) & 1u) ? (xg[ch] + gmig[ch]) * w : 0.f;
                     // ONE test per tap: inside the chunk and the image, and not all three channels zero (they vanish together:
                     // zero weight or an occluded / clamped sample)
-                    if (act && tx >= 0 && tx < We && ty >= 0 && ty < He && (dt[0] != 0.f || dt[1] != 0.f || dt[2] != 0.f) && SHADE_ABL != 1) {
+                    if (act && tx >= 0 && tx < We && ty >= 0 && ty < He && (dt[0] != 0.f || dt[1] != 0.f || dt[2] != 0.f)) {
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
                             if (env_in_lds) atomicAdd(&sEnv[idx + ch], (double)dt[ch]);   // ds_add_f64
@@ -1161,7 +1158,7 @@ __global__ void __launch_bounds__(BWAVES * 64) __attribute__((amdgpu_waves_per_e
                     if (i < 3 * cnt) ratio_acc += sS[(i / 3) * BREC + 12 + (i % 3)] * rawp[i];
                 }
             }
-            if (SHADE_ABL != 2 && a.d_radiance) {
+            if (a.d_radiance) {
                 float* out = a.d_radiance + (gg * Ns + s0) * 3;
                 const float rsc = RATIO ? ratio_now().ratio : 1.f;   // (RATIO: the parked values are masked dL/d(incident); d(incident)/d(raw) = ratio)
 #pragma unroll
