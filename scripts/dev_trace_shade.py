@@ -30,7 +30,10 @@ for it in range(3):
     n = reader(buf.ctypes.data, CAP, 0)
 fr = fbuf[:nf].astype(np.int64)
 ft = fr[:, 0].sum()
-print(f"{name} shade_fwd: {nf} reporting waves (one of four); kernel span {(fr[:, 2].max() - fr[:, 1].min()) / 100.0:.1f} us; cycles per surfel {ft / nf:.0f}: "
+if nf == 0:
+    print(f"{name} shade_fwd: no records (the quad kernel of the training sample counts carries no probes)")
+else:
+  print(f"{name} shade_fwd: {nf} reporting waves (one of four); kernel span {(fr[:, 2].max() - fr[:, 1].min()) / 100.0:.1f} us; cycles per surfel {ft / nf:.0f}: "
       f"prologue {fr[:, 5].sum() / nf:.0f} staging {fr[:, 6].sum() / nf:.0f} corner-x-sample loop {(fr[:, 7] >> 32).sum() / nf:.0f} "
       f"reductions + epilogue {(fr[:, 7] & 0xffffffff).sum() / nf:.0f}")
 rec = buf[:n].astype(np.int64)
